@@ -1,0 +1,607 @@
+// K5-K7: marginalised causal-LM cross-entropy for gfx950.
+//
+// Stands in for compute_marginalized_loss_from_logits / marginalize_log_probs /
+// get_nll (dalm/training/utils/train_utils.py:91-138).  The reference makes
+// ~6 full [B,Tg-1,V] copies (log_softmax, per-sample cat, stack, gather ...);
+// here every vocabulary row is read from HBM exactly once, held in registers
+// (V = 32000 f32 -> 62.5 floats/lane in a 512-thread block), reduced with
+// wave shuffles + one LDS hop, and - optionally - turned into its gradient and
+// written back in the same pass.  HBM-bound by construction:
+//   forward  : R*V*el bytes read                       (R = B*(Tg-1) rows)
+//   fwd+grad : R*V*el read + R*V*el written            (reference: ~12x that)
+//
+// Row addressing uses 16-byte aligned windows: a row may start at any element
+// offset; the first/last 16-byte slot is masked on load and stored with scalar
+// writes, all interior slots are single dwordx4 accesses.
+#include "common.hpp"
+
+namespace dalm {
+namespace {
+
+struct bf16_t { unsigned short v; };
+
+template <typename T> struct Elt;
+template <> struct Elt<float> {
+  static constexpr int VEC = 4;
+  __device__ static __forceinline__ void load(const float* p, float (&x)[4]) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+  }
+  __device__ static __forceinline__ void store(float* p, const float (&x)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(x[0], x[1], x[2], x[3]);
+  }
+  __device__ static __forceinline__ float get(const float* p) { return *p; }
+  __device__ static __forceinline__ void put(float* p, float v) { *p = v; }
+};
+template <> struct Elt<bf16_t> {
+  static constexpr int VEC = 8;
+  __device__ static __forceinline__ void load(const bf16_t* p, float (&x)[8]) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      x[2 * i] = __uint_as_float(w[i] << 16);
+      x[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  __device__ static __forceinline__ void store(bf16_t* p, const float (&x)[8]) {
+    unsigned int w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      w[i] = static_cast<unsigned int>(f32_to_bf16(x[2 * i])) |
+             (static_cast<unsigned int>(f32_to_bf16(x[2 * i + 1])) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  __device__ static __forceinline__ float get(const bf16_t* p) { return bf16_to_f32(p->v); }
+  __device__ static __forceinline__ void put(bf16_t* p, float v) { p->v = f32_to_bf16(v); }
+};
+
+// Geometry of one vocabulary row seen through 16-byte aligned slots.
+template <typename T>
+struct RowWin {
+  const T* abase;  // 16-byte aligned address at or before the row start
+  int lead;        // elements of the first slot that belong to the previous row
+  int nslots;      // slots covering [lead, lead+V)
+  int V;
+  __device__ __forceinline__ RowWin(const T* row, int V_) : V(V_) {
+    constexpr int VEC = Elt<T>::VEC;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(row);
+    lead = static_cast<int>((a & 15u) / sizeof(T));
+    abase = row - lead;
+    nslots = (lead + V + VEC - 1) / VEC;
+  }
+  __device__ __forceinline__ bool partial(int slot) const {
+    constexpr int VEC = Elt<T>::VEC;
+    return (slot == 0 && lead != 0) || (slot == nslots - 1 && ((lead + V) % VEC) != 0);
+  }
+};
+
+// Write `fill` over one full row (used for masked rows and the t = Tg-1 slot).
+template <typename T, int BS>
+__device__ __forceinline__ void fill_row(T* row, int V, float fill) {
+  constexpr int VEC = Elt<T>::VEC;
+  RowWin<T> w(row, V);
+  T* abase = const_cast<T*>(w.abase);
+  float z[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) z[e] = fill;
+  for (int slot = threadIdx.x; slot < w.nslots; slot += BS) {
+    if (!w.partial(slot)) {
+      Elt<T>::store(abase + static_cast<int64_t>(slot) * VEC, z);
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const int idx = slot * VEC + e - w.lead;
+        if (idx >= 0 && idx < V) Elt<T>::put(row + idx, fill);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Register-resident row kernel: one block = one (b,t) row.
+// ALIGNED: every row starts on a 16-byte boundary and V % VEC == 0 (decided on
+// the host) - no edge-slot logic at all; addresses are uniform base + 32-bit
+// lane offset so the loads/stores use the saddr form and no address VGPRs.
+// ---------------------------------------------------------------------------
+
+template <typename T, int BS, int SLOTS, bool WRITE_GRAD, bool ALIGNED>
+__global__ __launch_bounds__(BS, 4) void marg_ce_row_kernel(
+    const T* __restrict__ logits, int64_t stride_b, int64_t stride_t,
+    const int64_t* __restrict__ ids, const int64_t* __restrict__ mask, int Tg, int V,
+    const float* __restrict__ stats, float* __restrict__ row_lse, float* __restrict__ row_nll,
+    T* dlogits) {
+  constexpr int VEC = Elt<T>::VEC;
+  __shared__ float red[BS / kWave];
+  const int64_t row = blockIdx.x;
+  const int b = static_cast<int>(row / Tg), t = static_cast<int>(row % Tg);
+  const int tid = threadIdx.x;
+  const int64_t off = b * stride_b + t * stride_t;
+  const bool last = (t == Tg - 1);
+  const int64_t mi = last ? 0 : mask[static_cast<int64_t>(b) * Tg + t + 1];
+  const float M = stats[0];
+
+  if (last || mi == 0) {
+    if (tid == 0) { row_lse[row] = 0.f; row_nll[row] = 0.f; }
+    if constexpr (WRITE_GRAD) {
+      // reference: masked rows get 0 * (1/M); with M == 0 that is NaN (0*inf)
+      const float fill = (!last && M == 0.f) ? __builtin_nanf("") : 0.f;
+      fill_row<T, BS>(dlogits + off, V, fill);
+    }
+    return;
+  }
+
+  const T* xrow = logits + off;
+  const int64_t y = ids[static_cast<int64_t>(b) * Tg + t + 1];
+  int lead = 0, nslots = V / VEC;
+  if constexpr (!ALIGNED) {
+    RowWin<T> w(xrow, V);
+    lead = w.lead; nslots = w.nslots;
+  }
+  const bool tail_partial = !ALIGNED && ((lead + V) % VEC) != 0;
+  const char* abase = reinterpret_cast<const char*>(xrow - lead);  // wave-uniform
+
+  // ---- single HBM pass: the whole row lands in registers -------------------
+  float x[SLOTS][VEC];
+#pragma unroll
+  for (int k = 0; k < SLOTS; ++k) {
+    const int slot = k * BS + tid;
+    if (slot < nslots) {
+      Elt<T>::load(reinterpret_cast<const T*>(abase + static_cast<unsigned>(slot) * 16u), x[k]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) x[k][e] = -INFINITY;
+    }
+  }
+  float xy = 0.f;
+  if (tid == 0) xy = (y >= 0 && y < V) ? Elt<T>::get(xrow + y) : __builtin_nanf("");
+
+  float tmax = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < SLOTS; ++k) {
+    if constexpr (!ALIGNED) {
+      const int slot = k * BS + tid;
+      if ((slot == 0 && lead != 0) || (slot == nslots - 1 && tail_partial)) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const int idx = slot * VEC + e - lead;
+          if (idx < 0 || idx >= V) x[k][e] = -INFINITY;
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) tmax = fmaxf(tmax, x[k][e]);
+  }
+  const float m = block_max<BS>(tmax, red);
+  const float mneg = -m * kLog2e;
+
+  float tsum = 0.f;
+#pragma unroll
+  for (int k = 0; k < SLOTS; ++k) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      x[k][e] = __builtin_amdgcn_exp2f(fmaf(x[k][e], kLog2e, mneg));  // exp(x - m); -inf -> 0
+      tsum += x[k][e];
+    }
+  }
+  const float l = block_sum<BS>(tsum, red);
+  const float lse = m + __logf(l);
+  const float mval = static_cast<float>(mi);
+  if (tid == 0) {
+    row_lse[row] = lse;
+    row_nll[row] = mval * (lse - xy);
+  }
+
+  if constexpr (WRITE_GRAD) {
+    // dL/dlogits = (m/M) (softmax - onehot(y))       [upstream grad = 1]
+    T* grow = dlogits + off;
+    char* gbase = reinterpret_cast<char*>(grow - lead);  // wave-uniform
+    const float coef = mval / M;
+    const float inv = coef / l;
+    const int ys = static_cast<int>(y) + lead;
+    const int slot_y = (y >= 0 && y < V) ? ys / VEC : -1, e_y = ys % VEC;
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) {
+      const int slot = k * BS + tid;
+      if (slot >= nslots) continue;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) x[k][e] *= inv;
+      if (slot == slot_y) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if (e == e_y) x[k][e] -= coef;
+      }
+      bool part = false;
+      if constexpr (!ALIGNED) part = (slot == 0 && lead != 0) || (slot == nslots - 1 && tail_partial);
+      if (!part) {
+        Elt<T>::store(reinterpret_cast<T*>(gbase + static_cast<unsigned>(slot) * 16u), x[k]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const int idx = slot * VEC + e - lead;
+          if (idx >= 0 && idx < V) Elt<T>::put(grow + idx, x[k][e]);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Streaming fallback for rows that do not fit the register file (V > 65k f32):
+// online (max,sum) pass, then an L2-served second pass for the gradient.
+// ---------------------------------------------------------------------------
+template <typename T, int BS, bool WRITE_GRAD>
+__global__ __launch_bounds__(BS) void marg_ce_stream_kernel(
+    const T* __restrict__ logits, int64_t stride_b, int64_t stride_t,
+    const int64_t* __restrict__ ids, const int64_t* __restrict__ mask, int Tg, int V,
+    const float* __restrict__ stats, float* __restrict__ row_lse, float* __restrict__ row_nll,
+    T* dlogits) {
+  constexpr int VEC = Elt<T>::VEC;
+  __shared__ float red[BS / kWave];
+  const int64_t row = blockIdx.x;
+  const int b = static_cast<int>(row / Tg), t = static_cast<int>(row % Tg);
+  const int tid = threadIdx.x;
+  const int64_t off = b * stride_b + t * stride_t;
+  const bool last = (t == Tg - 1);
+  const int64_t mi = last ? 0 : mask[static_cast<int64_t>(b) * Tg + t + 1];
+  const float M = stats[0];
+  if (last || mi == 0) {
+    if (tid == 0) { row_lse[row] = 0.f; row_nll[row] = 0.f; }
+    if constexpr (WRITE_GRAD) {
+      const float fill = (!last && M == 0.f) ? __builtin_nanf("") : 0.f;
+      fill_row<T, BS>(dlogits + off, V, fill);
+    }
+    return;
+  }
+  const T* xrow = logits + off;
+  const int64_t y = ids[static_cast<int64_t>(b) * Tg + t + 1];
+  RowWin<T> w(xrow, V);
+
+  float tm = -INFINITY, tl = 0.f;
+  for (int slot = tid; slot < w.nslots; slot += BS) {
+    float v[VEC];
+    Elt<T>::load(w.abase + static_cast<int64_t>(slot) * VEC, v);
+    if (w.partial(slot)) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const int idx = slot * VEC + e - w.lead;
+        if (idx < 0 || idx >= V) v[e] = -INFINITY;
+      }
+    }
+    float vm = v[0];
+#pragma unroll
+    for (int e = 1; e < VEC; ++e) vm = fmaxf(vm, v[e]);
+    const float mn = fmaxf(tm, vm);
+    float acc = (tm == -INFINITY) ? 0.f : tl * fast_exp(tm - mn);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc += fast_exp(v[e] - mn);
+    tm = mn; tl = acc;
+  }
+  const float m = block_max<BS>(tm, red);
+  const float l = block_sum<BS>((tm == -INFINITY) ? 0.f : tl * fast_exp(tm - m), red);
+  const float lse = m + __logf(l);
+  const float mval = static_cast<float>(mi);
+  if (tid == 0) {
+    const float xy = (y >= 0 && y < V) ? Elt<T>::get(xrow + y) : __builtin_nanf("");
+    row_lse[row] = lse;
+    row_nll[row] = mval * (lse - xy);
+  }
+  if constexpr (WRITE_GRAD) {
+    T* grow = dlogits + off;
+    T* gbase = grow - w.lead;
+    const float coef = mval / M;
+    // in-place safe only if every thread re-reads exactly the slots it writes: it does.
+    for (int slot = tid; slot < w.nslots; slot += BS) {
+      float v[VEC];
+      Elt<T>::load(w.abase + static_cast<int64_t>(slot) * VEC, v);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const int idx = slot * VEC + e - w.lead;
+        v[e] = coef * fast_exp(v[e] - lse) - ((idx == y) ? coef : 0.f);
+      }
+      if (!w.partial(slot)) {
+        Elt<T>::store(gbase + static_cast<int64_t>(slot) * VEC, v);
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const int idx = slot * VEC + e - w.lead;
+          if (idx >= 0 && idx < V) Elt<T>::put(grow + idx, v[e]);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Stand-alone backward from the saved row_lse (one read + one write of [R,V]).
+// ---------------------------------------------------------------------------
+template <typename T, int BS>
+__global__ __launch_bounds__(BS) void marg_ce_bwd_kernel(
+    const T* __restrict__ logits, int64_t stride_b, int64_t stride_t,
+    const int64_t* __restrict__ ids, const int64_t* __restrict__ mask, int Tg, int V,
+    const float* __restrict__ stats, const float* __restrict__ row_lse,
+    const float* __restrict__ gscale, T* dlogits) {
+  constexpr int VEC = Elt<T>::VEC;
+  const int64_t row = blockIdx.x;
+  const int b = static_cast<int>(row / Tg), t = static_cast<int>(row % Tg);
+  const int tid = threadIdx.x;
+  const int64_t off = b * stride_b + t * stride_t;
+  const bool last = (t == Tg - 1);
+  const int64_t mi = last ? 0 : mask[static_cast<int64_t>(b) * Tg + t + 1];
+  const float M = stats[0];
+  const float g = gscale ? gscale[0] : 1.f;
+  if (last || mi == 0) {
+    const float fill = (!last && M == 0.f) ? __builtin_nanf("") : 0.f;
+    fill_row<T, BS>(dlogits + off, V, fill);
+    return;
+  }
+  const T* xrow = logits + off;
+  const int64_t y = ids[static_cast<int64_t>(b) * Tg + t + 1];
+  RowWin<T> w(xrow, V);
+  T* grow = dlogits + off;
+  T* gbase = grow - w.lead;
+  const float coef = g * static_cast<float>(mi) / M;
+  const float nlse = -row_lse[row] * kLog2e;
+  for (int slot = tid; slot < w.nslots; slot += BS) {
+    float v[VEC];
+    Elt<T>::load(w.abase + static_cast<int64_t>(slot) * VEC, v);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int idx = slot * VEC + e - w.lead;
+      v[e] = coef * __builtin_amdgcn_exp2f(fmaf(v[e], kLog2e, nlse)) - ((idx == y) ? coef : 0.f);
+    }
+    if (!w.partial(slot)) {
+      Elt<T>::store(gbase + static_cast<int64_t>(slot) * VEC, v);
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const int idx = slot * VEC + e - w.lead;
+        if (idx >= 0 && idx < V) Elt<T>::put(grow + idx, v[e]);
+      }
+    }
+  }
+}
+
+// ---- prep: M = sum mask[:,1:], N_b = sum_t mask[b,t+1] [t >= qlen_b-1] -----
+// stage 1: one wave per sample -> Mb[b], Nb[b]; stage 2: one block -> stats[0] = M.
+__global__ __launch_bounds__(64) void ce_prep_rows_kernel(const int64_t* __restrict__ mask,
+                                                          const int64_t* __restrict__ qlen, int Tg,
+                                                          float* __restrict__ Mb, float* __restrict__ Nb) {
+  const int b = blockIdx.x;
+  // python slice semantics of lp[:qlen-1] / lp[qlen-1:] over the Tg-1 shifted rows
+  // (train_utils.py:100-103): a negative start counts from the end.
+  int64_t cut = qlen ? qlen[b] - 1 : static_cast<int64_t>(Tg);
+  if (cut < 0) cut = (cut + (Tg - 1) < 0) ? 0 : cut + (Tg - 1);
+  float ms = 0.f, ns = 0.f;
+  for (int t = threadIdx.x; t < Tg - 1; t += 64) {
+    const float mv = static_cast<float>(mask[static_cast<int64_t>(b) * Tg + t + 1]);
+    ms += mv;
+    if (static_cast<int64_t>(t) >= cut) ns += mv;
+  }
+  ms = wave_sum(ms);
+  ns = wave_sum(ns);
+  if (threadIdx.x == 0) { Mb[b] = ms; Nb[b] = ns; }
+}
+__global__ __launch_bounds__(256) void ce_prep_total_kernel(const float* __restrict__ Mb, int B,
+                                                            float* __restrict__ stats) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) s += Mb[i];
+  s = block_sum<256>(s, red);
+  if (threadIdx.x == 0) { stats[0] = s; stats[1] = static_cast<float>(B); }
+}
+
+// ---- finalize: deterministic reduction to L_gen -----------------------------
+__global__ __launch_bounds__(1024) void ce_finalize_kernel(const float* __restrict__ row_nll, int64_t R,
+                                                           const float* __restrict__ Nb,
+                                                           const float* __restrict__ doc_lp, int B,
+                                                           const float* __restrict__ stats,
+                                                           float* __restrict__ out) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < R; i += 1024) s += row_nll[i];
+  if (doc_lp)
+    for (int i = threadIdx.x; i < B; i += 1024) s -= Nb[i] * doc_lp[i];
+  s = block_sum<1024>(s, red);
+  if (threadIdx.x == 0) out[0] = s / stats[0];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scale_inplace_kernel(T* x, int64_t n, const float* __restrict__ gscale) {
+  constexpr int VEC = Elt<T>::VEC;
+  const float g = gscale[0];
+  if (g == 1.f) return;  // uniform: the common loss.backward() case costs one tiny launch
+  const int64_t nvec = n / VEC;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < nvec; i += gridDim.x * 256ll) {
+    float v[VEC];
+    Elt<T>::load(x + i * VEC, v);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] *= g;
+    Elt<T>::store(x + i * VEC, v);
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = nvec * VEC + threadIdx.x; i < n; i += 256) Elt<T>::put(x + i, Elt<T>::get(x + i) * g);
+}
+
+__global__ __launch_bounds__(256) void gather_nll_kernel(const float* __restrict__ lp,
+                                                         const int64_t* __restrict__ labels, int64_t R,
+                                                         int64_t V, float* __restrict__ out) {
+  const int64_t r = blockIdx.x * 256ll + threadIdx.x;
+  if (r >= R) return;
+  const int64_t y = labels[r];
+  out[r] = (y >= 0 && y < V) ? -lp[r * V + y] : __builtin_nanf("");
+}
+
+__global__ __launch_bounds__(256) void marginalize_rows_kernel(const float* __restrict__ lp, int64_t T,
+                                                               int64_t V, const float* __restrict__ doc_lp,
+                                                               int64_t qlen, float* __restrict__ out) {
+  const int64_t n = T * V;
+  const float d = doc_lp[0];
+  // python slice semantics of lp[:qlen-1] / lp[qlen-1:] (train_utils.py:100-103)
+  int64_t cut = qlen - 1;
+  if (cut < 0) cut = (cut + T < 0) ? 0 : cut + T;
+  if (cut > T) cut = T;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) {
+    const int64_t t = i / V;
+    out[i] = lp[i] + ((t >= cut) ? d : 0.f);
+  }
+}
+
+template <typename T, bool GRAD, bool ALIGNED>
+void launch_fwd2(const T* logits, int64_t B, int64_t Tg, int64_t V, int64_t sb, int64_t st,
+                 const int64_t* ids, const int64_t* mask, const float* stats, float* row_lse,
+                 float* row_nll, T* dlogits, hipStream_t s) {
+  constexpr int VEC = Elt<T>::VEC;
+  const int64_t need = ALIGNED ? V / VEC : (V + 2 * (VEC - 1)) / VEC;  // slots incl. worst-case lead
+  const dim3 grid(static_cast<unsigned>(B * Tg));
+  const int Tgi = static_cast<int>(Tg), Vi = static_cast<int>(V);
+  constexpr int S_BIG = 64 / VEC;    // 64 floats per lane: <=128 VGPRs, 4 waves/SIMD
+  constexpr int S_SMALL = 16 / VEC;  // 16 floats per lane
+#define DALM_CE_ARGS logits, sb, st, ids, mask, Tgi, Vi, stats, row_lse, row_nll, dlogits
+  if (need <= 256 * S_SMALL)
+    hipLaunchKernelGGL((marg_ce_row_kernel<T, 256, S_SMALL, GRAD, ALIGNED>), grid, dim3(256), 0, s, DALM_CE_ARGS);
+  else if (need <= 256 * S_BIG)
+    hipLaunchKernelGGL((marg_ce_row_kernel<T, 256, S_BIG, GRAD, ALIGNED>), grid, dim3(256), 0, s, DALM_CE_ARGS);
+  else if (need <= 512 * S_BIG)
+    hipLaunchKernelGGL((marg_ce_row_kernel<T, 512, S_BIG, GRAD, ALIGNED>), grid, dim3(512), 0, s, DALM_CE_ARGS);
+  else if (need <= 1024 * S_BIG)
+    hipLaunchKernelGGL((marg_ce_row_kernel<T, 1024, S_BIG, GRAD, ALIGNED>), grid, dim3(1024), 0, s, DALM_CE_ARGS);
+  else
+    hipLaunchKernelGGL((marg_ce_stream_kernel<T, 1024, GRAD>), grid, dim3(1024), 0, s, DALM_CE_ARGS);
+#undef DALM_CE_ARGS
+}
+
+template <typename T, bool GRAD>
+int launch_fwd(const T* logits, int64_t B, int64_t Tg, int64_t V, int64_t sb, int64_t st,
+               const int64_t* ids, const int64_t* mask, const float* stats, float* row_lse,
+               float* row_nll, T* dlogits, hipStream_t s) {
+  constexpr int VEC = Elt<T>::VEC;
+  const bool aligned = (reinterpret_cast<uintptr_t>(logits) % 16 == 0) && (V % VEC == 0) &&
+                       (sb % VEC == 0) && (st % VEC == 0) &&
+                       (!GRAD || reinterpret_cast<uintptr_t>(dlogits) % 16 == 0);
+  if (aligned) launch_fwd2<T, GRAD, true>(logits, B, Tg, V, sb, st, ids, mask, stats, row_lse, row_nll, dlogits, s);
+  else launch_fwd2<T, GRAD, false>(logits, B, Tg, V, sb, st, ids, mask, stats, row_lse, row_nll, dlogits, s);
+  return 0;
+}
+
+int check_common(const void* logits, int dtype, int64_t B, int64_t Tg, int64_t V, int64_t sb, int64_t st,
+                 const int64_t* ids, const int64_t* mask, const float* stats, const char* fn) {
+  if (!logits || !ids || !mask || !stats) return fail(DALM_E_NULL, fn, "null pointer argument");
+  if (dtype != DALM_F32 && dtype != DALM_BF16) return fail(DALM_E_DTYPE, fn, "dtype must be DALM_F32 or DALM_BF16");
+  if (B <= 0 || Tg < 2 || V <= 0) return fail(DALM_E_SHAPE, fn, "need B>0, Tg>=2, V>0");
+  if (st < V || sb < Tg * st) return fail(DALM_E_SHAPE, fn, "strides must describe non-overlapping rows");
+  if (B * Tg > 0x7fffffffll || V > 0x3fffffffll) return fail(DALM_E_SHAPE, fn, "B*Tg or V too large");
+  const size_t es = (dtype == DALM_F32) ? 4 : 2;
+  if (reinterpret_cast<uintptr_t>(logits) % es) return fail(DALM_E_ALIGN, fn, "logits not element-aligned");
+  return 0;
+}
+
+}  // namespace
+}  // namespace dalm
+
+using namespace dalm;
+
+extern "C" int dalm_marg_ce_prep(const int64_t* mask, const int64_t* qlen, int64_t B, int64_t Tg,
+                                 float* stats, float* Nb, float* Mb, dalm_stream_t stream) {
+  DALM_REQUIRE(mask && stats && Nb && Mb, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(B > 0 && Tg >= 2 && B <= 0x7fffffffll && Tg <= 0x7fffffffll, DALM_E_SHAPE, "need B>0, Tg>=2");
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(ce_prep_rows_kernel, dim3(static_cast<unsigned>(B)), dim3(64), 0, s, mask, qlen,
+                     static_cast<int>(Tg), Mb, Nb);
+  hipLaunchKernelGGL(ce_prep_total_kernel, dim3(1), dim3(256), 0, s, Mb, static_cast<int>(B), stats);
+  return check_launch(__func__);
+}
+
+extern "C" int dalm_marg_ce_fwd(const void* logits, int dtype, int64_t B, int64_t Tg, int64_t V,
+                                int64_t stride_b, int64_t stride_t, const int64_t* ids,
+                                const int64_t* mask, const float* stats, float* row_lse, float* row_nll,
+                                void* dlogits, dalm_stream_t stream) {
+  if (int e = check_common(logits, dtype, B, Tg, V, stride_b, stride_t, ids, mask, stats, __func__)) return e;
+  DALM_REQUIRE(row_lse && row_nll, DALM_E_NULL, "row_lse/row_nll are required");
+  hipStream_t s = as_stream(stream);
+  if (dtype == DALM_F32) {
+    auto* x = static_cast<const float*>(logits);
+    auto* g = static_cast<float*>(dlogits);
+    if (g) launch_fwd<float, true>(x, B, Tg, V, stride_b, stride_t, ids, mask, stats, row_lse, row_nll, g, s);
+    else launch_fwd<float, false>(x, B, Tg, V, stride_b, stride_t, ids, mask, stats, row_lse, row_nll, g, s);
+  } else {
+    auto* x = static_cast<const bf16_t*>(logits);
+    auto* g = static_cast<bf16_t*>(dlogits);
+    if (g) launch_fwd<bf16_t, true>(x, B, Tg, V, stride_b, stride_t, ids, mask, stats, row_lse, row_nll, g, s);
+    else launch_fwd<bf16_t, false>(x, B, Tg, V, stride_b, stride_t, ids, mask, stats, row_lse, row_nll, g, s);
+  }
+  return check_launch(__func__);
+}
+
+extern "C" int dalm_marg_ce_bwd(const void* logits, int dtype, int64_t B, int64_t Tg, int64_t V,
+                                int64_t stride_b, int64_t stride_t, const int64_t* ids,
+                                const int64_t* mask, const float* stats, const float* row_lse,
+                                const float* gscale, void* dlogits, dalm_stream_t stream) {
+  if (int e = check_common(logits, dtype, B, Tg, V, stride_b, stride_t, ids, mask, stats, __func__)) return e;
+  DALM_REQUIRE(row_lse && dlogits, DALM_E_NULL, "row_lse/dlogits are required");
+  hipStream_t s = as_stream(stream);
+  const dim3 grid(static_cast<unsigned>(B * Tg));
+  const int Tgi = static_cast<int>(Tg), Vi = static_cast<int>(V);
+  if (dtype == DALM_F32)
+    hipLaunchKernelGGL((marg_ce_bwd_kernel<float, 256>), grid, dim3(256), 0, s,
+                       static_cast<const float*>(logits), stride_b, stride_t, ids, mask, Tgi, Vi, stats,
+                       row_lse, gscale, static_cast<float*>(dlogits));
+  else
+    hipLaunchKernelGGL((marg_ce_bwd_kernel<bf16_t, 256>), grid, dim3(256), 0, s,
+                       static_cast<const bf16_t*>(logits), stride_b, stride_t, ids, mask, Tgi, Vi, stats,
+                       row_lse, gscale, static_cast<bf16_t*>(dlogits));
+  return check_launch(__func__);
+}
+
+extern "C" int dalm_scale_inplace(void* x, int dtype, int64_t n, const float* gscale, dalm_stream_t stream) {
+  DALM_REQUIRE(x && gscale, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(n >= 0, DALM_E_SHAPE, "n must be >= 0");
+  DALM_REQUIRE(dtype == DALM_F32 || dtype == DALM_BF16, DALM_E_DTYPE, "bad dtype");
+  DALM_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0, DALM_E_ALIGN, "x must be 16-byte aligned");
+  if (n == 0) return 0;
+  hipStream_t s = as_stream(stream);
+  const int64_t per = (dtype == DALM_F32) ? 4 : 8;
+  int64_t blocks = (n / per + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 4096) blocks = 4096;
+  if (dtype == DALM_F32)
+    hipLaunchKernelGGL(scale_inplace_kernel<float>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s,
+                       static_cast<float*>(x), n, gscale);
+  else
+    hipLaunchKernelGGL(scale_inplace_kernel<bf16_t>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s,
+                       static_cast<bf16_t*>(x), n, gscale);
+  return check_launch(__func__);
+}
+
+extern "C" int dalm_marg_ce_finalize(const float* row_nll, int64_t num_rows, const float* Nb,
+                                     const float* doc_lp, int64_t B, const float* stats, float* out,
+                                     dalm_stream_t stream) {
+  DALM_REQUIRE(row_nll && stats && out, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(!doc_lp || Nb, DALM_E_NULL, "Nb is required when doc_lp is given");
+  DALM_REQUIRE(num_rows > 0 && B > 0, DALM_E_SHAPE, "need num_rows>0, B>0");
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1024), 0, as_stream(stream), row_nll, num_rows, Nb,
+                     doc_lp, static_cast<int>(B), stats, out);
+  return check_launch(__func__);
+}
+
+extern "C" int dalm_gather_nll(const float* lp, const int64_t* labels, int64_t R, int64_t V, float* out,
+                               dalm_stream_t stream) {
+  DALM_REQUIRE(lp && labels && out, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(R >= 0 && V > 0, DALM_E_SHAPE, "need R>=0, V>0");
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(gather_nll_kernel, dim3(static_cast<unsigned>((R + 255) / 256)), dim3(256), 0,
+                     as_stream(stream), lp, labels, R, V, out);
+  return check_launch(__func__);
+}
+
+extern "C" int dalm_marginalize_rows(const float* lp, int64_t T, int64_t V, const float* doc_lp,
+                                     int64_t qlen, float* out, dalm_stream_t stream) {
+  DALM_REQUIRE(lp && doc_lp && out, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(T >= 0 && V > 0, DALM_E_SHAPE, "need T>=0, V>0");
+  if (T == 0) return 0;
+  int64_t blocks = (T * V + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(marginalize_rows_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
+                     as_stream(stream), lp, T, V, doc_lp, qlen, out);
+  return check_launch(__func__);
+}

@@ -1,0 +1,94 @@
+// Shared device/host helpers for libdalm_hip.so (gfx950 only, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "../../include/dalm_hip.h"
+
+namespace dalm {
+
+// ---- error plumbing (host) -------------------------------------------------
+void set_error(const std::string& msg);
+int fail(int code, const char* fn, const char* what);
+int check_launch(const char* fn);
+
+#define DALM_REQUIRE(cond, code, what) \
+  do { if (!(cond)) return ::dalm::fail((code), __func__, (what)); } while (0)
+
+static inline hipStream_t as_stream(dalm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- device helpers ----------------------------------------------------------
+constexpr int kWave = 64;
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// Block-wide reductions through a small LDS scratch (one float per wave).
+// Every thread gets the result.  `red` must hold >= BS/64 floats; two barriers
+// so that the scratch may be reused right after return.
+template <int BS>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  constexpr int NW = BS / kWave;
+  v = wave_sum(v);
+  if constexpr (NW == 1) return v;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float r = 0.f;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) r += red[i];  // fixed order: deterministic
+  __syncthreads();
+  return r;
+}
+template <int BS>
+__device__ __forceinline__ float block_max(float v, float* red) {
+  constexpr int NW = BS / kWave;
+  v = wave_max(v);
+  if constexpr (NW == 1) return v;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float r = red[0];
+#pragma unroll
+  for (int i = 1; i < NW; ++i) r = fmaxf(r, red[i]);
+  __syncthreads();
+  return r;
+}
+
+// exp(x) for x <= 0 via v_exp_f32 (2^x); results below the normal range flush to 0.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
+
+// bf16 <-> f32 (round-to-nearest-even on the way down, as torch does)
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) {
+  return __uint_as_float(static_cast<unsigned int>(h) << 16);
+}
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+  unsigned int u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<unsigned short>((u >> 16) | 0x40u);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return static_cast<unsigned short>(u >> 16);
+}
+
+// (max, sum-exp) pair merge for online log-sum-exp.
+struct MaxSum {
+  float m, l;
+};
+__device__ __forceinline__ MaxSum merge(MaxSum a, MaxSum b) {
+  const float m = fmaxf(a.m, b.m);
+  // m == -inf only if both are empty; keep l = 0 without producing NaN
+  const float sa = (a.m == -INFINITY) ? 0.f : a.l * fast_exp(a.m - m);
+  const float sb = (b.m == -INFINITY) ? 0.f : b.l * fast_exp(b.m - m);
+  return {m, sa + sb};
+}
+
+}  // namespace dalm

@@ -1,0 +1,244 @@
+// K1: masked mean-pool + L2 normalise of bi-encoder token states (gfx950).
+//
+// Stands in for AutoModelForRagE2E.mean_pooling + F.normalize
+//   dalm/models/rag_e2e_base_model.py:95-97,108-111
+//   dalm/models/retriever_only_base_model.py:60-68
+// The reference materialises three [B,T,D] temporaries (mask.expand().float(),
+// the product, the sum); here each unmasked token row is read once with 16-byte
+// lane accesses and padded tokens are never touched.  HBM-bound:
+//   forward : n_tok*D*eh bytes read (n_tok = unmasked tokens) + B*D*4 written
+//   backward: B*T*D*eh bytes written
+#include "common.hpp"
+
+namespace dalm {
+namespace {
+
+struct bf16_t { unsigned short v; };
+
+template <typename T> struct HV;
+template <> struct HV<float> {
+  static constexpr int VEC = 4;
+  __device__ static __forceinline__ void load(const float* p, int nvalid, bool vec, float (&x)[4]) {
+    if (nvalid >= 4 && vec) {
+      const float4 v = *reinterpret_cast<const float4*>(p);
+      x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = (e < nvalid) ? p[e] : 0.f;
+    }
+  }
+  __device__ static __forceinline__ void store(float* p, int nvalid, bool vec, const float (&x)[4]) {
+    if (nvalid >= 4 && vec) {
+      *reinterpret_cast<float4*>(p) = make_float4(x[0], x[1], x[2], x[3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (e < nvalid) p[e] = x[e];
+    }
+  }
+};
+template <> struct HV<bf16_t> {
+  static constexpr int VEC = 8;
+  __device__ static __forceinline__ void load(const bf16_t* p, int nvalid, bool vec, float (&x)[8]) {
+    if (nvalid >= 8 && vec) {
+      const uint4 v = *reinterpret_cast<const uint4*>(p);
+      const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        x[2 * i] = __uint_as_float(w[i] << 16);
+        x[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = (e < nvalid) ? bf16_to_f32(p[e].v) : 0.f;
+    }
+  }
+  __device__ static __forceinline__ void store(bf16_t* p, int nvalid, bool vec, const float (&x)[8]) {
+    if (nvalid >= 8 && vec) {
+      unsigned int w[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        w[i] = static_cast<unsigned int>(f32_to_bf16(x[2 * i])) |
+               (static_cast<unsigned int>(f32_to_bf16(x[2 * i + 1])) << 16);
+      *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (e < nvalid) p[e].v = f32_to_bf16(x[e]);
+    }
+  }
+};
+
+// grid (DC, B); 4 waves share one 64*VEC-wide d-chunk and split the tokens.
+template <typename T>
+__global__ __launch_bounds__(256) void pool_sum_kernel(const T* __restrict__ h, const int64_t* __restrict__ mask,
+                                                       int Tn, int D, int vec_ok, float* __restrict__ emb,
+                                                       float* __restrict__ inv_count) {
+  constexpr int VEC = HV<T>::VEC;
+  __shared__ float part[4][64 * VEC];
+  __shared__ float cnt_part[4];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d = (blockIdx.x * 64 + lane) * VEC;
+  int nvalid = D - d;
+  nvalid = nvalid < 0 ? 0 : (nvalid > VEC ? VEC : nvalid);
+  const T* hb = h + static_cast<int64_t>(b) * Tn * D + d;
+  const int64_t* mb = mask + static_cast<int64_t>(b) * Tn;
+
+  float acc[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+  float cnt = 0.f;
+  // tokens wave, wave+4, ... ; two in flight per iteration
+  for (int t = wave; t < Tn; t += 8) {
+    const int t2 = t + 4;
+    const int64_t m0 = mb[t];
+    const int64_t m1 = (t2 < Tn) ? mb[t2] : 0;
+    float x0[VEC], x1[VEC];
+    if (m0 != 0 && nvalid > 0) HV<T>::load(hb + static_cast<int64_t>(t) * D, nvalid, vec_ok, x0);
+    if (m1 != 0 && nvalid > 0) HV<T>::load(hb + static_cast<int64_t>(t2) * D, nvalid, vec_ok, x1);
+    const float f0 = static_cast<float>(m0), f1 = static_cast<float>(m1);
+    cnt += f0 + f1;
+    if (m0 != 0 && nvalid > 0) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] = fmaf(f0, x0[e], acc[e]);
+    }
+    if (m1 != 0 && nvalid > 0) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] = fmaf(f1, x1[e], acc[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) part[wave][lane * VEC + e] = acc[e];
+  if (lane == 0) cnt_part[wave] = cnt;
+  __syncthreads();
+  if (wave == 0) {
+    const float c = fmaxf(cnt_part[0] + cnt_part[1] + cnt_part[2] + cnt_part[3], 1e-9f);
+    const float ic = 1.f / c;
+    if (blockIdx.x == 0 && lane == 0) inv_count[b] = ic;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int i = lane * VEC + e;
+      const float s = (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]);
+      if (e < nvalid) emb[static_cast<int64_t>(b) * D + d + e] = s / c;
+    }
+  }
+}
+
+// one block per sample: |u| and (optionally) e = u / max(|u|, 1e-12) in place
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ emb, int D, int normalize,
+                                                          float* __restrict__ norm) {
+  __shared__ float red[4];
+  float* row = emb + static_cast<int64_t>(blockIdx.x) * D;
+  float ss = 0.f;
+  for (int i = threadIdx.x; i < D; i += 256) ss = fmaf(row[i], row[i], ss);
+  ss = block_sum<256>(ss, red);
+  const float nrm = sqrtf(ss);
+  if (threadIdx.x == 0) norm[blockIdx.x] = nrm;
+  if (normalize) {
+    const float denom = fmaxf(nrm, 1e-12f);
+    for (int i = threadIdx.x; i < D; i += 256) row[i] = row[i] / denom;
+  }
+}
+
+// grid (DC, B, TZ).  dh[b,t,:] = mask[b,t] * inv_count[b] * du[b,:], with
+//   du = d_emb                                  (normalize == 0)
+//   du = (d_emb - e (e . d_emb)) / |u|           (|u| >= 1e-12)
+//   du = d_emb / 1e-12                           (|u| <  1e-12: clamp_min branch)
+template <typename T>
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ d_emb,
+                                                       const float* __restrict__ emb,
+                                                       const float* __restrict__ norm,
+                                                       const float* __restrict__ inv_count,
+                                                       const int64_t* __restrict__ mask, int Tn, int D,
+                                                       int normalize, int vec_ok, T* __restrict__ dh) {
+  constexpr int VEC = HV<T>::VEC;
+  __shared__ float red[4];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d = (blockIdx.x * 64 + lane) * VEC;
+  int nvalid = D - d;
+  nvalid = nvalid < 0 ? 0 : (nvalid > VEC ? VEC : nvalid);
+  const float* de = d_emb + static_cast<int64_t>(b) * D;
+  const float* eb = emb + static_cast<int64_t>(b) * D;
+
+  float g[VEC];
+  const float ic = inv_count[b];
+  if (normalize) {
+    float dot = 0.f;
+    for (int i = threadIdx.x; i < D; i += 256) dot = fmaf(eb[i], de[i], dot);
+    dot = block_sum<256>(dot, red);
+    const float nrm = norm[b];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float v = 0.f;
+      if (e < nvalid) v = (nrm >= 1e-12f) ? (de[d + e] - eb[d + e] * dot) / nrm : de[d + e] / 1e-12f;
+      g[e] = v * ic;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) g[e] = (e < nvalid) ? de[d + e] * ic : 0.f;
+  }
+  if (nvalid == 0) return;
+  T* hb = dh + static_cast<int64_t>(b) * Tn * D + d;
+  const int64_t* mb = mask + static_cast<int64_t>(b) * Tn;
+  const int tz = gridDim.z, z = blockIdx.z;
+  const int per = (Tn + tz - 1) / tz;
+  const int t_end = min(Tn, (z + 1) * per);
+  for (int t = z * per + wave; t < t_end; t += 4) {
+    const float f = static_cast<float>(mb[t]);
+    float o[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o[e] = f * g[e];
+    HV<T>::store(hb + static_cast<int64_t>(t) * D, nvalid, vec_ok, o);
+  }
+}
+
+}  // namespace
+}  // namespace dalm
+
+using namespace dalm;
+
+extern "C" int dalm_pool_l2norm_fwd(const void* h, int dtype, const int64_t* mask, int64_t B, int64_t T,
+                                    int64_t D, int normalize, float* emb, float* norm, float* inv_count,
+                                    dalm_stream_t stream) {
+  DALM_REQUIRE(h && mask && emb && norm && inv_count, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(dtype == DALM_F32 || dtype == DALM_BF16, DALM_E_DTYPE, "dtype must be DALM_F32 or DALM_BF16");
+  DALM_REQUIRE(B > 0 && T > 0 && D > 0 && B <= 65535 && T <= 0x7fffffffll && D <= 0x3fffffffll, DALM_E_SHAPE,
+               "need 0<B<=65535, T>0, D>0");
+  hipStream_t s = as_stream(stream);
+  const int vec = (dtype == DALM_F32) ? 4 : 8;
+  const int vok = (reinterpret_cast<uintptr_t>(h) % 16 == 0) && (D % vec == 0);
+  const dim3 grid(static_cast<unsigned>((D + 64 * vec - 1) / (64 * vec)), static_cast<unsigned>(B));
+  if (dtype == DALM_F32)
+    hipLaunchKernelGGL(pool_sum_kernel<float>, grid, dim3(256), 0, s, static_cast<const float*>(h), mask,
+                       static_cast<int>(T), static_cast<int>(D), vok, emb, inv_count);
+  else
+    hipLaunchKernelGGL(pool_sum_kernel<bf16_t>, grid, dim3(256), 0, s, static_cast<const bf16_t*>(h), mask,
+                       static_cast<int>(T), static_cast<int>(D), vok, emb, inv_count);
+  hipLaunchKernelGGL(l2norm_rows_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 0, s, emb,
+                     static_cast<int>(D), normalize, norm);
+  return check_launch(__func__);
+}
+
+extern "C" int dalm_pool_l2norm_bwd(const float* d_emb, const float* emb, const float* norm,
+                                    const float* inv_count, const int64_t* mask, int64_t B, int64_t T,
+                                    int64_t D, int normalize, void* dh, int dtype, dalm_stream_t stream) {
+  DALM_REQUIRE(d_emb && emb && norm && inv_count && mask && dh, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(dtype == DALM_F32 || dtype == DALM_BF16, DALM_E_DTYPE, "dtype must be DALM_F32 or DALM_BF16");
+  DALM_REQUIRE(B > 0 && T > 0 && D > 0 && B <= 65535 && T <= 0x7fffffffll && D <= 0x3fffffffll, DALM_E_SHAPE,
+               "need 0<B<=65535, T>0, D>0");
+  hipStream_t s = as_stream(stream);
+  const int vec = (dtype == DALM_F32) ? 4 : 8;
+  const int vok = (reinterpret_cast<uintptr_t>(dh) % 16 == 0) && (D % vec == 0);
+  const int64_t dc = (D + 64 * vec - 1) / (64 * vec);
+  int64_t tz = (1024 + B * dc - 1) / (B * dc);
+  const int64_t tz_max = (T + 3) / 4;
+  if (tz > tz_max) tz = tz_max;
+  if (tz < 1) tz = 1;
+  if (tz > 64) tz = 64;
+  const dim3 grid(static_cast<unsigned>(dc), static_cast<unsigned>(B), static_cast<unsigned>(tz));
+  if (dtype == DALM_F32)
+    hipLaunchKernelGGL(pool_bwd_kernel<float>, grid, dim3(256), 0, s, d_emb, emb, norm, inv_count, mask,
+                       static_cast<int>(T), static_cast<int>(D), normalize, vok, static_cast<float*>(dh));
+  else
+    hipLaunchKernelGGL(pool_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, d_emb, emb, norm, inv_count, mask,
+                       static_cast<int>(T), static_cast<int>(D), normalize, vok, static_cast<bf16_t*>(dh));
+  return check_launch(__func__);
+}

@@ -1,0 +1,483 @@
+// K2-K4: in-batch similarity on the gfx950 matrix cores, exact f32.
+//
+// Stands in for get_cosine_sim + get_nt_xent_loss (+ log_softmax(scores).diag())
+//   dalm/training/utils/train_utils.py:76-88,124
+//   dalm/training/rag_e2e/train_rage2e.py:441-446
+//
+// One LDS-tiled GEMM kernel on v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate:
+// bit-for-bit an fmaf chain, so |S| <= 100 keeps ~1e-5 absolute error - a bf16
+// product would be off by ~0.4 in the logit at logit_scale = 100) with three
+// epilogues:
+//   EPI_STORE     C = alpha * A.B                       (get_cosine_sim, generic GEMM)
+//   EPI_ROWSTATS  per-row (max, sum-exp) partials of S  (S never reaches HBM)
+//   EPI_DS        closed-form dL/dS from the saved row/col log-sum-exps
+// 256-thread workgroups = 4 waves (2x2), 128x128x32 tiles (64x64 per wave =
+// 2x2 MFMA tiles, 64 accumulator VGPRs), operands staged k-major in LDS so that
+// every MFMA fragment read is one conflict-free ds_read_b32 per lane.
+// MFMA-bound: 2*m*n*D flop per launch against the 157 TF f32-matrix peak.
+#include "common.hpp"
+
+namespace dalm {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BK = 32;
+
+enum { EPI_STORE = 0, EPI_ROWSTATS = 1, EPI_DS = 2 };
+
+struct GemmParams {
+  const float* A; int64_t lda;
+  const float* B; int64_t ldb;
+  int M, N, K;
+  float alpha;
+  int a_vec, b_vec;  // 16-byte vector loads legal for A / B
+  // EPI_STORE / EPI_DS
+  float* C; int64_t ldc;
+  // EPI_ROWSTATS
+  float* part_m; float* part_l;  // [P][M], P = 2 * gridDim.x
+  float* diag; int64_t diag_offset;
+  // EPI_DS
+  const float* row_coef; const float* row_lse; const float* col_coef; const float* col_lse;
+};
+
+__device__ __forceinline__ float4 guarded_ld4(const float* p, int nvalid, bool vec_ok) {
+  if (nvalid >= 4 && vec_ok) return *reinterpret_cast<const float4*>(p);
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (nvalid > 0) r.x = p[0];
+  if (nvalid > 1) r.y = p[1];
+  if (nvalid > 2) r.z = p[2];
+  if (nvalid > 3) r.w = p[3];
+  return r;
+}
+
+// Stages one operand tile (BR rows in the non-K dimension x BK) global -> regs -> LDS[k][r].
+// KC: source is X[r][k] (k contiguous) -> transposing ds_write_b32 (stride BR+1: conflict-free)
+// !KC: source is X[k][r] (r contiguous) -> ds_write_b128 rows (stride BR+4: 16-byte aligned)
+template <int BR, bool KC>
+struct Stage {
+  static constexpr int STRIDE = KC ? BR + 1 : BR + 4;
+  static constexpr int NV = BR * BK / 4 / 256;
+  float4 v[NV];
+
+  __device__ __forceinline__ void load(const float* X, int64_t ld, int r0, int k0, int R, int K, bool vec_ok) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+      const int idx = p * 256 + tid;
+      if constexpr (KC) {
+        const int rr = idx / (BK / 4), kq = idx % (BK / 4);
+        const int r = r0 + rr, k = k0 + kq * 4;
+        int nv = (r < R) ? (K - k) : 0;
+        nv = nv < 0 ? 0 : nv;
+        v[p] = guarded_ld4(X + static_cast<int64_t>(r) * ld + k, nv, vec_ok);
+      } else {
+        const int kk = idx / (BR / 4), rq = idx % (BR / 4);
+        const int k = k0 + kk, r = r0 + rq * 4;
+        int nv = (k < K) ? (R - r) : 0;
+        nv = nv < 0 ? 0 : nv;
+        v[p] = guarded_ld4(X + static_cast<int64_t>(k) * ld + r, nv, vec_ok);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(float* S) const {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+      const int idx = p * 256 + tid;
+      if constexpr (KC) {
+        const int rr = idx / (BK / 4), kq = idx % (BK / 4);
+        float* d = S + (kq * 4) * STRIDE + rr;
+        d[0] = v[p].x; d[STRIDE] = v[p].y; d[2 * STRIDE] = v[p].z; d[3 * STRIDE] = v[p].w;
+      } else {
+        const int kk = idx / (BR / 4), rq = idx % (BR / 4);
+        *reinterpret_cast<float4*>(S + kk * STRIDE + rq * 4) = v[p];
+      }
+    }
+  }
+};
+
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(const GemmParams p) {
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  using SA = Stage<BM, A_KC>;
+  using SB = Stage<BN, B_KC>;
+  __shared__ __attribute__((aligned(16))) float lds[BK * SA::STRIDE + BK * SB::STRIDE];
+  float* As = lds;
+  float* Bs = lds + BK * SA::STRIDE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  SA sa; SB sb;
+  const int nk = (p.K + BK - 1) / BK;
+  sa.load(p.A, p.lda, bm0, 0, p.M, p.K, p.a_vec);
+  sb.load(p.B, p.ldb, bn0, 0, p.N, p.K, p.b_vec);
+  sa.store(As); sb.store(Bs);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = (kt + 1 < nk);
+    if (more) {  // prefetch the next slab into registers while the MFMAs run
+      sa.load(p.A, p.lda, bm0, (kt + 1) * BK, p.M, p.K, p.a_vec);
+      sb.load(p.B, p.ldb, bn0, (kt + 1) * BK, p.N, p.K, p.b_vec);
+    }
+    const float* a_base = As + lhi * SA::STRIDE + wm * WM + l31;
+    const float* b_base = Bs + lhi * SB::STRIDE + wn * WN + l31;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = a_base[kk * SA::STRIDE + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = b_base[kk * SB::STRIDE + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (more) {
+      sa.store(As); sb.store(Bs);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31,
+  //      row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = bm0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      const bool row_ok = row < p.M;
+      if constexpr (EPI == EPI_STORE) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = bn0 + wn * WN + j * 32 + l31;
+          if (row_ok && col < p.N) p.C[static_cast<int64_t>(row) * p.ldc + col] = p.alpha * acc[i][j][r];
+        }
+      } else if constexpr (EPI == EPI_DS) {
+        const float rc = row_ok ? p.row_coef[row] : 0.f;
+        const float rl = row_ok ? p.row_lse[row] : 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = bn0 + wn * WN + j * 32 + l31;
+          if (row_ok && col < p.N) {
+            const float s = p.alpha * acc[i][j][r];
+            const float cc = p.col_coef[col];
+            float d = rc * fast_exp(s - rl) + cc * fast_exp(s - p.col_lse[col]);
+            if (static_cast<int64_t>(col) == p.diag_offset + row) d -= (rc + cc);
+            p.C[static_cast<int64_t>(row) * p.ldc + col] = d;
+          }
+        }
+      } else {  // EPI_ROWSTATS
+        float v[TN];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = bn0 + wn * WN + j * 32 + l31;
+          v[j] = (col < p.N) ? p.alpha * acc[i][j][r] : -INFINITY;
+          if (row_ok && col < p.N && static_cast<int64_t>(col) == p.diag_offset + row) p.diag[row] = v[j];
+          mx = fmaxf(mx, v[j]);
+        }
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        float s = 0.f;
+        if (mx != -INFINITY) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) s += fast_exp(v[j] - mx);
+        }
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (row_ok && l31 == 0) {
+          const int64_t pi = static_cast<int64_t>(blockIdx.x * 2 + wn) * p.M + row;
+          p.part_m[pi] = mx;
+          p.part_l[pi] = s;
+        }
+      }
+    }
+  }
+}
+
+// merge P partial (max,sum) pairs per row -> row_lse
+__global__ __launch_bounds__(256) void rowstats_merge_kernel(const float* __restrict__ part_m,
+                                                             const float* __restrict__ part_l, int P, int M,
+                                                             float* __restrict__ row_lse) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= M) return;
+  float m = -INFINITY;
+  for (int q = 0; q < P; ++q) m = fmaxf(m, part_m[static_cast<int64_t>(q) * M + row]);
+  float l = 0.f;
+  for (int q = 0; q < P; ++q) {
+    const float pm = part_m[static_cast<int64_t>(q) * M + row];
+    if (pm != -INFINITY) l += part_l[static_cast<int64_t>(q) * M + row] * fast_exp(pm - m);
+  }
+  row_lse[row] = m + __logf(l);
+}
+
+// ---- small row kernels on a materialised S (drop-in get_nt_xent_loss etc.) ----
+// one block per row: row_lse[i] = logsumexp_j S[i,j]; optional doc_lp[i] = S[i,i] - row_lse[i]
+__global__ __launch_bounds__(256) void rows_lse_kernel(const float* __restrict__ S, int n_cols, int64_t sr,
+                                                       int64_t sc, float* __restrict__ row_lse,
+                                                       float* __restrict__ doc_lp) {
+  __shared__ float red[4];
+  const int i = blockIdx.x;
+  const float* row = S + i * sr;
+  float m = -INFINITY;
+  for (int j = threadIdx.x; j < n_cols; j += 256) m = fmaxf(m, row[j * sc]);
+  m = block_max<256>(m, red);
+  float l = 0.f;
+  for (int j = threadIdx.x; j < n_cols; j += 256) l += fast_exp(row[j * sc] - m);
+  l = block_sum<256>(l, red);
+  if (threadIdx.x == 0) {
+    const float lse = m + __logf(l);
+    row_lse[i] = lse;
+    if (doc_lp) doc_lp[i] = row[i * sc] - lse;
+  }
+}
+
+// loss = mean_i (row_lse[i] - S[i,i])      (cross_entropy(S, arange(n)))
+__global__ __launch_bounds__(256) void nt_xent_reduce_kernel(const float* __restrict__ S, int n, int64_t sr,
+                                                             int64_t sc, const float* __restrict__ row_lse,
+                                                             float* __restrict__ loss) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += row_lse[i] - S[i * sr + i * sc];
+  s = block_sum<256>(s, red);
+  if (threadIdx.x == 0) loss[0] = s / static_cast<float>(n);
+}
+
+// dS[i,j] (+)= c_i * (exp(S_ij - lse_i) - [i==j]) with c_i = sign * (coef ? coef[i] : gscale/n)
+__global__ __launch_bounds__(256) void rows_softmax_grad_kernel(const float* __restrict__ S, int n_cols,
+                                                                int64_t sr, int64_t sc,
+                                                                const float* __restrict__ row_lse,
+                                                                const float* __restrict__ coef,
+                                                                const float* __restrict__ gscale, float cdiv,
+                                                                float sign, float* dS, int64_t dsr,
+                                                                int64_t dsc, int accumulate) {
+  const int i = blockIdx.x;
+  const float c = sign * (coef ? coef[i] : gscale[0] / cdiv);
+  const float lse = row_lse[i];
+  for (int j = threadIdx.x; j < n_cols; j += 256) {
+    float d = c * (fast_exp(S[i * sr + j * sc] - lse) - ((j == i) ? 1.f : 0.f));
+    float* o = dS + i * dsr + j * dsc;
+    *o = accumulate ? (*o + d) : d;
+  }
+}
+
+__global__ __launch_bounds__(256) void contrastive_finalize_kernel(const float* __restrict__ row_lse,
+                                                                   const float* __restrict__ col_lse,
+                                                                   const float* __restrict__ diag, int n_local,
+                                                                   float n_global, float* __restrict__ out,
+                                                                   float* __restrict__ doc_lp) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n_local; i += 256) {
+    const float d = diag[i];
+    s += (row_lse[i] - d) + (col_lse[i] - d);
+    if (doc_lp) doc_lp[i] = d - row_lse[i];
+  }
+  s = block_sum<256>(s, red);
+  if (threadIdx.x == 0) out[0] = 0.5f * s / n_global;
+}
+
+inline bool vec_ok(const float* p, int64_t ld) {
+  return (reinterpret_cast<uintptr_t>(p) % 16 == 0) && (ld % 4 == 0);
+}
+
+template <int BM, int BN, int EPI>
+void launch_gemm_tile(bool a_kc, bool b_kc, const GemmParams& p, hipStream_t s) {
+  const dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM);
+  if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, true, true, EPI>), grid, dim3(256), 0, s, p);
+  else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, true, false, EPI>), grid, dim3(256), 0, s, p);
+  else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, false, true, EPI>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, false, false, EPI>), grid, dim3(256), 0, s, p);
+}
+
+// 128x128 tiles once the grid fills the chip, 64x64 below that.
+inline bool use_big_tiles(int64_t M, int64_t N) {
+  return ((M + 127) / 128) * ((N + 127) / 128) >= 128;
+}
+inline int64_t rowstats_parts(int64_t m, int64_t n) {
+  const int64_t bn = use_big_tiles(m, n) ? 128 : 64;
+  return 2 * ((n + bn - 1) / bn);
+}
+
+template <int EPI>
+void launch_gemm(bool a_kc, bool b_kc, const GemmParams& p, hipStream_t s) {
+  if (use_big_tiles(p.M, p.N)) launch_gemm_tile<128, 128, EPI>(a_kc, b_kc, p, s);
+  else launch_gemm_tile<64, 64, EPI>(a_kc, b_kc, p, s);
+}
+
+int check_gemm_dims(int64_t M, int64_t N, int64_t K, const char* fn) {
+  if (M <= 0 || N <= 0 || K <= 0) return fail(DALM_E_SHAPE, fn, "dimensions must be positive");
+  if (M > 0x7fffffffll - 256 || N > 0x7fffffffll - 256 || K > 0x7fffffffll - 256)
+    return fail(DALM_E_SHAPE, fn, "dimension exceeds int32 range");
+  if ((M + 63) / 64 > 65535) return fail(DALM_E_SHAPE, fn, "too many row tiles (M > 4.19M)");
+  return 0;
+}
+
+}  // namespace
+}  // namespace dalm
+
+using namespace dalm;
+
+extern "C" int dalm_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+                             const float* A, int64_t lda, const float* Bm, int64_t ldb, float* C,
+                             int64_t ldc, dalm_stream_t stream) {
+  DALM_REQUIRE(A && Bm && C, DALM_E_NULL, "null pointer argument");
+  if (int e = check_gemm_dims(M, N, K, __func__)) return e;
+  DALM_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, DALM_E_SHAPE,
+               "leading dimension too small");
+  GemmParams p{};
+  p.A = A; p.lda = lda; p.B = Bm; p.ldb = ldb;
+  p.M = static_cast<int>(M); p.N = static_cast<int>(N); p.K = static_cast<int>(K);
+  p.alpha = alpha; p.a_vec = vec_ok(A, lda); p.b_vec = vec_ok(Bm, ldb);
+  p.C = C; p.ldc = ldc;
+  // A k-contiguous <=> not transposed; B k-contiguous <=> transposed ([N,K])
+  launch_gemm<EPI_STORE>(!transA, transB != 0, p, as_stream(stream));
+  return check_launch(__func__);
+}
+
+extern "C" int dalm_sim_matmul(const float* A, const float* Bm, int64_t m, int64_t n, int64_t D,
+                               float scale, float* S, int64_t ldS, dalm_stream_t stream) {
+  return dalm_gemm_f32(0, 1, m, n, D, scale, A, D, Bm, D, S, ldS, stream);
+}
+
+extern "C" size_t dalm_sim_rowstats_workspace_bytes(int64_t m, int64_t n, int64_t D) {
+  (void)D;
+  if (m <= 0 || n <= 0) return 0;
+  return static_cast<size_t>(rowstats_parts(m, n)) * static_cast<size_t>(m) * 2 * sizeof(float);
+}
+
+extern "C" int dalm_sim_rowstats(const float* A, const float* Bm, int64_t m, int64_t n, int64_t D,
+                                 float scale, int64_t diag_offset, float* row_lse, float* diag, void* ws,
+                                 size_t ws_bytes, dalm_stream_t stream) {
+  DALM_REQUIRE(A && Bm && row_lse && diag && ws, DALM_E_NULL, "null pointer argument");
+  if (int e = check_gemm_dims(m, n, D, __func__)) return e;
+  DALM_REQUIRE(diag_offset >= 0 && diag_offset + m <= n, DALM_E_SHAPE, "diag_offset + m must be <= n");
+  DALM_REQUIRE(ws_bytes >= dalm_sim_rowstats_workspace_bytes(m, n, D), DALM_E_WORKSPACE, "workspace too small");
+  DALM_REQUIRE(reinterpret_cast<uintptr_t>(ws) % 4 == 0, DALM_E_ALIGN, "workspace must be 4-byte aligned");
+  hipStream_t s = as_stream(stream);
+  const int64_t P = rowstats_parts(m, n);
+  GemmParams p{};
+  p.A = A; p.lda = D; p.B = Bm; p.ldb = D;
+  p.M = static_cast<int>(m); p.N = static_cast<int>(n); p.K = static_cast<int>(D);
+  p.alpha = scale; p.a_vec = vec_ok(A, D); p.b_vec = vec_ok(Bm, D);
+  p.part_m = static_cast<float*>(ws);
+  p.part_l = p.part_m + P * m;
+  p.diag = diag; p.diag_offset = diag_offset;
+  launch_gemm<EPI_ROWSTATS>(true, true, p, s);
+  hipLaunchKernelGGL(rowstats_merge_kernel, dim3(static_cast<unsigned>((m + 255) / 256)), dim3(256), 0, s,
+                     p.part_m, p.part_l, static_cast<int>(P), p.M, row_lse);
+  return check_launch(__func__);
+}
+
+static inline int64_t round_up4(int64_t x) { return (x + 3) / 4 * 4; }
+
+extern "C" size_t dalm_sim_grad_workspace_bytes(int64_t m, int64_t n, int64_t D) {
+  (void)D;
+  if (m <= 0 || n <= 0) return 0;
+  return static_cast<size_t>(m) * static_cast<size_t>(round_up4(n)) * sizeof(float);
+}
+
+extern "C" int dalm_sim_grad(const float* A, const float* Bm, int64_t m, int64_t n, int64_t D, float scale,
+                             int64_t diag_offset, const float* row_coef, const float* row_lse,
+                             const float* col_coef, const float* col_lse, float* dA, void* ws,
+                             size_t ws_bytes, dalm_stream_t stream) {
+  DALM_REQUIRE(A && Bm && row_coef && row_lse && col_coef && col_lse && dA && ws, DALM_E_NULL,
+               "null pointer argument");
+  if (int e = check_gemm_dims(m, n, D, __func__)) return e;
+  DALM_REQUIRE(diag_offset >= 0 && diag_offset + m <= n, DALM_E_SHAPE, "diag_offset + m must be <= n");
+  DALM_REQUIRE(ws_bytes >= dalm_sim_grad_workspace_bytes(m, n, D), DALM_E_WORKSPACE, "workspace too small");
+  DALM_REQUIRE(reinterpret_cast<uintptr_t>(ws) % 16 == 0, DALM_E_ALIGN, "workspace must be 16-byte aligned");
+  hipStream_t s = as_stream(stream);
+  const int64_t ldd = round_up4(n);
+  float* dS = static_cast<float*>(ws);
+  {  // dS panel: recompute S tiles on the MFMA, transform in the epilogue
+    GemmParams p{};
+    p.A = A; p.lda = D; p.B = Bm; p.ldb = D;
+    p.M = static_cast<int>(m); p.N = static_cast<int>(n); p.K = static_cast<int>(D);
+    p.alpha = scale; p.a_vec = vec_ok(A, D); p.b_vec = vec_ok(Bm, D);
+    p.C = dS; p.ldc = ldd; p.diag_offset = diag_offset;
+    p.row_coef = row_coef; p.row_lse = row_lse; p.col_coef = col_coef; p.col_lse = col_lse;
+    launch_gemm<EPI_DS>(true, true, p, s);
+  }
+  {  // dA[m,D] = scale * dS[m,n] . B[n,D]
+    GemmParams p{};
+    p.A = dS; p.lda = ldd; p.B = Bm; p.ldb = D;
+    p.M = static_cast<int>(m); p.N = static_cast<int>(D); p.K = static_cast<int>(n);
+    p.alpha = scale; p.a_vec = vec_ok(dS, ldd); p.b_vec = vec_ok(Bm, D);
+    p.C = dA; p.ldc = D;
+    launch_gemm<EPI_STORE>(true, false, p, s);
+  }
+  return check_launch(__func__);
+}
+
+extern "C" int dalm_nt_xent_fwd(const float* S, int64_t n, int64_t stride_r, int64_t stride_c, float* loss,
+                                float* row_lse, dalm_stream_t stream) {
+  DALM_REQUIRE(S && loss && row_lse, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(n > 0 && n <= 0x7fffffffll, DALM_E_SHAPE, "n must be positive");
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(rows_lse_kernel, dim3(static_cast<unsigned>(n)), dim3(256), 0, s, S, static_cast<int>(n),
+                     stride_r, stride_c, row_lse, static_cast<float*>(nullptr));
+  hipLaunchKernelGGL(nt_xent_reduce_kernel, dim3(1), dim3(256), 0, s, S, static_cast<int>(n), stride_r,
+                     stride_c, row_lse, loss);
+  return check_launch(__func__);
+}
+
+extern "C" int dalm_nt_xent_bwd(const float* S, int64_t n, int64_t stride_r, int64_t stride_c,
+                                const float* row_lse, const float* gscale, float* dS, int accumulate,
+                                dalm_stream_t stream) {
+  DALM_REQUIRE(S && row_lse && gscale && dS, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(n > 0 && n <= 0x7fffffffll, DALM_E_SHAPE, "n must be positive");
+  hipLaunchKernelGGL(rows_softmax_grad_kernel, dim3(static_cast<unsigned>(n)), dim3(256), 0, as_stream(stream),
+                     S, static_cast<int>(n), stride_r, stride_c, row_lse, static_cast<const float*>(nullptr),
+                     gscale, static_cast<float>(n), 1.f, dS, stride_r, stride_c, accumulate);
+  return check_launch(__func__);
+}
+
+extern "C" int dalm_doc_logprob_fwd(const float* S, int64_t n, int64_t ldS, float* doc_lp, float* row_lse,
+                                    dalm_stream_t stream) {
+  DALM_REQUIRE(S && doc_lp && row_lse, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(n > 0 && n <= 0x7fffffffll && ldS >= n, DALM_E_SHAPE, "need n>0, ldS>=n");
+  hipLaunchKernelGGL(rows_lse_kernel, dim3(static_cast<unsigned>(n)), dim3(256), 0, as_stream(stream), S,
+                     static_cast<int>(n), ldS, static_cast<int64_t>(1), row_lse, doc_lp);
+  return check_launch(__func__);
+}
+
+extern "C" int dalm_doc_logprob_bwd(const float* S, int64_t n, int64_t ldS, const float* row_lse,
+                                    const float* coef, float* dS, int64_t lddS, int accumulate,
+                                    dalm_stream_t stream) {
+  DALM_REQUIRE(S && row_lse && coef && dS, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(n > 0 && n <= 0x7fffffffll && ldS >= n && lddS >= n, DALM_E_SHAPE, "need n>0, ld>=n");
+  // d doc_lp[b] / dS[b,j] = [j==b] - softmax_row(S)[b,j]  => sign = -1 on (softmax - onehot)
+  hipLaunchKernelGGL(rows_softmax_grad_kernel, dim3(static_cast<unsigned>(n)), dim3(256), 0, as_stream(stream),
+                     S, static_cast<int>(n), ldS, static_cast<int64_t>(1), row_lse, coef,
+                     static_cast<const float*>(nullptr), 1.f, -1.f, dS, lddS, static_cast<int64_t>(1),
+                     accumulate);
+  return check_launch(__func__);
+}
+
+extern "C" int dalm_contrastive_finalize(const float* row_lse, const float* col_lse, const float* diag,
+                                         int64_t n_local, int64_t n_global, float* out, float* doc_lp,
+                                         dalm_stream_t stream) {
+  DALM_REQUIRE(row_lse && col_lse && diag && out, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(n_local > 0 && n_global >= n_local && n_local <= 0x7fffffffll, DALM_E_SHAPE,
+               "need 0 < n_local <= n_global");
+  hipLaunchKernelGGL(contrastive_finalize_kernel, dim3(1), dim3(256), 0, as_stream(stream), row_lse, col_lse,
+                     diag, static_cast<int>(n_local), static_cast<float>(n_global), out, doc_lp);
+  return check_launch(__func__);
+}

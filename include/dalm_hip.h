@@ -1,0 +1,200 @@
+/*
+ * dalm_hip.h — C ABI of libdalm_hip.so: the MI355X (gfx950) kernels behind the
+ * RAG-end2end / retriever-only training-step loss path of arcee-ai/DALM.
+ *
+ * The reference has no FFI of its own (it is pure Python on torch); the seam this
+ * library replaces is the eager-torch op sequences listed below.  Every entry
+ * point cites the reference lines (relative to the DALM repo root) it stands in
+ * for.  The Python host side (dalm_amd/hip.py) binds these with ctypes.
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers, borrowed for the duration of the call.
+ *     The library never allocates or frees caller memory; scratch space is
+ *     passed in (`ws`, size from the matching *_workspace_bytes()).
+ *   - Work is enqueued on `stream` (a hipStream_t; pass torch's current stream).
+ *     Calls are asynchronous and re-entrant; there is no global mutable state
+ *     apart from the thread-local last-error string.
+ *   - Return value: 0 = ok; negative = argument error (DALM_E_*); positive =
+ *     a hipError_t from the launch.  dalm_last_error_string() describes the last
+ *     non-zero return on the calling thread.
+ *   - Integer tensors (ids, masks, lengths) are int64, exactly what
+ *     transformers.default_data_collator hands the reference trainer.
+ *   - `dtype` arguments: DALM_F32 or DALM_BF16 (storage type of hidden states /
+ *     logits; all arithmetic is fp32 in registers, as in the reference where
+ *     accelerate up-casts model outputs to fp32 before the loss code).
+ */
+#ifndef DALM_HIP_H
+#define DALM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dalm_stream_t; /* hipStream_t */
+
+enum { DALM_F32 = 0, DALM_BF16 = 1 };
+
+enum {
+  DALM_OK = 0,
+  DALM_E_NULL = -1,     /* required pointer is NULL            */
+  DALM_E_SHAPE = -2,    /* negative / inconsistent sizes        */
+  DALM_E_DTYPE = -3,    /* unknown dtype code                   */
+  DALM_E_ALIGN = -4,    /* pointer not aligned to element size  */
+  DALM_E_WORKSPACE = -5 /* workspace too small                  */
+};
+
+/* ---- library ----------------------------------------------------------- */
+int dalm_version(void);                     /* 10000*major + 100*minor + patch */
+const char* dalm_last_error_string(void);   /* thread-local, never NULL        */
+
+/* ---- K1: masked mean-pool + L2 normalise -------------------------------
+ * Replaces AutoModelForRagE2E.mean_pooling + F.normalize
+ *   dalm/models/rag_e2e_base_model.py:95-97,108-111
+ *   dalm/models/retriever_only_base_model.py:60-68
+ *   u_b = sum_t m_bt h_bt / max(sum_t m_bt, 1e-9);  e_b = u_b / max(|u_b|, 1e-12)
+ * h: [B,T,D] contiguous (dtype), mask: [B,T] int64 (any integer weights).
+ * Outputs: emb [B,D] f32 (e if normalize else u), norm [B] f32 (|u_b|),
+ *          inv_count [B] f32 (1/max(sum m,1e-9)); norm/inv_count feed the bwd.
+ */
+int dalm_pool_l2norm_fwd(const void* h, int dtype, const int64_t* mask,
+                         int64_t B, int64_t T, int64_t D, int normalize,
+                         float* emb, float* norm, float* inv_count,
+                         dalm_stream_t stream);
+/* dh: [B,T,D] (dtype) is fully written (zeros where mask == 0). */
+int dalm_pool_l2norm_bwd(const float* d_emb, const float* emb, const float* norm,
+                         const float* inv_count, const int64_t* mask,
+                         int64_t B, int64_t T, int64_t D, int normalize,
+                         void* dh, int dtype, dalm_stream_t stream);
+
+/* ---- K2: similarity matmul (materialising) -----------------------------
+ * Replaces get_cosine_sim: dalm/training/utils/train_utils.py:76-77
+ *   S[m,n] = (A[m,D] . B[n,D]^T) * scale     (exact-f32 MFMA)
+ */
+int dalm_sim_matmul(const float* A, const float* Bm, int64_t m, int64_t n,
+                    int64_t D, float scale, float* S, int64_t ldS,
+                    dalm_stream_t stream);
+
+/* General f32 GEMM on the same MFMA kernel, C = alpha * op(A) op(B):
+ *   transA == 0: A is [M,K] (lda >= K);  transA != 0: A is [K,M] (lda >= M)
+ *   transB == 0: B is [K,N] (ldb >= N);  transB != 0: B is [N,K] (ldb >= K)
+ * Used for autograd of get_cosine_sim (dQ = scale dS P, dP = scale dS^T Q). */
+int dalm_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                  float alpha, const float* A, int64_t lda, const float* Bm,
+                  int64_t ldb, float* C, int64_t ldc, dalm_stream_t stream);
+
+/* ---- K2-K4 fused: in-batch-negatives row statistics ---------------------
+ * Replaces get_cosine_sim + get_nt_xent_loss (+ the log_softmax(scores).diag()
+ * of compute_marginalized_loss_from_logits) without materialising S:
+ *   dalm/training/utils/train_utils.py:76-88,124
+ *   dalm/training/rag_e2e/train_rage2e.py:441-446
+ * For S = scale * A[m,D] . B[n,D]^T:
+ *   row_lse[i] = logsumexp_j S[i,j],   diag[i] = S[i, diag_offset + i]
+ * Called once with (A,B) = (Q_local, P_all) and once with (P_local, Q_all): the
+ * second call's row statistics are the column statistics of the first.
+ * diag_offset = rank * B_local (0 on one GPU).
+ */
+size_t dalm_sim_rowstats_workspace_bytes(int64_t m, int64_t n, int64_t D);
+int dalm_sim_rowstats(const float* A, const float* Bm, int64_t m, int64_t n,
+                      int64_t D, float scale, int64_t diag_offset,
+                      float* row_lse, float* diag, void* ws, size_t ws_bytes,
+                      dalm_stream_t stream);
+
+/* Closed-form backward of the above:
+ *   dS[i,j] = row_coef[i] exp(S_ij - row_lse[i]) + col_coef[j] exp(S_ij - col_lse[j])
+ *             - [j == diag_offset+i] (row_coef[i] + col_coef[j])
+ *   dA = scale * dS . B
+ * row_* are length m, col_* length n.  ws holds the m x n dS panel. */
+size_t dalm_sim_grad_workspace_bytes(int64_t m, int64_t n, int64_t D);
+int dalm_sim_grad(const float* A, const float* Bm, int64_t m, int64_t n,
+                  int64_t D, float scale, int64_t diag_offset,
+                  const float* row_coef, const float* row_lse,
+                  const float* col_coef, const float* col_lse, float* dA,
+                  void* ws, size_t ws_bytes, dalm_stream_t stream);
+
+/* ---- K3 drop-in: get_nt_xent_loss on a materialised square S -----------
+ * dalm/training/utils/train_utils.py:80-88 (cross_entropy(S, arange(n)), mean).
+ * S may be a transposed view: element (i,j) at S[i*stride_r + j*stride_c].
+ * Writes loss[0] and row_lse[n] (kept for the backward). */
+int dalm_nt_xent_fwd(const float* S, int64_t n, int64_t stride_r,
+                     int64_t stride_c, float* loss, float* row_lse,
+                     dalm_stream_t stream);
+/* dS[i,j] (+)= gscale[0]/n * (exp(S_ij - row_lse[i]) - [i==j]);  dS uses the
+ * same strides as S; accumulate != 0 adds into dS. */
+int dalm_nt_xent_bwd(const float* S, int64_t n, int64_t stride_r,
+                     int64_t stride_c, const float* row_lse,
+                     const float* gscale, float* dS, int accumulate,
+                     dalm_stream_t stream);
+
+/* ---- K5-K7: marginalised causal-LM cross-entropy ------------------------
+ * Replaces compute_marginalized_loss_from_logits / marginalize_log_probs /
+ * get_nll:  dalm/training/utils/train_utils.py:91-138.
+ *   m_bt = mask[b,t+1], y_bt = ids[b,t+1], t in [0,Tg-2]
+ *   M = sum m_bt,  N_b = sum_t m_bt [t >= qlen_b - 1]
+ *   L_gen = ( sum_bt m_bt (lse_bt - logits[b,t,y_bt]) - sum_b N_b doc_lp_b ) / M
+ */
+/* prep: stats[0] = M, stats[1] = B (stats holds 2 floats); Nb[B] as above;
+ * Mb[B] = sum_t m_bt (per-sample token counts).  qlen may be NULL (N_b = 0).
+ * "t >= qlen_b - 1" follows python slice semantics of train_utils.py:100-103
+ * (a negative qlen_b - 1 counts from the end of the Tg-1 rows). */
+int dalm_marg_ce_prep(const int64_t* mask, const int64_t* qlen, int64_t B,
+                      int64_t Tg, float* stats, float* Nb, float* Mb,
+                      dalm_stream_t stream);
+/* main pass: one read of logits.  row_lse/row_nll are [B*Tg] (entry b*Tg+t; the
+ * t = Tg-1 slot and masked rows hold 0).  If dlogits != NULL the gradient for an
+ * upstream grad of 1 is written in the same pass,
+ *   dlogits[b,t,:] = (m_bt / M) (softmax(logits[b,t,:]) - onehot(y_bt)),  0 at t=Tg-1,
+ * and dlogits may alias logits (in-place).  strides are in elements. */
+int dalm_marg_ce_fwd(const void* logits, int dtype, int64_t B, int64_t Tg,
+                     int64_t V, int64_t stride_b, int64_t stride_t,
+                     const int64_t* ids, const int64_t* mask, const float* stats,
+                     float* row_lse, float* row_nll, void* dlogits,
+                     dalm_stream_t stream);
+/* separate backward from the saved row_lse: dlogits = gscale[0] * (m/M)(softmax - onehot). */
+int dalm_marg_ce_bwd(const void* logits, int dtype, int64_t B, int64_t Tg,
+                     int64_t V, int64_t stride_b, int64_t stride_t,
+                     const int64_t* ids, const int64_t* mask, const float* stats,
+                     const float* row_lse, const float* gscale, void* dlogits,
+                     dalm_stream_t stream);
+/* x *= gscale[0] in place (n elements); no-op kernel exit when gscale[0] == 1. */
+int dalm_scale_inplace(void* x, int dtype, int64_t n, const float* gscale,
+                       dalm_stream_t stream);
+/* deterministic reduction:
+ *   out[0] = ( sum_r row_nll[r] - sum_b Nb[b] doc_lp[b] ) / M      (L_gen)
+ * doc_lp may be NULL (no retrieval term).  num_rows = B*Tg. */
+int dalm_marg_ce_finalize(const float* row_nll, int64_t num_rows,
+                          const float* Nb, const float* doc_lp, int64_t B,
+                          const float* stats, float* out, dalm_stream_t stream);
+
+/* doc_lp[b] = S[b,b] - logsumexp_j S[b,j] on a materialised S
+ * (train_utils.py:124), plus its backward
+ *   dS[b,j] += coef[b] * ([j==b] - exp(S_bj - row_lse[b])). */
+int dalm_doc_logprob_fwd(const float* S, int64_t n, int64_t ldS, float* doc_lp,
+                         float* row_lse, dalm_stream_t stream);
+int dalm_doc_logprob_bwd(const float* S, int64_t n, int64_t ldS,
+                         const float* row_lse, const float* coef, float* dS,
+                         int64_t lddS, int accumulate, dalm_stream_t stream);
+
+/* get_nll (train_utils.py:91-93): out[r] = -lp[r, labels[r]] for R rows of V. */
+int dalm_gather_nll(const float* lp, const int64_t* labels, int64_t R, int64_t V,
+                    float* out, dalm_stream_t stream);
+/* marginalize_log_probs (train_utils.py:96-110): out[t,:] = lp[t,:] + (t >= qlen-1 ? doc_lp[0] : 0). */
+int dalm_marginalize_rows(const float* lp, int64_t T, int64_t V,
+                          const float* doc_lp, int64_t qlen, float* out,
+                          dalm_stream_t stream);
+
+/* contrastive loss assembly (train_rage2e.py:443-446) from row/col statistics:
+ *   out[0] = 0.5 ( sum_i (row_lse[i]-diag[i]) + sum_j (col_lse[j]-diag[j]) ) / n_global
+ *   doc_lp[i] = diag[i] - row_lse[i]      (may be NULL)
+ * n_local entries are summed (this rank's rows/columns). */
+int dalm_contrastive_finalize(const float* row_lse, const float* col_lse,
+                              const float* diag, int64_t n_local,
+                              int64_t n_global, float* out, float* doc_lp,
+                              dalm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DALM_HIP_H */
