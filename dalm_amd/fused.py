@@ -1,0 +1,316 @@
+"""Autograd layer over the HIP loss kernels, single- and multi-GPU.
+
+Fused entry points (never materialise S or the [B,Tg,V] log-probs):
+    contrastive_loss(q_emb, p_emb, logit_scale)            retriever-only step
+    rag_e2e_loss(q_emb, p_emb, logits, ids, mask, qlen, s)  RAG-end2end step
+They reproduce, per step, dalm/training/rag_e2e/train_rage2e.py:441-467 and
+dalm/training/retriever_only/train_retriever_only.py:369-374.
+
+Multi-GPU: rank r owns rows [r*B_l, (r+1)*B_l) of Q, P and the logits.  Q and P
+are all-gathered (RCCL over xGMI; tiny: B_l*D*4 bytes per rank), every rank runs
+two row-problems on the matrix cores,
+    rows    : S_r  = s * Q_r . P_all^T   -> lse_r[i], S_ii     (i in rank r)
+    columns : S_r' = s * P_r . Q_all^T   -> lse_c[j]            (j in rank r)
+and the closed-form backward needs only the all-gathered
+(lse_r, lse_c, a) vectors - no autograd through a collective, no reduce-scatter.
+The per-rank value is the rank's share L_r of the GLOBAL-batch loss
+(sum_r L_r = loss of one process at batch B_g); parameter gradients must be
+SUMMED over ranks (dalm_amd.sharded.allreduce_grads does that).
+The reference itself never gathers negatives (DDP, local B_l x B_l only).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, Optional
+
+import torch
+
+from .ops import default_ops
+
+
+# ---------------------------------------------------------------------------
+# communicators
+# ---------------------------------------------------------------------------
+class LocalComm:
+    """world_size == 1: every collective is the identity."""
+
+    world_size = 1
+    rank = 0
+
+    def all_gather_rows(self, t: torch.Tensor) -> torch.Tensor:
+        return t
+
+    def all_reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
+        return t
+
+
+class TorchDistComm:
+    """torch.distributed process group (backend "nccl" == RCCL on ROCm; "gloo" in CPU tests)."""
+
+    def __init__(self, group: Any = None):
+        import torch.distributed as dist
+
+        self._dist = dist
+        self.group = group
+        self.world_size = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def all_gather_rows(self, t: torch.Tensor) -> torch.Tensor:
+        t = t.contiguous()
+        out = torch.empty((self.world_size * t.shape[0],) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+        self._dist.all_gather_into_tensor(out, t, group=self.group)
+        return out
+
+    def all_reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
+        return t
+
+
+class GatherHandle:
+    """An all-gather of embeddings started early on a side stream (overlap with the other tower)."""
+
+    def __init__(self, local: torch.Tensor, comm, side_stream: Optional["torch.cuda.Stream"] = None):
+        self.local = local
+        self.comm = comm
+        self.result: Optional[torch.Tensor] = None
+        self.event = None
+        if comm.world_size == 1:
+            self.result = local.detach()
+            return
+        if side_stream is not None and local.is_cuda:
+            side_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side_stream):
+                self.result = comm.all_gather_rows(local.detach())
+                self.event = torch.cuda.Event()
+                self.event.record(side_stream)
+            self.result.record_stream(torch.cuda.current_stream()) if hasattr(self.result, "record_stream") else None
+        else:
+            self.result = comm.all_gather_rows(local.detach())
+
+    def wait(self) -> torch.Tensor:
+        if self.event is not None:
+            torch.cuda.current_stream().wait_event(self.event)
+            self.event = None
+        assert self.result is not None
+        return self.result
+
+
+# ---------------------------------------------------------------------------
+# K1
+# ---------------------------------------------------------------------------
+class _PoolL2Norm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, mask, normalize, ops):
+        emb, norm, inv_count = ops.pool_fwd(h, mask, normalize)
+        ctx.save_for_backward(emb, norm, inv_count, mask)
+        ctx.normalize, ctx.ops, ctx.T, ctx.h_dtype = normalize, ops, h.shape[1], h.dtype
+        return emb
+
+    @staticmethod
+    def backward(ctx, d_emb):
+        emb, norm, inv_count, mask = ctx.saved_tensors
+        dh = ctx.ops.pool_bwd(d_emb, emb, norm, inv_count, mask, ctx.normalize, ctx.T, ctx.h_dtype)
+        return dh, None, None, None
+
+
+def pool_l2norm(token_embeddings: torch.Tensor, attention_mask: torch.Tensor, normalize: bool = True, ops=None):
+    """mean_pooling (+ F.normalize(p=2, dim=1)) of rag_e2e_base_model.py:95-97,108-111 in one HIP pass."""
+    return _PoolL2Norm.apply(token_embeddings, attention_mask, bool(normalize), ops or default_ops())
+
+
+# ---------------------------------------------------------------------------
+# shared forward/backward pieces
+# ---------------------------------------------------------------------------
+@dataclass
+class _ConState:
+    q: torch.Tensor
+    p: torch.Tensor
+    q_all: torch.Tensor
+    p_all: torch.Tensor
+    lse_r: torch.Tensor   # local rows
+    lse_c: torch.Tensor   # local columns
+    diag: torch.Tensor
+    offset: int
+    n_global: int
+
+
+def _contrastive_forward(ops, comm, q, p, scale, q_all=None, p_all=None):
+    q = q.detach().float().contiguous()
+    p = p.detach().float().contiguous()
+    if q.shape != p.shape or q.dim() != 2:
+        raise ValueError(f"query/passage embeddings must both be [B,D], got {tuple(q.shape)} / {tuple(p.shape)}")
+    b_l = q.shape[0]
+    offset = comm.rank * b_l
+    if p_all is None:
+        p_all = comm.all_gather_rows(p)
+    if q_all is None:
+        q_all = comm.all_gather_rows(q)
+    lse_r, diag = ops.sim_rowstats(q, p_all, scale, offset)
+    lse_c, _ = ops.sim_rowstats(p, q_all, scale, offset)
+    return _ConState(q, p, q_all, p_all, lse_r, lse_c, diag, offset, comm.world_size * b_l)
+
+
+def _contrastive_backward(ops, comm, st: _ConState, scale, a_local, b_local):
+    """a: row coefficients (this rank's queries), b: column coefficients (this rank's passages)."""
+    if comm.world_size > 1:
+        packed = torch.stack([st.lse_r, st.lse_c, a_local, b_local], dim=1)  # [B_l,4] -> one all-gather
+        allv = comm.all_gather_rows(packed)
+        lse_r_all, lse_c_all, a_all, b_all = (allv[:, k].contiguous() for k in range(4))
+    else:
+        lse_r_all, lse_c_all, a_all, b_all = st.lse_r, st.lse_c, a_local, b_local
+    dq = ops.sim_grad(st.q, st.p_all, scale, st.offset, a_local, st.lse_r, b_all, lse_c_all)
+    dp = ops.sim_grad(st.p, st.q_all, scale, st.offset, b_local, st.lse_c, a_all, lse_r_all)
+    return dq, dp
+
+
+# ---------------------------------------------------------------------------
+# retriever-only: symmetric in-batch-negatives loss
+# ---------------------------------------------------------------------------
+class _Contrastive(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, p, scale, ops, comm, q_gather, p_gather):
+        st = _contrastive_forward(ops, comm, q, p, scale,
+                                  q_gather.wait() if q_gather is not None else None,
+                                  p_gather.wait() if p_gather is not None else None)
+        loss, _ = ops.contrastive_finalize(st.lse_r, st.lse_c, st.diag, st.n_global)
+        ctx.st, ctx.scale, ctx.ops, ctx.comm = st, scale, ops, comm
+        ctx.in_dtypes = (q.dtype, p.dtype)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        st = ctx.st
+        coef = (g.float() / (2.0 * st.n_global)).reshape(1).expand(st.q.shape[0]).contiguous()
+        dq, dp = _contrastive_backward(ctx.ops, ctx.comm, st, ctx.scale, coef, coef)
+        return dq.to(ctx.in_dtypes[0]), dp.to(ctx.in_dtypes[1]), None, None, None, None, None
+
+
+def contrastive_loss(query_embs, passage_embs, logit_scale, *, comm=None, ops=None, q_gather=None, p_gather=None):
+    """(get_nt_xent_loss(S) + get_nt_xent_loss(S.t())) / 2 with S = get_cosine_sim(q, p, scale),
+    train_retriever_only.py:369-374, without materialising S.  With comm.world_size > 1 this is
+    rank r's share of the global-batch loss."""
+    return _Contrastive.apply(query_embs, passage_embs, float(logit_scale), ops or default_ops(),
+                              comm or LocalComm(), q_gather, p_gather)
+
+
+# ---------------------------------------------------------------------------
+# RAG-end2end: contrastive + marginalised causal-LM cross-entropy
+# ---------------------------------------------------------------------------
+class _RagE2E(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, p, logits, ids, mask, qlen, scale, ops, comm, fuse_grad, inplace_grad, q_gather, p_gather, aux):
+        st = _contrastive_forward(ops, comm, q, p, scale,
+                                  q_gather.wait() if q_gather is not None else None,
+                                  p_gather.wait() if p_gather is not None else None)
+        con, doc_lp = ops.contrastive_finalize(st.lse_r, st.lse_c, st.diag, st.n_global)
+        stats, Nb, _Mb = ops.ce_prep(mask, qlen)
+        if comm.world_size > 1:
+            comm.all_reduce_sum_(stats)  # stats[0] = M over the global batch
+        need_grad = logits.requires_grad and fuse_grad
+        row_lse, row_nll, dlogits = ops.ce_fwd(logits.detach(), ids, mask, stats, need_grad, inplace_grad)
+        gen = ops.ce_finalize(row_nll, Nb, doc_lp, stats)
+        ctx.st, ctx.scale, ctx.ops, ctx.comm = st, scale, ops, comm
+        ctx.in_dtypes = (q.dtype, p.dtype)
+        ctx.fused = need_grad
+        if need_grad:
+            ctx.save_for_backward(stats, Nb, dlogits)
+        else:
+            ctx.save_for_backward(stats, Nb, logits.detach(), ids, mask, row_lse)
+        if aux is not None:
+            aux["contrastive"] = con.reshape(())
+            aux["generator"] = gen.reshape(())
+            aux["doc_logprobs"] = doc_lp
+            aux["num_target_tokens"] = stats[0]
+        return (con + gen).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        ops, st = ctx.ops, ctx.st
+        g = g.float().reshape(1)
+        if ctx.fused:
+            stats, Nb, dlogits = ctx.saved_tensors
+            dlogits = ops.scale_inplace(dlogits, g)  # no-op launch when g == 1
+        else:
+            stats, Nb, logits, ids, mask, row_lse = ctx.saved_tensors
+            dlogits = ops.ce_bwd(logits, ids, mask, stats, row_lse, g) if ctx.needs_input_grad[2] else None
+        dq = dp = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            # dL/dS = (a_i softmax_row - ...) + (b_j softmax_col - ...),  a_i = g (1/(2B) + N_i/M), b_j = g/(2B)
+            b = (g / (2.0 * st.n_global)).expand(st.q.shape[0]).contiguous()
+            a = b + g * Nb / stats[0]
+            dq, dp = _contrastive_backward(ops, ctx.comm, st, ctx.scale, a, b)
+            dq, dp = dq.to(ctx.in_dtypes[0]), dp.to(ctx.in_dtypes[1])
+        return (dq, dp, dlogits) + (None,) * 11
+
+
+def rag_e2e_loss(query_embs, passage_embs, generator_logits, input_ids, attention_mask, query_token_length,
+                 logit_scale, *, comm=None, ops=None, fuse_grad=True, inplace_grad=False, q_gather=None,
+                 p_gather=None, aux: Optional[dict] = None):
+    """combined_loss of train_rage2e.py:441-467 in ~10 kernel launches:
+       (CE_row(S) + CE_col(S))/2 + compute_marginalized_loss_from_logits(logits, ids, mask, S, qlen).
+
+    fuse_grad    : write dL/dlogits in the same pass that reads the logits (2x instead of 3x bytes)
+    inplace_grad : let that gradient overwrite the logits buffer (caller must not reuse the logits)
+    aux          : optional dict receiving detached {"contrastive","generator","doc_logprobs",...}
+    """
+    return _RagE2E.apply(query_embs, passage_embs, generator_logits, input_ids, attention_mask,
+                         query_token_length, float(logit_scale), ops or default_ops(), comm or LocalComm(),
+                         bool(fuse_grad), bool(inplace_grad), q_gather, p_gather, aux)
+
+
+# ---------------------------------------------------------------------------
+# drop-ins with the reference's signatures (materialised S / log-probs)
+# ---------------------------------------------------------------------------
+class _CosineSim(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, p, scale, ops):
+        ctx.save_for_backward(q, p)
+        ctx.scale, ctx.ops = scale, ops
+        return ops.sim_matmul(q, p, scale)
+
+    @staticmethod
+    def backward(ctx, dS):
+        q, p = ctx.saved_tensors
+        ops, s = ctx.ops, ctx.scale
+        dS = dS.float().contiguous()
+        dq = ops.gemm(dS, p, s, False, False).to(q.dtype) if ctx.needs_input_grad[0] else None
+        dp = ops.gemm(dS, q, s, True, False).to(p.dtype) if ctx.needs_input_grad[1] else None
+        return dq, dp, None, None
+
+
+class _NtXent(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, S, ops):
+        loss, row_lse, S32 = ops.nt_xent_fwd(S)
+        ctx.save_for_backward(S32, row_lse)
+        ctx.ops, ctx.dtype = ops, S.dtype
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        S32, row_lse = ctx.saved_tensors
+        return ctx.ops.nt_xent_bwd(S32, row_lse, g.float().reshape(1)).to(ctx.dtype), None
+
+
+class _MargLossFromLogits(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, ids, mask, scores, qlen, ops):
+        doc_lp, s_lse, S32 = ops.doc_logprob_fwd(scores.detach())
+        stats, Nb, _ = ops.ce_prep(mask, qlen)
+        row_lse, row_nll, _ = ops.ce_fwd(logits.detach(), ids, mask, stats, False)
+        out = ops.ce_finalize(row_nll, Nb, doc_lp, stats)
+        ctx.save_for_backward(logits.detach(), ids, mask, stats, row_lse, Nb, S32, s_lse)
+        ctx.ops, ctx.s_dtype = ops, scores.dtype
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, ids, mask, stats, row_lse, Nb, S32, s_lse = ctx.saved_tensors
+        ops = ctx.ops
+        g = g.float().reshape(1)
+        dlogits = ops.ce_bwd(logits, ids, mask, stats, row_lse, g) if ctx.needs_input_grad[0] else None
+        dS = None
+        if ctx.needs_input_grad[3]:
+            # L_gen = -(1/M) sum_b N_b doc_lp_b + ...  =>  dL/d doc_lp_b = -g N_b / M
+            dS = ops.doc_logprob_bwd(S32, s_lse, -g * Nb / stats[0]).to(ctx.s_dtype)
+        return dlogits, None, None, dS, None, None

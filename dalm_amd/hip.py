@@ -1,0 +1,129 @@
+"""ctypes binding of libdalm_hip.so (the C ABI in include/dalm_hip.h).
+
+This module is the only place that touches the shared object.  There is NO CPU
+fallback: if the library is missing, or a tensor is not on a HIP device, the
+call raises.  torch is used for device memory and the current stream only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from typing import Optional
+
+import torch
+
+_LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libdalm_hip.so"
+_lib: Optional[C.CDLL] = None
+
+F32, BF16 = 0, 1
+_i64, _f32, _int, _vp, _sz = C.c_int64, C.c_float, C.c_int, C.c_void_p, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/dalm_hip.h one to one
+SIGNATURES = {
+    "dalm_version": (_int, []),
+    "dalm_last_error_string": (C.c_char_p, []),
+    "dalm_pool_l2norm_fwd": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp]),
+    "dalm_pool_l2norm_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _int, _vp, _int, _vp]),
+    "dalm_sim_matmul": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _vp, _i64, _vp]),
+    "dalm_gemm_f32": (_int, [_int, _int, _i64, _i64, _i64, _f32, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "dalm_sim_rowstats_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "dalm_sim_rowstats": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "dalm_sim_grad_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "dalm_sim_grad": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dalm_nt_xent_fwd": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "dalm_nt_xent_bwd": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp]),
+    "dalm_marg_ce_prep": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "dalm_marg_ce_fwd": (_int, [_vp, _int, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dalm_marg_ce_bwd": (_int, [_vp, _int, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dalm_scale_inplace": (_int, [_vp, _int, _i64, _vp, _vp]),
+    "dalm_marg_ce_finalize": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "dalm_doc_logprob_fwd": (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
+    "dalm_doc_logprob_bwd": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _int, _vp]),
+    "dalm_gather_nll": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "dalm_marginalize_rows": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp]),
+    "dalm_contrastive_finalize": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+}
+
+
+def library_path() -> Path:
+    return _LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load (once) and return the shared library; raise if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise RuntimeError(
+            f"{_LIB_PATH} is missing: the HIP extension is required (no CPU fallback). "
+            "Build it with `python -m dalm_amd._build` (needs hipcc, targets gfx950)."
+        )
+    lib = C.CDLL(str(_LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == header/library drift
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class DalmHipError(RuntimeError):
+    pass
+
+
+def _check(rc: int, name: str) -> None:
+    if rc == 0:
+        return
+    msg = load().dalm_last_error_string().decode("utf-8", "replace")
+    if rc < 0:
+        raise ValueError(f"{name} rejected its arguments (code {rc}): {msg}")
+    raise DalmHipError(f"{name} failed with hipError {rc}: {msg}")
+
+
+def call(name: str, *args) -> None:
+    _check(getattr(load(), name)(*args), name)
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(*tensors: torch.Tensor) -> torch.device:
+    """All tensors must live on the same HIP device; returns it."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "dalm_amd: tensor is on %s; the loss path runs only as HIP kernels on an MI355X "
+                "(there is no CPU implementation in this package)" % t.device
+            )
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"dalm_amd: tensors on different devices ({dev} vs {t.device})")
+    if dev is None:
+        raise RuntimeError("dalm_amd: no tensor arguments")
+    return dev
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"dalm_amd: unsupported dtype {t.dtype} (float32 or bfloat16 expected)")
+
+
+def as_i64(t: torch.Tensor) -> torch.Tensor:
+    return t if (t.dtype == torch.int64 and t.is_contiguous()) else t.to(torch.int64).contiguous()
+
+
+def as_f32c(t: torch.Tensor) -> torch.Tensor:
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()

@@ -1,0 +1,110 @@
+"""AutoModelForRagE2E with the reference's surface (dalm/models/rag_e2e_base_model.py:16-160).
+
+Encoder / causal-LM forward and backward run through PyTorch-ROCm (hipBLASLt, SDPA); the tail
+of the retrieval path - masked mean-pool + L2 normalise - is the hand-written HIP kernel
+`dalm_pool_l2norm_{fwd,bwd}` instead of the reference's three [B,T,D] temporaries.
+"""
+from __future__ import annotations
+
+from enum import Enum
+from typing import Optional
+
+import torch
+
+from ..fused import pool_l2norm
+from ..utils import eos_mask
+from . import lora
+
+
+class Mode(Enum):
+    GENERATOR = "generator"
+    RETRIEVER = "retriever"
+    BOTH = "both"
+
+
+_BNB_MSG = ("use_bnb (bitsandbytes nf4) is not available in this MI355X build: bitsandbytes is CUDA-only "
+            "and outside the accelerated path; pass use_bnb=None (bf16 weights fit 288 GB HBM3E).")
+
+
+class AutoModelForRagE2E(torch.nn.Module):
+    def __init__(
+        self,
+        retriever_name: str,
+        generator_name: str,
+        normalize: bool = True,
+        get_peft: Optional[Mode] = None,
+        use_bnb: Optional[Mode] = None,
+        retriever_is_autoregressive: bool = False,
+        *,
+        torch_dtype: Optional[torch.dtype] = None,
+    ) -> None:
+        super().__init__()
+        if use_bnb is not None:
+            raise NotImplementedError(_BNB_MSG)
+        from transformers import AutoModel, AutoModelForCausalLM, AutoTokenizer
+
+        kw = {} if torch_dtype is None else {"dtype": torch_dtype}
+        retriever = AutoModel.from_pretrained(retriever_name, **kw)
+        generator = AutoModelForCausalLM.from_pretrained(generator_name, trust_remote_code=True, **kw)
+        self._assemble(retriever, generator, AutoTokenizer.from_pretrained(retriever_name),
+                       AutoTokenizer.from_pretrained(generator_name), normalize, get_peft,
+                       retriever_is_autoregressive)
+
+    @classmethod
+    def from_modules(cls, retriever_model, generator_model, retriever_tokenizer=None, generator_tokenizer=None,
+                     normalize: bool = True, get_peft: Optional[Mode] = None,
+                     retriever_is_autoregressive: bool = False) -> "AutoModelForRagE2E":
+        """Build from already-constructed modules (random-init benchmarks, tests)."""
+        self = cls.__new__(cls)
+        torch.nn.Module.__init__(self)
+        self._assemble(retriever_model, generator_model, retriever_tokenizer, generator_tokenizer, normalize,
+                       get_peft, retriever_is_autoregressive)
+        return self
+
+    def _assemble(self, retriever, generator, r_tok, g_tok, normalize, get_peft, autoregressive) -> None:
+        self.retriever_model = retriever
+        self.generator_model = generator
+        self.retriever_tokenizer = r_tok
+        self.generator_tokenizer = g_tok
+        if autoregressive and r_tok is not None:
+            r_tok.add_eos_token = True
+            r_tok.pad_token = r_tok.eos_token
+        self.normalize = normalize
+        self.retriever_is_autoregressive = autoregressive
+        if get_peft is not None:
+            get_peft = Mode(get_peft)
+            if get_peft in (Mode.RETRIEVER, Mode.BOTH):
+                targets = ["key", "query", "value"] if not autoregressive else ["q_proj", "v_proj"]
+                lora.inject_lora(self.retriever_model, targets)
+            if get_peft in (Mode.GENERATOR, Mode.BOTH):
+                lora.inject_lora(self.generator_model, ["q_proj", "v_proj"])
+
+    # ---- retrieval tower ---------------------------------------------------------------
+    def retrieval_hidden(self, input_ids: torch.Tensor, attention_mask: torch.Tensor):
+        """Token states + the mask that pools them (reference :84-93)."""
+        if self.retriever_is_autoregressive:
+            h = self.retriever_model(input_ids, attention_mask=attention_mask, output_hidden_states=True,
+                                     return_dict=True).hidden_states[-1]
+            return h, eos_mask(attention_mask)
+        return self.retriever_model(input_ids, attention_mask)[0], attention_mask
+
+    def retrieval_forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+        h, pool_mask = self.retrieval_hidden(input_ids, attention_mask)
+        return pool_l2norm(h, pool_mask, self.normalize)
+
+    def forward(self, task: str, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+        if task == "retrieval":
+            return self.retrieval_forward(input_ids, attention_mask)
+        return self.generator_model(input_ids=input_ids, attention_mask=attention_mask).logits
+
+    def mean_pooling(self, model_output: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+        return pool_l2norm(model_output, attention_mask, False)
+
+    def attach_pre_trained_peft_layers(self, peft_retriever_path: Optional[str], peft_generator_path: Optional[str],
+                                       device: str) -> None:
+        if peft_retriever_path is not None:
+            lora.load_adapter(self.retriever_model, peft_retriever_path)
+            self.retriever_model = lora.merge_and_unload(self.retriever_model).to(device).eval()
+        if peft_generator_path is not None:
+            lora.load_adapter(self.generator_model, peft_generator_path)
+            self.generator_model = lora.merge_and_unload(self.generator_model).to(device).eval()

@@ -1,0 +1,252 @@
+"""Primitive device operations of the loss path, one method per C-ABI entry point.
+
+`HipOps` is the product implementation: every method enqueues hand-written
+gfx950 kernels from libdalm_hip.so on torch's current stream and returns freshly
+allocated device tensors.  There is no CPU implementation here - CPU tensors
+raise (see dalm_amd.hip.require_gpu).
+
+The autograd layer (dalm_amd.fused) and the sharded-negatives logic
+(dalm_amd.sharded) are written against this interface only, which is what lets
+the world_size>1 host logic be exercised on CPU under gloo with a checker
+backend injected by the tests.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import hip
+
+
+class HipOps:
+    name = "hip"
+
+    # ---- K1 ---------------------------------------------------------------
+    def pool_fwd(self, h: torch.Tensor, mask: torch.Tensor, normalize: bool):
+        """mean_pooling + F.normalize (rag_e2e_base_model.py:95-97,108-111)."""
+        dev = hip.require_gpu(h, mask)
+        if h.dim() != 3 or mask.shape != h.shape[:2]:
+            raise ValueError(f"pool: expected h [B,T,D] and mask [B,T], got {tuple(h.shape)} / {tuple(mask.shape)}")
+        h = h.contiguous()
+        mask = hip.as_i64(mask)
+        B, T, D = h.shape
+        emb = torch.empty((B, D), device=dev, dtype=torch.float32)
+        norm = torch.empty((B,), device=dev, dtype=torch.float32)
+        inv_count = torch.empty((B,), device=dev, dtype=torch.float32)
+        hip.call("dalm_pool_l2norm_fwd", hip.ptr(h), hip.dtype_code(h), hip.ptr(mask), B, T, D, int(normalize),
+                 hip.ptr(emb), hip.ptr(norm), hip.ptr(inv_count), hip.stream())
+        return emb, norm, inv_count
+
+    def pool_bwd(self, d_emb, emb, norm, inv_count, mask, normalize: bool, T: int, dtype: torch.dtype):
+        dev = hip.require_gpu(d_emb, emb, norm, inv_count, mask)
+        d_emb = hip.as_f32c(d_emb)
+        mask = hip.as_i64(mask)
+        B, D = emb.shape
+        dh = torch.empty((B, T, D), device=dev, dtype=dtype)
+        hip.call("dalm_pool_l2norm_bwd", hip.ptr(d_emb), hip.ptr(emb), hip.ptr(norm), hip.ptr(inv_count),
+                 hip.ptr(mask), B, T, D, int(normalize), hip.ptr(dh), hip.dtype_code(dh), hip.stream())
+        return dh
+
+    # ---- K2 materialising ---------------------------------------------------
+    def sim_matmul(self, A: torch.Tensor, Bm: torch.Tensor, scale: float) -> torch.Tensor:
+        """get_cosine_sim (train_utils.py:76-77): (A @ Bm.T) * scale."""
+        dev = hip.require_gpu(A, Bm)
+        A, Bm = hip.as_f32c(A), hip.as_f32c(Bm)
+        if A.dim() != 2 or Bm.dim() != 2 or A.shape[1] != Bm.shape[1]:
+            raise ValueError(f"sim: mat1 and mat2 shapes cannot be multiplied ({tuple(A.shape)} and {tuple(Bm.shape)}^T)")
+        m, D = A.shape
+        n = Bm.shape[0]
+        S = torch.empty((m, n), device=dev, dtype=torch.float32)
+        hip.call("dalm_sim_matmul", hip.ptr(A), hip.ptr(Bm), m, n, D, float(scale), hip.ptr(S), n, hip.stream())
+        return S
+
+    def gemm(self, A: torch.Tensor, Bm: torch.Tensor, alpha: float, transA: bool, transB: bool) -> torch.Tensor:
+        dev = hip.require_gpu(A, Bm)
+        A, Bm = hip.as_f32c(A), hip.as_f32c(Bm)
+        M, K = (A.shape[1], A.shape[0]) if transA else A.shape
+        N = Bm.shape[0] if transB else Bm.shape[1]
+        Kb = Bm.shape[1] if transB else Bm.shape[0]
+        if K != Kb:
+            raise ValueError("gemm: inner dimensions differ")
+        Cm = torch.empty((M, N), device=dev, dtype=torch.float32)
+        hip.call("dalm_gemm_f32", int(transA), int(transB), M, N, K, float(alpha), hip.ptr(A), A.shape[1],
+                 hip.ptr(Bm), Bm.shape[1], hip.ptr(Cm), N, hip.stream())
+        return Cm
+
+    # ---- K2-K4 fused ----------------------------------------------------------
+    def sim_rowstats(self, A: torch.Tensor, Bm: torch.Tensor, scale: float, diag_offset: int):
+        """row_lse[i] = logsumexp_j scale*A_i.B_j ; diag[i] = scale*A_i.B_{off+i}."""
+        dev = hip.require_gpu(A, Bm)
+        A, Bm = hip.as_f32c(A), hip.as_f32c(Bm)
+        m, D = A.shape
+        n = Bm.shape[0]
+        lib = hip.load()
+        ws_bytes = lib.dalm_sim_rowstats_workspace_bytes(m, n, D)
+        ws = torch.empty((max(ws_bytes, 4) // 4,), device=dev, dtype=torch.float32)
+        row_lse = torch.empty((m,), device=dev, dtype=torch.float32)
+        diag = torch.empty((m,), device=dev, dtype=torch.float32)
+        hip.call("dalm_sim_rowstats", hip.ptr(A), hip.ptr(Bm), m, n, D, float(scale), int(diag_offset),
+                 hip.ptr(row_lse), hip.ptr(diag), hip.ptr(ws), ws_bytes, hip.stream())
+        return row_lse, diag
+
+    def sim_grad(self, A, Bm, scale: float, diag_offset: int, row_coef, row_lse, col_coef, col_lse):
+        """dA = scale * dS . Bm with the closed-form dS of include/dalm_hip.h."""
+        dev = hip.require_gpu(A, Bm, row_coef, row_lse, col_coef, col_lse)
+        A, Bm = hip.as_f32c(A), hip.as_f32c(Bm)
+        row_coef, row_lse = hip.as_f32c(row_coef), hip.as_f32c(row_lse)
+        col_coef, col_lse = hip.as_f32c(col_coef), hip.as_f32c(col_lse)
+        m, D = A.shape
+        n = Bm.shape[0]
+        lib = hip.load()
+        ws_bytes = lib.dalm_sim_grad_workspace_bytes(m, n, D)
+        ws = torch.empty((max(ws_bytes, 4) // 4,), device=dev, dtype=torch.float32)
+        dA = torch.empty((m, D), device=dev, dtype=torch.float32)
+        hip.call("dalm_sim_grad", hip.ptr(A), hip.ptr(Bm), m, n, D, float(scale), int(diag_offset),
+                 hip.ptr(row_coef), hip.ptr(row_lse), hip.ptr(col_coef), hip.ptr(col_lse), hip.ptr(dA),
+                 hip.ptr(ws), ws_bytes, hip.stream())
+        return dA
+
+    def contrastive_finalize(self, row_lse, col_lse, diag, n_global: int):
+        dev = hip.require_gpu(row_lse, col_lse, diag)
+        n_local = row_lse.shape[0]
+        out = torch.empty((1,), device=dev, dtype=torch.float32)
+        doc_lp = torch.empty((n_local,), device=dev, dtype=torch.float32)
+        hip.call("dalm_contrastive_finalize", hip.ptr(row_lse), hip.ptr(col_lse), hip.ptr(diag), n_local,
+                 int(n_global), hip.ptr(out), hip.ptr(doc_lp), hip.stream())
+        return out, doc_lp
+
+    # ---- K3 / K4 on a materialised S ---------------------------------------------
+    def nt_xent_fwd(self, S: torch.Tensor):
+        dev = hip.require_gpu(S)
+        if S.dim() != 2 or S.shape[0] != S.shape[1]:
+            raise ValueError("get_nt_xent_loss expects a square similarity matrix")
+        if S.dtype != torch.float32:
+            S = S.float()
+        n = S.shape[0]
+        loss = torch.empty((1,), device=dev, dtype=torch.float32)
+        row_lse = torch.empty((n,), device=dev, dtype=torch.float32)
+        hip.call("dalm_nt_xent_fwd", hip.ptr(S), n, S.stride(0), S.stride(1), hip.ptr(loss), hip.ptr(row_lse),
+                 hip.stream())
+        return loss, row_lse, S
+
+    def nt_xent_bwd(self, S, row_lse, gscale):
+        dev = hip.require_gpu(S, row_lse, gscale)
+        n = S.shape[0]
+        dS = torch.empty_strided(S.shape, S.stride(), device=dev, dtype=torch.float32)
+        hip.call("dalm_nt_xent_bwd", hip.ptr(S), n, S.stride(0), S.stride(1), hip.ptr(row_lse), hip.ptr(gscale),
+                 hip.ptr(dS), 0, hip.stream())
+        return dS
+
+    def doc_logprob_fwd(self, S: torch.Tensor):
+        dev = hip.require_gpu(S)
+        S = hip.as_f32c(S)
+        n = S.shape[0]
+        doc_lp = torch.empty((n,), device=dev, dtype=torch.float32)
+        row_lse = torch.empty((n,), device=dev, dtype=torch.float32)
+        hip.call("dalm_doc_logprob_fwd", hip.ptr(S), n, S.shape[1], hip.ptr(doc_lp), hip.ptr(row_lse), hip.stream())
+        return doc_lp, row_lse, S
+
+    def doc_logprob_bwd(self, S, row_lse, coef):
+        dev = hip.require_gpu(S, row_lse, coef)
+        n = S.shape[0]
+        dS = torch.empty((n, S.shape[1]), device=dev, dtype=torch.float32)
+        hip.call("dalm_doc_logprob_bwd", hip.ptr(S), n, S.shape[1], hip.ptr(row_lse), hip.ptr(hip.as_f32c(coef)),
+                 hip.ptr(dS), S.shape[1], 0, hip.stream())
+        return dS
+
+    # ---- K5-K7 -------------------------------------------------------------------
+    def ce_prep(self, mask: torch.Tensor, qlen: Optional[torch.Tensor]):
+        """stats[0] = M = sum mask[:,1:]; Nb[b] = sum_t mask[b,t+1][t >= qlen_b-1]; Mb[b] = sum_t mask[b,t+1]."""
+        dev = hip.require_gpu(mask)
+        mask = hip.as_i64(mask)
+        B, Tg = mask.shape
+        if qlen is not None:
+            qlen = hip.as_i64(qlen.reshape(-1))
+            if qlen.shape[0] != B:
+                # the reference zips with strict=True (train_utils.py:127-129)
+                raise ValueError("zip() argument lengths differ: query_token_length vs batch")
+        stats = torch.empty((2,), device=dev, dtype=torch.float32)
+        Nb = torch.empty((B,), device=dev, dtype=torch.float32)
+        Mb = torch.empty((B,), device=dev, dtype=torch.float32)
+        hip.call("dalm_marg_ce_prep", hip.ptr(mask), hip.ptr(qlen), B, Tg, hip.ptr(stats), hip.ptr(Nb), hip.ptr(Mb),
+                 hip.stream())
+        return stats, Nb, Mb
+
+    @staticmethod
+    def _logits_view(logits: torch.Tensor) -> Tuple[torch.Tensor, int, int]:
+        if logits.dim() != 3:
+            raise ValueError(f"logits must be [B,Tg,V], got {tuple(logits.shape)}")
+        if logits.stride(2) != 1 or logits.stride(1) < logits.shape[2] or logits.stride(0) < logits.shape[1] * logits.stride(1):
+            logits = logits.contiguous()
+        return logits, logits.stride(0), logits.stride(1)
+
+    def ce_fwd(self, logits, ids, mask, stats, want_grad: bool, inplace: bool = False):
+        """One pass over the logits: row_lse, row_nll and (optionally) dlogits for upstream grad 1."""
+        dev = hip.require_gpu(logits, ids, mask, stats)
+        logits, sb, st = self._logits_view(logits)
+        ids, mask = hip.as_i64(ids), hip.as_i64(mask)
+        B, Tg, V = logits.shape
+        if ids.shape != (B, Tg) or mask.shape != (B, Tg):
+            raise ValueError(f"ids/mask must be [B,Tg]={B, Tg}, got {tuple(ids.shape)} / {tuple(mask.shape)}")
+        row_lse = torch.empty((B * Tg,), device=dev, dtype=torch.float32)
+        row_nll = torch.empty((B * Tg,), device=dev, dtype=torch.float32)
+        dlogits = None
+        if want_grad:
+            dlogits = logits if inplace else torch.empty_strided(logits.shape, logits.stride(), device=dev, dtype=logits.dtype)
+        hip.call("dalm_marg_ce_fwd", hip.ptr(logits), hip.dtype_code(logits), B, Tg, V, sb, st, hip.ptr(ids),
+                 hip.ptr(mask), hip.ptr(stats), hip.ptr(row_lse), hip.ptr(row_nll), hip.ptr(dlogits), hip.stream())
+        return row_lse, row_nll, dlogits
+
+    def ce_bwd(self, logits, ids, mask, stats, row_lse, gscale):
+        dev = hip.require_gpu(logits, ids, mask, stats, row_lse, gscale)
+        logits, sb, st = self._logits_view(logits)
+        ids, mask = hip.as_i64(ids), hip.as_i64(mask)
+        B, Tg, V = logits.shape
+        dlogits = torch.empty_strided(logits.shape, logits.stride(), device=dev, dtype=logits.dtype)
+        hip.call("dalm_marg_ce_bwd", hip.ptr(logits), hip.dtype_code(logits), B, Tg, V, sb, st, hip.ptr(ids),
+                 hip.ptr(mask), hip.ptr(stats), hip.ptr(row_lse), hip.ptr(gscale), hip.ptr(dlogits), hip.stream())
+        return dlogits
+
+    def scale_inplace(self, x: torch.Tensor, gscale: torch.Tensor) -> torch.Tensor:
+        hip.require_gpu(x, gscale)
+        if not x.is_contiguous():
+            raise ValueError("scale_inplace needs a contiguous tensor")
+        hip.call("dalm_scale_inplace", hip.ptr(x), hip.dtype_code(x), x.numel(), hip.ptr(gscale), hip.stream())
+        return x
+
+    def ce_finalize(self, row_nll, Nb, doc_lp, stats):
+        dev = hip.require_gpu(row_nll, stats)
+        out = torch.empty((1,), device=dev, dtype=torch.float32)
+        hip.call("dalm_marg_ce_finalize", hip.ptr(row_nll), row_nll.numel(), hip.ptr(Nb), hip.ptr(doc_lp),
+                 Nb.shape[0], hip.ptr(stats), hip.ptr(out), hip.stream())
+        return out
+
+    # ---- get_nll / marginalize_log_probs drop-ins -----------------------------------
+    def gather_nll(self, log_probs: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        dev = hip.require_gpu(log_probs, labels)
+        lp = hip.as_f32c(log_probs)
+        labels = hip.as_i64(labels)
+        V = lp.shape[-1]
+        R = lp.numel() // V
+        if labels.numel() != R:
+            raise RuntimeError("Size does not match at dimension 1 (gather index vs log_probs)")
+        out = torch.empty(labels.shape, device=dev, dtype=torch.float32)
+        hip.call("dalm_gather_nll", hip.ptr(lp), hip.ptr(labels), R, V, hip.ptr(out), hip.stream())
+        return out
+
+    def marginalize_rows(self, lp: torch.Tensor, doc_lp: torch.Tensor, qlen: int) -> torch.Tensor:
+        dev = hip.require_gpu(lp, doc_lp)
+        lp = hip.as_f32c(lp)
+        T, V = lp.shape
+        out = torch.empty((T, V), device=dev, dtype=torch.float32)
+        hip.call("dalm_marginalize_rows", hip.ptr(lp), T, V, hip.ptr(hip.as_f32c(doc_lp.reshape(-1)[:1])), int(qlen),
+                 hip.ptr(out), hip.stream())
+        return out
+
+
+_DEFAULT = HipOps()
+
+
+def default_ops() -> HipOps:
+    return _DEFAULT

@@ -1,0 +1,265 @@
+"""CPU oracle for the RAG-end2end / retriever-only loss path of arcee-ai/DALM.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under dalm_amd/ imports this module; it is
+used by tests/, by __graft_entry__.smoke() and by bench.py's `cpu_baseline` leg
+as the checker / CPU baseline, never as the thing shipped or measured as the
+product.
+
+Pinning: the reference's own tests hold no vectors for this path
+(tests/training/rag_e2e/test_*.py are `assert True`), so this restatement is
+pinned against the reference CODE executed in the build container:
+oracle/make_golden.py imports /root/reference (dalm.training.utils.train_utils,
+dalm.models.rag_e2e_base_model, dalm.utils), runs it under autograd on seeded
+inputs and commits inputs+outputs+gradients to tests/golden/*.npz;
+tests/test_oracle_golden.py checks every function below against those files.
+
+Two families:
+  * `ref_*`     - op-for-op restatements of the reference's eager torch code
+                  (same op sequence, so they double as the CPU-baseline "port").
+  * `closed_*`  - the closed-form forward/backward that
+                  the HIP kernels implement, written independently of autograd.
+All functions are dtype-generic (run them in float64 for tight checks).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+
+# ---------------------------------------------------------------------------
+# ref_*: follow the reference line by line
+# ---------------------------------------------------------------------------
+def ref_mean_pooling(token_embeddings: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+    """dalm/models/rag_e2e_base_model.py:108-111 (== retriever_only_base_model.py:66-68)."""
+    m = attention_mask.unsqueeze(-1).expand(token_embeddings.size()).to(token_embeddings.dtype)
+    return torch.sum(token_embeddings * m, 1) / torch.clamp(m.sum(1), min=1e-9)
+
+
+def ref_retrieval_embed(token_embeddings: torch.Tensor, attention_mask: torch.Tensor, normalize: bool = True):
+    """pool + F.normalize(p=2, dim=1): rag_e2e_base_model.py:95-97."""
+    e = ref_mean_pooling(token_embeddings, attention_mask)
+    return F.normalize(e, p=2, dim=1) if normalize else e
+
+
+def ref_eos_mask(mask: torch.Tensor, padding: str = "left") -> torch.Tensor:
+    """dalm/utils.py:22-35."""
+    new_mask = torch.zeros_like(mask)
+    if padding == "right":
+        ones = mask.sum(dim=1)
+        new_mask[torch.arange(mask.size(0)), ones - 1] = 1
+    else:
+        new_mask[:, -1] = 1
+    return new_mask
+
+
+def ref_cosine_sim(q: torch.Tensor, p: torch.Tensor, logit_scale) -> torch.Tensor:
+    """train_utils.py:76-77."""
+    return torch.matmul(q, p.t()) * logit_scale
+
+
+def ref_nt_xent(sim: torch.Tensor) -> torch.Tensor:
+    """train_utils.py:80-88."""
+    return F.cross_entropy(sim, torch.arange(len(sim), device=sim.device))
+
+
+def ref_nll(log_probs: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """train_utils.py:91-93."""
+    return -torch.gather(log_probs, 2, labels.unsqueeze(2)).squeeze(-1)
+
+
+def ref_marginalize_log_probs(lp: torch.Tensor, doc_lp: torch.Tensor, qlen) -> torch.Tensor:
+    """train_utils.py:96-110 (python slice semantics on qlen-1 included)."""
+    qlen = int(qlen)
+    head = lp[: qlen - 1, :]
+    tail = lp[qlen - 1:, :] + doc_lp
+    return torch.cat([head, tail], dim=0)
+
+
+def ref_marginalized_loss(logits, input_ids, attention_mask, scores, query_token_length) -> torch.Tensor:
+    """compute_marginalized_loss_from_logits, train_utils.py:113-138."""
+    lp = F.log_softmax(logits[:, :-1, :], dim=2).view(logits.shape[0], -1, logits.size(-1))
+    doc = torch.log_softmax(scores, dim=1).diag().unsqueeze(-1).unsqueeze(-1)
+    rows = [ref_marginalize_log_probs(a, b, c) for a, b, c in zip(lp, doc, query_token_length, strict=True)]
+    marg = torch.stack(rows)
+    loss = ref_nll(marg, input_ids[:, 1:])
+    lt = loss * attention_mask[:, 1:]
+    return lt.sum() / attention_mask[:, 1:].sum()
+
+
+def ref_step_loss(q, p, logits, ids, mask, qlen, logit_scale) -> Dict[str, torch.Tensor]:
+    """The loss part of the RAG-e2e step body, train_rage2e.py:441-467."""
+    S = ref_cosine_sim(q, p, logit_scale)
+    con = (ref_nt_xent(S) + ref_nt_xent(S.t())) / 2.0
+    out = {"S": S, "contrastive": con}
+    if logits is not None:
+        gen = ref_marginalized_loss(logits, ids, mask, S, qlen)
+        out["generator"] = gen
+        out["loss"] = con + gen
+    else:
+        out["loss"] = con
+    return out
+
+
+# ---------------------------------------------------------------------------
+# closed_*: what the kernels compute
+# ---------------------------------------------------------------------------
+def _cut_rows(qlen: torch.Tensor, T: int) -> torch.Tensor:
+    """First shifted row that receives the doc term: python slice start of lp[qlen-1:] over T rows."""
+    cut = qlen.to(torch.int64) - 1
+    cut = torch.where(cut < 0, torch.clamp(cut + T, min=0), cut)
+    return cut
+
+
+def closed_pool(h: torch.Tensor, mask: torch.Tensor, normalize: bool = True):
+    m = mask.to(h.dtype)
+    cnt = torch.clamp(m.sum(1, keepdim=True), min=1e-9)
+    u = (h * m.unsqueeze(-1)).sum(1) / cnt
+    nrm = u.norm(dim=1, keepdim=True)
+    e = u / torch.clamp(nrm, min=1e-12) if normalize else u
+    return e, nrm.squeeze(1), (1.0 / cnt).squeeze(1)
+
+
+def closed_pool_bwd(d_emb, emb, nrm, inv_cnt, mask, normalize: bool = True):
+    if normalize:
+        dot = (emb * d_emb).sum(1, keepdim=True)
+        big = (nrm >= 1e-12).unsqueeze(1)
+        du = torch.where(big, (d_emb - emb * dot) / nrm.unsqueeze(1).clamp(min=1e-300), d_emb / 1e-12)
+    else:
+        du = d_emb
+    g = du * inv_cnt.unsqueeze(1)
+    return mask.to(d_emb.dtype).unsqueeze(-1) * g.unsqueeze(1)
+
+
+def closed_forward(q, p, logits, ids, mask, qlen, scale) -> Dict[str, torch.Tensor]:
+    S = scale * (q @ p.t())
+    B = S.shape[0]
+    lse_r = torch.logsumexp(S, dim=1)
+    lse_c = torch.logsumexp(S, dim=0)
+    d = S.diag()
+    con = 0.5 * ((lse_r - d).mean() + (lse_c - d).mean())
+    out = {"S": S, "lse_r": lse_r, "lse_c": lse_c, "diag": d, "contrastive": con, "doc_lp": d - lse_r, "B": B}
+    if logits is None:
+        out["loss"] = con
+        return out
+    x = logits[:, :-1, :]
+    T = x.shape[1]
+    m = mask[:, 1:].to(x.dtype)
+    y = ids[:, 1:]
+    lse = torch.logsumexp(x, dim=2)
+    xy = torch.gather(x, 2, y.unsqueeze(2)).squeeze(2)
+    M = m.sum()
+    cut = _cut_rows(qlen.reshape(-1), T)
+    a = (torch.arange(T).unsqueeze(0) >= cut.unsqueeze(1)).to(x.dtype)
+    Nb = (m * a).sum(1)
+    gen = ((m * (lse - xy)).sum() - (Nb * out["doc_lp"]).sum()) / M
+    out.update({"row_lse": lse, "M": M, "Nb": Nb, "Mb": m.sum(1), "generator": gen, "loss": con + gen})
+    return out
+
+
+def closed_backward(q, p, logits, ids, mask, qlen, scale, fwd: Optional[dict] = None, g: float = 1.0):
+    """dL/dq, dL/dp, dL/dlogits from the closed form (no autograd)."""
+    f = fwd or closed_forward(q, p, logits, ids, mask, qlen, scale)
+    S, B = f["S"], f["B"]
+    eye = torch.eye(B, dtype=S.dtype)
+    soft_r = torch.exp(S - f["lse_r"].unsqueeze(1))
+    soft_c = torch.exp(S - f["lse_c"].unsqueeze(0))
+    dS = g * ((soft_r - eye) + (soft_c - eye)) / (2.0 * B)
+    dlogits = None
+    if logits is not None:
+        dS = dS + g * (f["Nb"] / f["M"]).unsqueeze(1) * (soft_r - eye)
+        x = logits[:, :-1, :]
+        m = mask[:, 1:].to(x.dtype)
+        soft = torch.softmax(x, dim=2)
+        onehot = F.one_hot(ids[:, 1:], x.shape[2]).to(x.dtype)
+        dl = g * (m / f["M"]).unsqueeze(2) * (soft - onehot)
+        dlogits = torch.cat([dl, torch.zeros_like(logits[:, -1:, :])], dim=1)
+    dq = scale * (dS @ p)
+    dp = scale * (dS.t() @ q)
+    return {"dS": dS, "dq": dq, "dp": dp, "dlogits": dlogits}
+
+
+# ---------------------------------------------------------------------------
+# OracleOps: the dalm_amd.ops.HipOps interface on CPU tensors (float64 inside).
+# Injected by tests/test_sharded_gloo.py to exercise the world_size>1 host logic
+# without a GPU.  NOT importable from the product package.
+# ---------------------------------------------------------------------------
+class OracleOps:
+    name = "oracle"
+    dt = torch.float64
+
+    def pool_fwd(self, h, mask, normalize):
+        e, nrm, ic = closed_pool(h.to(self.dt), mask, normalize)
+        return e.float(), nrm.float(), ic.float()
+
+    def pool_bwd(self, d_emb, emb, norm, inv_count, mask, normalize, T, dtype):
+        return closed_pool_bwd(d_emb.to(self.dt), emb.to(self.dt), norm.to(self.dt), inv_count.to(self.dt), mask,
+                               normalize).to(dtype)
+
+    def sim_rowstats(self, A, Bm, scale, diag_offset):
+        S = scale * (A.to(self.dt) @ Bm.to(self.dt).t())
+        idx = torch.arange(A.shape[0])
+        return torch.logsumexp(S, 1).float(), S[idx, diag_offset + idx].float()
+
+    def sim_grad(self, A, Bm, scale, diag_offset, row_coef, row_lse, col_coef, col_lse):
+        A64, B64 = A.to(self.dt), Bm.to(self.dt)
+        S = scale * (A64 @ B64.t())
+        rc, cc = row_coef.to(self.dt).unsqueeze(1), col_coef.to(self.dt).unsqueeze(0)
+        dS = rc * torch.exp(S - row_lse.to(self.dt).unsqueeze(1)) + cc * torch.exp(S - col_lse.to(self.dt).unsqueeze(0))
+        idx = torch.arange(A.shape[0])
+        dS[idx, diag_offset + idx] -= (rc.squeeze(1) + cc.squeeze(0)[diag_offset + idx])
+        return (scale * (dS @ B64)).float()
+
+    def contrastive_finalize(self, row_lse, col_lse, diag, n_global):
+        r, c, d = row_lse.to(self.dt), col_lse.to(self.dt), diag.to(self.dt)
+        out = 0.5 * ((r - d).sum() + (c - d).sum()) / n_global
+        return out.reshape(1).float(), (d - r).float()
+
+    def ce_prep(self, mask, qlen):
+        m = mask[:, 1:].to(self.dt)
+        T = m.shape[1]
+        if qlen is None:
+            Nb = torch.zeros(m.shape[0], dtype=self.dt)
+        else:
+            cut = _cut_rows(qlen.reshape(-1), T)
+            a = (torch.arange(T).unsqueeze(0) >= cut.unsqueeze(1)).to(self.dt)
+            Nb = (m * a).sum(1)
+        stats = torch.tensor([m.sum(), float(m.shape[0])], dtype=torch.float32)
+        return stats, Nb.float(), m.sum(1).float()
+
+    def ce_fwd(self, logits, ids, mask, stats, want_grad, inplace=False):
+        B, Tg, V = logits.shape
+        x = logits[:, :-1, :].to(self.dt)
+        m = mask[:, 1:].to(self.dt)
+        y = ids[:, 1:]
+        lse = torch.logsumexp(x, 2)
+        xy = torch.gather(x, 2, y.unsqueeze(2)).squeeze(2)
+        row_lse = torch.zeros(B, Tg, dtype=self.dt)
+        row_nll = torch.zeros(B, Tg, dtype=self.dt)
+        row_lse[:, :-1] = lse * (m != 0)
+        row_nll[:, :-1] = m * (lse - xy)
+        dl = None
+        if want_grad:
+            M = stats[0].to(self.dt)
+            soft = torch.softmax(x, 2)
+            onehot = F.one_hot(y, V).to(self.dt)
+            d = (m / M).unsqueeze(2) * (soft - onehot)
+            dl = torch.cat([d, torch.zeros(B, 1, V, dtype=self.dt)], 1).to(logits.dtype)
+            if inplace:
+                logits.copy_(dl)
+                dl = logits
+        return row_lse.reshape(-1).float(), row_nll.reshape(-1).float(), dl
+
+    def ce_bwd(self, logits, ids, mask, stats, row_lse, gscale):
+        _, _, dl = self.ce_fwd(logits, ids, mask, stats, True)
+        return (dl.to(self.dt) * gscale.to(self.dt)).to(logits.dtype)
+
+    def scale_inplace(self, x, gscale):
+        return x.mul_(gscale.to(x.dtype))
+
+    def ce_finalize(self, row_nll, Nb, doc_lp, stats):
+        s = row_nll.to(self.dt).sum()
+        if doc_lp is not None:
+            s = s - (Nb.to(self.dt) * doc_lp.to(self.dt)).sum()
+        return (s / stats[0].to(self.dt)).reshape(1).float()

@@ -1,0 +1,191 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own code on CPU.
+
+Runs only in the build container (needs /root/reference).  Recipe (SURVEY.md
+section 8c): import transformers first, plant a 4-name dummy `peft` module so
+`dalm.models.*` imports, import the reference modules, remove the stub again.
+The functions exercised are exactly
+    dalm.training.utils.train_utils.{get_cosine_sim,get_nt_xent_loss,get_nll,
+        marginalize_log_probs,compute_marginalized_loss_from_logits}
+    dalm.models.rag_e2e_base_model.AutoModelForRagE2E.mean_pooling (+F.normalize)
+    dalm.utils.eos_mask
+executed in float64 AND float32 under autograd; inputs, outputs and gradients
+are stored.  The committed .npz files travel to the GPU box; this script and
+/root/reference do not need to.
+
+    python oracle/make_golden.py            # rewrites tests/golden/
+"""
+from __future__ import annotations
+
+import sys
+import types
+import zlib
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REF = Path("/root/reference")
+OUT = Path(__file__).resolve().parent.parent / "tests" / "golden"
+
+
+def import_reference():
+    import transformers  # noqa: F401  (must be imported before the stub goes in)
+
+    stub = types.ModuleType("peft")
+    for name in ("LoraConfig", "PeftModel", "TaskType", "get_peft_model"):
+        setattr(stub, name, type(name, (), {}))
+    sys.modules["peft"] = stub
+    sys.path.insert(0, str(REF))
+    try:
+        import dalm.models.rag_e2e_base_model as m_rag
+        import dalm.training.utils.train_utils as tu
+        import dalm.utils as du
+    finally:
+        sys.modules.pop("peft", None)
+        sys.path.remove(str(REF))
+    return tu, m_rag, du
+
+
+def make_batch(gen: torch.Generator, B, D, Tg, V, *, pad_side="right", qlen_mode="normal", dead_row=False,
+               logit_gain=2.0, normalize=True):
+    q = torch.randn(B, D, generator=gen, dtype=torch.float64)
+    p = torch.randn(B, D, generator=gen, dtype=torch.float64)
+    if normalize:
+        q = q / q.norm(dim=1, keepdim=True)
+        p = p / p.norm(dim=1, keepdim=True)
+    logits = logit_gain * torch.randn(B, Tg, V, generator=gen, dtype=torch.float64)
+    ids = torch.randint(0, V, (B, Tg), generator=gen)
+    lens = torch.randint(max(2, Tg // 3), Tg + 1, (B,), generator=gen)
+    mask = torch.zeros(B, Tg, dtype=torch.int64)
+    for b in range(B):
+        n = int(lens[b])
+        if pad_side == "right":
+            mask[b, :n] = 1
+        else:
+            mask[b, Tg - n:] = 1
+    if dead_row and B > 1:
+        mask[B - 1] = 0
+    if qlen_mode == "normal":
+        qlen = torch.clamp((lens.float() * 0.8).floor().long(), min=1)
+    elif qlen_mode == "beyond":      # qlen >= Tg: no doc term anywhere (un-truncated prompt longer than Tg)
+        qlen = torch.full((B,), Tg + 7, dtype=torch.int64)
+    elif qlen_mode == "one":         # qlen == 1: every shifted row gets the doc term
+        qlen = torch.ones(B, dtype=torch.int64)
+    elif qlen_mode == "mixed":
+        qlen = torch.tensor([(1, Tg - 1, Tg, Tg + 3, 2)[i % 5] for i in range(B)], dtype=torch.int64)
+    else:
+        raise ValueError(qlen_mode)
+    return q, p, logits, ids, mask, qlen
+
+
+def run_reference_loss(tu, q, p, logits, ids, mask, qlen, scale, dtype):
+    q = q.to(dtype).clone().requires_grad_(True)
+    p = p.to(dtype).clone().requires_grad_(True)
+    lg = logits.to(dtype).clone().requires_grad_(True)
+    S = tu.get_cosine_sim(q, p, scale)
+    S.retain_grad()
+    loss_q = tu.get_nt_xent_loss(S)
+    loss_p = tu.get_nt_xent_loss(S.t())
+    con = (loss_q + loss_p) / 2.0
+    gen = tu.compute_marginalized_loss_from_logits(lg, ids, mask, S, qlen)
+    total = con + gen
+    total.backward()
+    return {
+        "S": S.detach(), "loss_query": loss_q.detach(), "loss_passage": loss_p.detach(),
+        "contrastive": con.detach(), "generator": gen.detach(), "loss": total.detach(),
+        "dS": S.grad, "dq": q.grad, "dp": p.grad, "dlogits": lg.grad,
+    }
+
+
+def run_reference_con_only(tu, q, p, scale, dtype):
+    q = q.to(dtype).clone().requires_grad_(True)
+    p = p.to(dtype).clone().requires_grad_(True)
+    S = tu.get_cosine_sim(q, p, scale)
+    con = (tu.get_nt_xent_loss(S) + tu.get_nt_xent_loss(S.t())) / 2.0
+    con.backward()
+    return {"con_only": con.detach(), "con_only_dq": q.grad, "con_only_dp": p.grad}
+
+
+def to_np(d):
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
+
+
+LOSS_CASES = {
+    # name: (B, D, Tg, V, kwargs)
+    "base_right_pad":      (4, 32, 12, 50, {}),
+    "left_pad":            (3, 32, 12, 50, {"pad_side": "left"}),
+    "batch_one":           (1, 16, 10, 30, {}),
+    "partial_batch_3":     (3, 48, 9, 37, {"qlen_mode": "mixed"}),
+    "qlen_beyond_Tg":      (4, 32, 12, 50, {"qlen_mode": "beyond"}),
+    "qlen_one":            (4, 32, 12, 50, {"qlen_mode": "one"}),
+    "dead_row":            (5, 32, 12, 50, {"dead_row": True, "qlen_mode": "mixed"}),
+    "bge_small_dim":       (5, 384, 16, 201, {"qlen_mode": "mixed"}),
+    "unnormalised_embs":   (4, 24, 8, 33, {"normalize": False}),
+    "odd_vocab_1000":      (6, 64, 24, 1003, {"pad_side": "left", "qlen_mode": "mixed", "logit_gain": 4.0}),
+}
+
+
+def main() -> None:
+    tu, m_rag, du = import_reference()
+    OUT.mkdir(parents=True, exist_ok=True)
+    torch.manual_seed(0)
+
+    # ---- loss path ------------------------------------------------------------
+    for i, (name, (B, D, Tg, V, kw)) in enumerate(LOSS_CASES.items()):
+        gen = torch.Generator().manual_seed(1000 + i)
+        scale = 100 if kw.get("normalize", True) else 1
+        q, p, logits, ids, mask, qlen = make_batch(gen, B, D, Tg, V, **kw)
+        rec = {"q": q, "p": p, "logits": logits, "ids": ids, "mask": mask, "qlen": qlen,
+               "scale": np.int64(scale)}
+        r64 = run_reference_loss(tu, q, p, logits, ids, mask, qlen, scale, torch.float64)
+        r32 = run_reference_loss(tu, q, p, logits, ids, mask, qlen, scale, torch.float32)
+        rec.update({f"ref64_{k}": v for k, v in r64.items()})
+        rec.update({f"ref32_{k}": v for k, v in r32.items()})
+        rec.update({f"ref64_{k}": v for k, v in run_reference_con_only(tu, q, p, scale, torch.float64).items()})
+        np.savez_compressed(OUT / f"loss_{name}.npz", **to_np(rec))
+        print(f"loss_{name}: loss={float(r64['loss']):.12f} (fp32 {float(r32['loss']):.8f})")
+
+    # ---- get_nll / marginalize_log_probs on their own ----------------------------
+    gen = torch.Generator().manual_seed(77)
+    lp = torch.log_softmax(torch.randn(3, 7, 19, generator=gen, dtype=torch.float64), dim=2)
+    labels = torch.randint(0, 19, (3, 7), generator=gen)
+    rec = {"lp": lp, "labels": labels, "nll": tu.get_nll(lp, labels)}
+    for ql in (1, 2, 4, 7, 8, 12):
+        rec[f"marg_q{ql}"] = tu.marginalize_log_probs(lp[0], torch.tensor([[-1.25]], dtype=torch.float64)[0],
+                                                      torch.tensor(ql))
+    np.savez_compressed(OUT / "pieces.npz", **to_np(rec))
+
+    # ---- pooling + normalise + eos_mask -----------------------------------------------
+    pool = m_rag.AutoModelForRagE2E.mean_pooling
+    for name, (B, T, D, normalize, dead) in {
+        "pool_base": (4, 9, 32, True, False),
+        "pool_bge_small": (3, 13, 384, True, False),
+        "pool_no_norm": (3, 7, 20, False, False),
+        "pool_dead_row": (4, 6, 16, True, True),
+    }.items():
+        gen = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
+        h = torch.randn(B, T, D, generator=gen, dtype=torch.float64)
+        lens = torch.randint(1, T + 1, (B,), generator=gen)
+        mask = (torch.arange(T).unsqueeze(0) < lens.unsqueeze(1)).long()
+        if dead:
+            mask[-1] = 0
+        up = torch.randn(B, D, generator=gen, dtype=torch.float64)
+        rec = {"h": h, "mask": mask, "upstream": up, "normalize": np.bool_(normalize)}
+        for dt, tag in ((torch.float64, "ref64"), (torch.float32, "ref32")):
+            hh = h.to(dt).clone().requires_grad_(True)
+            e = pool(None, hh, mask)
+            if normalize:
+                e = torch.nn.functional.normalize(e, p=2, dim=1)
+            (e * up.to(dt)).sum().backward()
+            rec[f"{tag}_emb"] = e.detach()
+            rec[f"{tag}_dh"] = hh.grad
+        rec["eos_mask_left"] = du.eos_mask(mask)
+        rec["eos_mask_right"] = du.eos_mask(mask.clamp(min=0) if not dead else torch.ones_like(mask), padding="right")
+        np.savez_compressed(OUT / f"{name}.npz", **to_np(rec))
+        print(name, "ok")
+
+
+if __name__ == "__main__":
+    if not REF.exists():
+        sys.exit("/root/reference not present: golden vectors can only be regenerated in the build container")
+    main()

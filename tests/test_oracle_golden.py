@@ -1,0 +1,105 @@
+"""Pin the CPU oracle to the reference: every oracle function vs the golden vectors that
+oracle/make_golden.py dumped from the reference's own code."""
+import pytest
+import torch
+
+import dalm_oracle as O
+from helpers import LOSS_CASES, POOL_CASES, load_npz
+
+
+def test_golden_files_present():
+    assert len(LOSS_CASES) >= 10 and len(POOL_CASES) >= 4
+
+
+@pytest.mark.parametrize("case", LOSS_CASES)
+def test_ref_restatement_matches_reference_fp64(case):
+    z = load_npz(case)
+    q = z["q"].clone().requires_grad_(True)
+    p = z["p"].clone().requires_grad_(True)
+    lg = z["logits"].clone().requires_grad_(True)
+    out = O.ref_step_loss(q, p, lg, z["ids"], z["mask"], z["qlen"], int(z["scale"]))
+    out["loss"].backward()
+    for k in ("S", "contrastive", "generator", "loss"):
+        torch.testing.assert_close(out[k].detach(), z[f"ref64_{k}"], rtol=1e-12, atol=1e-12, equal_nan=True)
+    torch.testing.assert_close(q.grad, z["ref64_dq"], rtol=1e-11, atol=1e-12, equal_nan=True)
+    torch.testing.assert_close(p.grad, z["ref64_dp"], rtol=1e-11, atol=1e-12, equal_nan=True)
+    torch.testing.assert_close(lg.grad, z["ref64_dlogits"], rtol=1e-11, atol=1e-13, equal_nan=True)
+
+
+@pytest.mark.parametrize("case", LOSS_CASES)
+def test_closed_form_matches_reference_fp64(case):
+    z = load_npz(case)
+    s = float(z["scale"])
+    f = O.closed_forward(z["q"], z["p"], z["logits"], z["ids"], z["mask"], z["qlen"], s)
+    for k in ("contrastive", "generator", "loss"):
+        torch.testing.assert_close(f[k], z[f"ref64_{k}"], rtol=1e-11, atol=1e-11, equal_nan=True)
+    b = O.closed_backward(z["q"], z["p"], z["logits"], z["ids"], z["mask"], z["qlen"], s, f)
+    torch.testing.assert_close(b["dS"], z["ref64_dS"], rtol=1e-10, atol=1e-13)
+    torch.testing.assert_close(b["dq"], z["ref64_dq"], rtol=1e-10, atol=1e-11)
+    torch.testing.assert_close(b["dp"], z["ref64_dp"], rtol=1e-10, atol=1e-11)
+    torch.testing.assert_close(b["dlogits"], z["ref64_dlogits"], rtol=1e-10, atol=1e-13)
+
+
+@pytest.mark.parametrize("case", LOSS_CASES)
+def test_contrastive_only_closed_form(case):
+    z = load_npz(case)
+    s = float(z["scale"])
+    f = O.closed_forward(z["q"], z["p"], None, None, None, None, s)
+    torch.testing.assert_close(f["loss"], z["ref64_con_only"], rtol=1e-11, atol=1e-11)
+    b = O.closed_backward(z["q"], z["p"], None, None, None, None, s, f)
+    torch.testing.assert_close(b["dq"], z["ref64_con_only_dq"], rtol=1e-10, atol=1e-11)
+    torch.testing.assert_close(b["dp"], z["ref64_con_only_dp"], rtol=1e-10, atol=1e-11)
+
+
+def test_fp32_reference_within_tolerance_of_fp64():
+    """How far the reference's own fp32 run is from fp64: sets the scale of the 1e-3 target."""
+    for case in LOSS_CASES:
+        z = load_npz(case)
+        a, b = float(z["ref32_loss"]), float(z["ref64_loss"])
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (case, a, b)
+
+
+def test_pieces_nll_and_marginalize():
+    z = load_npz("pieces")
+    torch.testing.assert_close(O.ref_nll(z["lp"], z["labels"]), z["nll"], rtol=0, atol=0)
+    doc = torch.tensor([-1.25], dtype=torch.float64)
+    for ql in (1, 2, 4, 7, 8, 12):
+        torch.testing.assert_close(O.ref_marginalize_log_probs(z["lp"][0], doc, ql), z[f"marg_q{ql}"], rtol=0, atol=0)
+        # closed-form row rule used by the kernels
+        T = z["lp"].shape[1]
+        cut = int(O._cut_rows(torch.tensor([ql]), T)[0])
+        exp = z["lp"][0].clone()
+        exp[cut:] += doc
+        torch.testing.assert_close(exp, z[f"marg_q{ql}"], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("case", POOL_CASES)
+def test_pool_oracle_matches_reference(case):
+    z = load_npz(case)
+    normalize = bool(z["normalize"])
+    h = z["h"].clone().requires_grad_(True)
+    e = O.ref_retrieval_embed(h, z["mask"], normalize)
+    (e * z["upstream"]).sum().backward()
+    torch.testing.assert_close(e.detach(), z["ref64_emb"], rtol=1e-12, atol=1e-12)
+    torch.testing.assert_close(h.grad, z["ref64_dh"], rtol=1e-11, atol=1e-12)
+    e2, nrm, ic = O.closed_pool(z["h"], z["mask"], normalize)
+    torch.testing.assert_close(e2, z["ref64_emb"], rtol=1e-11, atol=1e-12)
+    dh = O.closed_pool_bwd(z["upstream"], e2, nrm, ic, z["mask"], normalize)
+    torch.testing.assert_close(dh, z["ref64_dh"], rtol=1e-9, atol=1e-11)
+    torch.testing.assert_close(O.ref_eos_mask(z["mask"]), z["eos_mask_left"], rtol=0, atol=0)
+
+
+def test_oracle_ops_consistent_with_closed_form():
+    """OracleOps (the checker backend injected into the sharded-loss tests) == closed form."""
+    z = load_npz("loss_dead_row")
+    ops = O.OracleOps()
+    q, p, s = z["q"].float(), z["p"].float(), float(z["scale"])
+    lse_r, diag = ops.sim_rowstats(q, p, s, 0)
+    lse_c, _ = ops.sim_rowstats(p, q, s, 0)
+    con, doc = ops.contrastive_finalize(lse_r, lse_c, diag, q.shape[0])
+    stats, Nb, Mb = ops.ce_prep(z["mask"], z["qlen"])
+    rl, rn, dl = ops.ce_fwd(z["logits"].float(), z["ids"], z["mask"], stats, True)
+    gen = ops.ce_finalize(rn, Nb, doc, stats)
+    assert abs(float(con) - float(z["ref64_contrastive"])) < 1e-4 * abs(float(z["ref64_contrastive"]))
+    assert abs(float(gen) - float(z["ref64_generator"])) < 1e-4 * abs(float(z["ref64_generator"]))
+    torch.testing.assert_close(dl.double(), z["ref64_dlogits"], rtol=1e-4, atol=1e-7)
