@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(const GemmParams 
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int col = bn0 + wn * WN + j * 32 + l31;
-          if (row_ok && col < p.N) p.C[static_cast<int64_t>(row) * p.ldc + col] = p.alpha * acc[i][j][r];
+          if (row_ok && col < p.N) p.C[static_cast<int64_t>(row) * p.ldc + col] = __fmul_rn(p.alpha, acc[i][j][r]);
         }
       } else if constexpr (EPI == EPI_DS) {
         const float rc = row_ok ? p.row_coef[row] : 0.f;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(const GemmParams 
         for (int j = 0; j < TN; ++j) {
           const int col = bn0 + wn * WN + j * 32 + l31;
           if (row_ok && col < p.N) {
-            const float s = p.alpha * acc[i][j][r];
+            const float s = __fmul_rn(p.alpha, acc[i][j][r]);  // no fma contraction: same S bits as the rowstats pass
             const float cc = p.col_coef[col];
             float d = rc * fast_exp(s - rl) + cc * fast_exp(s - p.col_lse[col]);
             if (static_cast<int64_t>(col) == p.diag_offset + row) d -= (rc + cc);
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(const GemmParams 
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int col = bn0 + wn * WN + j * 32 + l31;
-          v[j] = (col < p.N) ? p.alpha * acc[i][j][r] : -INFINITY;
+          v[j] = (col < p.N) ? __fmul_rn(p.alpha, acc[i][j][r]) : -INFINITY;
           if (row_ok && col < p.N && static_cast<int64_t>(col) == p.diag_offset + row) p.diag[row] = v[j];
           mx = fmaxf(mx, v[j]);
         }

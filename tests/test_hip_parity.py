@@ -34,15 +34,15 @@ def assert_grad_close(got, ref, rtol=GRAD_NORM_RTOL, name=""):
     assert torch.equal(nan_g, nan_r), f"{name}: NaN pattern differs"
     got, ref = torch.nan_to_num(got), torch.nan_to_num(ref)
     scale = float(ref.abs().max())
-    if scale == 0.0:
-        assert float(got.abs().max()) == 0.0, name
+    if scale == 0.0:  # analytically zero gradient (e.g. B == 1): allow rounding residue only
+        assert float(got.abs().max()) <= 1e-5, name
         return
     assert norm_rel_err(got, ref) <= rtol, (name, norm_rel_err(got, ref))
     assert float((got - ref).abs().max()) <= 10 * rtol * scale, (name, float((got - ref).abs().max()), scale)
 
 
 def assert_loss_close(got, ref, rtol=LOSS_RTOL):
-    got, ref = float(got), float(ref)
+    got, ref = float(got.detach()) if torch.is_tensor(got) else float(got), float(ref)
     if ref != ref:
         assert got != got
         return
