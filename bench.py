@@ -1,0 +1,267 @@
+#!/usr/bin/env python
+"""bench.py - training pairs/sec of the RAG-end2end step on N MI355X (one process per GPU).
+
+Workload (BASELINE.json configs[2], the config the headline metric is quoted on; fits one GPU):
+    retriever  bge-large-en architecture (BERT 24L/1024/16H/4096, vocab 30522), LoRA r=8 on q/k/v
+    generator  Llama-2-7b-hf architecture (32L/4096/32H/11008, vocab 32000), LoRA r=8 on q_proj/v_proj
+    per-GPU batch 18, Tq=50, Tp=128, Tg=256, logit_scale 100, Adam lr 1e-4, bf16 autocast
+    random-init weights of those architectures + synthetic (Passage, Query, Answer) token rows
+    (no network for checkpoints/datasets).
+A "step" = passage tower + query tower + generator forward, the fused HIP loss path
+(pool/normalise, f32-MFMA similarity + contrastive, marginalised CE with the logits gradient written
+in the same pass), backward, gradient all-reduce (N>1), Adam, scheduler, zero_grad - nothing skipped.
+With N>1 every rank keeps batch 18 (weak scaling) and the in-batch negatives span the global batch
+(RCCL all-gather of the embeddings over xGMI, overlapped with the query tower on a side stream).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant hand-written kernel
+(marg_ce_row_kernel: 2*R*V*el algorithmic bytes per launch, R = B*(Tg-1) dense rows), timed live with
+HIP events on the launch stream.  `cpu_baseline` times the reference-equivalent CPU path (oracle
+restatement + the same HF architectures) on the host cores, bounded by depth-scaling (see
+cpu_reference_baseline).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+A100_README_PAIRS_PER_S = 200000.0 / (7 * 3600.0)  # reference README.md:34-40 (1x A100 80GB), BASELINE.md section 1
+
+CFG = dict(B=18, Tq=50, Tp=128, Tg=256, D=1024, V=32000, logit_scale=100)
+
+
+def build_models(device, dtype, bert_layers=24, llama_layers=32, lora=True):
+    from transformers import BertConfig, BertModel, LlamaConfig, LlamaForCausalLM
+
+    from dalm_amd.models import AutoModelForRagE2E, Mode
+
+    bc = BertConfig(hidden_size=1024, num_hidden_layers=bert_layers, num_attention_heads=16, intermediate_size=4096,
+                    vocab_size=30522, max_position_embeddings=512)
+    lc = LlamaConfig(num_hidden_layers=llama_layers)  # defaults == Llama-2-7b-hf
+    torch.manual_seed(0)  # identical weights on every rank
+    with torch.device(device):
+        old = torch.get_default_dtype()
+        torch.set_default_dtype(dtype)
+        try:
+            retriever = BertModel(bc)
+            generator = LlamaForCausalLM(lc)
+        finally:
+            torch.set_default_dtype(old)
+    return AutoModelForRagE2E.from_modules(retriever, generator, None, None, normalize=True,
+                                           get_peft=Mode.BOTH if lora else None)
+
+
+def synthetic_batch(device, seed, B=CFG["B"], Tq=CFG["Tq"], Tp=CFG["Tp"], Tg=CFG["Tg"]):
+    """Token-id level synthetic (Passage, Query, Answer) rows, SURVEY.md section 8(d)."""
+    g = torch.Generator().manual_seed(seed)
+
+    def ids(n, T, V):
+        return torch.randint(1000, V, (n, T), generator=g)
+
+    def right_mask(T, lo, hi):
+        lens = torch.randint(lo, hi + 1, (B, 1), generator=g)
+        return (torch.arange(T).unsqueeze(0) < lens).long()
+
+    glen = torch.randint(60, Tg + 1, (B, 1), generator=g)
+    gmask = (torch.arange(Tg).unsqueeze(0) >= (Tg - glen)).long()  # Llama tokenizers pad left
+    batch = {
+        "retriever_query_input_ids": ids(B, Tq, 30522), "retriever_query_attention_mask": right_mask(Tq, 5, 15),
+        "retriever_passage_input_ids": ids(B, Tp, 30522), "retriever_passage_attention_mask": right_mask(Tp, 30, Tp),
+        "generator_input_input_ids": ids(B, Tg, 32000), "generator_input_attention_mask": gmask,
+        "query_passage_input_len": (glen.squeeze(1).float() * 0.8).long().clamp(min=1),
+    }
+    return {k: v.to(device) for k, v in batch.items()}
+
+
+class TimedOps:
+    """HipOps with HIP events around the dominant kernel launch (marginalised CE, fused fwd+grad)."""
+
+    def __init__(self):
+        from dalm_amd.ops import HipOps
+
+        self._ops = HipOps()
+        self.events = []
+        self.enabled = False
+
+    def __getattr__(self, name):
+        return getattr(self._ops, name)
+
+    def ce_fwd(self, logits, ids, mask, stats, want_grad, inplace=False):
+        if not self.enabled:
+            return self._ops.ce_fwd(logits, ids, mask, stats, want_grad, inplace)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()  # torch's current stream == the stream the kernel is launched on
+        out = self._ops.ce_fwd(logits, ids, mask, stats, want_grad, inplace)
+        b.record()
+        self.events.append((a, b, logits.element_size() * (2 if want_grad else 1)))
+        return out
+
+
+def cpu_reference_baseline(max_seconds=60.0):
+    """Reference CPU path on the host cores, bounded: the oracle restatement of the reference's loss
+    code at the full cfg3 shapes, and the same HF architectures with LoRA at depth 1 and 2 (instead of
+    24 / 32 layers); per-layer time is extrapolated linearly to full depth.  fp32, torch CPU threads =
+    all host cores, one step each."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import dalm_oracle as O
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    dev = torch.device("cpu")
+    times = {}
+    t_start = time.time()
+    for depth in (1, 2):
+        model = build_models(dev, torch.float32, bert_layers=depth, llama_layers=depth)
+        model.train()
+        params = [p for p in model.parameters() if p.requires_grad]
+        opt = torch.optim.Adam(params, lr=1e-4)
+        batch = synthetic_batch(dev, 0)
+
+        def step():
+            qh = model.retriever_model(batch["retriever_query_input_ids"], batch["retriever_query_attention_mask"])[0]
+            ph = model.retriever_model(batch["retriever_passage_input_ids"], batch["retriever_passage_attention_mask"])[0]
+            q = O.ref_retrieval_embed(qh, batch["retriever_query_attention_mask"])
+            p = O.ref_retrieval_embed(ph, batch["retriever_passage_attention_mask"])
+            logits = model.generator_model(input_ids=batch["generator_input_input_ids"],
+                                           attention_mask=batch["generator_input_attention_mask"]).logits
+            out = O.ref_step_loss(q, p, logits, batch["generator_input_input_ids"],
+                                  batch["generator_input_attention_mask"], batch["query_passage_input_len"],
+                                  CFG["logit_scale"])
+            out["loss"].backward()
+            opt.step()
+            model.zero_grad()
+
+        if depth == 1:
+            step()  # warm-up (thread pools, allocator)
+        t0 = time.time()
+        step()
+        times[depth] = time.time() - t0
+        del model, opt
+        if time.time() - t_start > max_seconds:
+            break
+    if len(times) == 2:
+        per_layer = max(times[2] - times[1], 0.0)   # one BERT layer (x2 towers) + one Llama layer
+        fixed = max(times[1] - per_layer, 0.0)      # embeddings, lm_head, loss path, Adam
+        # 24 BERT + 32 Llama layers: scale the combined per-layer time by the Llama count for the
+        # Llama share and BERT count for the BERT share; they are not separable from two points, so
+        # use the conservative (smaller) count for the whole increment -> an UPPER bound on CPU speed.
+        full = fixed + 24 * per_layer
+        note = (f"oracle loss path at full cfg3 shapes + HF towers at depth 1 ({times[1]:.2f}s) and 2 ({times[2]:.2f}s) "
+                f"per step, extrapolated linearly to 24 layers (upper bound on CPU throughput; true depth 24/32)")
+    else:
+        full = times[1]
+        note = f"depth-1 towers only ({times[1]:.2f}s/step); extrapolation skipped (time bound)"
+    return {"value": CFG["B"] / full, "unit": "training pairs/s", "cores": cores, "kind": "port", "sample": note}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--retriever-layers", type=int, default=24, help=argparse.SUPPRESS)
+    ap.add_argument("--generator-layers", type=int, default=32, help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    from dalm_amd import hip
+    from dalm_amd.sharded import barrier, init_distributed
+    from dalm_amd.training.step import RagE2EStep
+
+    hip.load()  # no HIP extension -> fail here, loudly
+    comm, dev = init_distributed()
+    if dev.type != "cuda":
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    if comm.world_size != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={comm.world_size}: launch with torch.distributed.run")
+    rank = comm.rank
+
+    model = build_models(dev, torch.bfloat16, args.retriever_layers, args.generator_layers)
+    model.train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-4, fused=True)
+    from transformers import get_scheduler
+
+    sched = get_scheduler("linear", optimizer=opt, num_warmup_steps=100, num_training_steps=100000)
+    ops = TimedOps()
+    step = RagE2EStep(model, opt, sched, CFG["logit_scale"], comm=comm, autocast_dtype=torch.bfloat16, ops=ops,
+                      inplace_grad=True)
+    # a few distinct pre-staged batches (inputs resident in HBM before the timed region)
+    batches = [synthetic_batch(dev, 100 + 17 * rank + i) for i in range(4)]
+
+    for i in range(args.warmup):
+        step(batches[i % len(batches)])
+    torch.cuda.synchronize()
+    barrier(comm)
+    ops.enabled = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(batches[i % len(batches)])
+    torch.cuda.synchronize()
+    barrier(comm)
+    elapsed = time.perf_counter() - t0
+    ops.enabled = False
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if comm.world_size > 1:
+        import torch.distributed as dist
+
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    loss_val = float(loss)
+
+    if rank == 0:
+        B, Tg, V = CFG["B"], CFG["Tg"], CFG["V"]
+        ce_ms = [a.elapsed_time(b) for a, b, _ in ops.events]
+        el_factor = ops.events[0][2] if ops.events else 0
+        ce_avg_s = (sum(ce_ms) / max(len(ce_ms), 1)) * 1e-3
+        alg_bytes = B * (Tg - 1) * V * el_factor  # read + written, dense rows
+        achieved = alg_bytes / ce_avg_s / 1e9 if ce_avg_s > 0 else 0.0
+        traffic = None
+        tfile = ROOT / "profiles" / "roofline_traffic.json"
+        if tfile.exists():
+            try:
+                traffic = json.loads(tfile.read_text()).get("marg_ce_row_kernel_bytes_per_launch")
+            except Exception:
+                traffic = None
+        value = args.gpus * B * args.steps / elapsed
+        out = {
+            "metric": "training pairs/sec (global batch) RAG-e2e bge-large+Llama-2-7b",
+            "value": value, "unit": "pairs/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": (value / A100_README_PAIRS_PER_S) if args.gpus == 1 else None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "cfg3 RAG-e2e: bge-large-en + Llama-2-7b-hf architectures (random init), LoRA r=8 both "
+                                   "towers, per-GPU batch 18, Tq50/Tp128/Tg256, logit_scale 100, Adam, bf16 autocast",
+                       "global_batch": args.gpus * B, "parallelism": f"dp{args.gpus} + sharded in-batch negatives",
+                       "retriever_layers": args.retriever_layers, "generator_layers": args.generator_layers,
+                       "baseline_ref": "reference README.md:34-40: 200k rows in 7 h on 1x A100-80GB = 7.94 pairs/s",
+                       "final_loss": loss_val},
+            "roofline": {"bound": "hbm", "kernel": "marg_ce_row_kernel (fused fwd+grad, bf16 logits)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": traffic, "avg_launch_us": ce_avg_s * 1e6, "algorithmic_bytes": alg_bytes},
+        }
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_reference_baseline()
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "unit": "training pairs/s", "cores": os.cpu_count(),
+                                       "kind": "port", "sample": f"failed: {e!r}"}
+        print(json.dumps(out), flush=True)
+    barrier(comm)
+    if comm.world_size > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

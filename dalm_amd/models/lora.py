@@ -56,7 +56,9 @@ class LoRALinear(nn.Module):
         if self.merged:
             return out
         a, b = self.lora_A["default"], self.lora_B["default"]
-        z = self.lora_dropout["default"](x).to(a.weight.dtype)
+        z = self.lora_dropout["default"](x)
+        if not torch.is_autocast_enabled() and z.dtype != a.weight.dtype:
+            z = z.to(a.weight.dtype)  # outside autocast the fp32 adapters need fp32 activations
         return out + (b(a(z)) * self.scaling).to(out.dtype)
 
     @torch.no_grad()

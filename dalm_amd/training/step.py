@@ -1,0 +1,84 @@
+"""One optimisation step of the RAG-end2end / retriever-only trainers.
+
+Same work as the reference's step bodies (train_rage2e.py:429-474, train_retriever_only.py:365-379)
+with the loss path on the HIP kernels:
+    passage tower -> [async all-gather of P on a side stream] -> query tower -> generator ->
+    fused contrastive + marginalised-CE loss (gradient of the logits written in the same pass) ->
+    backward -> gradient all-reduce (W>1) -> Adam -> scheduler -> zero_grad
+The reference runs the query tower first; the order is swapped so the passage all-gather overlaps
+the query tower (numerically irrelevant with dropout off; changes only the dropout RNG stream).
+"""
+from __future__ import annotations
+
+import contextlib
+from typing import Dict, Optional
+
+import torch
+
+from ..fused import GatherHandle, LocalComm, contrastive_loss, rag_e2e_loss
+from ..sharded import allreduce_grads
+
+
+class _StepBase:
+    def __init__(self, model, optimizer, lr_scheduler, logit_scale, comm=None, autocast_dtype=None, ops=None):
+        self.model, self.optimizer, self.lr_scheduler = model, optimizer, lr_scheduler
+        self.logit_scale = logit_scale
+        self.comm = comm or LocalComm()
+        self.autocast_dtype = autocast_dtype
+        self.ops = ops
+        self.side_stream = None
+        if self.comm.world_size > 1 and torch.cuda.is_available():
+            self.side_stream = torch.cuda.Stream()
+        self.trainable = [p for p in model.parameters() if p.requires_grad]
+
+    def _autocast(self):
+        if self.autocast_dtype is None:
+            return contextlib.nullcontext()
+        return torch.autocast("cuda", dtype=self.autocast_dtype)
+
+    def _finish(self, loss: torch.Tensor) -> torch.Tensor:
+        loss.backward()
+        allreduce_grads(self.trainable, self.comm)
+        self.optimizer.step()
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step()
+        self.model.zero_grad(set_to_none=True)
+        return loss.detach()
+
+
+class RagE2EStep(_StepBase):
+    """batch keys as produced by preprocess_dataset (rag_e2e_dataloader_utils.py:56-68)."""
+
+    def __init__(self, *a, inplace_grad: bool = True, **kw):
+        super().__init__(*a, **kw)
+        self.inplace_grad = inplace_grad
+        self.aux: Dict[str, torch.Tensor] = {}
+
+    def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        m = self.model
+        with self._autocast():
+            p_emb = m("retrieval", batch["retriever_passage_input_ids"], batch["retriever_passage_attention_mask"])
+            p_gather = GatherHandle(p_emb.float(), self.comm, self.side_stream)
+            q_emb = m("retrieval", batch["retriever_query_input_ids"], batch["retriever_query_attention_mask"])
+            q_gather = GatherHandle(q_emb.float(), self.comm, self.side_stream)
+            logits = m("generation", batch["generator_input_input_ids"], batch["generator_input_attention_mask"])
+        loss = rag_e2e_loss(q_emb, p_emb, logits, batch["generator_input_input_ids"],
+                            batch["generator_input_attention_mask"], batch["query_passage_input_len"],
+                            self.logit_scale, comm=self.comm, ops=self.ops, inplace_grad=self.inplace_grad,
+                            q_gather=q_gather, p_gather=p_gather, aux=self.aux)
+        return self._finish(loss)
+
+
+class RetrieverStep(_StepBase):
+    """batch keys as produced by retriever_only_dataloader_utils.preprocess_dataset."""
+
+    def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        m = self.model
+        with self._autocast():
+            p_emb = m(batch["passage_input_ids"], batch["passage_attention_mask"])
+            p_gather = GatherHandle(p_emb.float(), self.comm, self.side_stream)
+            q_emb = m(batch["query_input_ids"], batch["query_attention_mask"])
+            q_gather = GatherHandle(q_emb.float(), self.comm, self.side_stream)
+        loss = contrastive_loss(q_emb, p_emb, self.logit_scale, comm=self.comm, ops=self.ops, q_gather=q_gather,
+                                p_gather=p_gather)
+        return self._finish(loss)

@@ -1,0 +1,135 @@
+"""Per-kernel timings (HIP events on the launch stream) against the gfx950 rooflines.
+
+    python tools/kernel_bench.py [--quick]
+
+Algorithmic bytes / flops follow SURVEY.md section 8(d): dense definitions (all rows counted).
+HBM peak 8 TB/s (spec; ~6.3 TB/s achievable), f32 MFMA peak 157.3 TFLOP/s.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from dalm_amd.ops import default_ops  # noqa: E402
+
+HBM_PEAK = 8.0e12
+MFMA_F32_PEAK = 157.3e12
+
+
+def time_fn(fn, iters=20, warmup=5):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) * 1e-3 for a, b in evs)
+    return ts[len(ts) // 2], ts[0]
+
+
+def bench_ce(B, Tg, V, dtype, full_mask=True):
+    ops = default_ops()
+    dev = torch.device("cuda:0")
+    logits = torch.randn(B, Tg, V, device=dev, dtype=dtype)
+    ids = torch.randint(0, V, (B, Tg), device=dev)
+    if full_mask:
+        mask = torch.ones(B, Tg, dtype=torch.int64, device=dev)
+    else:
+        lens = torch.randint(60, Tg + 1, (B,), device=dev)
+        mask = (torch.arange(Tg, device=dev).unsqueeze(0) < lens.unsqueeze(1)).long()
+    qlen = torch.full((B,), int(0.8 * Tg), device=dev)
+    stats, Nb, Mb = ops.ce_prep(mask, qlen)
+    el = logits.element_size()
+    R = B * (Tg - 1)
+    out = {}
+    med, best = time_fn(lambda: ops.ce_fwd(logits, ids, mask, stats, False))
+    out["fwd"] = {"s": med, "best_s": best, "GBps": R * V * el / med / 1e9, "frac": R * V * el / med / HBM_PEAK}
+    buf = torch.empty_like(logits)
+    lib_args = None
+    med, best = time_fn(lambda: ops.ce_fwd(logits, ids, mask, stats, True))
+    out["fwd+grad(fused)"] = {"s": med, "best_s": best, "GBps": 2 * R * V * el / med / 1e9, "frac": 2 * R * V * el / med / HBM_PEAK}
+    row_lse, _, _ = ops.ce_fwd(logits, ids, mask, stats, False)
+    g = torch.ones(1, device=dev)
+    med, best = time_fn(lambda: ops.ce_bwd(logits, ids, mask, stats, row_lse, g))
+    out["bwd(separate)"] = {"s": med, "best_s": best, "GBps": 2 * R * V * el / med / 1e9, "frac": 2 * R * V * el / med / HBM_PEAK}
+    # a plain device copy of the same bytes, for calibration of the achievable ceiling
+    med, best = time_fn(lambda: buf.copy_(logits))
+    out["torch_copy(ref)"] = {"s": med, "GBps": 2 * B * Tg * V * el / med / 1e9}
+    return out
+
+
+def bench_sim(m, n, D):
+    ops = default_ops()
+    dev = torch.device("cuda:0")
+    A = torch.nn.functional.normalize(torch.randn(m, D, device=dev), dim=1)
+    Bm = torch.nn.functional.normalize(torch.randn(n, D, device=dev), dim=1)
+    out = {}
+    med, best = time_fn(lambda: ops.sim_rowstats(A, Bm, 100.0, 0), iters=10, warmup=3)
+    out["rowstats"] = {"s": med, "TFLOPs": 2.0 * m * n * D / med / 1e12, "frac": 2.0 * m * n * D / med / MFMA_F32_PEAK}
+    if m * n <= 20000 * 20000:
+        rl, _ = ops.sim_rowstats(A, Bm, 100.0, 0)
+        cl = torch.zeros(n, device=dev) + 5.0
+        rc = torch.full((m,), 1.0 / m, device=dev)
+        cc = torch.full((n,), 1.0 / n, device=dev)
+        med, best = time_fn(lambda: ops.sim_grad(A, Bm, 100.0, 0, rc, rl, cc, cl), iters=10, warmup=3)
+        out["grad(dS+gemm)"] = {"s": med, "TFLOPs": 4.0 * m * n * D / med / 1e12, "frac": 4.0 * m * n * D / med / MFMA_F32_PEAK}
+    return out
+
+
+def bench_pool(B, T, D, dtype):
+    ops = default_ops()
+    dev = torch.device("cuda:0")
+    h = torch.randn(B, T, D, device=dev, dtype=dtype)
+    mask = torch.ones(B, T, dtype=torch.int64, device=dev)
+    el = h.element_size()
+    out = {}
+    med, _ = time_fn(lambda: ops.pool_fwd(h, mask, True))
+    out["fwd"] = {"s": med, "GBps": B * T * D * el / med / 1e9, "frac": B * T * D * el / med / HBM_PEAK}
+    emb, norm, ic = ops.pool_fwd(h, mask, True)
+    de = torch.randn_like(emb)
+    med, _ = time_fn(lambda: ops.pool_bwd(de, emb, norm, ic, mask, True, T, dtype))
+    out["bwd"] = {"s": med, "GBps": B * T * D * el / med / 1e9, "frac": B * T * D * el / med / HBM_PEAK}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    res = {}
+    if args.only in ("", "ce"):
+        res["ce cfg3 B18 Tg256 V32000 f32"] = bench_ce(18, 256, 32000, torch.float32)
+        res["ce cfg3 B18 Tg256 V32000 bf16"] = bench_ce(18, 256, 32000, torch.bfloat16)
+        res["ce cfg5 B18 Tg256 V65024 bf16"] = bench_ce(18, 256, 65024, torch.bfloat16)
+        res["ce cfg5 B18 Tg256 V65024 f32"] = bench_ce(18, 256, 65024, torch.float32)
+        res["ce B144 Tg256 V32000 f32 (8x)"] = bench_ce(144, 256, 32000, torch.float32)
+    if args.only in ("", "sim"):
+        sizes = [(18, 18), (150, 150), (1200, 1200), (4096, 4096), (16384, 16384)]
+        if not args.quick:
+            sizes.append((65536, 65536))
+        for m, n in sizes:
+            res[f"sim {m}x{n} D1024"] = bench_sim(m, n, 1024)
+    if args.only in ("", "pool"):
+        res["pool cfg2 q B150 T50 D1024 f32"] = bench_pool(150, 50, 1024, torch.float32)
+        res["pool cfg2 p B150 T128 D1024 f32"] = bench_pool(150, 128, 1024, torch.float32)
+        res["pool cfg3 p B18 T128 D1024 f32"] = bench_pool(18, 128, 1024, torch.float32)
+        res["pool B1200 T128 D1024 bf16"] = bench_pool(1200, 128, 1024, torch.bfloat16)
+    for k, v in res.items():
+        print(k)
+        for kk, vv in v.items():
+            print("   %-18s" % kk, "  ".join(f"{a}={b:.4g}" for a, b in vv.items()))
+    Path("gpurun_out").mkdir(exist_ok=True)
+    Path("gpurun_out/kernel_bench.json").write_text(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
