@@ -48,8 +48,7 @@ template <> struct Elt<bf16_t> {
     unsigned int w[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      w[i] = static_cast<unsigned int>(f32_to_bf16(x[2 * i])) |
-             (static_cast<unsigned int>(f32_to_bf16(x[2 * i + 1])) << 16);
+      w[i] = pack_bf16x2(x[2 * i], x[2 * i + 1]);
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
   }
   __device__ static __forceinline__ float get(const bf16_t* p) { return bf16_to_f32(p->v); }
@@ -153,8 +152,9 @@ __global__ __launch_bounds__(BS, 4) void marg_ce_row_kernel(
       for (int e = 0; e < VEC; ++e) x[k][e] = -INFINITY;
     }
   }
-  float xy = 0.f;
-  if (tid == 0) xy = (y >= 0 && y < V) ? Elt<T>::get(xrow + y) : __builtin_nanf("");
+  // every lane reads the label logit (one broadcast request per wave): lane 0 needs it for the
+  // NLL, the lane owning the label's slot for the gradient patch
+  const float xy = (y >= 0 && y < V) ? Elt<T>::get(xrow + y) : __builtin_nanf("");
 
   float tmax = -INFINITY;
 #pragma unroll
@@ -194,23 +194,19 @@ __global__ __launch_bounds__(BS, 4) void marg_ce_row_kernel(
 
   if constexpr (WRITE_GRAD) {
     // dL/dlogits = (m/M) (softmax - onehot(y))       [upstream grad = 1]
+    // The row is stored as coef*softmax with plain vector stores; the one label entry is then
+    // patched by the lane that just stored it (same lane, same address: program order), which
+    // keeps ~3 predicated VALU ops per element out of the store loop.
     T* grow = dlogits + off;
     char* gbase = reinterpret_cast<char*>(grow - lead);  // wave-uniform
     const float coef = mval / M;
     const float inv = coef / l;
-    const int ys = static_cast<int>(y) + lead;
-    const int slot_y = (y >= 0 && y < V) ? ys / VEC : -1, e_y = ys % VEC;
 #pragma unroll
     for (int k = 0; k < SLOTS; ++k) {
       const int slot = k * BS + tid;
       if (slot >= nslots) continue;
 #pragma unroll
       for (int e = 0; e < VEC; ++e) x[k][e] *= inv;
-      if (slot == slot_y) {
-#pragma unroll
-        for (int e = 0; e < VEC; ++e)
-          if (e == e_y) x[k][e] -= coef;
-      }
       bool part = false;
       if constexpr (!ALIGNED) part = (slot == 0 && lead != 0) || (slot == nslots - 1 && tail_partial);
       if (!part) {
@@ -221,6 +217,14 @@ __global__ __launch_bounds__(BS, 4) void marg_ce_row_kernel(
           const int idx = slot * VEC + e - lead;
           if (idx >= 0 && idx < V) Elt<T>::put(grow + idx, x[k][e]);
         }
+      }
+    }
+    if (y >= 0 && y < V) {
+      const int slot_y = (static_cast<int>(y) + lead) / VEC;
+      if (tid == slot_y % BS) {  // the lane that owns (and has just stored) the label's slot
+        const float py = __builtin_amdgcn_exp2f(fmaf(xy, kLog2e, mneg)) * inv;  // same ops as the row pass
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // its vector stores are acknowledged first
+        Elt<T>::put(grow + y, py - coef);
       }
     }
   }

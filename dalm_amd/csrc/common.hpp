@@ -72,11 +72,16 @@ __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) {
   return __uint_as_float(static_cast<unsigned int>(h) << 16);
 }
+// f32 -> bf16 through the gfx950 hardware converter (v_cvt_pk_bf16_f32: RNE, NaN-preserving)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+  f32x2_t v;
+  v.x = lo; v.y = hi;
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
+}
 __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
-  unsigned int u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<unsigned short>((u >> 16) | 0x40u);  // NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return static_cast<unsigned short>(u >> 16);
+  return __builtin_bit_cast(unsigned short, static_cast<__bf16>(f));
 }
 
 // (max, sum-exp) pair merge for online log-sum-exp.

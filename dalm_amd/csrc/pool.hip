@@ -57,8 +57,7 @@ template <> struct HV<bf16_t> {
       unsigned int w[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        w[i] = static_cast<unsigned int>(f32_to_bf16(x[2 * i])) |
-               (static_cast<unsigned int>(f32_to_bf16(x[2 * i + 1])) << 16);
+        w[i] = pack_bf16x2(x[2 * i], x[2 * i + 1]);
       *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     } else {
 #pragma unroll
