@@ -1,0 +1,168 @@
+"""Shared trainer machinery: flag tables -> argparse, data loading, schedules, checkpoint naming, logging.
+
+Mirrors the behaviour of the reference drivers (train_rage2e.py:229-527, train_retriever_only.py:175-422)
+without `accelerate`: one process per GPU (torchrun env), torch.distributed(nccl = RCCL) for the few
+collectives, explicit HIP streams for overlap.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import logging
+import math
+import os
+import random
+import time
+from typing import Any, Callable, Dict, Iterable, List, Optional, Tuple
+
+import torch
+
+logger = logging.getLogger("dalm_amd.train")
+
+SCHEDULERS = ["linear", "cosine", "cosine_with_restarts", "polynomial", "constant", "constant_with_warmup"]
+
+
+def build_parser(description: str, flags: List[Tuple[str, Dict[str, Any]]]) -> argparse.ArgumentParser:
+    ap = argparse.ArgumentParser(description=description)
+    for name, spec in flags:
+        ap.add_argument("--" + name, **spec)
+    return ap
+
+
+def seed_everything(seed: Optional[int]) -> None:
+    if seed is None:
+        return
+    import numpy as np
+
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+class ShardedBatches:
+    """Shuffled fixed-size batches of a tokenised `datasets.Dataset`, sharded over ranks.
+
+    Rank r takes rows [r*B, (r+1)*B) of every global batch of W*B rows (the layout the sharded loss
+    assumes).  Like the reference's DataLoader there is no drop_last on one GPU (the last batch is
+    partial); with W > 1 a tail that cannot give every rank the same number of rows is dropped so that
+    the all-gathers stay rectangular (the reference would pad by re-using samples instead)."""
+
+    def __init__(self, dataset, batch_size: int, rank: int, world: int, seed: int, columns: List[str]):
+        self.ds, self.B, self.rank, self.world, self.seed = dataset, batch_size, rank, world, seed
+        self.columns = columns
+        n = len(dataset)
+        if world == 1:
+            self.num_batches = math.ceil(n / batch_size)
+        else:
+            full = n // (batch_size * world)
+            rest = (n - full * batch_size * world) // world
+            self.num_batches = full + (1 if rest > 0 else 0)
+            self._tail = rest
+
+    def __len__(self) -> int:
+        return self.num_batches
+
+    def epoch(self, epoch: int, device: torch.device, skip: int = 0) -> Iterable[Dict[str, torch.Tensor]]:
+        g = torch.Generator().manual_seed(self.seed + epoch)
+        perm = torch.randperm(len(self.ds), generator=g).tolist()
+        W, B = self.world, self.B
+        pos = 0
+        for i in range(self.num_batches):
+            remaining = len(perm) - pos
+            b = B if remaining >= W * B else (remaining // W if W > 1 else remaining)
+            rows = perm[pos + self.rank * b: pos + (self.rank + 1) * b]
+            pos += W * b
+            if i < skip:
+                continue
+            chunk = self.ds[rows]
+            batch = {k: torch.tensor(chunk[k], dtype=torch.int64) for k in self.columns}
+            yield {k: v.pin_memory().to(device, non_blocking=True) if device.type == "cuda" else v
+                   for k, v in batch.items()}
+
+
+def steps_and_epochs(num_batches: int, grad_accum: int, num_train_epochs: int, max_train_steps: Optional[int]):
+    per_epoch = math.ceil(num_batches / grad_accum)
+    if max_train_steps is None:
+        max_train_steps = num_train_epochs * per_epoch
+    num_train_epochs = math.ceil(max_train_steps / max(per_epoch, 1))
+    return per_epoch, max_train_steps, num_train_epochs
+
+
+def parse_resume(path: str, per_epoch: int, num_batches: int, grad_accum: int):
+    """`step_N` / `epoch_N` folder name -> (starting_epoch, resume_step, completed_steps)."""
+    tag = os.path.splitext(os.path.basename(path.rstrip("/")))[0]
+    if "epoch" in tag:
+        e = int(tag.replace("epoch_", "")) + 1
+        return e, None, e * per_epoch
+    s = int(tag.replace("step_", "")) * grad_accum
+    e = s // num_batches
+    s -= e * num_batches
+    return e, s, s // grad_accum + e * per_epoch
+
+
+class Tracker:
+    """Tiny stand-in for accelerate's trackers: JSON-lines under <output_dir>/logs (tensorboard when present)."""
+
+    def __init__(self, enabled: bool, output_dir: Optional[str], run_name: str, config: Dict[str, Any], is_main: bool):
+        self.f = None
+        self.tb = None
+        if not (enabled and is_main and output_dir):
+            return
+        d = os.path.join(output_dir, "logs")
+        os.makedirs(d, exist_ok=True)
+        self.f = open(os.path.join(d, f"{run_name}.jsonl"), "a")
+        self.f.write(json.dumps({"config": config}) + "\n")
+        try:
+            from torch.utils.tensorboard import SummaryWriter  # optional
+
+            self.tb = SummaryWriter(os.path.join(d, run_name))
+        except Exception:
+            self.tb = None
+
+    def log(self, values: Dict[str, float], step: int) -> None:
+        if self.f:
+            self.f.write(json.dumps({"step": step, **values}) + "\n")
+            self.f.flush()
+        if self.tb:
+            for k, v in values.items():
+                self.tb.add_scalar(k, v, step)
+
+    def close(self) -> None:
+        if self.f:
+            self.f.close()
+        if self.tb:
+            self.tb.close()
+
+
+class Throughput:
+    """pairs/sec over rows actually consumed (the reference has no throughput metric)."""
+
+    def __init__(self):
+        self.t0 = time.perf_counter()
+        self.rows = 0
+
+    def add(self, rows: int) -> None:
+        self.rows += rows
+
+    def rate(self) -> float:
+        return self.rows / max(time.perf_counter() - self.t0, 1e-9)
+
+
+def save_training_state(path: str, model, optimizer, scheduler, extra: Dict[str, Any], save_models: Callable[[str], None]) -> None:
+    os.makedirs(path, exist_ok=True)
+    save_models(path)
+    torch.save({"optimizer": optimizer.state_dict(), "scheduler": scheduler.state_dict() if scheduler else None,
+                "extra": extra}, os.path.join(path, "trainer_state.pt"))
+
+
+def load_training_state(path: str, optimizer, scheduler) -> Dict[str, Any]:
+    f = os.path.join(path, "trainer_state.pt")
+    if not os.path.exists(f):
+        return {}
+    st = torch.load(f, map_location="cpu")
+    optimizer.load_state_dict(st["optimizer"])
+    if scheduler and st.get("scheduler"):
+        scheduler.load_state_dict(st["scheduler"])
+    return st.get("extra", {})

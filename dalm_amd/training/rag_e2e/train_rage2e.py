@@ -1,0 +1,219 @@
+"""RAG-end2end trainer: the reference's CLI and `train_e2e` signature
+(dalm/training/rag_e2e/train_rage2e.py:54-226, 229-260) driving the MI355X step in dalm_amd.training.step.
+
+    python -m dalm_amd.training.rag_e2e.train_rage2e --dataset_path rows.csv \
+        --retriever_name_or_path <bert-like> --generator_name_or_path <causal-lm> [--use_peft both] ...
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 -m dalm_amd.training.rag_e2e.train_rage2e ...
+
+Differences from the reference that a user can observe are listed in INTEGRATION.md section 5.
+"""
+from __future__ import annotations
+
+import logging
+import os
+from argparse import Namespace
+from typing import Optional, Union
+
+import torch
+
+from ...models.rag_e2e_base_model import AutoModelForRagE2E, Mode
+from ...sharded import barrier, init_distributed
+from ...utils import load_dataset
+from .. import common
+from .._hooks import load_submodel, save_submodel
+from ..step import RagE2EStep
+from ..utils.rag_e2e_dataloader_utils import preprocess_dataset
+
+logger = logging.getLogger("dalm_amd.train_rage2e")
+
+_S, _I, _F = str, int, float
+FLAGS = [
+    ("dataset_path", dict(type=_S, default=None, help="Dataset path: a huggingface dataset directory or a csv file.")),
+    ("passage_column_name", dict(type=_S, default="Abstract", help="Column holding the passage")),
+    ("query_column_name", dict(type=_S, default="Question", help="Column holding the query")),
+    ("answer_column_name", dict(type=_S, default="Answer", help="Column holding the answer")),
+    ("query_max_len", dict(type=_I, default=50, help="Max query length after tokenization (truncates)")),
+    ("passage_max_len", dict(type=_I, default=160, help="Max passage length after tokenization (truncates)")),
+    ("generator_max_len", dict(type=_I, default=256, help="Max generator input length after tokenization (truncates)")),
+    ("retriever_name_or_path", dict(type=_S, required=True, help="Retriever model path or hub id")),
+    ("generator_name_or_path", dict(type=_S, required=True, help="Generator model path or hub id")),
+    ("per_device_train_batch_size", dict(type=_I, default=32, help="Batch size per device")),
+    ("learning_rate", dict(type=_F, default=1e-4, help="Initial learning rate (after warmup)")),
+    ("logit_scale", dict(type=_I, default=100, help="Logit scale of the contrastive loss")),
+    ("weight_decay", dict(type=_F, default=0.0, help="Weight decay (accepted; Adam ignores it, as upstream)")),
+    ("num_train_epochs", dict(type=_I, default=1, help="Number of training epochs")),
+    ("max_train_steps", dict(type=_I, default=None, help="Total training steps; overrides num_train_epochs")),
+    ("gradient_accumulation_steps", dict(type=_I, default=1, help="Accepted for CLI compatibility")),
+    ("lr_scheduler_type", dict(type=_S, default="linear", choices=common.SCHEDULERS, help="LR scheduler")),
+    ("num_warmup_steps", dict(type=_I, default=100, help="Warmup steps of the LR scheduler")),
+    ("output_dir", dict(type=_S, default=None, help="Where to store the final model")),
+    ("seed", dict(type=_I, default=None, help="Seed for reproducible training")),
+    ("hub_model_id", dict(type=_S, help="Unused (kept for CLI compatibility)")),
+    ("hub_token", dict(type=_S, help="Unused (kept for CLI compatibility)")),
+    ("checkpointing_steps", dict(type=_S, default=None, help="Save state every n steps, or 'epoch'")),
+    ("resume_from_checkpoint", dict(type=_S, default=None, help="Checkpoint folder to continue from")),
+    ("with_tracking", dict(action="store_true", help="Enable experiment tracking")),
+    ("report_to", dict(type=_S, default="all", help="Tracker name(s); only with --with_tracking")),
+    ("sanity_test", dict(action="store_true", help="Unused (kept for CLI compatibility)")),
+    ("use_peft", dict(type=Mode, choices=list(Mode), required=False, help="LoRA on generator / retriever / both")),
+    ("use_bnb", dict(type=Mode, choices=list(Mode), help="4-bit quantisation (not available on this build)")),
+    ("retriever_is_autoregressive", dict(action="store_true", help="Retriever is an autoregressive LM")),
+    # extensions (not in the reference)
+    ("mixed_precision", dict(type=_S, default="bf16", choices=["no", "bf16"], help="[ext] autocast dtype of the towers")),
+]
+
+
+def parse_args(argv=None) -> Namespace:
+    return common.build_parser("training a PEFT model for Semantic Search task", FLAGS).parse_args(argv)
+
+
+def train_e2e(
+    dataset_or_path,
+    retriever_name_or_path: str,
+    generator_name_or_path: str,
+    passage_column_name: str = "Abstract",
+    query_column_name: str = "Question",
+    answer_column_name: str = "Answer",
+    query_max_len: int = 50,
+    passage_max_len: int = 128,
+    generator_max_len: int = 256,
+    per_device_train_batch_size: int = 32,
+    learning_rate: float = 1e-4,
+    logit_scale: int = 100,
+    weight_decay: float = 0.0,
+    num_train_epochs: int = 1,
+    max_train_steps: Optional[int] = None,
+    gradient_accumulation_steps: int = 1,
+    lr_scheduler_type="linear",
+    num_warmup_steps: int = 100,
+    output_dir: Optional[str] = None,
+    seed: int = 42,
+    hub_model_id: Optional[str] = None,
+    hub_token: Optional[str] = None,
+    checkpointing_steps: Optional[Union[int, str]] = None,
+    resume_from_checkpoint: Optional[str] = None,
+    with_tracking: bool = True,
+    report_to: str = "all",
+    sanity_test: bool = True,
+    use_peft: Optional[Mode] = None,
+    use_bnb: Optional[Mode] = None,
+    retriever_is_autoregressive: bool = False,
+    *,
+    mixed_precision: str = "bf16",
+    rag_model: Optional[AutoModelForRagE2E] = None,
+    on_step=None,
+) -> None:
+    """Train retriever and generator jointly.  `rag_model` (pre-built wrapper) and `on_step`
+    (callback(step, loss)) are extensions used by tests and benchmarks."""
+    config = {k: v for k, v in dict(locals()).items() if v is None or isinstance(v, (float, int, str))}
+    comm, device = init_distributed()
+    if device.type != "cuda":
+        raise RuntimeError("train_e2e needs an MI355X: the loss path has no CPU implementation in this package")
+    is_main = comm.rank == 0
+    common.seed_everything(seed)
+    if rag_model is None:
+        dtype = torch.bfloat16 if (mixed_precision == "bf16" and use_peft is not None) else None
+        rag_model = AutoModelForRagE2E(retriever_name_or_path, generator_name_or_path, get_peft=use_peft,
+                                       use_bnb=use_bnb, retriever_is_autoregressive=retriever_is_autoregressive,
+                                       torch_dtype=dtype)
+    rag_model.to(device)
+    if is_main and output_dir is not None:
+        os.makedirs(output_dir, exist_ok=True)
+    barrier(comm)
+
+    # ---- data: tokenise once on the host (reference :298-322) -------------------------------
+    dataset = load_dataset(dataset_or_path)
+    r_tok, g_tok = rag_model.retriever_tokenizer, rag_model.generator_tokenizer
+    g_tok.pad_token = g_tok.eos_token
+    g_tok.add_eos_token = True
+    processed = dataset.map(
+        lambda ex: preprocess_dataset(ex, retriever_tokenizer=r_tok, generator_tokenizer=g_tok,
+                                      query_column_name=query_column_name, passage_column_name=passage_column_name,
+                                      answer_column_name=answer_column_name, query_max_len=query_max_len,
+                                      passage_max_len=passage_max_len, generator_max_len=generator_max_len),
+        batched=True, remove_columns=dataset.column_names, desc="Running tokenizer on dataset", num_proc=1)
+    columns = ["retriever_query_input_ids", "retriever_query_attention_mask", "retriever_passage_input_ids",
+               "retriever_passage_attention_mask", "generator_input_input_ids", "generator_input_attention_mask",
+               "query_passage_input_len"]
+    batches = common.ShardedBatches(processed, per_device_train_batch_size, comm.rank, comm.world_size,
+                                    seed if seed is not None else 0, columns)
+
+    # ---- optimiser / schedule (reference :336-362) ----------------------------------------------
+    params = [p for p in rag_model.parameters() if p.requires_grad]
+    optimizer = torch.optim.Adam(params, lr=learning_rate, fused=True)
+    per_epoch, max_train_steps, num_train_epochs = common.steps_and_epochs(
+        len(batches), gradient_accumulation_steps, num_train_epochs, max_train_steps)
+    from transformers import get_scheduler
+
+    name = getattr(lr_scheduler_type, "value", lr_scheduler_type)
+    scheduler = get_scheduler(name=name, optimizer=optimizer, num_warmup_steps=num_warmup_steps,
+                              num_training_steps=max_train_steps)
+    if checkpointing_steps is not None and str(checkpointing_steps).isdigit():
+        checkpointing_steps = int(checkpointing_steps)
+    tracker = common.Tracker(with_tracking, output_dir, "peft_rag_e2e_learning", config, is_main)
+
+    def save_models(path: str) -> None:
+        save_submodel(rag_model.generator_model, os.path.join(path, "generator"))
+        save_submodel(rag_model.retriever_model, os.path.join(path, "retriever"))
+
+    starting_epoch, resume_step, completed = 0, None, 0
+    if resume_from_checkpoint:
+        logger.info("Resumed from checkpoint: %s", resume_from_checkpoint)
+        load_submodel(rag_model.generator_model, os.path.join(resume_from_checkpoint, "generator"))
+        load_submodel(rag_model.retriever_model, os.path.join(resume_from_checkpoint, "retriever"))
+        common.load_training_state(resume_from_checkpoint, optimizer, scheduler)
+        starting_epoch, resume_step, completed = common.parse_resume(resume_from_checkpoint, per_epoch, len(batches),
+                                                                     gradient_accumulation_steps)
+
+    if is_main:
+        logger.info("***** Running E2E training *****  examples=%d epochs=%d per-device batch=%d global batch=%d steps=%d",
+                    len(processed), num_train_epochs, per_device_train_batch_size,
+                    per_device_train_batch_size * comm.world_size, max_train_steps)
+    step_fn = RagE2EStep(rag_model, optimizer, scheduler, logit_scale, comm=comm,
+                         autocast_dtype=torch.bfloat16 if mixed_precision == "bf16" else None)
+    meter = common.Throughput()
+    for epoch in range(starting_epoch, num_train_epochs):
+        rag_model.train()
+        total_loss = torch.zeros((), device=device)
+        skip = resume_step if (resume_from_checkpoint and epoch == starting_epoch and resume_step) else 0
+        for step, batch in enumerate(batches.epoch(epoch, device, skip)):
+            loss = step_fn(batch)  # rank share of the global-batch loss
+            total_loss += loss
+            completed += 1
+            meter.add(batch["query_passage_input_len"].shape[0] * comm.world_size)
+            if on_step is not None:
+                on_step(completed, loss)
+            if (step + 1) % 100 == 0:
+                tl = comm.all_reduce_sum_(total_loss.clone())
+                if is_main:
+                    logger.info("Step: %d, Loss: %.6f, pairs/s: %.1f", step + 1, float(tl) / (step + 1), meter.rate())
+                tracker.log({"train/loss": float(tl) / (step + 1), "train/pairs_per_sec": meter.rate()}, completed)
+            if isinstance(checkpointing_steps, int) and completed % checkpointing_steps == 0 and output_dir and is_main:
+                common.save_training_state(os.path.join(output_dir, f"step_{completed}"), rag_model, optimizer,
+                                           scheduler, {"completed_steps": completed}, save_models)
+            if completed >= max_train_steps:
+                break
+        tl = comm.all_reduce_sum_(total_loss.clone())
+        tracker.log({"train/epoch_loss": float(tl) / max(len(batches), 1)}, completed)
+        if output_dir is not None:
+            barrier(comm)
+            if is_main:
+                if isinstance(checkpointing_steps, str):
+                    common.save_training_state(os.path.join(output_dir, f"epoch_{epoch}"), rag_model, optimizer,
+                                               scheduler, {"completed_steps": completed}, save_models)
+                save_models(output_dir)  # <output_dir>/retriever, <output_dir>/generator (reference :508-524)
+                r_tok.save_pretrained(os.path.join(output_dir, "retriever"))
+                g_tok.save_pretrained(os.path.join(output_dir, "generator"))
+            barrier(comm)
+    tracker.close()
+
+
+def main() -> None:
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(levelname)s - %(name)s - %(message)s")
+    a = parse_args()
+    kw = {k: v for k, v in vars(a).items() if k not in ("dataset_path", "retriever_name_or_path", "generator_name_or_path")}
+    train_e2e(a.dataset_path, a.retriever_name_or_path, a.generator_name_or_path, **kw)
+
+
+if __name__ == "__main__":
+    main()

@@ -185,7 +185,93 @@ def main() -> None:
         print(name, "ok")
 
 
+def make_tokenizer(words, path):
+    """Small local WordLevel tokenizer (no network): [PAD]=0 [UNK]=1 [CLS]=2 [SEP]=3 + words."""
+    from tokenizers import Tokenizer, models, pre_tokenizers, processors
+    from transformers import PreTrainedTokenizerFast
+
+    vocab = {"[PAD]": 0, "[UNK]": 1, "[CLS]": 2, "[SEP]": 3}
+    for w in words:
+        vocab.setdefault(w, len(vocab))
+    tok = Tokenizer(models.WordLevel(vocab, unk_token="[UNK]"))
+    tok.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    tok.post_processor = processors.TemplateProcessing(single="[CLS] $A [SEP]", special_tokens=[("[CLS]", 2), ("[SEP]", 3)])
+    fast = PreTrainedTokenizerFast(tokenizer_object=tok, pad_token="[PAD]", unk_token="[UNK]", cls_token="[CLS]",
+                                   sep_token="[SEP]", eos_token="[SEP]")
+    fast.save_pretrained(path)
+    return fast
+
+
+ROWS = {
+    "Question": ["what is a heat pump", "who invented the transistor", "why is the sky blue at noon",
+                 "how do vaccines train the immune system", "what does a compiler do"],
+    "Abstract": ["a heat pump moves thermal energy from a cold space to a warm space using a refrigeration cycle",
+                 "the transistor was invented at bell labs in 1947 by bardeen brattain and shockley",
+                 "rayleigh scattering of sunlight by air molecules is stronger for short blue wavelengths",
+                 "vaccines present harmless antigens so that the adaptive immune system forms memory cells",
+                 "a compiler translates source code written in one language into another language usually machine code"],
+    "Answer": ["it moves heat", "bardeen brattain shockley", "rayleigh scattering", "memory cells", "translates code"],
+}
+
+
+def main_host_goldens() -> None:
+    """CLI defaults and preprocess_dataset outputs of the reference (host-side parity)."""
+    import json
+
+    tu, m_rag, du = import_reference()
+    import transformers  # noqa: F401
+    # resolve every lazy transformers / accelerate import the trainers need while `peft` is still absent
+    import accelerate  # noqa: F401
+    import datasets  # noqa: F401
+    from accelerate import Accelerator  # noqa: F401
+    from transformers import (AutoModel, AutoModelForCausalLM, AutoTokenizer, BitsAndBytesConfig,  # noqa: F401
+                              SchedulerType, default_data_collator, get_scheduler)
+
+    stub = types.ModuleType("peft")
+    for name in ("LoraConfig", "PeftModel", "TaskType", "get_peft_model"):
+        setattr(stub, name, type(name, (), {}))
+    sys.modules["peft"] = stub
+    sys.path.insert(0, str(REF))
+    try:
+        import dalm.training.rag_e2e.train_rage2e as ref_e2e
+        import dalm.training.retriever_only.train_retriever_only as ref_ret
+        from dalm.training.utils.rag_e2e_dataloader_utils import preprocess_dataset as ref_pre_e2e
+        from dalm.training.utils.retriever_only_dataloader_utils import preprocess_dataset as ref_pre_ret
+    finally:
+        sys.modules.pop("peft", None)
+        sys.path.remove(str(REF))
+
+    out = {}
+    old = sys.argv
+    try:
+        sys.argv = ["x", "--retriever_name_or_path", "R", "--generator_name_or_path", "G"]
+        ns = vars(ref_e2e.parse_args())
+        out["e2e_defaults"] = {k: (v.value if hasattr(v, "value") else v) for k, v in ns.items()}
+        sys.argv = ["x", "--retriever_name_or_path", "R"]
+        ns = vars(ref_ret.parse_args())
+        out["retriever_defaults"] = {k: (v.value if hasattr(v, "value") else v) for k, v in ns.items()}
+    finally:
+        sys.argv = old
+    import inspect
+
+    out["train_e2e_signature"] = [[n, (p.default.value if hasattr(p.default, "value") else p.default)
+                                   if p.default is not inspect._empty else "<required>"]
+                                  for n, p in inspect.signature(ref_e2e.train_e2e).parameters.items()]
+    out["train_retriever_signature"] = [[n, (p.default.value if hasattr(p.default, "value") else p.default)
+                                         if p.default is not inspect._empty else "<required>"]
+                                        for n, p in inspect.signature(ref_ret.train_retriever).parameters.items()]
+    words = sorted({w for col in ROWS.values() for t in col for w in t.split()} | {"#query#", "#passage#", "#answer#"})
+    tok = make_tokenizer(words, str(OUT / "wordlevel_tokenizer"))
+    out["rows"] = ROWS
+    out["pre_e2e"] = ref_pre_e2e(ROWS, tok, tok, "Question", "Abstract", "Answer", 12, 24, 40)
+    out["pre_e2e"] = {k: v for k, v in out["pre_e2e"].items()}
+    out["pre_ret"] = dict(ref_pre_ret(ROWS, tok, "Question", "Abstract", 12, 24))
+    (OUT / "host_golden.json").write_text(json.dumps(out, indent=1, default=str))
+    print("host_golden.json ok")
+
+
 if __name__ == "__main__":
     if not REF.exists():
         sys.exit("/root/reference not present: golden vectors can only be regenerated in the build container")
     main()
+    main_host_goldens()
