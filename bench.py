@@ -211,7 +211,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ops.enabled = False
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if comm.world_size > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         import torch.distributed as dist
 
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -257,10 +257,8 @@ def main():
                                        "kind": "port", "sample": f"failed: {e!r}"}
         print(json.dumps(out), flush=True)
     barrier(comm)
-    if comm.world_size > 1:
-        import torch.distributed as dist
-
-        dist.destroy_process_group()
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -13,6 +13,8 @@
 // Row addressing uses 16-byte aligned windows: a row may start at any element
 // offset; the first/last 16-byte slot is masked on load and stored with scalar
 // writes, all interior slots are single dwordx4 accesses.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace dalm {
@@ -105,7 +107,7 @@ __device__ __forceinline__ void fill_row(T* row, int V, float fill) {
 // ---------------------------------------------------------------------------
 
 template <typename T, int BS, int SLOTS, bool WRITE_GRAD, bool ALIGNED>
-__global__ __launch_bounds__(BS, 4) void marg_ce_row_kernel(
+__global__ __launch_bounds__(BS, (SLOTS * Elt<T>::VEC > 64 ? 3 : 4)) void marg_ce_row_kernel(
     const T* __restrict__ logits, int64_t stride_b, int64_t stride_t,
     const int64_t* __restrict__ ids, const int64_t* __restrict__ mask, int Tg, int V,
     const float* __restrict__ stats, float* __restrict__ row_lse, float* __restrict__ row_nll,
@@ -462,7 +464,17 @@ void launch_fwd2(const T* logits, int64_t B, int64_t Tg, int64_t V, int64_t sb, 
   constexpr int S_BIG = 64 / VEC;    // 64 floats per lane: <=128 VGPRs, 4 waves/SIMD
   constexpr int S_SMALL = 16 / VEC;  // 16 floats per lane
 #define DALM_CE_ARGS logits, sb, st, ids, mask, Tgi, Vi, stats, row_lse, row_nll, dlogits
-  if (need <= 256 * S_SMALL)
+  // tuning knob for A/B runs (tools/kernel_bench.py): DALM_CE_VARIANT=stream | t256
+  static const char* variant = getenv("DALM_CE_VARIANT");
+  constexpr int S_WIDE = 128 / VEC;  // 128 floats per lane, 4 waves per row (fewer barrier participants)
+  // forward-only bf16 rows: the online streaming kernel wins (measured 63 vs 76 us at V=32000, 108 vs
+  // 171 us at V=65024): 8 waves/SIMD of independent 16-byte streams, no register-resident phases
+  const bool prefer_stream = !GRAD && sizeof(T) == 2 && V >= 8192;
+  if ((variant && variant[0] == 's') || (!variant && prefer_stream))
+    hipLaunchKernelGGL((marg_ce_stream_kernel<T, 1024, GRAD>), grid, dim3(1024), 0, s, DALM_CE_ARGS);
+  else if (variant && variant[0] == 't' && need <= 256 * S_WIDE)
+    hipLaunchKernelGGL((marg_ce_row_kernel<T, 256, S_WIDE, GRAD, ALIGNED>), grid, dim3(256), 0, s, DALM_CE_ARGS);
+  else if (need <= 256 * S_SMALL)
     hipLaunchKernelGGL((marg_ce_row_kernel<T, 256, S_SMALL, GRAD, ALIGNED>), grid, dim3(256), 0, s, DALM_CE_ARGS);
   else if (need <= 256 * S_BIG)
     hipLaunchKernelGGL((marg_ce_row_kernel<T, 256, S_BIG, GRAD, ALIGNED>), grid, dim3(256), 0, s, DALM_CE_ARGS);

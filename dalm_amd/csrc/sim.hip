@@ -12,7 +12,8 @@
 //   EPI_ROWSTATS  per-row (max, sum-exp) partials of S  (S never reaches HBM)
 //   EPI_DS        closed-form dL/dS from the saved row/col log-sum-exps
 // 256-thread workgroups = 4 waves (2x2), 128x128x32 tiles (64x64 per wave =
-// 2x2 MFMA tiles, 64 accumulator VGPRs), operands staged k-major in LDS so that
+// 2x2 MFMA tiles, 64 accumulator VGPRs; 64x64x128 tiles for latency-bound small
+// problems), operands staged k-major in LDS so that
 // every MFMA fragment read is one conflict-free ds_read_b32 per lane.
 // MFMA-bound: 2*m*n*D flop per launch against the 157 TF f32-matrix peak.
 #include "common.hpp"
@@ -22,7 +23,8 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int BK = 32;
+constexpr int BK_BIG = 32;    // 128x128 tiles: 33 KB LDS, 3 blocks/CU
+constexpr int BK_SMALL = 128;  // 64x64 tiles of latency-bound small problems: 4x fewer barrier rounds
 
 enum { EPI_STORE = 0, EPI_ROWSTATS = 1, EPI_DS = 2 };
 
@@ -54,7 +56,7 @@ __device__ __forceinline__ float4 guarded_ld4(const float* p, int nvalid, bool v
 // Stages one operand tile (BR rows in the non-K dimension x BK) global -> regs -> LDS[k][r].
 // KC: source is X[r][k] (k contiguous) -> transposing ds_write_b32 (stride BR+1: conflict-free)
 // !KC: source is X[k][r] (r contiguous) -> ds_write_b128 rows (stride BR+4: 16-byte aligned)
-template <int BR, bool KC>
+template <int BR, int BK, bool KC>
 struct Stage {
   static constexpr int STRIDE = KC ? BR + 1 : BR + 4;
   static constexpr int NV = BR * BK / 4 / 256;
@@ -97,11 +99,11 @@ struct Stage {
   }
 };
 
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
+template <int BM, int BN, int BK, bool A_KC, bool B_KC, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(const GemmParams p) {
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-  using SA = Stage<BM, A_KC>;
-  using SB = Stage<BN, B_KC>;
+  using SA = Stage<BM, BK, A_KC>;
+  using SB = Stage<BN, BK, B_KC>;
   __shared__ __attribute__((aligned(16))) float lds[BK * SA::STRIDE + BK * SB::STRIDE];
   float* As = lds;
   float* Bs = lds + BK * SA::STRIDE;
@@ -297,13 +299,13 @@ inline bool vec_ok(const float* p, int64_t ld) {
   return (reinterpret_cast<uintptr_t>(p) % 16 == 0) && (ld % 4 == 0);
 }
 
-template <int BM, int BN, int EPI>
+template <int BM, int BN, int BK, int EPI>
 void launch_gemm_tile(bool a_kc, bool b_kc, const GemmParams& p, hipStream_t s) {
   const dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM);
-  if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, true, true, EPI>), grid, dim3(256), 0, s, p);
-  else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, true, false, EPI>), grid, dim3(256), 0, s, p);
-  else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, false, true, EPI>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, false, false, EPI>), grid, dim3(256), 0, s, p);
+  if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, true, true, EPI>), grid, dim3(256), 0, s, p);
+  else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, true, false, EPI>), grid, dim3(256), 0, s, p);
+  else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, false, true, EPI>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, false, false, EPI>), grid, dim3(256), 0, s, p);
 }
 
 // 128x128 tiles once the grid fills the chip, 64x64 below that.
@@ -317,8 +319,8 @@ inline int64_t rowstats_parts(int64_t m, int64_t n) {
 
 template <int EPI>
 void launch_gemm(bool a_kc, bool b_kc, const GemmParams& p, hipStream_t s) {
-  if (use_big_tiles(p.M, p.N)) launch_gemm_tile<128, 128, EPI>(a_kc, b_kc, p, s);
-  else launch_gemm_tile<64, 64, EPI>(a_kc, b_kc, p, s);
+  if (use_big_tiles(p.M, p.N)) launch_gemm_tile<128, 128, BK_BIG, EPI>(a_kc, b_kc, p, s);
+  else launch_gemm_tile<64, 64, BK_SMALL, EPI>(a_kc, b_kc, p, s);
 }
 
 int check_gemm_dims(int64_t M, int64_t N, int64_t K, const char* fn) {

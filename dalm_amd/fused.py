@@ -74,7 +74,7 @@ class GatherHandle:
         self.comm = comm
         self.result: Optional[torch.Tensor] = None
         self.event = None
-        if comm.world_size == 1:
+        if isinstance(comm, LocalComm):
             self.result = local.detach()
             return
         if side_stream is not None and local.is_cuda:
@@ -152,7 +152,7 @@ def _contrastive_forward(ops, comm, q, p, scale, q_all=None, p_all=None):
 
 def _contrastive_backward(ops, comm, st: _ConState, scale, a_local, b_local):
     """a: row coefficients (this rank's queries), b: column coefficients (this rank's passages)."""
-    if comm.world_size > 1:
+    if not isinstance(comm, LocalComm):
         packed = torch.stack([st.lse_r, st.lse_c, a_local, b_local], dim=1)  # [B_l,4] -> one all-gather
         allv = comm.all_gather_rows(packed)
         lse_r_all, lse_c_all, a_all, b_all = (allv[:, k].contiguous() for k in range(4))
@@ -204,8 +204,8 @@ class _RagE2E(torch.autograd.Function):
                                   p_gather.wait() if p_gather is not None else None)
         con, doc_lp = ops.contrastive_finalize(st.lse_r, st.lse_c, st.diag, st.n_global)
         stats, Nb, _Mb = ops.ce_prep(mask, qlen)
-        if comm.world_size > 1:
-            comm.all_reduce_sum_(stats)  # stats[0] = M over the global batch
+        if not isinstance(comm, LocalComm):
+            comm.all_reduce_sum_(stats)  # stats[0] = M over the global batch (stats[1] becomes B_g)
         need_grad = logits.requires_grad and fuse_grad
         row_lse, row_nll, dlogits = ops.ce_fwd(logits.detach(), ids, mask, stats, need_grad, inplace_grad)
         gen = ops.ce_finalize(row_nll, Nb, doc_lp, stats)

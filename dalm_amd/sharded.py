@@ -23,7 +23,9 @@ from .fused import GatherHandle, LocalComm, TorchDistComm  # noqa: F401
 def init_distributed(backend: Optional[str] = None):
     """Initialise torch.distributed from the torchrun environment; returns (comm, device)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1:
+    # DALM_FORCE_DIST=1 runs the RCCL code path even with one rank (used to smoke-test the collectives,
+    # side-stream gathers and the gradient bucket on a single-GPU box)
+    if world == 1 and os.environ.get("DALM_FORCE_DIST", "0") != "1":
         dev = torch.device("cuda", 0) if torch.cuda.is_available() else torch.device("cpu")
         if dev.type == "cuda":
             torch.cuda.set_device(dev)
@@ -40,6 +42,9 @@ def init_distributed(backend: Optional[str] = None):
         backend = backend or "gloo"
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group(backend=backend, device_id=dev)
         else:
@@ -50,7 +55,7 @@ def init_distributed(backend: Optional[str] = None):
 def allreduce_grads(params: Iterable[torch.nn.Parameter], comm) -> None:
     """SUM the gradients over ranks through one flat bucket (rank losses are shares of the
     global-batch loss, so summing reproduces the single-process gradient)."""
-    if comm.world_size == 1:
+    if isinstance(comm, LocalComm):
         return
     ps: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
     for p in ps:
@@ -66,7 +71,7 @@ def allreduce_grads(params: Iterable[torch.nn.Parameter], comm) -> None:
 
 
 def barrier(comm) -> None:
-    if comm.world_size > 1:
+    if not isinstance(comm, LocalComm):
         import torch.distributed as dist
 
         dist.barrier()

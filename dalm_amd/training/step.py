@@ -27,7 +27,7 @@ class _StepBase:
         self.autocast_dtype = autocast_dtype
         self.ops = ops
         self.side_stream = None
-        if self.comm.world_size > 1 and torch.cuda.is_available():
+        if not isinstance(self.comm, LocalComm) and torch.cuda.is_available():
             self.side_stream = torch.cuda.Stream()
         self.trainable = [p for p in model.parameters() if p.requires_grad]
 

@@ -270,8 +270,68 @@ def main_host_goldens() -> None:
     print("host_golden.json ok")
 
 
+def main_step_golden() -> None:
+    """a12: the reference's step body (train_rage2e.py:431-474) on tiny random-init models, fixed batches,
+    dropout 0, fp32, Adam + linear schedule -> per-step losses.  The tiny models are saved under
+    tests/golden/ so the GPU test loads identical weights."""
+    import json
+
+    from transformers import BertConfig, BertModel, LlamaConfig, LlamaForCausalLM, PreTrainedTokenizerFast, get_scheduler
+
+    tu, m_rag, du = import_reference()
+    sys.path.insert(0, str(REF))
+    try:
+        from dalm.training.utils.rag_e2e_dataloader_utils import preprocess_dataset as ref_pre_e2e
+    finally:
+        sys.path.remove(str(REF))
+    tok_dir = OUT / "wordlevel_tokenizer"
+    tok = PreTrainedTokenizerFast.from_pretrained(str(tok_dir))
+    V = len(tok)
+    torch.manual_seed(1234)
+    bert = BertModel(BertConfig(hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64,
+                                vocab_size=V, max_position_embeddings=64, hidden_dropout_prob=0.0,
+                                attention_probs_dropout_prob=0.0))
+    llama = LlamaForCausalLM(LlamaConfig(hidden_size=32, num_hidden_layers=2, num_attention_heads=2,
+                                         num_key_value_heads=2, intermediate_size=64, vocab_size=V,
+                                         max_position_embeddings=64, attention_dropout=0.0, pad_token_id=0))
+    for name, model in (("tiny_retriever", bert), ("tiny_generator", llama)):
+        d = OUT / name
+        model.save_pretrained(str(d))
+        tok.save_pretrained(str(d))
+    rag = m_rag.AutoModelForRagE2E(str(OUT / "tiny_retriever"), str(OUT / "tiny_generator"))
+    g_tok = rag.generator_tokenizer
+    g_tok.pad_token = g_tok.eos_token
+    enc = ref_pre_e2e(ROWS, rag.retriever_tokenizer, g_tok, "Question", "Abstract", "Answer", 12, 24, 40)
+    full = {k: torch.tensor(v) for k, v in enc.items()}
+    batches = [full, {k: v[:3] for k, v in full.items()}, full, {k: v[1:5] for k, v in full.items()}, full]
+    opt = torch.optim.Adam(rag.parameters(), lr=1e-3)
+    sched = get_scheduler("linear", optimizer=opt, num_warmup_steps=0, num_training_steps=20)
+    rag.train()
+    losses, cons, gens = [], [], []
+    for b in batches:
+        q = rag("retrieval", b["retriever_query_input_ids"], b["retriever_query_attention_mask"])
+        p = rag("retrieval", b["retriever_passage_input_ids"], b["retriever_passage_attention_mask"])
+        S = tu.get_cosine_sim(q, p, 100)
+        con = (tu.get_nt_xent_loss(S) + tu.get_nt_xent_loss(S.t())) / 2.0
+        lg = rag("generation", b["generator_input_input_ids"], b["generator_input_attention_mask"])
+        gen = tu.compute_marginalized_loss_from_logits(lg, b["generator_input_input_ids"],
+                                                       b["generator_input_attention_mask"], S,
+                                                       b["query_passage_input_len"])
+        loss = con + gen
+        loss.backward()
+        opt.step(); sched.step(); rag.zero_grad()
+        losses.append(float(loss)); cons.append(float(con)); gens.append(float(gen))
+    rec = {"losses": losses, "contrastive": cons, "generator": gens, "lr": 1e-3, "warmup": 0, "total_steps": 20,
+           "batch_rows": [[0, 5], [0, 3], [0, 5], [1, 5], [0, 5]], "query_max_len": 12, "passage_max_len": 24,
+           "generator_max_len": 40,
+           "final_param_abs_sum": float(sum(p.detach().abs().sum() for p in rag.parameters()))}
+    (OUT / "step_golden.json").write_text(json.dumps(rec, indent=1))
+    print("step_golden.json", losses)
+
+
 if __name__ == "__main__":
     if not REF.exists():
         sys.exit("/root/reference not present: golden vectors can only be regenerated in the build container")
     main()
     main_host_goldens()
+    main_step_golden()
