@@ -233,6 +233,153 @@ __global__ __launch_bounds__(BS, (SLOTS * Elt<T>::VEC > 64 ? 3 : 4)) void marg_c
 }
 
 // ---------------------------------------------------------------------------
+// bf16 rows kept PACKED in registers (4 VGPRs per 8 logits): 32 data VGPRs per lane for a 32768-wide
+// row in a 512-thread block -> <= 64 VGPRs, 8 waves/SIMD, four rows resident per CU.  With that many
+// independent rows per CU the read phase of one row overlaps the write phase of another, which the
+// unpacked variant (2 rows/CU, time = T_read + T_write) could not do.  exp() is recomputed in the
+// gradient phase instead of being kept in f32 registers (VALU is far from the limit here).
+// ---------------------------------------------------------------------------
+template <int BS, int SLOTS, bool WRITE_GRAD, bool ALIGNED>
+__global__ __launch_bounds__(BS, 8) void marg_ce_row_bf16_kernel(
+    const bf16_t* __restrict__ logits, int64_t stride_b, int64_t stride_t,
+    const int64_t* __restrict__ ids, const int64_t* __restrict__ mask, int Tg, int V,
+    const float* __restrict__ stats, float* __restrict__ row_lse, float* __restrict__ row_nll,
+    bf16_t* dlogits) {
+  using T = bf16_t;
+  constexpr int VEC = 8;
+  __shared__ float red[BS / kWave];
+  const int64_t row = blockIdx.x;
+  const int b = static_cast<int>(row / Tg), t = static_cast<int>(row % Tg);
+  const int tid = threadIdx.x;
+  const int64_t off = b * stride_b + t * stride_t;
+  const bool last = (t == Tg - 1);
+  const int64_t mi = last ? 0 : mask[static_cast<int64_t>(b) * Tg + t + 1];
+  const float M = stats[0];
+  if (last || mi == 0) {
+    if (tid == 0) { row_lse[row] = 0.f; row_nll[row] = 0.f; }
+    if constexpr (WRITE_GRAD) {
+      const float fill = (!last && M == 0.f) ? __builtin_nanf("") : 0.f;
+      fill_row<T, BS>(dlogits + off, V, fill);
+    }
+    return;
+  }
+  const T* xrow = logits + off;
+  const int64_t y = ids[static_cast<int64_t>(b) * Tg + t + 1];
+  int lead = 0, nslots = V / VEC;
+  if constexpr (!ALIGNED) {
+    RowWin<T> w(xrow, V);
+    lead = w.lead; nslots = w.nslots;
+  }
+  const bool tail_partial = !ALIGNED && ((lead + V) % VEC) != 0;
+  const char* abase = reinterpret_cast<const char*>(xrow - lead);  // wave-uniform
+
+  constexpr unsigned kNegInf2 = 0xff80ff80u;  // two bf16 -inf
+  uint4 raw[SLOTS];
+#pragma unroll
+  for (int k = 0; k < SLOTS; ++k) {
+    const int slot = k * BS + tid;
+    if (slot < nslots) raw[k] = *reinterpret_cast<const uint4*>(abase + static_cast<unsigned>(slot) * 16u);
+    else raw[k] = make_uint4(kNegInf2, kNegInf2, kNegInf2, kNegInf2);
+  }
+  const float xy = (y >= 0 && y < V) ? bf16_to_f32(xrow[y].v) : __builtin_nanf("");
+
+  if constexpr (!ALIGNED) {  // mask the elements of edge slots that belong to neighbouring rows
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) {
+      const int slot = k * BS + tid;
+      if (slot < nslots && ((slot == 0 && lead != 0) || (slot == nslots - 1 && tail_partial))) {
+        unsigned w[4] = {raw[k].x, raw[k].y, raw[k].z, raw[k].w};
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const int idx = slot * VEC + e - lead;
+          if (idx < 0 || idx >= V) w[e >> 1] = (e & 1) ? ((w[e >> 1] & 0x0000ffffu) | 0xff800000u)
+                                                        : ((w[e >> 1] & 0xffff0000u) | 0x0000ff80u);
+        }
+        raw[k] = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    }
+  }
+
+  float tmax = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < SLOTS; ++k) {
+    const unsigned w[4] = {raw[k].x, raw[k].y, raw[k].z, raw[k].w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      tmax = fmaxf(tmax, fmaxf(__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const float m = block_max<BS>(tmax, red);
+  const float mneg = -m * kLog2e;
+  // make raw[] opaque between the passes: otherwise the unpacked f32 values are CSE'd across the
+  // three passes and stay live (64 extra VGPRs), which is exactly what packing is meant to avoid
+#define DALM_LAUNDER_RAW()                                                                          \
+  _Pragma("unroll") for (int k = 0; k < SLOTS; ++k)                                                 \
+      asm volatile("" : "+v"(raw[k].x), "+v"(raw[k].y), "+v"(raw[k].z), "+v"(raw[k].w))
+  DALM_LAUNDER_RAW();
+  float tsum = 0.f;
+#pragma unroll
+  for (int k = 0; k < SLOTS; ++k) {
+    const unsigned w[4] = {raw[k].x, raw[k].y, raw[k].z, raw[k].w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      tsum += __builtin_amdgcn_exp2f(fmaf(__uint_as_float(w[i] << 16), kLog2e, mneg));
+      tsum += __builtin_amdgcn_exp2f(fmaf(__uint_as_float(w[i] & 0xffff0000u), kLog2e, mneg));
+    }
+    __builtin_amdgcn_sched_barrier(0);  // one slot at a time: keeps the live set at raw[] + a few temporaries
+  }
+  const float l = block_sum<BS>(tsum, red);
+  const float lse = m + __logf(l);
+  const float mval = static_cast<float>(mi);
+  if (tid == 0) {
+    row_lse[row] = lse;
+    row_nll[row] = mval * (lse - xy);
+  }
+  if constexpr (WRITE_GRAD) {
+    DALM_LAUNDER_RAW();
+    T* grow = dlogits + off;
+    char* gbase = reinterpret_cast<char*>(grow - lead);
+    const float coef = mval / M;
+    // softmax = exp(x - lse): a different exponent offset than the sum pass on purpose - with the
+    // same expression the compiler CSEs the two passes and keeps all 64 exps live (+64 VGPRs)
+    const float nlse = -lse * kLog2e;
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) {
+      const int slot = k * BS + tid;
+      if (slot >= nslots) continue;
+      const unsigned w[4] = {raw[k].x, raw[k].y, raw[k].z, raw[k].w};
+      float g[VEC];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        g[2 * i] = __builtin_amdgcn_exp2f(fmaf(__uint_as_float(w[i] << 16), kLog2e, nlse)) * coef;
+        g[2 * i + 1] = __builtin_amdgcn_exp2f(fmaf(__uint_as_float(w[i] & 0xffff0000u), kLog2e, nlse)) * coef;
+      }
+      bool part = false;
+      if constexpr (!ALIGNED) part = (slot == 0 && lead != 0) || (slot == nslots - 1 && tail_partial);
+      if (!part) {
+        Elt<T>::store(reinterpret_cast<T*>(gbase + static_cast<unsigned>(slot) * 16u), g);
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const int idx = slot * VEC + e - lead;
+          if (idx >= 0 && idx < V) Elt<T>::put(grow + idx, g[e]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (y >= 0 && y < V) {
+      const int slot_y = (static_cast<int>(y) + lead) / VEC;
+      if (tid == slot_y % BS) {
+        const float py = __builtin_amdgcn_exp2f(fmaf(xy, kLog2e, nlse)) * coef;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        Elt<T>::put(grow + y, py - coef);
+      }
+    }
+  }
+}
+#undef DALM_LAUNDER_RAW
+
+// ---------------------------------------------------------------------------
 // Streaming fallback for rows that do not fit the register file (V > 65k f32):
 // online (max,sum) pass, then an L2-served second pass for the gradient.
 // ---------------------------------------------------------------------------
@@ -474,7 +621,16 @@ void launch_fwd2(const T* logits, int64_t B, int64_t Tg, int64_t V, int64_t sb, 
     hipLaunchKernelGGL((marg_ce_stream_kernel<T, 1024, GRAD>), grid, dim3(1024), 0, s, DALM_CE_ARGS);
   else if (variant && variant[0] == 't' && need <= 256 * S_WIDE)
     hipLaunchKernelGGL((marg_ce_row_kernel<T, 256, S_WIDE, GRAD, ALIGNED>), grid, dim3(256), 0, s, DALM_CE_ARGS);
-  else if (need <= 256 * S_SMALL)
+  else if (sizeof(T) == 2 && !(variant && variant[0] == 'u') && need > 256 * S_SMALL && need <= 1024 * 8) {
+    if constexpr (sizeof(T) == 2) {  // packed-register bf16 rows (see marg_ce_row_bf16_kernel)
+      if (need <= 512 * 4)
+        hipLaunchKernelGGL((marg_ce_row_bf16_kernel<512, 4, GRAD, ALIGNED>), grid, dim3(512), 0, s, DALM_CE_ARGS);
+      else if (need <= 512 * 8)
+        hipLaunchKernelGGL((marg_ce_row_bf16_kernel<512, 8, GRAD, ALIGNED>), grid, dim3(512), 0, s, DALM_CE_ARGS);
+      else
+        hipLaunchKernelGGL((marg_ce_row_bf16_kernel<1024, 8, GRAD, ALIGNED>), grid, dim3(1024), 0, s, DALM_CE_ARGS);
+    }
+  } else if (need <= 256 * S_SMALL)
     hipLaunchKernelGGL((marg_ce_row_kernel<T, 256, S_SMALL, GRAD, ALIGNED>), grid, dim3(256), 0, s, DALM_CE_ARGS);
   else if (need <= 256 * S_BIG)
     hipLaunchKernelGGL((marg_ce_row_kernel<T, 256, S_BIG, GRAD, ALIGNED>), grid, dim3(256), 0, s, DALM_CE_ARGS);

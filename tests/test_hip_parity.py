@@ -212,7 +212,9 @@ def test_marg_ce_kernels_vs_oracle(dev, B, Tg, V, dtype, view):
     # forward-only + separate backward agree with the fused pass
     row_lse2, row_nll2, none = ops.ce_fwd(lg_dev, ids.to(dev), mask.to(dev), stats, False)
     assert none is None
-    assert torch.equal(row_nll, row_nll2) and torch.equal(row_lse, row_lse2)
+    # (different kernels may serve the two modes - e.g. bf16 forward-only streams - so compare to rounding)
+    torch.testing.assert_close(row_nll2, row_nll, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(row_lse2, row_lse, rtol=1e-5, atol=1e-5)
     g = torch.tensor([0.37], device=dev)
     dl2 = ops.ce_bwd(lg_dev, ids.to(dev), mask.to(dev), stats, row_lse, g)
     assert_grad_close(dl2, 0.37 * ref_dl, tol, "dlogits(bwd)")
