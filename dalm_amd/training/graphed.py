@@ -1,0 +1,73 @@
+"""hipGraph capture of a whole optimisation step (towers + HIP loss path + backward + Adam).
+
+The eager step issues ~10k kernel launches (HF eager elementwise ops dominate the count); replaying
+them from one captured graph removes the host launch path from the critical loop.  Static-shape
+batches are copied into captured input buffers; a batch with another shape (the partial last batch)
+runs eagerly.  Requirements: optimizer built with `capturable=True` and a tensor `lr`
+(`make_capturable_adam`), the LR scheduler stepped outside the graph (it `fill_`s the lr tensor).
+Single-GPU only for now: with W > 1 the step stays eager (RCCL inside a captured step is left for a
+later round).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+
+
+def make_capturable_adam(params, lr: float, device) -> torch.optim.Adam:
+    return torch.optim.Adam(params, lr=torch.tensor(float(lr), device=device), fused=True, capturable=True)
+
+
+class GraphedStep:
+    def __init__(self, step, warmup: int = 3):
+        self.step = step
+        self.warmup = warmup
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.static: Optional[Dict[str, torch.Tensor]] = None
+        self.static_loss: Optional[torch.Tensor] = None
+        self.key: Optional[Tuple] = None
+        self.failed: Optional[str] = None
+        # the LR scheduler must not be captured: it runs on the host and writes the lr tensor
+        self.scheduler = step.lr_scheduler
+        step.lr_scheduler = None
+
+    @staticmethod
+    def _key(batch) -> Tuple:
+        return tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(batch.items()))
+
+    def _capture(self, batch) -> None:
+        self.static = {k: v.clone() for k, v in batch.items()}
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):  # warm-up off the default stream, as the capture API asks
+            for _ in range(self.warmup):
+                self.step(self.static)
+                if self.scheduler is not None:
+                    self.scheduler.step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.static_loss = self.step(self.static)
+        self.graph, self.key = g, self._key(batch)
+
+    def __call__(self, batch) -> torch.Tensor:
+        if self.failed is None and self.graph is None:
+            try:
+                self._capture(batch)
+                # the capture itself does not execute the step; fall through to the replay below
+            except Exception as e:  # keep training: same kernels, eager launches
+                self.failed = repr(e)
+                self.graph = None
+                torch.cuda.synchronize()
+        if self.graph is not None and self._key(batch) == self.key:
+            for k, v in batch.items():
+                self.static[k].copy_(v, non_blocking=True)
+            self.graph.replay()
+            loss = self.static_loss
+        else:
+            loss = self.step(batch)
+        if self.scheduler is not None:
+            self.scheduler.step()
+        return loss

@@ -16,9 +16,10 @@ def load(pattern, counter):
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") != counter:
                 continue
-            k = r["Kernel_Name"].split("(")[0]
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "")
             if "dalm" not in k:
                 continue
+            k = k.split("(")[0].replace("void ", "").replace("dalm::", "")
             a = agg[k]
             a[0] += 1
             a[1] += float(r["Counter_Value"])
