@@ -177,6 +177,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-overlap", action="store_true", help="run the retriever towers on the main stream")
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2"],
+                    help="cfg3 = RAG-e2e bge-large + Llama-2-7b batch 18 (headline, default); "
+                         "cfg2 = retriever-only bge-large batch 150 (BASELINE.json configs[1])")
     ap.add_argument("--retriever-layers", type=int, default=24, help=argparse.SUPPRESS)
     ap.add_argument("--generator-layers", type=int, default=32, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -186,6 +190,8 @@ def main():
     from dalm_amd.training.step import RagE2EStep
 
     hip.load()  # no HIP extension -> fail here, loudly
+    if args.workload == "cfg2":
+        return main_retriever_only(args)
     comm, dev = init_distributed()
     if dev.type != "cuda":
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
@@ -207,7 +213,7 @@ def main():
     sched = get_scheduler("linear", optimizer=opt, num_warmup_steps=100, num_training_steps=100000)
     ops = TimedOps()
     step = RagE2EStep(model, opt, sched, CFG["logit_scale"], comm=comm, autocast_dtype=torch.bfloat16, ops=ops,
-                      inplace_grad=True)
+                      inplace_grad=True, overlap_towers=not args.no_overlap)
     if use_graph:
         step = GraphedStep(step)
     # a few distinct pre-staged batches (inputs resident in HBM before the timed region)
@@ -290,6 +296,78 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "training pairs/s", "cores": os.cpu_count(),
                                        "kind": "port", "sample": f"failed: {e!r}"}
         print(json.dumps(out), flush=True)
+    barrier(comm)
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+def main_retriever_only(args):
+    """BASELINE.json configs[1]: retriever-only contrastive step, bge-large-en architecture, batch 150 per GPU,
+    Tq=50 / Tp=128, LoRA on q/k/v.  Secondary workload (not the headline line)."""
+    from transformers import BertConfig, BertModel, get_scheduler
+
+    from dalm_amd.fused import LocalComm
+    from dalm_amd.models import AutoModelForSentenceEmbedding
+    from dalm_amd.sharded import barrier, init_distributed
+    from dalm_amd.training.graphed import GraphedStep, make_capturable_adam
+    from dalm_amd.training.step import RetrieverStep
+
+    comm, dev = init_distributed()
+    B, Tq, Tp = 150, 50, 128
+    torch.manual_seed(0)
+    with torch.device(dev):
+        old = torch.get_default_dtype()
+        torch.set_default_dtype(torch.bfloat16)
+        try:
+            bert = BertModel(BertConfig(hidden_size=1024, num_hidden_layers=args.retriever_layers, num_attention_heads=16,
+                                        intermediate_size=4096, vocab_size=30522, max_position_embeddings=512))
+        finally:
+            torch.set_default_dtype(old)
+    model = AutoModelForSentenceEmbedding.from_modules(bert, None, normalize=True, get_peft=True)
+    model.train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    use_graph = isinstance(comm, LocalComm) and not args.no_graph
+    opt = make_capturable_adam(params, 1e-4, dev) if use_graph else torch.optim.Adam(params, lr=1e-4, fused=True)
+    sched = get_scheduler("linear", optimizer=opt, num_warmup_steps=0, num_training_steps=100000)
+    step = RetrieverStep(model, opt, sched, CFG["logit_scale"], comm=comm, autocast_dtype=torch.bfloat16)
+    if use_graph:
+        step = GraphedStep(step)
+
+    def batch(seed):
+        g = torch.Generator().manual_seed(seed)
+        ql = torch.randint(5, 16, (B, 1), generator=g)
+        pl = torch.randint(30, Tp + 1, (B, 1), generator=g)
+        return {k: v.to(dev) for k, v in {
+            "query_input_ids": torch.randint(1000, 30522, (B, Tq), generator=g),
+            "query_attention_mask": (torch.arange(Tq).unsqueeze(0) < ql).long(),
+            "passage_input_ids": torch.randint(1000, 30522, (B, Tp), generator=g),
+            "passage_attention_mask": (torch.arange(Tp).unsqueeze(0) < pl).long()}.items()}
+
+    batches = [batch(200 + 17 * comm.rank + i) for i in range(4)]
+    for i in range(args.warmup):
+        step(batches[i % 4])
+    torch.cuda.synchronize()
+    barrier(comm)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(batches[i % 4])
+    torch.cuda.synchronize()
+    barrier(comm)
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    if comm.rank == 0:
+        value = args.gpus * B * args.steps / float(t.item())
+        print(json.dumps({
+            "metric": "training pairs/sec (global batch) retriever-only bge-large", "value": value, "unit": "pairs/s",
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * float(t.item()) / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "cfg2 retriever-only: bge-large-en architecture (random init), LoRA r=8 q/k/v, per-GPU batch 150, "
+                                   "Tq50/Tp128, logit_scale 100, Adam, bf16 autocast", "global_batch": args.gpus * B,
+                       "parallelism": f"dp{args.gpus} + sharded in-batch negatives", "final_loss": float(loss),
+                       "launch": "hipGraph replay" if (use_graph and getattr(step, "graph", None) is not None) else "eager"}}),
+              flush=True)
     barrier(comm)
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

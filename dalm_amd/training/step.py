@@ -49,19 +49,40 @@ class _StepBase:
 class RagE2EStep(_StepBase):
     """batch keys as produced by preprocess_dataset (rag_e2e_dataloader_utils.py:56-68)."""
 
-    def __init__(self, *a, inplace_grad: bool = True, **kw):
+    def __init__(self, *a, inplace_grad: bool = True, overlap_towers: bool = True, **kw):
         super().__init__(*a, **kw)
         self.inplace_grad = inplace_grad
         self.aux: Dict[str, torch.Tensor] = {}
+        # the two retriever towers are many small kernels (3204 tokens through BERT) and are independent of
+        # the generator until the loss: run them on their own HIP stream so they fill the gaps between the
+        # generator's large GEMMs; autograd replays each backward on its forward stream, so the backward
+        # overlaps the same way
+        self.tower_stream = torch.cuda.Stream() if (overlap_towers and torch.cuda.is_available()) else None
+
+    def _towers(self, batch):
+        m = self.model
+        p_emb = m("retrieval", batch["retriever_passage_input_ids"], batch["retriever_passage_attention_mask"])
+        p_gather = GatherHandle(p_emb.float(), self.comm, self.side_stream)
+        q_emb = m("retrieval", batch["retriever_query_input_ids"], batch["retriever_query_attention_mask"])
+        q_gather = GatherHandle(q_emb.float(), self.comm, self.side_stream)
+        return p_emb, q_emb, p_gather, q_gather
 
     def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         m = self.model
         with self._autocast():
-            p_emb = m("retrieval", batch["retriever_passage_input_ids"], batch["retriever_passage_attention_mask"])
-            p_gather = GatherHandle(p_emb.float(), self.comm, self.side_stream)
-            q_emb = m("retrieval", batch["retriever_query_input_ids"], batch["retriever_query_attention_mask"])
-            q_gather = GatherHandle(q_emb.float(), self.comm, self.side_stream)
-            logits = m("generation", batch["generator_input_input_ids"], batch["generator_input_attention_mask"])
+            if self.tower_stream is not None:
+                cur = torch.cuda.current_stream()
+                self.tower_stream.wait_stream(cur)
+                with torch.cuda.stream(self.tower_stream):
+                    p_emb, q_emb, p_gather, q_gather = self._towers(batch)
+                logits = m("generation", batch["generator_input_input_ids"], batch["generator_input_attention_mask"])
+                cur.wait_stream(self.tower_stream)
+                for t in (p_emb, q_emb, p_gather.result, q_gather.result):
+                    if t is not None and t.is_cuda:
+                        t.record_stream(cur)
+            else:
+                p_emb, q_emb, p_gather, q_gather = self._towers(batch)
+                logits = m("generation", batch["generator_input_input_ids"], batch["generator_input_attention_mask"])
         loss = rag_e2e_loss(q_emb, p_emb, logits, batch["generator_input_input_ids"],
                             batch["generator_input_attention_mask"], batch["query_passage_input_len"],
                             self.logit_scale, comm=self.comm, ops=self.ops, inplace_grad=self.inplace_grad,
