@@ -205,12 +205,15 @@ def main():
     from transformers import get_scheduler
 
     from dalm_amd.fused import LocalComm
-    from dalm_amd.training.graphed import GraphedStep, make_capturable_adam
+    from dalm_amd.training.graphed import GraphedStep, TensorLRScheduler, make_capturable_adam
 
     use_graph = isinstance(comm, LocalComm) and not args.no_graph
     opt = make_capturable_adam(params, 1e-4, dev) if use_graph else torch.optim.Adam(params, lr=1e-4, fused=True)
 
-    sched = get_scheduler("linear", optimizer=opt, num_warmup_steps=100, num_training_steps=100000)
+    def mk_sched(o):
+        return get_scheduler("linear", optimizer=o, num_warmup_steps=100, num_training_steps=100000)
+
+    sched = TensorLRScheduler(opt, 1e-4, mk_sched) if use_graph else mk_sched(opt)
     ops = TimedOps()
     step = RagE2EStep(model, opt, sched, CFG["logit_scale"], comm=comm, autocast_dtype=torch.bfloat16, ops=ops,
                       inplace_grad=True, overlap_towers=not args.no_overlap)
@@ -309,7 +312,7 @@ def main_retriever_only(args):
     from dalm_amd.fused import LocalComm
     from dalm_amd.models import AutoModelForSentenceEmbedding
     from dalm_amd.sharded import barrier, init_distributed
-    from dalm_amd.training.graphed import GraphedStep, make_capturable_adam
+    from dalm_amd.training.graphed import GraphedStep, TensorLRScheduler, make_capturable_adam
     from dalm_amd.training.step import RetrieverStep
 
     comm, dev = init_distributed()
@@ -328,7 +331,10 @@ def main_retriever_only(args):
     params = [p for p in model.parameters() if p.requires_grad]
     use_graph = isinstance(comm, LocalComm) and not args.no_graph
     opt = make_capturable_adam(params, 1e-4, dev) if use_graph else torch.optim.Adam(params, lr=1e-4, fused=True)
-    sched = get_scheduler("linear", optimizer=opt, num_warmup_steps=0, num_training_steps=100000)
+    def mk_sched(o):
+        return get_scheduler("linear", optimizer=o, num_warmup_steps=0, num_training_steps=100000)
+
+    sched = TensorLRScheduler(opt, 1e-4, mk_sched) if use_graph else mk_sched(opt)
     step = RetrieverStep(model, opt, sched, CFG["logit_scale"], comm=comm, autocast_dtype=torch.bfloat16)
     if use_graph:
         step = GraphedStep(step)

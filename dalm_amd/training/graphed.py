@@ -19,6 +19,62 @@ def make_capturable_adam(params, lr: float, device) -> torch.optim.Adam:
     return torch.optim.Adam(params, lr=torch.tensor(float(lr), device=device), fused=True, capturable=True)
 
 
+def init_adam_state(optimizer: torch.optim.Adam) -> None:
+    """Materialise Adam's lazily created state (step, exp_avg, exp_avg_sq) BEFORE a capture.
+
+    If the first optimizer.step() happens inside the capture, the zero-initialisation of the state is
+    recorded in the graph and every replay resets the moments - the first replay is right, all later
+    ones are wrong (caught by tests/test_step_parity_gpu.py)."""
+    for group in optimizer.param_groups:
+        for p in group["params"]:
+            if not p.requires_grad or len(optimizer.state[p]) != 0:
+                continue
+            st = optimizer.state[p]
+            st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if group.get("amsgrad"):
+                st["max_exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+
+
+class TensorLRScheduler:
+    """Drives the tensor-valued lr of a capturable optimizer from an ordinary scheduler.
+
+    The scheduler is built on a shadow optimizer with a FLOAT lr (schedulers keep `initial_lr` by
+    reference, so attaching one directly to a tensor lr compounds the decay: lr_t = lr_{t-1} * f(t));
+    after every shadow step the float is written into the real optimizer's lr tensor with fill_(),
+    which a captured graph picks up on its next replay."""
+
+    def __init__(self, optimizer, lr: float, factory: Callable[[torch.optim.Optimizer], object]):
+        self.optimizer = optimizer
+        self._shadow = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=float(lr))
+        self.scheduler = factory(self._shadow)
+        self._push()
+
+    def _push(self) -> None:
+        lr = float(self._shadow.param_groups[0]["lr"])
+        for g in self.optimizer.param_groups:
+            if torch.is_tensor(g["lr"]):
+                g["lr"].fill_(lr)
+            else:
+                g["lr"] = lr
+
+    def step(self) -> None:
+        self._shadow.step()
+        self.scheduler.step()
+        self._push()
+
+    def get_last_lr(self):
+        return self.scheduler.get_last_lr()
+
+    def state_dict(self):
+        return self.scheduler.state_dict()
+
+    def load_state_dict(self, sd) -> None:
+        self.scheduler.load_state_dict(sd)
+        self._push()
+
+
 class GraphedStep:
     def __init__(self, step, warmup: int = 3):
         self.step = step
@@ -46,6 +102,7 @@ class GraphedStep:
                 if self.scheduler is not None:
                     self.scheduler.step()
         torch.cuda.current_stream().wait_stream(s)
+        init_adam_state(self.step.optimizer)  # no-op after a warm-up step; essential with warmup == 0
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):

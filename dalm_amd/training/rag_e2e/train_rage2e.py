@@ -60,6 +60,7 @@ FLAGS = [
     ("retriever_is_autoregressive", dict(action="store_true", help="Retriever is an autoregressive LM")),
     # extensions (not in the reference)
     ("mixed_precision", dict(type=_S, default="bf16", choices=["no", "bf16"], help="[ext] autocast dtype of the towers")),
+    ("no_hip_graph", dict(action="store_true", help="[ext] launch every step eagerly instead of replaying a hipGraph")),
 ]
 
 
@@ -100,6 +101,7 @@ def train_e2e(
     retriever_is_autoregressive: bool = False,
     *,
     mixed_precision: str = "bf16",
+    no_hip_graph: bool = False,
     rag_model: Optional[AutoModelForRagE2E] = None,
     on_step=None,
 ) -> None:
@@ -140,14 +142,24 @@ def train_e2e(
 
     # ---- optimiser / schedule (reference :336-362) ----------------------------------------------
     params = [p for p in rag_model.parameters() if p.requires_grad]
-    optimizer = torch.optim.Adam(params, lr=learning_rate, fused=True)
+    # one GPU: the whole step is captured once and replayed as a hipGraph (capturable Adam + tensor lr);
+    # W > 1 launches eagerly (RCCL collectives stay outside graphs for now)
+    from ...fused import LocalComm
+    from ..graphed import GraphedStep, TensorLRScheduler, make_capturable_adam
+
+    use_graph = isinstance(comm, LocalComm) and not no_hip_graph
+    optimizer = (make_capturable_adam(params, learning_rate, device) if use_graph
+                 else torch.optim.Adam(params, lr=learning_rate, fused=True))
     per_epoch, max_train_steps, num_train_epochs = common.steps_and_epochs(
         len(batches), gradient_accumulation_steps, num_train_epochs, max_train_steps)
     from transformers import get_scheduler
 
     name = getattr(lr_scheduler_type, "value", lr_scheduler_type)
-    scheduler = get_scheduler(name=name, optimizer=optimizer, num_warmup_steps=num_warmup_steps,
-                              num_training_steps=max_train_steps)
+
+    def make_schedule(o):
+        return get_scheduler(name=name, optimizer=o, num_warmup_steps=num_warmup_steps, num_training_steps=max_train_steps)
+
+    scheduler = TensorLRScheduler(optimizer, learning_rate, make_schedule) if use_graph else make_schedule(optimizer)
     if checkpointing_steps is not None and str(checkpointing_steps).isdigit():
         checkpointing_steps = int(checkpointing_steps)
     tracker = common.Tracker(with_tracking, output_dir, "peft_rag_e2e_learning", config, is_main)
@@ -171,6 +183,8 @@ def train_e2e(
                     per_device_train_batch_size * comm.world_size, max_train_steps)
     step_fn = RagE2EStep(rag_model, optimizer, scheduler, logit_scale, comm=comm,
                          autocast_dtype=torch.bfloat16 if mixed_precision == "bf16" else None)
+    if use_graph:
+        step_fn = GraphedStep(step_fn, warmup=0)  # partial last batches (other shapes) run eagerly
     meter = common.Throughput()
     for epoch in range(starting_epoch, num_train_epochs):
         rag_model.train()

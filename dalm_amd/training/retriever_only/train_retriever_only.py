@@ -49,6 +49,7 @@ FLAGS = [
     ("use_bnb", dict(action="store_true", help="4-bit quantisation (not available on this build)")),
     ("is_autoregressive", dict(action="store_true", help="Retriever is an autoregressive LM")),
     ("mixed_precision", dict(type=_S, default="bf16", choices=["no", "bf16"], help="[ext] autocast dtype")),
+    ("no_hip_graph", dict(action="store_true", help="[ext] launch every step eagerly instead of replaying a hipGraph")),
 ]
 
 
@@ -86,6 +87,7 @@ def train_retriever(
     is_autoregressive: bool = False,
     *,
     mixed_precision: str = "bf16",
+    no_hip_graph: bool = False,
     model: Optional[AutoModelForSentenceEmbedding] = None,
     on_step=None,
 ) -> None:
@@ -115,13 +117,23 @@ def train_retriever(
     batches = common.ShardedBatches(processed, per_device_train_batch_size, comm.rank, comm.world_size,
                                     seed if seed is not None else 0, columns)
     params = [p for p in model.parameters() if p.requires_grad]
-    optimizer = torch.optim.Adam(params, lr=learning_rate, fused=True)
+    # one GPU: the whole step is captured once and replayed as a hipGraph (capturable Adam + tensor lr);
+    # W > 1 launches eagerly (RCCL collectives stay outside graphs for now)
+    from ...fused import LocalComm
+    from ..graphed import GraphedStep, TensorLRScheduler, make_capturable_adam
+
+    use_graph = isinstance(comm, LocalComm) and not no_hip_graph
+    optimizer = (make_capturable_adam(params, learning_rate, device) if use_graph
+                 else torch.optim.Adam(params, lr=learning_rate, fused=True))
     per_epoch, max_train_steps, num_train_epochs = common.steps_and_epochs(
         len(batches), gradient_accumulation_steps, num_train_epochs, max_train_steps)
     from transformers import get_scheduler
 
-    scheduler = get_scheduler(name=getattr(lr_scheduler_type, "value", lr_scheduler_type), optimizer=optimizer,
-                              num_warmup_steps=num_warmup_steps, num_training_steps=max_train_steps)
+    def make_schedule(o):
+        return get_scheduler(name=getattr(lr_scheduler_type, "value", lr_scheduler_type), optimizer=o,
+                             num_warmup_steps=num_warmup_steps, num_training_steps=max_train_steps)
+
+    scheduler = TensorLRScheduler(optimizer, learning_rate, make_schedule) if use_graph else make_schedule(optimizer)
     if checkpointing_steps is not None and str(checkpointing_steps).isdigit():
         checkpointing_steps = int(checkpointing_steps)
     tracker = common.Tracker(with_tracking, output_dir, "peft_contrastive_learning", config, is_main)
@@ -137,6 +149,8 @@ def train_retriever(
                                                                      gradient_accumulation_steps)
     step_fn = RetrieverStep(model, optimizer, scheduler, logit_scale, comm=comm,
                             autocast_dtype=torch.bfloat16 if mixed_precision == "bf16" else None)
+    if use_graph:
+        step_fn = GraphedStep(step_fn, warmup=0)
     meter = common.Throughput()
     for epoch in range(starting_epoch, num_train_epochs):
         model.train()

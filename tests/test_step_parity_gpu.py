@@ -22,11 +22,14 @@ def _batches(tok_r, tok_g, gold, dev):
     return [{k: v[a:b] for k, v in full.items()} for a, b in gold["batch_rows"]]
 
 
-@pytest.mark.parametrize("inplace", [False, True])
-def test_rag_e2e_step_trajectory_matches_reference(inplace):
+@pytest.mark.parametrize("inplace,graph", [(False, False), (True, False), (True, True)])
+def test_rag_e2e_step_trajectory_matches_reference(inplace, graph):
+    """graph=True: the step is captured into a hipGraph (5-row batches replay it, the 3- and 4-row batches
+    run eagerly), towers overlapped on a side stream - same trajectory as the reference either way."""
     from transformers import get_scheduler
 
     from dalm_amd.models import AutoModelForRagE2E
+    from dalm_amd.training.graphed import GraphedStep, TensorLRScheduler, make_capturable_adam
     from dalm_amd.training.step import RagE2EStep
 
     gold = json.loads((G / "step_golden.json").read_text())
@@ -35,12 +38,19 @@ def test_rag_e2e_step_trajectory_matches_reference(inplace):
     g_tok = rag.generator_tokenizer
     g_tok.pad_token = g_tok.eos_token
     rag.train()
-    opt = torch.optim.Adam(rag.parameters(), lr=gold["lr"])
-    sched = get_scheduler("linear", optimizer=opt, num_warmup_steps=gold["warmup"], num_training_steps=gold["total_steps"])
-    step = RagE2EStep(rag, opt, sched, 100, autocast_dtype=None, inplace_grad=inplace)
+    opt = make_capturable_adam(rag.parameters(), gold["lr"], dev) if graph else torch.optim.Adam(rag.parameters(), lr=gold["lr"])
+    def mk(o):
+        return get_scheduler("linear", optimizer=o, num_warmup_steps=gold["warmup"], num_training_steps=gold["total_steps"])
+
+    sched = TensorLRScheduler(opt, gold["lr"], mk) if graph else mk(opt)
+    step = RagE2EStep(rag, opt, sched, 100, autocast_dtype=None, inplace_grad=inplace, overlap_towers=graph)
+    if graph:
+        step = GraphedStep(step, warmup=0)  # no hidden warm-up steps: the trajectory must start at step 0
     losses = []
     for b in _batches(rag.retriever_tokenizer, g_tok, gold, dev):
         losses.append(float(step(b)))
+    if graph:
+        assert step.failed is None and step.graph is not None, step.failed
     for got, ref in zip(losses, gold["losses"]):
         assert abs(got - ref) <= 1e-3 * abs(ref), (losses, gold["losses"])
     final = float(sum(p.detach().abs().sum() for p in rag.parameters()))
@@ -66,3 +76,36 @@ def test_retriever_only_step_runs_and_decreases_loss():
     model.eval()  # LoRA dropout off: deterministic descent check
     losses = [float(step(batch)) for _ in range(8)]
     assert losses[-1] < losses[0]
+
+
+def test_train_e2e_end_to_end_on_csv(tmp_path):
+    """The trainer entry point itself: csv -> tokenise -> hipGraph-replayed steps -> checkpoints in the
+    reference's directory layout -> resume."""
+    import csv
+
+    from dalm_amd.training.rag_e2e.train_rage2e import train_e2e
+
+    rows = json.loads((G / "host_golden.json").read_text())["rows"]
+    path = tmp_path / "rows.csv"
+    with open(path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Question", "Abstract", "Answer"])
+        for i in range(12):
+            k = i % 5
+            w.writerow([rows["Question"][k], rows["Abstract"][k], rows["Answer"][k]])
+    out = tmp_path / "out"
+    losses = []
+    train_e2e(str(path), str(G / "tiny_retriever"), str(G / "tiny_generator"), query_max_len=12, passage_max_len=24,
+              generator_max_len=40, per_device_train_batch_size=4, learning_rate=1e-3, num_train_epochs=2,
+              num_warmup_steps=0, output_dir=str(out), checkpointing_steps="epoch", with_tracking=True,
+              mixed_precision="no", on_step=lambda s, l: losses.append(float(l)))
+    assert len(losses) == 6 and losses[-1] < losses[0]
+    for sub in ("retriever", "generator", "epoch_0/retriever", "epoch_1/generator", "logs"):
+        assert (out / sub).exists(), sub
+    assert (out / "epoch_1" / "trainer_state.pt").exists()
+    more = []
+    train_e2e(str(path), str(G / "tiny_retriever"), str(G / "tiny_generator"), query_max_len=12, passage_max_len=24,
+              generator_max_len=40, per_device_train_batch_size=4, learning_rate=1e-3, num_train_epochs=3,
+              num_warmup_steps=0, output_dir=str(out), resume_from_checkpoint=str(out / "epoch_1"), with_tracking=False,
+              mixed_precision="no", on_step=lambda s, l: more.append((s, float(l))))
+    assert [s for s, _ in more] == [7, 8, 9]  # epochs 0-1 are skipped, one more epoch of 3 steps runs
