@@ -32,12 +32,13 @@ struct GemmParams {
   const float* A; int64_t lda;
   const float* B; int64_t ldb;
   int M, N, K;
+  unsigned tiles_n;  // number of tile columns (set by the launcher)
   float alpha;
   int a_vec, b_vec;  // 16-byte vector loads legal for A / B
   // EPI_STORE / EPI_DS
   float* C; int64_t ldc;
   // EPI_ROWSTATS
-  float* part_m; float* part_l;  // [P][M], P = 2 * gridDim.x
+  float* part_m; float* part_l;  // [P][M], P = 2 * tiles_n
   float* diag; int64_t diag_offset;
   // EPI_DS
   const float* row_coef; const float* row_lse; const float* col_coef; const float* col_lse;
@@ -110,7 +111,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(const GemmParams 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
+  // XCD-aware tile order (1-D grid): workgroup L runs on XCD L % 8, each XCD has its own L2.  Give every
+  // XCD a contiguous run of logical tiles (bijective form for any grid size) so the N-tiles that share an
+  // A row-panel are co-resident on ONE XCD and the panel is fetched from HBM once instead of 8 times.
+  const unsigned nwg = gridDim.x, L = blockIdx.x;
+  const unsigned q8 = nwg >> 3, r8 = nwg & 7u, xcd = L & 7u;
+  const unsigned wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (L >> 3);
+  const int bx = static_cast<int>(wgid % p.tiles_n), by = static_cast<int>(wgid / p.tiles_n);
+  const int bm0 = by * BM, bn0 = bx * BN;
   const int l31 = lane & 31, lhi = lane >> 5;
 
   f32x16 acc[TM][TN];
@@ -204,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(const GemmParams 
 #pragma unroll
         for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
         if (row_ok && l31 == 0) {
-          const int64_t pi = static_cast<int64_t>(blockIdx.x * 2 + wn) * p.M + row;
+          const int64_t pi = static_cast<int64_t>(bx * 2 + wn) * p.M + row;
           p.part_m[pi] = mx;
           p.part_l[pi] = s;
         }
@@ -300,8 +308,9 @@ inline bool vec_ok(const float* p, int64_t ld) {
 }
 
 template <int BM, int BN, int BK, int EPI>
-void launch_gemm_tile(bool a_kc, bool b_kc, const GemmParams& p, hipStream_t s) {
-  const dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM);
+void launch_gemm_tile(bool a_kc, bool b_kc, GemmParams p, hipStream_t s) {
+  p.tiles_n = static_cast<unsigned>((p.N + BN - 1) / BN);
+  const dim3 grid(p.tiles_n * static_cast<unsigned>((p.M + BM - 1) / BM));
   if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, true, true, EPI>), grid, dim3(256), 0, s, p);
   else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, true, false, EPI>), grid, dim3(256), 0, s, p);
   else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, false, true, EPI>), grid, dim3(256), 0, s, p);
@@ -327,7 +336,7 @@ int check_gemm_dims(int64_t M, int64_t N, int64_t K, const char* fn) {
   if (M <= 0 || N <= 0 || K <= 0) return fail(DALM_E_SHAPE, fn, "dimensions must be positive");
   if (M > 0x7fffffffll - 256 || N > 0x7fffffffll - 256 || K > 0x7fffffffll - 256)
     return fail(DALM_E_SHAPE, fn, "dimension exceeds int32 range");
-  if ((M + 63) / 64 > 65535) return fail(DALM_E_SHAPE, fn, "too many row tiles (M > 4.19M)");
+  if (((M + 63) / 64) * ((N + 63) / 64) > 0x7fffffffll) return fail(DALM_E_SHAPE, fn, "too many tiles");
   return 0;
 }
 
