@@ -190,6 +190,9 @@ def main():
     from dalm_amd.training.step import RagE2EStep
 
     hip.load()  # no HIP extension -> fail here, loudly
+    from dalm_amd.tuning import enable_tuned_gemms
+
+    args.tuned_gemms = enable_tuned_gemms()  # replay-only hipBLASLt/rocBLAS solution table for the tower GEMMs
     if args.workload == "cfg2":
         return main_retriever_only(args)
     comm, dev = init_distributed()
@@ -279,6 +282,7 @@ def main():
                                    "towers, per-GPU batch 18, Tq50/Tp128/Tg256, logit_scale 100, Adam, bf16 autocast",
                        "global_batch": args.gpus * B, "parallelism": f"dp{args.gpus} + sharded in-batch negatives",
                        "retriever_layers": args.retriever_layers, "generator_layers": args.generator_layers,
+                       "tower_gemms": "pre-tuned solution table (dalm_amd/tuning)" if args.tuned_gemms else "library defaults",
                        "launch": ("hipGraph replay" if (use_graph and getattr(step, "graph", None) is not None)
                                   else "eager" + (f" (capture failed: {step.failed})" if getattr(step, "failed", None) else "")),
                        "baseline_ref": "reference README.md:34-40: 200k rows in 7 h on 1x A100-80GB = 7.94 pairs/s",

@@ -112,6 +112,9 @@ def train_e2e(
     if device.type != "cuda":
         raise RuntimeError("train_e2e needs an MI355X: the loss path has no CPU implementation in this package")
     is_main = comm.rank == 0
+    from ...tuning import enable_tuned_gemms
+
+    enable_tuned_gemms()  # replay-only GEMM solution table for the towers; unknown shapes use library defaults
     common.seed_everything(seed)
     if rag_model is None:
         dtype = torch.bfloat16 if (mixed_precision == "bf16" and use_peft is not None) else None

@@ -96,6 +96,9 @@ def train_retriever(
     if device.type != "cuda":
         raise RuntimeError("train_retriever needs an MI355X: the loss path has no CPU implementation in this package")
     is_main = comm.rank == 0
+    from ...tuning import enable_tuned_gemms
+
+    enable_tuned_gemms()  # replay-only GEMM solution table for the towers; unknown shapes use library defaults
     common.seed_everything(seed)
     if is_main and output_dir is not None:
         os.makedirs(output_dir, exist_ok=True)
