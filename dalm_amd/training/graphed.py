@@ -76,9 +76,15 @@ class TensorLRScheduler:
 
 
 class GraphedStep:
-    def __init__(self, step, warmup: int = 3):
+    def __init__(self, step, warmup: int = 3, eager_steps: int = 0):
+        """warmup: hidden extra steps run on a side stream right before the capture (benchmarks);
+        eager_steps: the first N REAL steps are launched eagerly and the capture happens after them
+        (trainers: no hidden steps, and every library - hipBLASLt workspaces, GEMM solution lookup,
+        allocator pools - has seen the shapes before anything is captured)."""
         self.step = step
         self.warmup = warmup
+        self.eager_steps = eager_steps
+        self.calls = 0
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.static: Optional[Dict[str, torch.Tensor]] = None
         self.static_loss: Optional[torch.Tensor] = None
@@ -110,7 +116,8 @@ class GraphedStep:
         self.graph, self.key = g, self._key(batch)
 
     def __call__(self, batch) -> torch.Tensor:
-        if self.failed is None and self.graph is None:
+        self.calls += 1
+        if self.failed is None and self.graph is None and self.calls > self.eager_steps:
             try:
                 self._capture(batch)
                 # the capture itself does not execute the step; fall through to the replay below

@@ -187,7 +187,7 @@ def train_e2e(
     step_fn = RagE2EStep(rag_model, optimizer, scheduler, logit_scale, comm=comm,
                          autocast_dtype=torch.bfloat16 if mixed_precision == "bf16" else None)
     if use_graph:
-        step_fn = GraphedStep(step_fn, warmup=0)  # partial last batches (other shapes) run eagerly
+        step_fn = GraphedStep(step_fn, warmup=0, eager_steps=2)  # partial last batches (other shapes) run eagerly
     meter = common.Throughput()
     for epoch in range(starting_epoch, num_train_epochs):
         rag_model.train()

@@ -153,7 +153,7 @@ def train_retriever(
     step_fn = RetrieverStep(model, optimizer, scheduler, logit_scale, comm=comm,
                             autocast_dtype=torch.bfloat16 if mixed_precision == "bf16" else None)
     if use_graph:
-        step_fn = GraphedStep(step_fn, warmup=0)
+        step_fn = GraphedStep(step_fn, warmup=0, eager_steps=2)
     meter = common.Throughput()
     for epoch in range(starting_epoch, num_train_epochs):
         model.train()
