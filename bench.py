@@ -339,7 +339,8 @@ def main_retriever_only(args):
         return get_scheduler("linear", optimizer=o, num_warmup_steps=0, num_training_steps=100000)
 
     sched = TensorLRScheduler(opt, 1e-4, mk_sched) if use_graph else mk_sched(opt)
-    step = RetrieverStep(model, opt, sched, CFG["logit_scale"], comm=comm, autocast_dtype=torch.bfloat16)
+    step = RetrieverStep(model, opt, sched, CFG["logit_scale"], comm=comm, autocast_dtype=torch.bfloat16,
+                         overlap_towers=not args.no_overlap)
     if use_graph:
         step = GraphedStep(step)
 

@@ -93,13 +93,31 @@ class RagE2EStep(_StepBase):
 class RetrieverStep(_StepBase):
     """batch keys as produced by retriever_only_dataloader_utils.preprocess_dataset."""
 
+    def __init__(self, *a, overlap_towers: bool = True, **kw):
+        super().__init__(*a, **kw)
+        # the query pass (Tq = 50) is small next to the passage pass (Tp = 128): run it on its own stream
+        self.tower_stream = torch.cuda.Stream() if (overlap_towers and torch.cuda.is_available()) else None
+
     def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         m = self.model
         with self._autocast():
-            p_emb = m(batch["passage_input_ids"], batch["passage_attention_mask"])
-            p_gather = GatherHandle(p_emb.float(), self.comm, self.side_stream)
-            q_emb = m(batch["query_input_ids"], batch["query_attention_mask"])
-            q_gather = GatherHandle(q_emb.float(), self.comm, self.side_stream)
+            if self.tower_stream is not None:
+                cur = torch.cuda.current_stream()
+                self.tower_stream.wait_stream(cur)
+                with torch.cuda.stream(self.tower_stream):
+                    q_emb = m(batch["query_input_ids"], batch["query_attention_mask"])
+                    q_gather = GatherHandle(q_emb.float(), self.comm, self.side_stream)
+                p_emb = m(batch["passage_input_ids"], batch["passage_attention_mask"])
+                p_gather = GatherHandle(p_emb.float(), self.comm, self.side_stream)
+                cur.wait_stream(self.tower_stream)
+                for t in (q_emb, q_gather.result):
+                    if t is not None and t.is_cuda:
+                        t.record_stream(cur)
+            else:
+                p_emb = m(batch["passage_input_ids"], batch["passage_attention_mask"])
+                p_gather = GatherHandle(p_emb.float(), self.comm, self.side_stream)
+                q_emb = m(batch["query_input_ids"], batch["query_attention_mask"])
+                q_gather = GatherHandle(q_emb.float(), self.comm, self.side_stream)
         loss = contrastive_loss(q_emb, p_emb, self.logit_scale, comm=self.comm, ops=self.ops, q_gather=q_gather,
                                 p_gather=p_gather)
         return self._finish(loss)
