@@ -59,7 +59,7 @@ class LoRALinear(nn.Module):
         z = self.lora_dropout["default"](x)
         if not torch.is_autocast_enabled() and z.dtype != a.weight.dtype:
             z = z.to(a.weight.dtype)  # outside autocast the fp32 adapters need fp32 activations
-        return out + (b(a(z)) * self.scaling).to(out.dtype)
+        return torch.add(out, b(a(z)).to(out.dtype), alpha=self.scaling)  # one kernel for scale + add
 
     @torch.no_grad()
     def merge(self) -> nn.Linear:

@@ -14,6 +14,7 @@ import torch
 from ..fused import pool_l2norm
 from ..utils import eos_mask
 from . import lora
+from .fastpath import use_native_rms_norm
 
 
 class Mode(Enum):
@@ -71,6 +72,9 @@ class AutoModelForRagE2E(torch.nn.Module):
             r_tok.pad_token = r_tok.eos_token
         self.normalize = normalize
         self.retriever_is_autoregressive = autoregressive
+        use_native_rms_norm(self.generator_model)
+        if autoregressive:
+            use_native_rms_norm(self.retriever_model)
         if get_peft is not None:
             get_peft = Mode(get_peft)
             if get_peft in (Mode.RETRIEVER, Mode.BOTH):

@@ -9,6 +9,7 @@ import torch
 from ..fused import pool_l2norm
 from ..utils import eos_mask
 from . import lora
+from .fastpath import use_native_rms_norm
 from .rag_e2e_base_model import _BNB_MSG
 
 
@@ -41,6 +42,8 @@ class AutoModelForSentenceEmbedding(torch.nn.Module):
 
     def _assemble(self, model, tokenizer, normalize, get_peft, is_autoregressive) -> None:
         self.model = model
+        if is_autoregressive:
+            use_native_rms_norm(self.model)
         if get_peft:
             lora.inject_lora(self.model, ["key", "query", "value"] if not is_autoregressive else ["q_proj", "v_proj"])
         self.normalize = normalize
