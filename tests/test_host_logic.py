@@ -156,3 +156,72 @@ def test_use_bnb_is_rejected_loudly():
 
     with pytest.raises(NotImplementedError, match="bitsandbytes"):
         AutoModelForRagE2E("r", "g", use_bnb=Mode.BOTH)
+
+
+def test_native_rms_norm_patch_matches_hf_module():
+    from transformers.models.llama.modeling_llama import LlamaRMSNorm
+
+    from dalm_amd.models.fastpath import use_native_rms_norm
+
+    torch.manual_seed(0)
+    m = LlamaRMSNorm(48, eps=1e-5)
+    with torch.no_grad():
+        m.weight.copy_(torch.randn(48))
+    x = torch.randn(5, 7, 48, requires_grad=True)
+    ref = m(x)
+    ref.sum().backward()
+    gx, gw = x.grad.clone(), m.weight.grad.clone()
+    x.grad = None
+    m.weight.grad = None
+    holder = torch.nn.Sequential(m)
+    assert use_native_rms_norm(holder) == 1
+    out = m(x)
+    out.sum().backward()
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(x.grad, gx, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(m.weight.grad, gw, rtol=1e-4, atol=1e-5)
+
+
+def test_tensor_lr_scheduler_follows_a_plain_scheduler():
+    """The shadow scheduler must reproduce the plain schedule exactly (no compounding through a tensor lr)."""
+    from transformers import get_scheduler
+
+    from dalm_amd.training.graphed import TensorLRScheduler
+
+    def mk(o):
+        return get_scheduler("linear", optimizer=o, num_warmup_steps=2, num_training_steps=10)
+
+    p1, p2 = torch.nn.Parameter(torch.zeros(1)), torch.nn.Parameter(torch.zeros(1))
+    plain_opt = torch.optim.Adam([p1], lr=1e-3)
+    plain = mk(plain_opt)
+    tens_opt = torch.optim.Adam([p2], lr=torch.tensor(1e-3))
+    shadow = TensorLRScheduler(tens_opt, 1e-3, mk)
+    for _ in range(10):
+        assert abs(float(tens_opt.param_groups[0]["lr"]) - plain_opt.param_groups[0]["lr"]) < 1e-9  # fp32 lr tensor
+        assert torch.is_tensor(tens_opt.param_groups[0]["lr"])
+        plain_opt.step(); plain.step()
+        shadow.step()
+    sd = shadow.state_dict()
+    shadow.load_state_dict(sd)
+
+
+def test_graphed_step_falls_back_to_eager_for_other_shapes_on_cpu_objects():
+    """GraphedStep bookkeeping that needs no GPU: shape keys and the eager-steps counter."""
+    from dalm_amd.training.graphed import GraphedStep
+
+    class Dummy:
+        lr_scheduler = None
+        optimizer = None
+
+        def __init__(self):
+            self.n = 0
+
+        def __call__(self, batch):
+            self.n += 1
+            return torch.tensor(float(self.n))
+
+    g = GraphedStep(Dummy(), warmup=0, eager_steps=3)
+    b = {"a": torch.zeros(2, 3, dtype=torch.int64)}
+    assert [float(g(b)) for _ in range(3)] == [1.0, 2.0, 3.0]  # the first 3 calls never touch the capture path
+    assert g.graph is None and g.failed is None
+    assert GraphedStep._key(b) != GraphedStep._key({"a": torch.zeros(2, 4, dtype=torch.int64)})
