@@ -105,9 +105,8 @@ class TimedOps:
         # bytes this launch really has to move: live rows are read once; with want_grad every row of the
         # [B,Tg,V] gradient is written (zeros for masked rows and the last position)
         B, Tg, V = logits.shape
-        live = int((mask[:, 1:] != 0).sum())
-        rows = live + (B * Tg if want_grad else 0)
-        self.events.append((a, b, rows * V * logits.element_size(), live))
+        live = (mask[:, 1:] != 0).sum()  # stays on the device: no host sync inside the timed region
+        self.events.append((a, b, live, (B * Tg if want_grad else 0), V * logits.element_size()))
         return out
 
 
@@ -178,6 +177,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-overlap", action="store_true", help="run the retriever towers on the main stream")
+    ap.add_argument("--fuse-lm-head", action="store_true",
+                    help="SURVEY 8(f) rank 1: chunked lm_head + CE, the [B,Tg,V] logits are never materialised")
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2"],
                     help="cfg3 = RAG-e2e bge-large + Llama-2-7b batch 18 (headline, default); "
                          "cfg2 = retriever-only bge-large batch 150 (BASELINE.json configs[1])")
@@ -219,7 +220,7 @@ def main():
     sched = TensorLRScheduler(opt, 1e-4, mk_sched) if use_graph else mk_sched(opt)
     ops = TimedOps()
     step = RagE2EStep(model, opt, sched, CFG["logit_scale"], comm=comm, autocast_dtype=torch.bfloat16, ops=ops,
-                      inplace_grad=True, overlap_towers=not args.no_overlap)
+                      inplace_grad=True, overlap_towers=not args.no_overlap, fuse_lm_head=args.fuse_lm_head)
     if use_graph:
         step = GraphedStep(step)
     # a few distinct pre-staged batches (inputs resident in HBM before the timed region)
@@ -260,8 +261,9 @@ def main():
         B, Tg, V = CFG["B"], CFG["Tg"], CFG["V"]
         ce_ms = [e[0].elapsed_time(e[1]) for e in ops.events]
         ce_avg_s = (sum(ce_ms) / max(len(ce_ms), 1)) * 1e-3
-        alg_bytes = sum(e[2] for e in ops.events) / max(len(ops.events), 1)   # per launch, live rows only
-        live_rows = sum(e[3] for e in ops.events) / max(len(ops.events), 1)
+        lives = [int(e[2]) for e in ops.events]
+        alg_bytes = sum((lv + e[3]) * e[4] for lv, e in zip(lives, ops.events)) / max(len(ops.events), 1)  # per launch
+        live_rows = sum(lives) / max(len(lives), 1)
         dense_bytes = 2 * B * (Tg - 1) * V * 2                                # SURVEY 8(d) dense definition, bf16
         achieved = alg_bytes / ce_avg_s / 1e9 if ce_avg_s > 0 else 0.0
         traffic = None
@@ -282,6 +284,7 @@ def main():
                                    "towers, per-GPU batch 18, Tq50/Tp128/Tg256, logit_scale 100, Adam, bf16 autocast",
                        "global_batch": args.gpus * B, "parallelism": f"dp{args.gpus} + sharded in-batch negatives",
                        "retriever_layers": args.retriever_layers, "generator_layers": args.generator_layers,
+                       "lm_head": "fused with the CE in sample chunks (no logits tensor)" if args.fuse_lm_head else "logits materialised (bf16)",
                        "tower_gemms": "pre-tuned solution table (dalm_amd/tuning)" if args.tuned_gemms else "library defaults",
                        "launch": ("hipGraph replay" if (use_graph and getattr(step, "graph", None) is not None)
                                   else "eager" + (f" (capture failed: {step.failed})" if getattr(step, "failed", None) else "")),

@@ -259,6 +259,76 @@ def rag_e2e_loss(query_embs, passage_embs, generator_logits, input_ids, attentio
 
 
 # ---------------------------------------------------------------------------
+# lm_head + marginalised CE without ever holding the [B,Tg,V] logits.
+# Samples are processed in chunks: logits_c = h_c W^T (hipBLASLt) -> the fused CE kernel turns the chunk into
+# its own gradient in place -> dh_c = dlogits_c W (and dW += dlogits_c^T h_c when the head is trainable).
+# A chunk (<= ~100 MB bf16) lives in the 256 MB Infinity Cache between the three passes, so the logits and
+# their gradient stop costing HBM round trips and 2 x B*Tg*V elements of memory.
+# ---------------------------------------------------------------------------
+class _LMHeadRagE2E(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, p, hidden, weight, ids, mask, qlen, scale, ops, comm, chunk, q_gather, p_gather, aux):
+        st = _contrastive_forward(ops, comm, q, p, scale,
+                                  q_gather.wait() if q_gather is not None else None,
+                                  p_gather.wait() if p_gather is not None else None)
+        con, doc_lp = ops.contrastive_finalize(st.lse_r, st.lse_c, st.diag, st.n_global)
+        stats, Nb, _Mb = ops.ce_prep(mask, qlen)
+        if not isinstance(comm, LocalComm):
+            comm.all_reduce_sum_(stats)
+        B, Tg, H = hidden.shape
+        h = hidden.detach()
+        w = weight.detach().to(h.dtype)
+        need_dw = weight.requires_grad
+        dh = torch.empty_like(h)
+        dw = torch.zeros(w.shape, device=w.device, dtype=torch.float32) if need_dw else None
+        row_nll = torch.empty((B * Tg,), device=h.device, dtype=torch.float32)
+        for b0 in range(0, B, chunk):
+            b1 = min(B, b0 + chunk)
+            hc = h[b0:b1].reshape(-1, H)
+            logits_c = (hc @ w.t()).view(b1 - b0, Tg, -1)
+            _lse, nll_c, dl_c = ops.ce_fwd(logits_c, ids[b0:b1], mask[b0:b1], stats, True, True)
+            row_nll[b0 * Tg:b1 * Tg] = nll_c
+            dl2 = dl_c.view(-1, dl_c.shape[-1])
+            dh[b0:b1] = (dl2 @ w).view(b1 - b0, Tg, H)
+            if need_dw:
+                dw.addmm_(dl2.t().float(), hc.float())
+        gen = ops.ce_finalize(row_nll, Nb, doc_lp, stats)
+        ctx.st, ctx.scale, ctx.ops, ctx.comm = st, scale, ops, comm
+        ctx.in_dtypes = (q.dtype, p.dtype, weight.dtype)
+        ctx.save_for_backward(stats, Nb, dh, dw if need_dw else stats)
+        ctx.need_dw = need_dw
+        if aux is not None:
+            aux["contrastive"], aux["generator"] = con.reshape(()), gen.reshape(())
+            aux["doc_logprobs"], aux["num_target_tokens"] = doc_lp, stats[0]
+        return (con + gen).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        ops, st = ctx.ops, ctx.st
+        stats, Nb, dh, dw = ctx.saved_tensors
+        g = g.float().reshape(1)
+        dh = ops.scale_inplace(dh, g) if dh.is_cuda else dh * g.to(dh.dtype)
+        dweight = (dw * g).to(ctx.in_dtypes[2]) if ctx.need_dw else None
+        dq = dp = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            b = (g / (2.0 * st.n_global)).expand(st.q.shape[0]).contiguous()
+            a = b + g * Nb / stats[0]
+            dq, dp = _contrastive_backward(ops, ctx.comm, st, ctx.scale, a, b)
+            dq, dp = dq.to(ctx.in_dtypes[0]), dp.to(ctx.in_dtypes[1])
+        return (dq, dp, dh, dweight) + (None,) * 10
+
+
+def rag_e2e_loss_from_hidden(query_embs, passage_embs, hidden_states, lm_head_weight, input_ids, attention_mask,
+                             query_token_length, logit_scale, *, comm=None, ops=None, chunk_samples: int = 6,
+                             q_gather=None, p_gather=None, aux: Optional[dict] = None):
+    """Same value and gradients as `rag_e2e_loss(q, p, hidden @ W^T, ...)`, without materialising the logits:
+    `hidden_states` [B,Tg,H] are the decoder's final (normed) states, `lm_head_weight` [V,H] (no bias)."""
+    return _LMHeadRagE2E.apply(query_embs, passage_embs, hidden_states, lm_head_weight, input_ids, attention_mask,
+                               query_token_length, float(logit_scale), ops or default_ops(), comm or LocalComm(),
+                               int(chunk_samples), q_gather, p_gather, aux)
+
+
+# ---------------------------------------------------------------------------
 # drop-ins with the reference's signatures (materialised S / log-probs)
 # ---------------------------------------------------------------------------
 class _CosineSim(torch.autograd.Function):

@@ -15,7 +15,7 @@ from typing import Dict, Optional
 
 import torch
 
-from ..fused import GatherHandle, LocalComm, contrastive_loss, rag_e2e_loss
+from ..fused import GatherHandle, LocalComm, contrastive_loss, rag_e2e_loss, rag_e2e_loss_from_hidden
 from ..sharded import allreduce_grads
 
 
@@ -49,9 +49,14 @@ class _StepBase:
 class RagE2EStep(_StepBase):
     """batch keys as produced by preprocess_dataset (rag_e2e_dataloader_utils.py:56-68)."""
 
-    def __init__(self, *a, inplace_grad: bool = True, overlap_towers: bool = True, **kw):
+    def __init__(self, *a, inplace_grad: bool = True, overlap_towers: bool = True, fuse_lm_head: bool = False,
+                 lm_head_chunk: int = 6, **kw):
         super().__init__(*a, **kw)
         self.inplace_grad = inplace_grad
+        # SURVEY 8(f) rank 1 (optional): run the decoder without its lm_head and let the loss consume the
+        # hidden states chunk by chunk - the [B,Tg,V] logits and their gradient never exist
+        self.fuse_lm_head = fuse_lm_head
+        self.lm_head_chunk = lm_head_chunk
         self.aux: Dict[str, torch.Tensor] = {}
         # the two retriever towers are many small kernels (3204 tokens through BERT) and are independent of
         # the generator until the loss: run them on their own HIP stream so they fill the gaps between the
@@ -67,6 +72,14 @@ class RagE2EStep(_StepBase):
         q_gather = GatherHandle(q_emb.float(), self.comm, self.side_stream)
         return p_emb, q_emb, p_gather, q_gather
 
+    def _generator(self, batch):
+        m = self.model
+        if not self.fuse_lm_head:
+            return m("generation", batch["generator_input_input_ids"], batch["generator_input_attention_mask"])
+        gm = m.generator_model
+        return gm.base_model(input_ids=batch["generator_input_input_ids"],
+                             attention_mask=batch["generator_input_attention_mask"])[0]
+
     def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         m = self.model
         with self._autocast():
@@ -75,14 +88,24 @@ class RagE2EStep(_StepBase):
                 self.tower_stream.wait_stream(cur)
                 with torch.cuda.stream(self.tower_stream):
                     p_emb, q_emb, p_gather, q_gather = self._towers(batch)
-                logits = m("generation", batch["generator_input_input_ids"], batch["generator_input_attention_mask"])
+                logits = self._generator(batch)
                 cur.wait_stream(self.tower_stream)
                 for t in (p_emb, q_emb, p_gather.result, q_gather.result):
                     if t is not None and t.is_cuda:
                         t.record_stream(cur)
             else:
                 p_emb, q_emb, p_gather, q_gather = self._towers(batch)
-                logits = m("generation", batch["generator_input_input_ids"], batch["generator_input_attention_mask"])
+                logits = self._generator(batch)
+        if self.fuse_lm_head:
+            head = m.generator_model.get_output_embeddings()
+            if getattr(head, "bias", None) is not None:
+                raise NotImplementedError("fuse_lm_head needs a bias-free lm_head")
+            loss = rag_e2e_loss_from_hidden(q_emb, p_emb, logits, head.weight, batch["generator_input_input_ids"],
+                                            batch["generator_input_attention_mask"], batch["query_passage_input_len"],
+                                            self.logit_scale, comm=self.comm, ops=self.ops,
+                                            chunk_samples=self.lm_head_chunk, q_gather=q_gather, p_gather=p_gather,
+                                            aux=self.aux)
+            return self._finish(loss)
         loss = rag_e2e_loss(q_emb, p_emb, logits, batch["generator_input_input_ids"],
                             batch["generator_input_attention_mask"], batch["query_passage_input_len"],
                             self.logit_scale, comm=self.comm, ops=self.ops, inplace_grad=self.inplace_grad,
@@ -97,6 +120,14 @@ class RetrieverStep(_StepBase):
         super().__init__(*a, **kw)
         # the query pass (Tq = 50) is small next to the passage pass (Tp = 128): run it on its own stream
         self.tower_stream = torch.cuda.Stream() if (overlap_towers and torch.cuda.is_available()) else None
+
+    def _generator(self, batch):
+        m = self.model
+        if not self.fuse_lm_head:
+            return m("generation", batch["generator_input_input_ids"], batch["generator_input_attention_mask"])
+        gm = m.generator_model
+        return gm.base_model(input_ids=batch["generator_input_input_ids"],
+                             attention_mask=batch["generator_input_attention_mask"])[0]
 
     def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         m = self.model

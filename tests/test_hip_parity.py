@@ -366,3 +366,32 @@ def test_full_size_properties_cfg3_cfg5(dev, V, dtype):
     if dtype == torch.float32:
         loss2 = rag_e2e_loss(q.detach(), p.detach(), (logits.detach() + shift), ids, mask, qlen, 100)
         assert abs(float(loss2) - float(loss)) <= 2e-5 * abs(float(loss))
+
+
+@pytest.mark.parametrize("dtype,train_head", [(torch.float32, False), (torch.float32, True), (torch.bfloat16, False)])
+def test_lm_head_fused_loss_equals_materialised_logits(dev, dtype, train_head):
+    """chunked lm_head + CE == lm_head then rag_e2e_loss (value and all gradients)."""
+    from dalm_amd.fused import rag_e2e_loss, rag_e2e_loss_from_hidden
+
+    B, Tg, H, V, D = 7, 24, 64, 1000, 32
+    q, p, _, ids, mask, qlen = synth_batch(77, B, D, Tg, V, pad_side="left")
+    g = torch.Generator().manual_seed(5)
+    hidden = torch.randn(B, Tg, H, generator=g).to(dtype)
+    W = (0.2 * torch.randn(V, H, generator=g)).to(dtype)
+    res = {}
+    for mode in ("ref", "fused"):
+        qq, pp = q.to(dev).requires_grad_(True), p.to(dev).requires_grad_(True)
+        hh = hidden.to(dev).requires_grad_(True)
+        ww = W.to(dev).requires_grad_(train_head)
+        if mode == "ref":
+            loss = rag_e2e_loss(qq, pp, hh @ ww.t(), ids.to(dev), mask.to(dev), qlen.to(dev), 100)
+        else:
+            loss = rag_e2e_loss_from_hidden(qq, pp, hh, ww, ids.to(dev), mask.to(dev), qlen.to(dev), 100, chunk_samples=3)
+        (loss * 1.5).backward()
+        res[mode] = (loss.detach(), qq.grad, pp.grad, hh.grad, ww.grad if train_head else None)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert abs(float(res["ref"][0]) - float(res["fused"][0])) <= 1e-5 * abs(float(res["ref"][0])) + 1e-6
+    for a, b, name in zip(res["ref"][1:], res["fused"][1:], ("dq", "dp", "dhidden", "dW")):
+        if a is None:
+            continue
+        assert norm_rel_err(b, a) <= tol, (name, norm_rel_err(b, a))
