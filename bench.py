@@ -177,6 +177,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-overlap", action="store_true", help="run the retriever towers on the main stream")
+    ap.add_argument("--graph-towers", action="store_true",
+                    help="graph the tower fwd/bwd and keep collectives eager (the default when --gpus > 1)")
     ap.add_argument("--fuse-lm-head", action="store_true",
                     help="SURVEY 8(f) rank 1: chunked lm_head + CE, the [B,Tg,V] logits are never materialised")
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2"],
@@ -211,7 +213,7 @@ def main():
     from dalm_amd.fused import LocalComm
     from dalm_amd.training.graphed import GraphedStep, TensorLRScheduler, make_capturable_adam
 
-    use_graph = isinstance(comm, LocalComm) and not args.no_graph
+    use_graph = isinstance(comm, LocalComm) and not args.no_graph and not args.graph_towers
     opt = make_capturable_adam(params, 1e-4, dev) if use_graph else torch.optim.Adam(params, lr=1e-4, fused=True)
 
     def mk_sched(o):
@@ -220,7 +222,9 @@ def main():
     sched = TensorLRScheduler(opt, 1e-4, mk_sched) if use_graph else mk_sched(opt)
     ops = TimedOps()
     step = RagE2EStep(model, opt, sched, CFG["logit_scale"], comm=comm, autocast_dtype=torch.bfloat16, ops=ops,
-                      inplace_grad=True, overlap_towers=not args.no_overlap, fuse_lm_head=args.fuse_lm_head)
+                      inplace_grad=True, overlap_towers=not args.no_overlap, fuse_lm_head=args.fuse_lm_head,
+                      graph_towers=(args.graph_towers or not isinstance(comm, LocalComm)) and not args.no_graph,
+                      graph_after=0)
     if use_graph:
         step = GraphedStep(step)
     # a few distinct pre-staged batches (inputs resident in HBM before the timed region)
@@ -286,8 +290,11 @@ def main():
                        "retriever_layers": args.retriever_layers, "generator_layers": args.generator_layers,
                        "lm_head": "fused with the CE in sample chunks (no logits tensor)" if args.fuse_lm_head else "logits materialised (bf16)",
                        "tower_gemms": "pre-tuned solution table (dalm_amd/tuning)" if args.tuned_gemms else "library defaults",
-                       "launch": ("hipGraph replay" if (use_graph and getattr(step, "graph", None) is not None)
-                                  else "eager" + (f" (capture failed: {step.failed})" if getattr(step, "failed", None) else "")),
+                       "launch": ("hipGraph replay of the whole step" if (use_graph and getattr(step, "graph", None) is not None)
+                                  else ("hipGraph replay of tower fwd/bwd, eager collectives+loss+optimizer"
+                                        if getattr(step, "towers", None) is not None else
+                                        "eager" + (f" (capture failed: {getattr(step, 'failed', None) or getattr(step, 'towers_failed', None)})"
+                                                   if (getattr(step, "failed", None) or getattr(step, "towers_failed", None)) else ""))),
                        "baseline_ref": "reference README.md:34-40: 200k rows in 7 h on 1x A100-80GB = 7.94 pairs/s",
                        "final_loss": loss_val},
             "roofline": {"bound": "hbm", "kernel": "marg_ce_row_kernel (fused fwd+grad, bf16 logits)",

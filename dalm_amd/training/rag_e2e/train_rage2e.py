@@ -185,7 +185,9 @@ def train_e2e(
                     len(processed), num_train_epochs, per_device_train_batch_size,
                     per_device_train_batch_size * comm.world_size, max_train_steps)
     step_fn = RagE2EStep(rag_model, optimizer, scheduler, logit_scale, comm=comm,
-                         autocast_dtype=torch.bfloat16 if mixed_precision == "bf16" else None)
+                         autocast_dtype=torch.bfloat16 if mixed_precision == "bf16" else None,
+                         # W > 1: graph the tower fwd/bwd, keep collectives + loss + optimizer eager
+                         graph_towers=(not use_graph) and (not no_hip_graph), graph_after=2)
     if use_graph:
         step_fn = GraphedStep(step_fn, warmup=0, eager_steps=2)  # partial last batches (other shapes) run eagerly
     meter = common.Throughput()

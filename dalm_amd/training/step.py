@@ -50,13 +50,19 @@ class RagE2EStep(_StepBase):
     """batch keys as produced by preprocess_dataset (rag_e2e_dataloader_utils.py:56-68)."""
 
     def __init__(self, *a, inplace_grad: bool = True, overlap_towers: bool = True, fuse_lm_head: bool = False,
-                 lm_head_chunk: int = 6, **kw):
+                 lm_head_chunk: int = 6, graph_towers: bool = False, graph_after: int = 2, **kw):
         super().__init__(*a, **kw)
         self.inplace_grad = inplace_grad
         # SURVEY 8(f) rank 1 (optional): run the decoder without its lm_head and let the loss consume the
         # hidden states chunk by chunk - the [B,Tg,V] logits and their gradient never exist
         self.fuse_lm_head = fuse_lm_head
         self.lm_head_chunk = lm_head_chunk
+        # W > 1: graph the towers (fwd + bwd), keep collectives / loss / optimizer eager (GraphedTowers)
+        self.graph_towers = graph_towers and torch.cuda.is_available() and not fuse_lm_head
+        self.towers = None
+        self.towers_failed: Optional[str] = None
+        self.calls = 0
+        self.graph_after = graph_after
         self.aux: Dict[str, torch.Tensor] = {}
         # the two retriever towers are many small kernels (3204 tokens through BERT) and are independent of
         # the generator until the loss: run them on their own HIP stream so they fill the gaps between the
@@ -64,16 +70,42 @@ class RagE2EStep(_StepBase):
         # overlaps the same way
         self.tower_stream = torch.cuda.Stream() if (overlap_towers and torch.cuda.is_available()) else None
 
+    def _maybe_build_towers(self, batch) -> None:
+        if not self.graph_towers or self.towers is not None or self.towers_failed is not None:
+            return
+        if self.calls <= self.graph_after:  # first real steps run eagerly (library warm-up, as GraphedStep)
+            return
+        try:
+            from .graphed import GraphedTowers
+
+            torch.cuda.synchronize()
+            self.towers = GraphedTowers(self.model, self.autocast_dtype, batch)
+        except Exception as e:  # same kernels, eager launches
+            self.towers_failed = repr(e)
+            self.towers = None
+            torch.cuda.synchronize()
+
+    def _use_graphs(self, batch) -> bool:
+        return self.towers is not None and self.towers.matches(batch)
+
     def _towers(self, batch):
         m = self.model
-        p_emb = m("retrieval", batch["retriever_passage_input_ids"], batch["retriever_passage_attention_mask"])
+        if self._use_graphs(batch):
+            p_emb = self.towers.passage(batch["retriever_passage_input_ids"], batch["retriever_passage_attention_mask"])
+        else:
+            p_emb = m("retrieval", batch["retriever_passage_input_ids"], batch["retriever_passage_attention_mask"])
         p_gather = GatherHandle(p_emb.float(), self.comm, self.side_stream)
-        q_emb = m("retrieval", batch["retriever_query_input_ids"], batch["retriever_query_attention_mask"])
+        if self._use_graphs(batch):
+            q_emb = self.towers.query(batch["retriever_query_input_ids"], batch["retriever_query_attention_mask"])
+        else:
+            q_emb = m("retrieval", batch["retriever_query_input_ids"], batch["retriever_query_attention_mask"])
         q_gather = GatherHandle(q_emb.float(), self.comm, self.side_stream)
         return p_emb, q_emb, p_gather, q_gather
 
     def _generator(self, batch):
         m = self.model
+        if self._use_graphs(batch):
+            return self.towers.generator(batch["generator_input_input_ids"], batch["generator_input_attention_mask"])
         if not self.fuse_lm_head:
             return m("generation", batch["generator_input_input_ids"], batch["generator_input_attention_mask"])
         gm = m.generator_model
@@ -82,6 +114,9 @@ class RagE2EStep(_StepBase):
 
     def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         m = self.model
+        self.calls += 1
+        self.graph_after = getattr(self, "graph_after", 2)
+        self._maybe_build_towers(batch)
         with self._autocast():
             if self.tower_stream is not None:
                 cur = torch.cuda.current_stream()
@@ -123,6 +158,8 @@ class RetrieverStep(_StepBase):
 
     def _generator(self, batch):
         m = self.model
+        if self._use_graphs(batch):
+            return self.towers.generator(batch["generator_input_input_ids"], batch["generator_input_attention_mask"])
         if not self.fuse_lm_head:
             return m("generation", batch["generator_input_input_ids"], batch["generator_input_attention_mask"])
         gm = m.generator_model

@@ -22,7 +22,7 @@ def _batches(tok_r, tok_g, gold, dev):
     return [{k: v[a:b] for k, v in full.items()} for a, b in gold["batch_rows"]]
 
 
-@pytest.mark.parametrize("inplace,graph", [(False, False), (True, False), (True, True)])
+@pytest.mark.parametrize("inplace,graph", [(False, False), (True, False), (True, True), (True, "towers")])
 def test_rag_e2e_step_trajectory_matches_reference(inplace, graph):
     """graph=True: the step is captured into a hipGraph (5-row batches replay it, the 3- and 4-row batches
     run eagerly), towers overlapped on a side stream - same trajectory as the reference either way."""
@@ -38,12 +38,15 @@ def test_rag_e2e_step_trajectory_matches_reference(inplace, graph):
     g_tok = rag.generator_tokenizer
     g_tok.pad_token = g_tok.eos_token
     rag.train()
+    towers = graph == "towers"  # tower fwd/bwd as graphs, collectives + loss + optimizer eager (the W > 1 mode)
+    graph = bool(graph) and not towers
     opt = make_capturable_adam(rag.parameters(), gold["lr"], dev) if graph else torch.optim.Adam(rag.parameters(), lr=gold["lr"])
     def mk(o):
         return get_scheduler("linear", optimizer=o, num_warmup_steps=gold["warmup"], num_training_steps=gold["total_steps"])
 
     sched = TensorLRScheduler(opt, gold["lr"], mk) if graph else mk(opt)
-    step = RagE2EStep(rag, opt, sched, 100, autocast_dtype=None, inplace_grad=inplace, overlap_towers=graph)
+    step = RagE2EStep(rag, opt, sched, 100, autocast_dtype=None, inplace_grad=inplace, overlap_towers=graph or towers,
+                      graph_towers=towers, graph_after=0)
     if graph:
         step = GraphedStep(step, warmup=0)  # no hidden warm-up steps: the trajectory must start at step 0
     losses = []
@@ -51,6 +54,8 @@ def test_rag_e2e_step_trajectory_matches_reference(inplace, graph):
         losses.append(float(step(b)))
     if graph:
         assert step.failed is None and step.graph is not None, step.failed
+    if towers:
+        assert step.towers_failed is None and step.towers is not None, step.towers_failed
     for got, ref in zip(losses, gold["losses"]):
         assert abs(got - ref) <= 1e-3 * abs(ref), (losses, gold["losses"])
     final = float(sum(p.detach().abs().sum() for p in rag.parameters()))
