@@ -114,3 +114,78 @@ def test_train_e2e_end_to_end_on_csv(tmp_path):
               num_warmup_steps=0, output_dir=str(out), resume_from_checkpoint=str(out / "epoch_1"), with_tracking=False,
               mixed_precision="no", on_step=lambda s, l: more.append((s, float(l))))
     assert [s for s, _ in more] == [7, 8, 9]  # epochs 0-1 are skipped, one more epoch of 3 steps runs
+
+
+def test_multi_gpu_code_path_on_one_rank_matches_reference(monkeypatch):
+    """The W > 1 step (RCCL all-gathers on a side stream, stats exchange, flat gradient all-reduce, graphed
+    towers) run through a real one-rank RCCL process group: collectives are identities, so the trajectory
+    must still be the reference's."""
+    import torch.distributed as dist
+    from transformers import get_scheduler
+
+    from dalm_amd.fused import TorchDistComm
+    from dalm_amd.models import AutoModelForRagE2E
+    from dalm_amd.sharded import init_distributed
+    from dalm_amd.training.step import RagE2EStep
+
+    monkeypatch.setenv("DALM_FORCE_DIST", "1")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29641")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    comm, dev = init_distributed()
+    try:
+        assert isinstance(comm, TorchDistComm) and comm.world_size == 1 and dist.get_backend() == "nccl"
+        gold = json.loads((G / "step_golden.json").read_text())
+        rag = AutoModelForRagE2E(str(G / "tiny_retriever"), str(G / "tiny_generator")).to(dev)
+        g_tok = rag.generator_tokenizer
+        g_tok.pad_token = g_tok.eos_token
+        rag.train()
+        opt = torch.optim.Adam(rag.parameters(), lr=gold["lr"])
+        sched = get_scheduler("linear", optimizer=opt, num_warmup_steps=gold["warmup"], num_training_steps=gold["total_steps"])
+        step = RagE2EStep(rag, opt, sched, 100, comm=comm, autocast_dtype=None, inplace_grad=True, overlap_towers=True,
+                          graph_towers=True, graph_after=0)
+        assert step.side_stream is not None
+        losses = [float(step(b)) for b in _batches(rag.retriever_tokenizer, g_tok, gold, dev)]
+        assert step.towers is not None, step.towers_failed
+        for got, ref in zip(losses, gold["losses"]):
+            assert abs(got - ref) <= 1e-3 * abs(ref), (losses, gold["losses"])
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_falcon_architecture_generator_runs_through_the_step():
+    """cfg5 uses a Falcon generator (vocab 65024, bf16): a tiny random-init Falcon goes through the same step
+    (1024-thread packed bf16 CE rows) and learns."""
+    from transformers import AutoModel, AutoTokenizer, FalconConfig, FalconForCausalLM
+
+    from dalm_amd.models import AutoModelForRagE2E
+    from dalm_amd.training.step import RagE2EStep
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    tok = AutoTokenizer.from_pretrained(str(G / "tiny_retriever"))
+    falcon = FalconForCausalLM(FalconConfig(vocab_size=65024, hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
+                                            new_decoder_architecture=False, multi_query=True, parallel_attn=True,
+                                            bias=False, hidden_dropout=0.0, attention_dropout=0.0))
+    rag = AutoModelForRagE2E.from_modules(AutoModel.from_pretrained(str(G / "tiny_retriever")), falcon, tok, tok).to(dev)
+    rag.train()
+    g = torch.Generator().manual_seed(1)
+    B, Tg = 4, 32
+    lens = torch.randint(10, Tg + 1, (B, 1), generator=g)
+    batch = {
+        "retriever_query_input_ids": torch.randint(4, 50, (B, 12), generator=g),
+        "retriever_query_attention_mask": torch.ones(B, 12, dtype=torch.int64),
+        "retriever_passage_input_ids": torch.randint(4, 50, (B, 24), generator=g),
+        "retriever_passage_attention_mask": torch.ones(B, 24, dtype=torch.int64),
+        "generator_input_input_ids": torch.randint(0, 65024, (B, Tg), generator=g),
+        "generator_input_attention_mask": (torch.arange(Tg).unsqueeze(0) < lens).long(),
+        "query_passage_input_len": (lens.squeeze(1).float() * 0.8).long().clamp(min=1),
+    }
+    batch = {k: v.to(dev) for k, v in batch.items()}
+    opt = torch.optim.Adam(rag.parameters(), lr=2e-3)
+    step = RagE2EStep(rag, opt, None, 100, autocast_dtype=torch.bfloat16, inplace_grad=True)
+    losses = [float(step(batch)) for _ in range(8)]
+    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
