@@ -177,6 +177,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-overlap", action="store_true", help="run the retriever towers on the main stream")
+    ap.add_argument("--graph-collectives", action="store_true",
+                    help="EXPERIMENTAL: capture the whole step including the RCCL collectives (W > 1)")
     ap.add_argument("--graph-towers", action="store_true",
                     help="graph the tower fwd/bwd and keep collectives eager (the default when --gpus > 1)")
     ap.add_argument("--fuse-lm-head", action="store_true",
@@ -213,7 +215,7 @@ def main():
     from dalm_amd.fused import LocalComm
     from dalm_amd.training.graphed import GraphedStep, TensorLRScheduler, make_capturable_adam
 
-    use_graph = isinstance(comm, LocalComm) and not args.no_graph and not args.graph_towers
+    use_graph = (isinstance(comm, LocalComm) or args.graph_collectives) and not args.no_graph and not args.graph_towers
     opt = make_capturable_adam(params, 1e-4, dev) if use_graph else torch.optim.Adam(params, lr=1e-4, fused=True)
 
     def mk_sched(o):
@@ -223,7 +225,8 @@ def main():
     ops = TimedOps()
     step = RagE2EStep(model, opt, sched, CFG["logit_scale"], comm=comm, autocast_dtype=torch.bfloat16, ops=ops,
                       inplace_grad=True, overlap_towers=not args.no_overlap, fuse_lm_head=args.fuse_lm_head,
-                      graph_towers=(args.graph_towers or not isinstance(comm, LocalComm)) and not args.no_graph,
+                      graph_towers=(args.graph_towers or not isinstance(comm, LocalComm)) and not args.no_graph
+                      and not args.graph_collectives,
                       graph_after=0)
     if use_graph:
         step = GraphedStep(step)

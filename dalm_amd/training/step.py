@@ -16,7 +16,7 @@ from typing import Dict, Optional
 import torch
 
 from ..fused import GatherHandle, LocalComm, contrastive_loss, rag_e2e_loss, rag_e2e_loss_from_hidden
-from ..sharded import allreduce_grads
+from ..sharded import GradBucket, allreduce_grads
 
 
 class _StepBase:
@@ -30,6 +30,14 @@ class _StepBase:
         if not isinstance(self.comm, LocalComm) and torch.cuda.is_available():
             self.side_stream = torch.cuda.Stream()
         self.trainable = [p for p in model.parameters() if p.requires_grad]
+        # W > 1: gradients live in one flat bucket (no per-step flatten / copy-back); fp32 trainables only
+        self.bucket = None
+        import os as _os
+
+        if _os.environ.get("DALM_GRAD_BUCKET", "1") != "0" and not isinstance(self.comm, LocalComm) and self.trainable and \
+                all(p.dtype == torch.float32 for p in self.trainable) and \
+                len({p.device for p in self.trainable}) == 1:
+            self.bucket = GradBucket(self.trainable, self.comm)
 
     def _autocast(self):
         if self.autocast_dtype is None:
@@ -38,11 +46,17 @@ class _StepBase:
 
     def _finish(self, loss: torch.Tensor) -> torch.Tensor:
         loss.backward()
-        allreduce_grads(self.trainable, self.comm)
+        if self.bucket is not None:
+            self.bucket.all_reduce()
+        else:
+            allreduce_grads(self.trainable, self.comm)
         self.optimizer.step()
         if self.lr_scheduler is not None:
             self.lr_scheduler.step()
-        self.model.zero_grad(set_to_none=True)
+        if self.bucket is not None:
+            self.bucket.zero()
+        else:
+            self.model.zero_grad(set_to_none=True)
         return loss.detach()
 
 

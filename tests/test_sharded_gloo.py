@@ -34,7 +34,7 @@ def _worker(rank, world, port, mode, out_dir):
 
     import dalm_oracle as O
     from dalm_amd.fused import GatherHandle, TorchDistComm, contrastive_loss, rag_e2e_loss
-    from dalm_amd.sharded import allreduce_grads
+    from dalm_amd.sharded import GradBucket, allreduce_grads
     from helpers import synth_batch
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -44,6 +44,7 @@ def _worker(rank, world, port, mode, out_dir):
     q, p, logits, ids, mask, qlen = synth_batch(42, world * B_l, D, Tg, V, pad_side="left", logit_gain=2.0)
     sl = slice(rank * B_l, (rank + 1) * B_l)
     w = torch.nn.Parameter(torch.eye(D) + 0.01 * torch.arange(D * D, dtype=torch.float32).reshape(D, D) / (D * D))
+    bucket = GradBucket([w], comm) if mode == "e2e" else None   # e2e: bucket views; contrastive: flatten path
     ql, pl = (q[sl] @ w), (p[sl] @ w)          # a shared "tower" parameter, replicated on every rank
     lg = logits[sl].clone().requires_grad_(True)
     if mode == "e2e":
@@ -52,7 +53,11 @@ def _worker(rank, world, port, mode, out_dir):
     else:
         loss = contrastive_loss(ql, pl, 100, comm=comm, ops=ops)
     loss.backward()
-    allreduce_grads([w], comm)                  # SUM over ranks
+    if bucket is not None:
+        assert w.grad.data_ptr() == bucket.flat.data_ptr()
+        bucket.all_reduce()                     # SUM over ranks, in the bucket
+    else:
+        allreduce_grads([w], comm)              # SUM over ranks
     total = loss.detach().clone()
     dist.all_reduce(total)
     torch.save({"loss_share": loss.detach(), "loss_total": total, "dw": w.grad.clone(),
