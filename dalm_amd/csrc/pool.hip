@@ -19,9 +19,10 @@ template <typename T> struct HV;
 template <> struct HV<float> {
   static constexpr int VEC = 4;
   __device__ static __forceinline__ void load(const float* p, int nvalid, bool vec, float (&x)[4]) {
-    if (nvalid >= 4 && vec) {  // non-temporal: each token row is read exactly once
-      typedef float f32x4 __attribute__((ext_vector_type(4)));
-      const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    if (nvalid >= 4 && vec) {
+      // cached loads on purpose: the token states were just written by the encoder's last layer and sit in
+      // L2 / Infinity Cache (non-temporal loads measured 20 % slower here, unlike the CE kernels)
+      const float4 v = *reinterpret_cast<const float4*>(p);
       x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
     } else {
 #pragma unroll
@@ -30,10 +31,7 @@ template <> struct HV<float> {
   }
   __device__ static __forceinline__ void store(float* p, int nvalid, bool vec, const float (&x)[4]) {
     if (nvalid >= 4 && vec) {
-      typedef float f32x4 __attribute__((ext_vector_type(4)));
-      f32x4 v;
-      v.x = x[0]; v.y = x[1]; v.z = x[2]; v.w = x[3];
-      __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+      *reinterpret_cast<float4*>(p) = make_float4(x[0], x[1], x[2], x[3]);
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e) if (e < nvalid) p[e] = x[e];
@@ -44,8 +42,7 @@ template <> struct HV<bf16_t> {
   static constexpr int VEC = 8;
   __device__ static __forceinline__ void load(const bf16_t* p, int nvalid, bool vec, float (&x)[8]) {
     if (nvalid >= 8 && vec) {
-      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-      const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+      const uint4 v = *reinterpret_cast<const uint4*>(p);
       const unsigned int w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -63,10 +60,7 @@ template <> struct HV<bf16_t> {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         w[i] = pack_bf16x2(x[2 * i], x[2 * i + 1]);
-      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-      u32x4 o;
-      o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
-      __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(p));
+      *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) if (e < nvalid) p[e].v = f32_to_bf16(x[e]);
