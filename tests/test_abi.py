@@ -81,3 +81,22 @@ def test_package_never_imports_oracle():
     for py in (ROOT / "dalm_amd").rglob("*.py"):
         src = py.read_text()
         assert "dalm_oracle" not in src and "import oracle" not in src and "from oracle" not in src, py
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/dalm_hip.h must be consumable by a C compiler (cgo / JNI / ctypes-style bindings): compile a C
+    translation unit that includes it and takes the address of every entry point."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    names = header_functions()
+    src = tmp_path / "abi_check.c"
+    body = "\n".join(f"  p[{i}] = (fn_t)&{n};" for i, n in enumerate(names))
+    src.write_text(f'#include "dalm_hip.h"\ntypedef void (*fn_t)(void);\nfn_t p[{len(names)}];\n'
+                   f'void fill(void) {{\n{body}\n}}\n')
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", str(ROOT / "include"), "-c", str(src),
+                        "-o", str(tmp_path / "abi_check.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
