@@ -26,13 +26,14 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int BK_BIG = 32;    // 128x128 tiles: 33 KB LDS, 3 blocks/CU
 constexpr int BK_SMALL = 128;  // 64x64 tiles of latency-bound small problems: 4x fewer barrier rounds
 
-enum { EPI_STORE = 0, EPI_ROWSTATS = 1, EPI_DS = 2 };
+enum { EPI_STORE = 0, EPI_ROWSTATS = 1, EPI_DS = 2, EPI_PARTIAL = 3 };
 
 struct GemmParams {
   const float* A; int64_t lda;
   const float* B; int64_t ldb;
   int M, N, K;
   unsigned tiles_n;  // number of tile columns (set by the launcher)
+  int k_chunk;       // K range per blockIdx.y (split-K); == K when gridDim.y == 1
   float alpha;
   int a_vec, b_vec;  // 16-byte vector loads legal for A / B
   // EPI_STORE / EPI_DS
@@ -130,17 +131,26 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(const GemmParams 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   SA sa; SB sb;
-  const int nk = (p.K + BK - 1) / BK;
-  sa.load(p.A, p.lda, bm0, 0, p.M, p.K, p.a_vec);
-  sb.load(p.B, p.ldb, bn0, 0, p.N, p.K, p.b_vec);
+  // split-K: blockIdx.y owns K range [k_lo, k_hi) (EPI_PARTIAL writes raw accumulators to its own slab;
+  // gridDim.y == 1 elsewhere).  Measured codegen effect on the 128x128 tiles (A/B on one box): with the run-time
+  // range the STORE / DS variants are 14 % faster at 16384^2 and the ROWSTATS variant 4-18 % slower, so the
+  // rowstats instantiation keeps the compile-time full range.
+  int k_lo = 0, k_hi = p.K;
+  if constexpr (EPI != EPI_ROWSTATS) {
+    k_lo = static_cast<int>(blockIdx.y) * p.k_chunk;
+    k_hi = min(p.K, k_lo + p.k_chunk);
+  }
+  const int nk = (k_hi - k_lo + BK - 1) / BK;
+  sa.load(p.A, p.lda, bm0, k_lo, p.M, k_hi, p.a_vec);
+  sb.load(p.B, p.ldb, bn0, k_lo, p.N, k_hi, p.b_vec);
   sa.store(As); sb.store(Bs);
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = (kt + 1 < nk);
     if (more) {  // prefetch the next slab into registers while the MFMAs run
-      sa.load(p.A, p.lda, bm0, (kt + 1) * BK, p.M, p.K, p.a_vec);
-      sb.load(p.B, p.ldb, bn0, (kt + 1) * BK, p.N, p.K, p.b_vec);
+      sa.load(p.A, p.lda, bm0, k_lo + (kt + 1) * BK, p.M, k_hi, p.a_vec);
+      sb.load(p.B, p.ldb, bn0, k_lo + (kt + 1) * BK, p.N, k_hi, p.b_vec);
     }
     const float* a_base = As + lhi * SA::STRIDE + wm * WM + l31;
     const float* b_base = Bs + lhi * SB::STRIDE + wn * WN + l31;
@@ -177,6 +187,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(const GemmParams 
         for (int j = 0; j < TN; ++j) {
           const int col = bn0 + wn * WN + j * 32 + l31;
           if (row_ok && col < p.N) p.C[static_cast<int64_t>(row) * p.ldc + col] = __fmul_rn(p.alpha, acc[i][j][r]);
+        }
+      } else if constexpr (EPI == EPI_PARTIAL) {
+        float* slab = p.C + static_cast<int64_t>(blockIdx.y) * p.M * p.ldc;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = bn0 + wn * WN + j * 32 + l31;
+          if (row_ok && col < p.N) slab[static_cast<int64_t>(row) * p.ldc + col] = acc[i][j][r];
         }
       } else if constexpr (EPI == EPI_DS) {
         const float rc = row_ok ? p.row_coef[row] : 0.f;
@@ -218,6 +235,52 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(const GemmParams 
         }
       }
     }
+  }
+}
+
+// ---- split-K epilogues: S_ij = alpha * sum_z partial[z][i][j] (fixed order: deterministic, and the
+// rowstats and dS passes see bit-identical S).  One block per row; n is small here (<= a few thousand).
+__device__ __forceinline__ float splitk_s(const float* __restrict__ part, int64_t slab, int64_t off, int SK,
+                                          float alpha) {
+  float acc = part[off];
+  for (int z = 1; z < SK; ++z) acc += part[z * slab + off];
+  return __fmul_rn(alpha, acc);
+}
+
+__global__ __launch_bounds__(256) void splitk_rowstats_kernel(const float* __restrict__ part, int SK, int M, int N,
+                                                              int64_t ldp, float alpha, int64_t diag_offset,
+                                                              float* __restrict__ row_lse, float* __restrict__ diag) {
+  __shared__ float red[4];
+  const int row = blockIdx.x;
+  const int64_t slab = static_cast<int64_t>(M) * ldp, base = static_cast<int64_t>(row) * ldp;
+  float m = -INFINITY;
+  for (int j = threadIdx.x; j < N; j += 256) m = fmaxf(m, splitk_s(part, slab, base + j, SK, alpha));
+  m = block_max<256>(m, red);
+  float l = 0.f;
+  for (int j = threadIdx.x; j < N; j += 256) l += fast_exp(splitk_s(part, slab, base + j, SK, alpha) - m);
+  l = block_sum<256>(l, red);
+  if (threadIdx.x == 0) {
+    row_lse[row] = m + __logf(l);
+    diag[row] = splitk_s(part, slab, base + diag_offset + row, SK, alpha);
+  }
+}
+
+__global__ __launch_bounds__(256) void splitk_ds_kernel(const float* __restrict__ part, int SK, int M, int N,
+                                                        int64_t ldp, float alpha, int64_t diag_offset,
+                                                        const float* __restrict__ row_coef,
+                                                        const float* __restrict__ row_lse,
+                                                        const float* __restrict__ col_coef,
+                                                        const float* __restrict__ col_lse, float* __restrict__ dS,
+                                                        int64_t ldd) {
+  const int row = blockIdx.x;
+  const int64_t slab = static_cast<int64_t>(M) * ldp, base = static_cast<int64_t>(row) * ldp;
+  const float rc = row_coef[row], rl = row_lse[row];
+  for (int j = threadIdx.x; j < N; j += 256) {
+    const float sij = splitk_s(part, slab, base + j, SK, alpha);
+    const float cc = col_coef[j];
+    float d = rc * fast_exp(sij - rl) + cc * fast_exp(sij - col_lse[j]);
+    if (static_cast<int64_t>(j) == diag_offset + row) d -= (rc + cc);
+    dS[static_cast<int64_t>(row) * ldd + j] = d;
   }
 }
 
@@ -308,9 +371,10 @@ inline bool vec_ok(const float* p, int64_t ld) {
 }
 
 template <int BM, int BN, int BK, int EPI>
-void launch_gemm_tile(bool a_kc, bool b_kc, GemmParams p, hipStream_t s) {
+void launch_gemm_tile(bool a_kc, bool b_kc, GemmParams p, hipStream_t s, int splitk = 1) {
   p.tiles_n = static_cast<unsigned>((p.N + BN - 1) / BN);
-  const dim3 grid(p.tiles_n * static_cast<unsigned>((p.M + BM - 1) / BM));
+  p.k_chunk = (splitk <= 1) ? p.K : ((p.K + splitk - 1) / splitk + BK - 1) / BK * BK;
+  const dim3 grid(p.tiles_n * static_cast<unsigned>((p.M + BM - 1) / BM), static_cast<unsigned>(splitk <= 1 ? 1 : splitk));
   if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, true, true, EPI>), grid, dim3(256), 0, s, p);
   else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, true, false, EPI>), grid, dim3(256), 0, s, p);
   else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, false, true, EPI>), grid, dim3(256), 0, s, p);
@@ -324,6 +388,19 @@ inline bool use_big_tiles(int64_t M, int64_t N) {
 inline int64_t rowstats_parts(int64_t m, int64_t n) {
   const int64_t bn = use_big_tiles(m, n) ? 128 : 64;
   return 2 * ((n + bn - 1) / bn);
+}
+
+inline int64_t round_up4(int64_t x) { return (x + 3) / 4 * 4; }
+
+// Split-K for S = A.B^T problems that cannot fill 256 CUs with 64x64 tiles (the real batch sizes: 18 ... ~1200
+// rows): SK partial slabs + a one-block-per-row epilogue.  Returns 1 when the direct kernels are used.
+inline int sim_splitk(int64_t m, int64_t n, int64_t D) {
+  if (use_big_tiles(m, n)) return 1;
+  const int64_t tiles = ((m + 63) / 64) * ((n + 63) / 64);
+  if (tiles > 512 || D < 256 || n > 8192) return 1;
+  int sk = 1;
+  while (sk < 8 && tiles * sk * 2 <= 1024 && D / (sk * 2) >= BK_SMALL) sk *= 2;
+  return sk;
 }
 
 template <int EPI>
@@ -368,8 +445,9 @@ extern "C" int dalm_sim_matmul(const float* A, const float* Bm, int64_t m, int64
 }
 
 extern "C" size_t dalm_sim_rowstats_workspace_bytes(int64_t m, int64_t n, int64_t D) {
-  (void)D;
   if (m <= 0 || n <= 0) return 0;
+  const int sk = sim_splitk(m, n, D);
+  if (sk > 1) return static_cast<size_t>(sk) * static_cast<size_t>(m) * static_cast<size_t>(round_up4(n)) * sizeof(float);
   return static_cast<size_t>(rowstats_parts(m, n)) * static_cast<size_t>(m) * 2 * sizeof(float);
 }
 
@@ -387,6 +465,13 @@ extern "C" int dalm_sim_rowstats(const float* A, const float* Bm, int64_t m, int
   p.A = A; p.lda = D; p.B = Bm; p.ldb = D;
   p.M = static_cast<int>(m); p.N = static_cast<int>(n); p.K = static_cast<int>(D);
   p.alpha = scale; p.a_vec = vec_ok(A, D); p.b_vec = vec_ok(Bm, D);
+  if (const int sk = sim_splitk(m, n, D); sk > 1) {
+    p.C = static_cast<float*>(ws); p.ldc = round_up4(n);
+    launch_gemm_tile<64, 64, BK_SMALL, EPI_PARTIAL>(true, true, p, s, sk);
+    hipLaunchKernelGGL(splitk_rowstats_kernel, dim3(static_cast<unsigned>(m)), dim3(256), 0, s, p.C, sk, p.M, p.N,
+                       p.ldc, scale, diag_offset, row_lse, diag);
+    return check_launch(__func__);
+  }
   p.part_m = static_cast<float*>(ws);
   p.part_l = p.part_m + P * m;
   p.diag = diag; p.diag_offset = diag_offset;
@@ -396,12 +481,12 @@ extern "C" int dalm_sim_rowstats(const float* A, const float* Bm, int64_t m, int
   return check_launch(__func__);
 }
 
-static inline int64_t round_up4(int64_t x) { return (x + 3) / 4 * 4; }
 
 extern "C" size_t dalm_sim_grad_workspace_bytes(int64_t m, int64_t n, int64_t D) {
-  (void)D;
   if (m <= 0 || n <= 0) return 0;
-  return static_cast<size_t>(m) * static_cast<size_t>(round_up4(n)) * sizeof(float);
+  const size_t panel = static_cast<size_t>(m) * static_cast<size_t>(round_up4(n)) * sizeof(float);
+  const int sk = sim_splitk(m, n, D);
+  return panel * static_cast<size_t>(sk > 1 ? 1 + sk : 1);  // dS panel (+ split-K slabs)
 }
 
 extern "C" int dalm_sim_grad(const float* A, const float* Bm, int64_t m, int64_t n, int64_t D, float scale,
@@ -422,9 +507,17 @@ extern "C" int dalm_sim_grad(const float* A, const float* Bm, int64_t m, int64_t
     p.A = A; p.lda = D; p.B = Bm; p.ldb = D;
     p.M = static_cast<int>(m); p.N = static_cast<int>(n); p.K = static_cast<int>(D);
     p.alpha = scale; p.a_vec = vec_ok(A, D); p.b_vec = vec_ok(Bm, D);
-    p.C = dS; p.ldc = ldd; p.diag_offset = diag_offset;
-    p.row_coef = row_coef; p.row_lse = row_lse; p.col_coef = col_coef; p.col_lse = col_lse;
-    launch_gemm<EPI_DS>(true, true, p, s);
+    if (const int sk = sim_splitk(m, n, D); sk > 1) {
+      float* part = dS + m * ldd;  // slabs live behind the dS panel
+      p.C = part; p.ldc = ldd;
+      launch_gemm_tile<64, 64, BK_SMALL, EPI_PARTIAL>(true, true, p, s, sk);
+      hipLaunchKernelGGL(splitk_ds_kernel, dim3(static_cast<unsigned>(m)), dim3(256), 0, s, part, sk, p.M, p.N, ldd,
+                         scale, diag_offset, row_coef, row_lse, col_coef, col_lse, dS, ldd);
+    } else {
+      p.C = dS; p.ldc = ldd; p.diag_offset = diag_offset;
+      p.row_coef = row_coef; p.row_lse = row_lse; p.col_coef = col_coef; p.col_lse = col_lse;
+      launch_gemm<EPI_DS>(true, true, p, s);
+    }
   }
   {  // dA[m,D] = scale * dS[m,n] . B[n,D]
     GemmParams p{};
