@@ -255,3 +255,26 @@ def test_typer_cli_mirrors_trainer_signatures():
     r = CliRunner()
     assert r.invoke(cli, ["version"]).exit_code == 0
     assert r.invoke(cli, ["train-rag-e2e", "only-one-arg"]).exit_code != 0  # missing positionals, like upstream
+
+
+def test_roll_rope_equals_transformers_rotate_half():
+    from transformers.models.llama import modeling_llama as ml
+
+    from dalm_amd.models.fastpath import _rope_roll
+
+    orig = getattr(ml, "_dalm_orig_apply_rotary_pos_emb", ml.apply_rotary_pos_emb)
+    g = torch.Generator().manual_seed(0)
+    q = torch.randn(2, 4, 7, 16, generator=g, dtype=torch.float64, requires_grad=True)
+    k = torch.randn(2, 2, 7, 16, generator=g, dtype=torch.float64, requires_grad=True)
+    ang = torch.randn(2, 7, 8, generator=g, dtype=torch.float64)
+    cos, sin = torch.cat([ang.cos(), ang.cos()], -1), torch.cat([ang.sin(), ang.sin()], -1)
+    a_q, a_k = orig(q, k, cos, sin)
+    (a_q.sum() * 1.3 + (a_k ** 2).sum()).backward()
+    gq, gk = q.grad.clone(), k.grad.clone()
+    q.grad = k.grad = None
+    b_q, b_k = _rope_roll(q, k, cos, sin)
+    (b_q.sum() * 1.3 + (b_k ** 2).sum()).backward()
+    torch.testing.assert_close(b_q, a_q, rtol=1e-12, atol=1e-12)
+    torch.testing.assert_close(b_k, a_k, rtol=1e-12, atol=1e-12)
+    torch.testing.assert_close(q.grad, gq, rtol=1e-12, atol=1e-12)
+    torch.testing.assert_close(k.grad, gk, rtol=1e-12, atol=1e-12)
