@@ -301,6 +301,7 @@ def main():
                        "baseline_ref": "reference README.md:34-40: 200k rows in 7 h on 1x A100-80GB = 7.94 pairs/s",
                        # informational step-level roofline: ~124 TFLOP of tower work per 18-pair step with
                        # LoRA (generator 2*6.74e9*4608 fwd, x2 for activation grads; retriever 2.1 TFLOP fwd x3)
+                       "peak_hbm_gb": torch.cuda.max_memory_allocated() / 1e9,
                        "step_model_tflops": 124.0 + 6.3,
                        "step_frac_of_bf16_mfma_peak": (124.0 + 6.3) / (elapsed / args.steps) / 2500.0,
                        "final_loss": loss_val},
