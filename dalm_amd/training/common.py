@@ -162,7 +162,11 @@ def load_training_state(path: str, optimizer, scheduler) -> Dict[str, Any]:
     if not os.path.exists(f):
         return {}
     st = torch.load(f, map_location="cpu")
+    lr_devices = [g["lr"].device if torch.is_tensor(g["lr"]) else None for g in optimizer.param_groups]
     optimizer.load_state_dict(st["optimizer"])
+    for g, dev in zip(optimizer.param_groups, lr_devices):  # a tensor lr (capturable Adam) must stay on its device
+        if dev is not None:
+            g["lr"] = torch.as_tensor(g["lr"], dtype=torch.float32).to(dev)
     if scheduler and st.get("scheduler"):
         scheduler.load_state_dict(st["scheduler"])
     return st.get("extra", {})

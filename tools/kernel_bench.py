@@ -118,6 +118,9 @@ def main():
             sizes.append((65536, 65536))
         for m, n in sizes:
             res[f"sim {m}x{n} D1024"] = bench_sim(m, n, 1024)
+        # per-rank blocks of the sharded negatives at W = 8: cfg3 (18 x 144) and cfg2 (150 x 1200)
+        for m, n in [(18, 144), (150, 1200)]:
+            res[f"sim sharded {m}x{n} D1024"] = bench_sim(m, n, 1024)
     if args.only in ("", "pool"):
         res["pool cfg2 q B150 T50 D1024 f32"] = bench_pool(150, 50, 1024, torch.float32)
         res["pool cfg2 p B150 T128 D1024 f32"] = bench_pool(150, 128, 1024, torch.float32)
