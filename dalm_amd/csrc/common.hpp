@@ -84,16 +84,4 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
   return __builtin_bit_cast(unsigned short, static_cast<__bf16>(f));
 }
 
-// (max, sum-exp) pair merge for online log-sum-exp.
-struct MaxSum {
-  float m, l;
-};
-__device__ __forceinline__ MaxSum merge(MaxSum a, MaxSum b) {
-  const float m = fmaxf(a.m, b.m);
-  // m == -inf only if both are empty; keep l = 0 without producing NaN
-  const float sa = (a.m == -INFINITY) ? 0.f : a.l * fast_exp(a.m - m);
-  const float sb = (b.m == -INFINITY) ? 0.f : b.l * fast_exp(b.m - m);
-  return {m, sa + sb};
-}
-
 }  // namespace dalm

@@ -53,7 +53,6 @@ def bench_ce(B, Tg, V, dtype, full_mask=True):
     med, best = time_fn(lambda: ops.ce_fwd(logits, ids, mask, stats, False))
     out["fwd"] = {"s": med, "best_s": best, "GBps": R * V * el / med / 1e9, "frac": R * V * el / med / HBM_PEAK}
     buf = torch.empty_like(logits)
-    lib_args = None
     med, best = time_fn(lambda: ops.ce_fwd(logits, ids, mask, stats, True))
     out["fwd+grad(fused)"] = {"s": med, "best_s": best, "GBps": 2 * R * V * el / med / 1e9, "frac": 2 * R * V * el / med / HBM_PEAK}
     row_lse, _, _ = ops.ce_fwd(logits, ids, mask, stats, False)
