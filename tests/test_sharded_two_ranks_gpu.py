@@ -1,0 +1,96 @@
+"""Two REAL ranks on one MI355X: both processes run the HIP kernels on cuda:0 and exchange through a host-staged
+gloo communicator (RCCL refuses two ranks on one device).  Checks the complete W = 2 path - sharded rows,
+diag offsets, the two row problems per rank, stats exchange, global token count, summed gradients - against a
+single process at the global batch (reference op sequence, fp64)."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+for p in (ROOT, ROOT / "oracle", ROOT / "tests"):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from dalm_amd.fused import TorchDistComm, pool_l2norm, rag_e2e_loss
+    from dalm_amd.sharded import GradBucket
+    from helpers import synth_batch
+
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class HostStagedComm(TorchDistComm):
+        def all_gather_rows(self, t):
+            return super().all_gather_rows(t.detach().cpu()).to(t.device)
+
+        def all_reduce_sum_(self, t):
+            h = t.detach().cpu()
+            super().all_reduce_sum_(h)
+            t.copy_(h)
+            return t
+
+    comm = HostStagedComm()
+    B_l, D, Tg, V, T = 5, 64, 24, 1000, 9
+    q, p, logits, ids, mask, qlen = synth_batch(7, world * B_l, D, Tg, V, pad_side="left", logit_gain=2.0)
+    g = torch.Generator().manual_seed(3)
+    hq = torch.randn(world * B_l, T, D, generator=g)
+    hp = torch.randn(world * B_l, T, D, generator=g)
+    tm = (torch.arange(T).unsqueeze(0) < torch.randint(2, T + 1, (world * B_l, 1), generator=g)).long()
+    sl = slice(rank * B_l, (rank + 1) * B_l)
+    w = torch.nn.Parameter(torch.eye(D, device=dev))            # shared "tower" parameter
+    bucket = GradBucket([w], comm)
+    lg = logits[sl].to(dev).requires_grad_(True)
+    qe = pool_l2norm(hq[sl].to(dev) @ w, tm[sl].to(dev), True)  # K1 -> K2-K4 -> K5-K7, all HIP
+    pe = pool_l2norm(hp[sl].to(dev) @ w, tm[sl].to(dev), True)
+    loss = rag_e2e_loss(qe, pe, lg, ids[sl].to(dev), mask[sl].to(dev), qlen[sl].to(dev), 100, comm=comm)
+    loss.backward()
+    bucket.all_reduce()
+    torch.save({"loss_share": loss.detach().cpu(), "dw": w.grad.detach().cpu().clone(), "dlogits": lg.grad.cpu()},
+               os.path.join(out_dir, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_gpu_ranks_equal_one_process_at_global_batch(tmp_path):
+    import dalm_oracle as O
+    from helpers import synth_batch
+
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(tmp_path / f"r{r}.pt") for r in range(world)]
+
+    B_l, D, Tg, V, T = 5, 64, 24, 1000, 9
+    q, p, logits, ids, mask, qlen = synth_batch(7, world * B_l, D, Tg, V, pad_side="left", logit_gain=2.0)
+    g = torch.Generator().manual_seed(3)
+    hq = torch.randn(world * B_l, T, D, generator=g).double()
+    hp = torch.randn(world * B_l, T, D, generator=g).double()
+    tm = (torch.arange(T).unsqueeze(0) < torch.randint(2, T + 1, (world * B_l, 1), generator=g)).long()
+    w = torch.eye(D, dtype=torch.float64, requires_grad=True)
+    lg = logits.double().requires_grad_(True)
+    out = O.ref_step_loss(O.ref_retrieval_embed(hq @ w, tm), O.ref_retrieval_embed(hp @ w, tm), lg, ids, mask, qlen, 100)
+    out["loss"].backward()
+
+    total = float(res[0]["loss_share"]) + float(res[1]["loss_share"])
+    assert abs(total - float(out["loss"])) <= 1e-4 * abs(float(out["loss"]))
+    for r in range(world):
+        torch.testing.assert_close(res[r]["dw"].double(), w.grad, rtol=1e-3, atol=1e-4 * float(w.grad.abs().max()))
+    got = torch.cat([res[r]["dlogits"] for r in range(world)]).double()
+    torch.testing.assert_close(got, lg.grad, rtol=1e-3, atol=1e-7)
