@@ -47,39 +47,64 @@ class ShardedBatches:
     Rank r takes rows [r*B, (r+1)*B) of every global batch of W*B rows (the layout the sharded loss
     assumes).  Like the reference's DataLoader there is no drop_last on one GPU (the last batch is
     partial); with W > 1 a tail that cannot give every rank the same number of rows is dropped so that
-    the all-gathers stay rectangular (the reference would pad by re-using samples instead)."""
+    the all-gathers stay rectangular (the reference would pad by re-using samples instead).
+
+    Host data path (SURVEY section 8 f, rank 2): every column is materialised ONCE as a contiguous int64
+    tensor [N, T] (pinned when a GPU is present), a batch is one index_select per column into a pinned
+    staging buffer, and the host->device copy of batch i+1 is issued on a copy stream while step i runs
+    (the reference tokenises to python lists and collates + copies synchronously every step)."""
 
     def __init__(self, dataset, batch_size: int, rank: int, world: int, seed: int, columns: List[str]):
-        self.ds, self.B, self.rank, self.world, self.seed = dataset, batch_size, rank, world, seed
+        self.B, self.rank, self.world, self.seed = batch_size, rank, world, seed
         self.columns = columns
-        n = len(dataset)
+        self.n = len(dataset)
+        pin = torch.cuda.is_available()
+        self.data: Dict[str, torch.Tensor] = {}
+        for k in columns:
+            t = torch.as_tensor(dataset[k], dtype=torch.int64).contiguous()
+            self.data[k] = t.pin_memory() if pin else t
+        n = self.n
         if world == 1:
             self.num_batches = math.ceil(n / batch_size)
         else:
             full = n // (batch_size * world)
             rest = (n - full * batch_size * world) // world
             self.num_batches = full + (1 if rest > 0 else 0)
-            self._tail = rest
+        self._copy_stream = torch.cuda.Stream() if pin else None
 
     def __len__(self) -> int:
         return self.num_batches
 
+    def _rows(self, perm: torch.Tensor, i: int) -> torch.Tensor:
+        W, B = self.world, self.B
+        pos = i * W * B
+        remaining = self.n - pos
+        b = B if remaining >= W * B else (remaining // W if W > 1 else remaining)
+        return perm[pos + self.rank * b: pos + (self.rank + 1) * b]
+
+    def _stage(self, rows: torch.Tensor, device: torch.device):
+        host = {k: v.index_select(0, rows) for k, v in self.data.items()}
+        if device.type != "cuda":
+            return host, None
+        ev = torch.cuda.Event()
+        with torch.cuda.stream(self._copy_stream):
+            dev = {k: v.pin_memory().to(device, non_blocking=True) for k, v in host.items()}
+            ev.record(self._copy_stream)
+        return dev, ev
+
     def epoch(self, epoch: int, device: torch.device, skip: int = 0) -> Iterable[Dict[str, torch.Tensor]]:
         g = torch.Generator().manual_seed(self.seed + epoch)
-        perm = torch.randperm(len(self.ds), generator=g).tolist()
-        W, B = self.world, self.B
-        pos = 0
-        for i in range(self.num_batches):
-            remaining = len(perm) - pos
-            b = B if remaining >= W * B else (remaining // W if W > 1 else remaining)
-            rows = perm[pos + self.rank * b: pos + (self.rank + 1) * b]
-            pos += W * b
-            if i < skip:
-                continue
-            chunk = self.ds[rows]
-            batch = {k: torch.tensor(chunk[k], dtype=torch.int64) for k in self.columns}
-            yield {k: v.pin_memory().to(device, non_blocking=True) if device.type == "cuda" else v
-                   for k, v in batch.items()}
+        perm = torch.randperm(self.n, generator=g)
+        order = list(range(skip, self.num_batches))
+        nxt = self._stage(self._rows(perm, order[0]), device) if order else None
+        for j, i in enumerate(order):
+            cur, ev = nxt
+            nxt = self._stage(self._rows(perm, order[j + 1]), device) if j + 1 < len(order) else None
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+                for t in cur.values():
+                    t.record_stream(torch.cuda.current_stream())
+            yield cur
 
 
 def steps_and_epochs(num_batches: int, grad_accum: int, num_train_epochs: int, max_train_steps: Optional[int]):
