@@ -395,3 +395,20 @@ def test_lm_head_fused_loss_equals_materialised_logits(dev, dtype, train_head):
         if a is None:
             continue
         assert norm_rel_err(b, a) <= tol, (name, norm_rel_err(b, a))
+
+
+def test_exact_topk_matches_fp64_argsort(dev):
+    """exact inner-product top-k on the similarity kernel (block merge included)."""
+    from dalm_amd.retrieval import construct_search_index, exact_topk, get_nearest_neighbours
+
+    g = torch.Generator().manual_seed(11)
+    corpus = torch.nn.functional.normalize(torch.randn(5000, 96, generator=g), dim=1)
+    queries = torch.nn.functional.normalize(corpus[:37] + 0.03 * torch.randn(37, 96, generator=g), dim=1)
+    ref = queries.double() @ corpus.double().t()
+    rs, ri = torch.topk(ref, 10, dim=1)
+    s, i = exact_topk(queries.to(dev), corpus.to(dev), 10, block=1024)   # 5 blocks -> merges exercised
+    assert torch.equal(i.cpu(), ri)
+    torch.testing.assert_close(s.cpu().double(), rs, rtol=1e-5, atol=1e-6)
+    idx = construct_search_index(96, 5000, corpus.to(dev))
+    hits = get_nearest_neighbours(5, idx, queries.to(dev), {j: f"doc{j}" for j in range(5000)}, threshold=0.5)
+    assert all(h and h[0][0] == f"doc{j}" for j, h in enumerate(hits))   # each query's source passage ranks first
