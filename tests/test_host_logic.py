@@ -278,3 +278,24 @@ def test_roll_rope_equals_transformers_rotate_half():
     torch.testing.assert_close(b_k, a_k, rtol=1e-12, atol=1e-12)
     torch.testing.assert_close(q.grad, gq, rtol=1e-12, atol=1e-12)
     torch.testing.assert_close(k.grad, gk, rtol=1e-12, atol=1e-12)
+
+
+def test_grad_bucket_views_and_zero():
+    from dalm_amd.fused import LocalComm
+    from dalm_amd.sharded import GradBucket
+
+    a, b = torch.nn.Parameter(torch.randn(3, 4)), torch.nn.Parameter(torch.randn(5))
+    frozen = torch.nn.Parameter(torch.randn(2), requires_grad=False)
+    bucket = GradBucket([a, frozen, b], LocalComm())
+    assert bucket.flat.numel() == 17 and frozen.grad is None
+    (a.sum() * 2 + (b * b).sum()).backward()               # autograd accumulates straight into the bucket
+    assert a.grad.data_ptr() == bucket.flat.data_ptr()
+    torch.testing.assert_close(bucket.flat[:12], torch.full((12,), 2.0))
+    torch.testing.assert_close(bucket.flat[12:], 2 * b.detach())
+    bucket.all_reduce()                                      # LocalComm: identity
+    a.grad = None                                            # something (zero_grad(set_to_none=True)) dropped a view
+    bucket.zero()
+    assert float(bucket.flat.abs().sum()) == 0.0 and a.grad is not None
+    assert a.grad.data_ptr() == bucket.flat.data_ptr() and b.grad.data_ptr() == bucket.flat.data_ptr() + 4 * 12
+    with pytest.raises(ValueError):
+        GradBucket([torch.nn.Parameter(torch.zeros(2, dtype=torch.bfloat16))], LocalComm())
