@@ -135,9 +135,17 @@ class RagE2EStep(_StepBase):
             if self.tower_stream is not None:
                 cur = torch.cuda.current_stream()
                 self.tower_stream.wait_stream(cur)
-                with torch.cuda.stream(self.tower_stream):
-                    p_emb, q_emb, p_gather, q_gather = self._towers(batch)
-                logits = self._generator(batch)
+                if self._use_graphs(batch):
+                    # graph launches cost host milliseconds each: get the generator's big graph onto the GPU
+                    # first, then feed the small tower graphs into the gaps (the tower stream only waits for
+                    # what was on the main stream BEFORE this point)
+                    logits = self._generator(batch)
+                    with torch.cuda.stream(self.tower_stream):
+                        p_emb, q_emb, p_gather, q_gather = self._towers(batch)
+                else:
+                    with torch.cuda.stream(self.tower_stream):
+                        p_emb, q_emb, p_gather, q_gather = self._towers(batch)
+                    logits = self._generator(batch)
                 cur.wait_stream(self.tower_stream)
                 for t in (p_emb, q_emb, p_gather.result, q_gather.result):
                     if t is not None and t.is_cuda:
