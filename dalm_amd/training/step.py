@@ -77,6 +77,9 @@ class RagE2EStep(_StepBase):
         self.towers_failed: Optional[str] = None
         self.calls = 0
         self.graph_after = graph_after
+        import os as _os2
+
+        self.early_gather = _os2.environ.get("DALM_EARLY_GATHER", "1") != "0"
         self.aux: Dict[str, torch.Tensor] = {}
         # the two retriever towers are many small kernels (3204 tokens through BERT) and are independent of
         # the generator until the loss: run them on their own HIP stream so they fill the gaps between the
@@ -102,18 +105,25 @@ class RagE2EStep(_StepBase):
     def _use_graphs(self, batch) -> bool:
         return self.towers is not None and self.towers.matches(batch)
 
+    def _gather(self, emb):
+        """Start the all-gather of an embedding matrix early on the side stream (overlaps the other tower) -
+        or, with early_gather off, leave it to the loss (gathered on the main stream right before use)."""
+        if not self.early_gather:
+            return None
+        return GatherHandle(emb.float(), self.comm, self.side_stream)
+
     def _towers(self, batch):
         m = self.model
         if self._use_graphs(batch):
             p_emb = self.towers.passage(batch["retriever_passage_input_ids"], batch["retriever_passage_attention_mask"])
         else:
             p_emb = m("retrieval", batch["retriever_passage_input_ids"], batch["retriever_passage_attention_mask"])
-        p_gather = GatherHandle(p_emb.float(), self.comm, self.side_stream)
+        p_gather = self._gather(p_emb)
         if self._use_graphs(batch):
             q_emb = self.towers.query(batch["retriever_query_input_ids"], batch["retriever_query_attention_mask"])
         else:
             q_emb = m("retrieval", batch["retriever_query_input_ids"], batch["retriever_query_attention_mask"])
-        q_gather = GatherHandle(q_emb.float(), self.comm, self.side_stream)
+        q_gather = self._gather(q_emb)
         return p_emb, q_emb, p_gather, q_gather
 
     def _generator(self, batch):
@@ -147,7 +157,7 @@ class RagE2EStep(_StepBase):
                         p_emb, q_emb, p_gather, q_gather = self._towers(batch)
                     logits = self._generator(batch)
                 cur.wait_stream(self.tower_stream)
-                for t in (p_emb, q_emb, p_gather.result, q_gather.result):
+                for t in (p_emb, q_emb, getattr(p_gather, "result", None), getattr(q_gather, "result", None)):
                     if t is not None and t.is_cuda:
                         t.record_stream(cur)
             else:
