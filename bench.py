@@ -31,6 +31,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
+import dalm_amd  # noqa: E402,F401  (sets GPU_MAX_HW_QUEUES before the HIP runtime starts - see dalm_amd/__init__.py)
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
