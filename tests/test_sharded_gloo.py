@@ -65,12 +65,11 @@ def _worker(rank, world, port, mode, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["e2e", "contrastive"])
-def test_two_ranks_equal_one_process_at_global_batch(tmp_path, mode):
+@pytest.mark.parametrize("mode,world", [("e2e", 2), ("contrastive", 2), ("e2e", 3)])
+def test_ranks_equal_one_process_at_global_batch(tmp_path, mode, world):
     import dalm_oracle as O
     from helpers import synth_batch
 
-    world = 2
     port = _free_port()
     mp.spawn(_worker, args=(world, port, mode, str(tmp_path)), nprocs=world, join=True)
     res = [torch.load(tmp_path / f"r{r}.pt") for r in range(world)]
@@ -84,7 +83,7 @@ def test_two_ranks_equal_one_process_at_global_batch(tmp_path, mode):
     out["loss"].backward()
 
     assert abs(float(res[0]["loss_total"]) - float(out["loss"])) <= 1e-5 * abs(float(out["loss"]))
-    assert abs(float(res[0]["loss_share"]) + float(res[1]["loss_share"]) - float(out["loss"])) <= 1e-5 * abs(float(out["loss"]))
+    assert abs(sum(float(r["loss_share"]) for r in res) - float(out["loss"])) <= 1e-5 * abs(float(out["loss"]))
     for r in range(world):  # every rank holds the same, fully reduced parameter gradient
         torch.testing.assert_close(res[r]["dw"].double(), w.grad, rtol=2e-4, atol=1e-6)
     if mode == "e2e":
