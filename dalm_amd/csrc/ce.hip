@@ -456,6 +456,10 @@ __global__ __launch_bounds__(BS) void marg_ce_stream_kernel(
   const T* xrow = logits + off;
   const int64_t y = ids[static_cast<int64_t>(b) * Tg + t + 1];
   RowWin<T> w(xrow, V);
+  // label logit first: with dlogits aliasing logits (in-place mode) other waves may already be storing the
+  // gradient of this row by the time thread 0 gets past the block reductions below
+  float xy = 0.f;
+  if (tid == 0) xy = (y >= 0 && y < V) ? Elt<T>::get(xrow + y) : __builtin_nanf("");
 
   float tm = -INFINITY, tl = 0.f;
   for (int slot = tid; slot < w.nslots; slot += BS) {
@@ -482,7 +486,6 @@ __global__ __launch_bounds__(BS) void marg_ce_stream_kernel(
   const float lse = m + __logf(l);
   const float mval = static_cast<float>(mi);
   if (tid == 0) {
-    const float xy = (y >= 0 && y < V) ? Elt<T>::get(xrow + y) : __builtin_nanf("");
     row_lse[row] = lse;
     row_nll[row] = mval * (lse - xy);
   }

@@ -10,7 +10,7 @@ from ..fused import pool_l2norm
 from ..utils import eos_mask
 from . import lora
 from .fastpath import use_native_rms_norm
-from .rag_e2e_base_model import _BNB_MSG
+from .rag_e2e_base_model import warn_bnb_ignored
 
 
 class AutoModelForSentenceEmbedding(torch.nn.Module):
@@ -19,7 +19,7 @@ class AutoModelForSentenceEmbedding(torch.nn.Module):
                  device: Optional[str] = None) -> None:
         super().__init__()
         if use_bnb:
-            raise NotImplementedError(_BNB_MSG.replace("use_bnb=None", "use_bnb=False"))
+            warn_bnb_ignored(use_bnb)
         from transformers import AutoModel, AutoModelForCausalLM, AutoTokenizer
 
         model_type = AutoModel if not is_autoregressive else AutoModelForCausalLM

@@ -83,13 +83,27 @@ class ShardedBatches:
         return perm[pos + self.rank * b: pos + (self.rank + 1) * b]
 
     def _stage(self, rows: torch.Tensor, device: torch.device):
-        host = {k: v.index_select(0, rows) for k, v in self.data.items()}
         if device.type != "cuda":
-            return host, None
+            return {k: v.index_select(0, rows) for k, v in self.data.items()}, None
+        # two persistent pinned staging sets (batch i+1 is staged while batch i's copy may still be in flight);
+        # index_select writes straight into the pinned buffer: no per-step pinned allocation
+        slot = self._slot = (getattr(self, "_slot", -1) + 1) % 2
+        if not hasattr(self, "_staging"):
+            self._staging = [{k: torch.empty((self.B,) + tuple(v.shape[1:]), dtype=v.dtype).pin_memory()
+                              for k, v in self.data.items()} for _ in range(2)]
+            self._staging_free = [None, None]
+        if self._staging_free[slot] is not None:
+            self._staging_free[slot].synchronize()  # the copy that last read this staging set has finished
+        n = rows.numel()
         ev = torch.cuda.Event()
         with torch.cuda.stream(self._copy_stream):
-            dev = {k: v.pin_memory().to(device, non_blocking=True) for k, v in host.items()}
+            dev = {}
+            for k, v in self.data.items():
+                host = self._staging[slot][k][:n]
+                torch.index_select(v, 0, rows, out=host)
+                dev[k] = host.to(device, non_blocking=True)
             ev.record(self._copy_stream)
+        self._staging_free[slot] = ev
         return dev, ev
 
     def epoch(self, epoch: int, device: torch.device, skip: int = 0) -> Iterable[Dict[str, torch.Tensor]]:
@@ -105,6 +119,18 @@ class ShardedBatches:
                 for t in cur.values():
                     t.record_stream(torch.cuda.current_stream())
             yield cur
+
+
+def effective_grad_accum(gradient_accumulation_steps: int) -> int:
+    """The trainers take one optimizer step per batch.  The reference accepts gradient_accumulation_steps
+    but zeroes the model's gradients after every micro-batch (train_rage2e.py:474), which defeats the
+    accumulation, so there is no reference behaviour worth reproducing for values > 1:
+    the flag is accepted, a warning is logged, and step counting / resume arithmetic use 1 so that every
+    batch of every epoch is consumed and the LR schedule spans all optimizer steps."""
+    if gradient_accumulation_steps and int(gradient_accumulation_steps) > 1:
+        logger.warning("gradient_accumulation_steps=%s is accepted for CLI compatibility only: every batch takes an "
+                       "optimizer step (treated as 1)", gradient_accumulation_steps)
+    return 1
 
 
 def steps_and_epochs(num_batches: int, grad_accum: int, num_train_epochs: int, max_train_steps: Optional[int]):

@@ -72,6 +72,12 @@ class TensorLRScheduler:
 
     def load_state_dict(self, sd) -> None:
         self.scheduler.load_state_dict(sd)
+        # LambdaLR.load_state_dict restores the schedule position but not the shadow optimizer's lr:
+        # take it from the restored schedule, otherwise _push() would overwrite the (correct) lr that
+        # optimizer.load_state_dict has just restored with the shadow's construction-time value
+        last = sd.get("_last_lr") or self.scheduler.get_last_lr()
+        for g, lr in zip(self._shadow.param_groups, last):
+            g["lr"] = float(lr)
         self._push()
 
 

@@ -93,6 +93,7 @@ def train_retriever(
 ) -> None:
     config = {k: v for k, v in dict(locals()).items() if v is None or isinstance(v, (float, int, str))}
     comm, device = init_distributed()
+    gradient_accumulation_steps = common.effective_grad_accum(gradient_accumulation_steps)
     if device.type != "cuda":
         raise RuntimeError("train_retriever needs an MI355X: the loss path has no CPU implementation in this package")
     is_main = comm.rank == 0

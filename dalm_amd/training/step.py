@@ -188,16 +188,6 @@ class RetrieverStep(_StepBase):
         # the query pass (Tq = 50) is small next to the passage pass (Tp = 128): run it on its own stream
         self.tower_stream = torch.cuda.Stream() if (overlap_towers and torch.cuda.is_available()) else None
 
-    def _generator(self, batch):
-        m = self.model
-        if self._use_graphs(batch):
-            return self.towers.generator(batch["generator_input_input_ids"], batch["generator_input_attention_mask"])
-        if not self.fuse_lm_head:
-            return m("generation", batch["generator_input_input_ids"], batch["generator_input_attention_mask"])
-        gm = m.generator_model
-        return gm.base_model(input_ids=batch["generator_input_input_ids"],
-                             attention_mask=batch["generator_input_attention_mask"])[0]
-
     def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         m = self.model
         with self._autocast():

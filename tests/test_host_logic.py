@@ -7,6 +7,7 @@ from pathlib import Path
 import pytest
 import torch
 
+GOLDEN = Path(__file__).parent / "golden"
 GOLD = json.loads((Path(__file__).parent / "golden" / "host_golden.json").read_text())
 
 
@@ -151,11 +152,55 @@ def test_lora_injector_matches_reference_config():
                                               intermediate_size=64, vocab_size=50)), ["nope"])
 
 
-def test_use_bnb_is_rejected_loudly():
-    from dalm_amd.models import AutoModelForRagE2E, Mode
+def test_use_bnb_warns_and_is_ignored():
+    """The reference's default call (`train_retriever(..., use_bnb=True)`) must run: the nf4 request is served
+    with unquantised weights and a warning (bitsandbytes is CUDA-only)."""
+    from dalm_amd.models.rag_e2e_base_model import warn_bnb_ignored
 
-    with pytest.raises(NotImplementedError, match="bitsandbytes"):
-        AutoModelForRagE2E("r", "g", use_bnb=Mode.BOTH)
+    with pytest.warns(UserWarning, match="bitsandbytes"):
+        warn_bnb_ignored(True)
+    from dalm_amd.models import AutoModelForSentenceEmbedding
+
+    path = str(GOLDEN / "tiny_retriever")
+    with pytest.warns(UserWarning, match="bitsandbytes"):
+        m = AutoModelForSentenceEmbedding(path, use_bnb=True, get_peft=False, device="cpu")
+    assert m.model is not None
+
+
+def test_grad_accum_is_treated_as_one(caplog):
+    from dalm_amd.training import common
+
+    assert common.effective_grad_accum(1) == 1
+    with caplog.at_level("WARNING", logger="dalm_amd.train"):
+        assert common.effective_grad_accum(4) == 1
+    assert "gradient_accumulation_steps=4" in caplog.text
+    # 100 batches: every batch is an optimizer step, the epoch is not cut short
+    assert common.steps_and_epochs(100, common.effective_grad_accum(4), 1, None) == (100, 100, 1)
+
+
+def test_tensor_lr_scheduler_resume_restores_lr():
+    """load_state_dict must restore the shadow optimizer's lr (warm-up 10, resume at step 50)."""
+    from transformers import get_scheduler
+
+    from dalm_amd.training.graphed import TensorLRScheduler
+
+    def mk(o):
+        return get_scheduler("linear", optimizer=o, num_warmup_steps=10, num_training_steps=100)
+
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=torch.tensor(1e-4))
+    s = TensorLRScheduler(opt, 1e-4, mk)
+    for _ in range(50):
+        s.step()
+    want = float(opt.param_groups[0]["lr"])
+    assert abs(want - 1e-4 * 50 / 90) < 1e-9
+    sd = s.state_dict()
+    opt2 = torch.optim.Adam([p], lr=torch.tensor(1e-4))
+    s2 = TensorLRScheduler(opt2, 1e-4, mk)
+    s2.load_state_dict(sd)
+    assert abs(float(opt2.param_groups[0]["lr"]) - want) < 1e-12
+    s.step(); s2.step()
+    assert abs(float(opt2.param_groups[0]["lr"]) - float(opt.param_groups[0]["lr"])) < 1e-12
 
 
 def test_native_rms_norm_patch_matches_hf_module():
