@@ -22,6 +22,9 @@ from .fused import GatherHandle, LocalComm, TorchDistComm  # noqa: F401
 
 def init_distributed(backend: Optional[str] = None):
     """Initialise torch.distributed from the torchrun environment; returns (comm, device)."""
+    from . import configure_hw_queues
+
+    configure_hw_queues()  # no effect once the HIP runtime is up; entry points call it first thing as well
     world = int(os.environ.get("WORLD_SIZE", "1"))
     # DALM_FORCE_DIST=1 runs the RCCL code path even with one rank (used to smoke-test the collectives,
     # side-stream gathers and the gradient bucket on a single-GPU box)
@@ -70,12 +73,30 @@ def allreduce_grads(params: Iterable[torch.nn.Parameter], comm) -> None:
         off += n
 
 
+class _Bucket:
+    __slots__ = ("lo", "hi", "count", "pending", "streams", "launched", "done")
+
+    def __init__(self, lo: int, hi: int, count: int):
+        self.lo, self.hi, self.count = lo, hi, count
+        self.pending, self.streams, self.launched, self.done = count, [], False, None
+
+
 class GradBucket:
     """All trainable gradients as views of ONE flat fp32 buffer (what DDP calls gradient_as_bucket_view):
-    backward accumulates straight into the bucket, the all-reduce runs on the bucket, the fused optimizer
-    reads the views - no per-step flatten / ~400 tiny copy-back launches.  Grads are zeroed, never set to None."""
+    backward accumulates straight into the buffer and the fused optimizer reads the views - no per-step
+    flatten / ~400 tiny copy-back launches.  Grads are zeroed, never set to None.
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], comm):
+    The buffer is cut into contiguous buckets of ~bucket_bytes.  Every parameter carries a
+    post-accumulate-grad hook; when the last gradient of a bucket has landed, that bucket's all-reduce (SUM)
+    is issued on a communication stream while the rest of the backward keeps running - the overlap the
+    reference gets from DDP's reducer (train_rage2e.py:416-418,471).  Buckets are launched in a FIXED order
+    (highest offset first: the backward produces the last layers' gradients first) so that every rank issues
+    the same sequence of collectives whatever order its hooks fire in.  `all_reduce()` after backward flushes
+    the buckets that never became ready (parameters without a gradient this step) and makes the current stream
+    wait for the communication stream.  overlap=False gives one blocking all-reduce of the whole buffer."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], comm, bucket_bytes: int = 4 << 20,
+                 overlap: Optional[bool] = None):
         self.comm = comm
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
@@ -84,11 +105,89 @@ class GradBucket:
         if any(p.dtype != torch.float32 or p.device != dev for p in self.params):
             raise ValueError("GradBucket needs fp32 trainable parameters on one device")
         self.flat = torch.zeros(sum(p.numel() for p in self.params), device=dev, dtype=torch.float32)
-        off = 0
+        if overlap is None:
+            overlap = os.environ.get("DALM_GRAD_OVERLAP", "1") != "0"
+        self.overlap = bool(overlap) and not isinstance(comm, LocalComm)
+        self.comm_stream = torch.cuda.Stream(device=dev) if (self.overlap and dev.type == "cuda") else None
+        self.buckets: List[_Bucket] = []
+        self._bucket_of: List[int] = []
+        off, lo, count = 0, 0, 0
+        per = max(int(bucket_bytes) // 4, 1)
         for p in self.params:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
+            self._bucket_of.append(len(self.buckets))
             off += n
+            count += 1
+            if off - lo >= per:
+                self.buckets.append(_Bucket(lo, off, count))
+                lo, count = off, 0
+        if count:
+            self.buckets.append(_Bucket(lo, off, count))
+        self._next = len(self.buckets) - 1  # next bucket allowed to launch (descending)
+        self.launch_log: List[int] = []     # bucket indices in launch order, last step (tests / debugging)
+        self._handles = []
+        if self.overlap:
+            for i, p in enumerate(self.params):
+                self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(self._bucket_of[i])))
+
+    # ---- hook side (autograd thread, during backward) ------------------------------------------------
+    def _make_hook(self, bi: int):
+        def hook(_param):
+            b = self.buckets[bi]
+            b.pending -= 1
+            if self.comm_stream is not None:
+                s = torch.cuda.current_stream()
+                if all(s != t for t in b.streams):
+                    b.streams.append(s)
+            if b.pending == 0:
+                self._launch_ready()
+        return hook
+
+    def _launch_ready(self) -> None:
+        while self._next >= 0 and self.buckets[self._next].pending <= 0:
+            self._launch(self.buckets[self._next])
+            self._next -= 1
+
+    def _launch(self, b: _Bucket) -> None:
+        view = self.flat[b.lo:b.hi]
+        if self.comm_stream is not None:
+            # gradients of one bucket may have been accumulated on several streams (towers / generator):
+            # the communication stream waits for everything queued so far on each of them
+            for s in (b.streams or [torch.cuda.current_stream()]):
+                ev = torch.cuda.Event()
+                ev.record(s)
+                self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                self.comm.all_reduce_sum_(view)
+                b.done = torch.cuda.Event()
+                b.done.record(self.comm_stream)
+        else:
+            self.comm.all_reduce_sum_(view)
+        b.launched = True
+        self.launch_log.append(self.buckets.index(b))
+
+    # ---- step side -------------------------------------------------------------------------------
+    def all_reduce(self) -> None:
+        """Call after backward: afterwards every .grad view holds the SUM over ranks (ordered on the current stream)."""
+        if isinstance(self.comm, LocalComm):
+            return
+        if not self.overlap:
+            self.comm.all_reduce_sum_(self.flat)
+            return
+        cur = torch.cuda.current_stream() if self.comm_stream is not None else None
+        while self._next >= 0:  # buckets whose hooks did not all fire (unused parameters): flush in order
+            b = self.buckets[self._next]
+            if cur is not None and all(cur != t for t in b.streams):
+                b.streams.append(cur)
+            self._launch(b)
+            self._next -= 1
+        for b in self.buckets:
+            if cur is not None and b.done is not None:
+                cur.wait_event(b.done)
+            b.pending, b.streams, b.launched, b.done = b.count, [], False, None
+        self._next = len(self.buckets) - 1
+        self.last_launch_log, self.launch_log = self.launch_log, []
 
     def zero(self) -> None:
         self.flat.zero_()
@@ -98,10 +197,6 @@ class GradBucket:
             if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * off:
                 p.grad = self.flat[off:off + n].view_as(p)
             off += n
-
-    def all_reduce(self) -> None:
-        if not isinstance(self.comm, LocalComm):
-            self.comm.all_reduce_sum_(self.flat)
 
 
 def barrier(comm) -> None:

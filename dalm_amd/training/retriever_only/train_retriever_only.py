@@ -192,6 +192,9 @@ def train_retriever(
 
 
 def main() -> None:
+    from ... import configure_hw_queues
+
+    configure_hw_queues()  # before the HIP runtime starts (see dalm_amd/__init__.py)
     logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(levelname)s - %(name)s - %(message)s")
     a = parse_args()
     kw = {k: v for k, v in vars(a).items() if k not in ("dataset_path", "retriever_name_or_path")}

@@ -20,7 +20,8 @@ from ..sharded import GradBucket, allreduce_grads
 
 
 class _StepBase:
-    def __init__(self, model, optimizer, lr_scheduler, logit_scale, comm=None, autocast_dtype=None, ops=None):
+    def __init__(self, model, optimizer, lr_scheduler, logit_scale, comm=None, autocast_dtype=None, ops=None,
+                 grad_overlap: bool = True):
         self.model, self.optimizer, self.lr_scheduler = model, optimizer, lr_scheduler
         self.logit_scale = logit_scale
         self.comm = comm or LocalComm()
@@ -37,7 +38,8 @@ class _StepBase:
         if _os.environ.get("DALM_GRAD_BUCKET", "1") != "0" and not isinstance(self.comm, LocalComm) and self.trainable and \
                 all(p.dtype == torch.float32 for p in self.trainable) and \
                 len({p.device for p in self.trainable}) == 1:
-            self.bucket = GradBucket(self.trainable, self.comm)
+            # bucketed all-reduce issued from post-accumulate hooks while the backward is still running
+            self.bucket = GradBucket(self.trainable, self.comm, overlap=None if grad_overlap else False)
 
     def _autocast(self):
         if self.autocast_dtype is None:
