@@ -19,5 +19,5 @@ int check_launch(const char* fn) {
 }
 }  // namespace dalm
 
-extern "C" int dalm_version(void) { return 100; /* 0.1.0 */ }
+extern "C" int dalm_version(void) { return 200; /* 0.2.0 */ }
 extern "C" const char* dalm_last_error_string(void) { return dalm::g_last_error.c_str(); }

@@ -139,6 +139,156 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ em
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fused forward: one 1024-thread workgroup walks the unmasked tokens of ONE sample (or of one token slice of
+// it, grid.x = TZ) across the full embedding width, so the mean, |u| and the normalisation happen in the
+// same launch (the two-launch form above costs ~20 us at batch 18 for ~2 us of data movement).
+//   TPR threads cover one token row (VEC elements each, NCH d-chunks per thread when D > TPR*VEC),
+//   G = 1024/TPR token groups stride through the tokens, 4 token rows in flight per group.
+//   TZ == 1: sums are combined through LDS in fixed group order, then u, |u|, e are written.
+//   TZ  > 1: raw partial sums go to part[b][z][D] (+ counts) and pool_finish_kernel completes the sample;
+//            used when B alone cannot occupy the chip (B * bytes per sample is large but B < ~128).
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int NCH>
+__global__ __launch_bounds__(1024) void pool_fused_kernel(const T* __restrict__ h, const int64_t* __restrict__ mask,
+                                                          int Tn, int D, int tpr_log2, int vec_ok, int normalize,
+                                                          float* __restrict__ emb, float* __restrict__ norm,
+                                                          float* __restrict__ inv_count, float* __restrict__ part,
+                                                          float* __restrict__ part_cnt) {
+  constexpr int VEC = HV<T>::VEC;
+  extern __shared__ float lds[];       // [G][Dp] partial sums, then reduction scratch
+  __shared__ float red[16];
+  __shared__ float cnt_s[16];
+  const int b = blockIdx.y, z = blockIdx.x, TZ = gridDim.x;
+  const int tid = threadIdx.x;
+  const int TPR = 1 << tpr_log2, G = 1024 >> tpr_log2;
+  const int g = tid >> tpr_log2, c = tid & (TPR - 1);
+  const int per = (Tn + TZ - 1) / TZ;
+  const int t_lo = z * per, t_hi = min(Tn, t_lo + per);
+  const T* hb = h + static_cast<int64_t>(b) * Tn * D;
+  const int64_t* mb = mask + static_cast<int64_t>(b) * Tn;
+
+  float acc[NCH][VEC];
+#pragma unroll
+  for (int q = 0; q < NCH; ++q)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[q][e] = 0.f;
+  float cnt = 0.f;
+  for (int t0 = t_lo + g; t0 < t_hi; t0 += 4 * G) {
+    int64_t m[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) m[u] = (t0 + u * G < t_hi) ? mb[t0 + u * G] : 0;
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      const int d = (q * TPR + c) * VEC;
+      int nvalid = D - d;
+      nvalid = nvalid < 0 ? 0 : (nvalid > VEC ? VEC : nvalid);
+      float x[4][VEC];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (m[u] != 0 && nvalid > 0) HV<T>::load(hb + static_cast<int64_t>(t0 + u * G) * D + d, nvalid, vec_ok, x[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (m[u] != 0 && nvalid > 0) {
+          const float f = static_cast<float>(m[u]);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc[q][e] = fmaf(f, x[u][e], acc[q][e]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) cnt += static_cast<float>(m[u]);
+  }
+  // ---- combine the G token groups (fixed order) ----
+  const int Dp = TPR * VEC * NCH;
+#pragma unroll
+  for (int q = 0; q < NCH; ++q)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) lds[g * Dp + (q * TPR + c) * VEC + e] = acc[q][e];
+  if (c == 0) cnt_s[g] = cnt;
+  __syncthreads();
+  float total = 0.f;
+  for (int i = 0; i < G; ++i) total += cnt_s[i];
+  float ss = 0.f;
+  float u[NCH][VEC];
+  if (g == 0) {
+#pragma unroll
+    for (int q = 0; q < NCH; ++q)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const int i = (q * TPR + c) * VEC + e;
+        float s = 0.f;
+        for (int k = 0; k < G; ++k) s += lds[k * Dp + i];
+        u[q][e] = s;
+      }
+  }
+  if (TZ > 1) {
+    if (g == 0) {
+      float* pr = part + (static_cast<int64_t>(b) * TZ + z) * D;
+#pragma unroll
+      for (int q = 0; q < NCH; ++q)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const int i = (q * TPR + c) * VEC + e;
+          if (i < D) pr[i] = u[q][e];
+        }
+      if (c == 0) part_cnt[b * TZ + z] = total;
+    }
+    return;
+  }
+  const float cden = fmaxf(total, 1e-9f);
+  if (g == 0) {
+#pragma unroll
+    for (int q = 0; q < NCH; ++q)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const int i = (q * TPR + c) * VEC + e;
+        u[q][e] = (i < D) ? u[q][e] / cden : 0.f;
+        ss = fmaf(u[q][e], u[q][e], ss);
+      }
+  }
+  ss = block_sum<1024>(ss, red);
+  const float nrm = sqrtf(ss);
+  if (tid == 0) { norm[b] = nrm; inv_count[b] = 1.f / cden; }
+  if (g == 0) {
+    const float denom = fmaxf(nrm, 1e-12f);
+#pragma unroll
+    for (int q = 0; q < NCH; ++q)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const int i = (q * TPR + c) * VEC + e;
+        if (i < D) emb[static_cast<int64_t>(b) * D + i] = normalize ? u[q][e] / denom : u[q][e];
+      }
+  }
+}
+
+// completes a sample from TZ partial sums (fixed z order): one block per sample
+__global__ __launch_bounds__(256) void pool_finish_kernel(const float* __restrict__ part,
+                                                          const float* __restrict__ part_cnt, int TZ, int D,
+                                                          int normalize, float* __restrict__ emb,
+                                                          float* __restrict__ norm, float* __restrict__ inv_count) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  float total = 0.f;
+  for (int z = 0; z < TZ; ++z) total += part_cnt[b * TZ + z];
+  const float cden = fmaxf(total, 1e-9f);
+  float* row = emb + static_cast<int64_t>(b) * D;
+  float ss = 0.f;
+  for (int i = threadIdx.x; i < D; i += 256) {
+    float s = 0.f;
+    for (int z = 0; z < TZ; ++z) s += part[(static_cast<int64_t>(b) * TZ + z) * D + i];
+    s /= cden;
+    row[i] = s;   // re-read below by the same thread only
+    ss = fmaf(s, s, ss);
+  }
+  ss = block_sum<256>(ss, red);
+  const float nrm = sqrtf(ss);
+  if (threadIdx.x == 0) { norm[b] = nrm; inv_count[b] = 1.f / cden; }
+  if (normalize) {
+    const float denom = fmaxf(nrm, 1e-12f);
+    for (int i = threadIdx.x; i < D; i += 256) row[i] = row[i] / denom;
+  }
+}
+
 // grid (DC, B, TZ).  dh[b,t,:] = mask[b,t] * inv_count[b] * du[b,:], with
 //   du = d_emb                                  (normalize == 0)
 //   du = (d_emb - e (e . d_emb)) / |u|           (|u| >= 1e-12)
@@ -196,9 +346,66 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
 
 using namespace dalm;
 
-extern "C" int dalm_pool_l2norm_fwd(const void* h, int dtype, const int64_t* mask, int64_t B, int64_t T,
-                                    int64_t D, int normalize, float* emb, float* norm, float* inv_count,
-                                    dalm_stream_t stream) {
+namespace dalm {
+namespace {
+// Geometry of the fused forward: TPR threads per token row (power of two), NCH chunks per thread, TZ token slices.
+struct PoolPlan { int tpr_log2, nch, tz; bool fused; };
+inline PoolPlan pool_plan(int64_t B, int64_t T, int64_t D, int vec) {
+  PoolPlan p{0, 1, 1, false};
+  const int64_t lanes = (D + vec - 1) / vec;
+  int lg = 6;                                  // at least one wave per row
+  while ((1ll << lg) < lanes && lg < 10) ++lg;
+  const int64_t tpr = 1ll << lg;
+  const int64_t nch = (lanes + tpr - 1) / tpr;
+  const int64_t lds_bytes = (1024 / tpr) * tpr * vec * nch * 4;
+  if (nch > 4 || lds_bytes > 64 * 1024) return p;   // very wide rows: two-launch kernels
+  p.tpr_log2 = lg; p.nch = static_cast<int>(nch); p.fused = true;
+  // token slices: only when the batch alone leaves most CUs idle AND a sample is big enough to matter
+  const int64_t groups = 1024 / tpr;
+  int64_t tz = 1;
+  if (B < 96 && T * D * (16 / vec) > (1 << 20)) {    // > 1 MiB per sample
+    tz = (192 + B - 1) / B;
+    const int64_t tz_max = (T + 4 * groups - 1) / (4 * groups);
+    if (tz > tz_max) tz = tz_max;
+    if (tz > 32) tz = 32;
+    if (tz < 1) tz = 1;
+  }
+  p.tz = static_cast<int>(tz);
+  return p;
+}
+template <typename T>
+void launch_pool_fused(const PoolPlan& pl, const T* h, const int64_t* mask, int B, int Tn, int D, int vok, int normalize,
+                       float* emb, float* norm, float* inv_count, float* part, float* part_cnt, hipStream_t s) {
+  const int vec = HV<T>::VEC;
+  const size_t lds = static_cast<size_t>(1024 >> pl.tpr_log2) * (1u << pl.tpr_log2) * vec * pl.nch * sizeof(float);
+  const dim3 grid(static_cast<unsigned>(pl.tz), static_cast<unsigned>(B));
+#define DALM_POOL_LAUNCH(N) \
+  hipLaunchKernelGGL((pool_fused_kernel<T, N>), grid, dim3(1024), lds, s, h, mask, Tn, D, pl.tpr_log2, vok, normalize, \
+                     emb, norm, inv_count, part, part_cnt)
+  switch (pl.nch) {
+    case 1: DALM_POOL_LAUNCH(1); break;
+    case 2: DALM_POOL_LAUNCH(2); break;
+    case 3: DALM_POOL_LAUNCH(3); break;
+    default: DALM_POOL_LAUNCH(4); break;
+  }
+#undef DALM_POOL_LAUNCH
+  if (pl.tz > 1)
+    hipLaunchKernelGGL(pool_finish_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 0, s, part, part_cnt, pl.tz, D,
+                       normalize, emb, norm, inv_count);
+}
+}  // namespace
+}  // namespace dalm
+
+extern "C" size_t dalm_pool_l2norm_fwd_workspace_bytes(int64_t B, int64_t T, int64_t D, int dtype) {
+  if (B <= 0 || T <= 0 || D <= 0) return 0;
+  const PoolPlan pl = pool_plan(B, T, D, dtype == DALM_F32 ? 4 : 8);
+  if (!pl.fused || pl.tz <= 1) return 0;
+  return static_cast<size_t>(B) * pl.tz * (static_cast<size_t>(D) + 1) * sizeof(float);
+}
+
+extern "C" int dalm_pool_l2norm_fwd_ws(const void* h, int dtype, const int64_t* mask, int64_t B, int64_t T,
+                                       int64_t D, int normalize, float* emb, float* norm, float* inv_count,
+                                       void* ws, size_t ws_bytes, dalm_stream_t stream) {
   DALM_REQUIRE(h && mask && emb && norm && inv_count, DALM_E_NULL, "null pointer argument");
   DALM_REQUIRE(dtype == DALM_F32 || dtype == DALM_BF16, DALM_E_DTYPE, "dtype must be DALM_F32 or DALM_BF16");
   DALM_REQUIRE(B > 0 && T > 0 && D > 0 && B <= 65535 && T <= 0x7fffffffll && D <= 0x3fffffffll, DALM_E_SHAPE,
@@ -206,6 +413,20 @@ extern "C" int dalm_pool_l2norm_fwd(const void* h, int dtype, const int64_t* mas
   hipStream_t s = as_stream(stream);
   const int vec = (dtype == DALM_F32) ? 4 : 8;
   const int vok = (reinterpret_cast<uintptr_t>(h) % 16 == 0) && (D % vec == 0);
+  PoolPlan pl = pool_plan(B, T, D, vec);
+  const size_t need = dalm_pool_l2norm_fwd_workspace_bytes(B, T, D, dtype);
+  if (pl.fused && pl.tz > 1 && (ws == nullptr || ws_bytes < need)) pl.tz = 1;   // no scratch: one slice per sample
+  if (pl.fused) {
+    float* part = static_cast<float*>(ws);
+    float* part_cnt = part ? part + static_cast<size_t>(B) * pl.tz * D : nullptr;
+    if (dtype == DALM_F32)
+      launch_pool_fused<float>(pl, static_cast<const float*>(h), mask, static_cast<int>(B), static_cast<int>(T),
+                               static_cast<int>(D), vok, normalize, emb, norm, inv_count, part, part_cnt, s);
+    else
+      launch_pool_fused<bf16_t>(pl, static_cast<const bf16_t*>(h), mask, static_cast<int>(B), static_cast<int>(T),
+                                static_cast<int>(D), vok, normalize, emb, norm, inv_count, part, part_cnt, s);
+    return check_launch(__func__);
+  }
   const dim3 grid(static_cast<unsigned>((D + 64 * vec - 1) / (64 * vec)), static_cast<unsigned>(B));
   if (dtype == DALM_F32)
     hipLaunchKernelGGL(pool_sum_kernel<float>, grid, dim3(256), 0, s, static_cast<const float*>(h), mask,
@@ -216,6 +437,12 @@ extern "C" int dalm_pool_l2norm_fwd(const void* h, int dtype, const int64_t* mas
   hipLaunchKernelGGL(l2norm_rows_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 0, s, emb,
                      static_cast<int>(D), normalize, norm);
   return check_launch(__func__);
+}
+
+extern "C" int dalm_pool_l2norm_fwd(const void* h, int dtype, const int64_t* mask, int64_t B, int64_t T,
+                                    int64_t D, int normalize, float* emb, float* norm, float* inv_count,
+                                    dalm_stream_t stream) {
+  return dalm_pool_l2norm_fwd_ws(h, dtype, mask, B, T, D, normalize, emb, norm, inv_count, nullptr, 0, stream);
 }
 
 extern "C" int dalm_pool_l2norm_bwd(const float* d_emb, const float* emb, const float* norm,

@@ -17,6 +17,7 @@
 // every MFMA fragment read is one conflict-free ds_read_b32 per lane.
 // MFMA-bound: 2*m*n*D flop per launch against the 157 TF f32-matrix peak.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace dalm {
 namespace {
@@ -366,6 +367,188 @@ __global__ __launch_bounds__(256) void contrastive_finalize_kernel(const float* 
   if (threadIdx.x == 0) out[0] = 0.5f * s / n_global;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Flash-style backward: dA[m,D] = alpha * dS[m,n] . B[n,D] with dS rebuilt tile by tile - no m x n panel in HBM.
+// A workgroup owns 32 rows of A and ALL D output columns (accumulators: 32 x D f32 = NT 32x32 MFMA tiles per
+// wave, 4 waves side by side over D <= 1024) and walks its share of the column blocks of B, 128 columns at a time:
+//   S phase   S[32 x 128] = A_blk . B_blk^T over K = D, the LDS-staged K loop of gemm_f32_mfma_kernel
+//             (same k order => the same S bits the row statistics saw); each wave one 32x32 tile
+//   transform dS = rc_i e^{S-rl_i} + cc_j e^{S-cl_j} - [diag](rc_i + cc_j) in registers -> LDS, k-major
+//   dA phase  acc[32 x D] += dS[32 x 128] . B_blk[128 x D]: A-fragments from the dS tile in LDS, B-fragments
+//             straight from global memory (lane (c,h) reads B[j+h][d+c]: full 128-byte rows, L2-resident because the
+//             S phase has just streamed the block), two steps prefetched in registers; no barrier in this phase
+// Both phases issue 512 MFMAs per wave per block at D = 1024.  Column blocks are split over `nsplit` workgroups
+// when m/32 row blocks cannot fill the chip; those write raw partial outputs and flash_reduce_kernel sums them in
+// fixed order (workspace nsplit*m*D floats, bounded by ~512 row blocks worth, never m*n).
+// MFMA-bound: 4*m*n*D flop per launch against the 157 TF f32-matrix peak.
+// ---------------------------------------------------------------------------------------------------
+struct FlashParams {
+  const float* A; const float* B;
+  int m, n, D;
+  float alpha;
+  int a_vec, b_vec;
+  int64_t diag_offset;
+  const float* row_coef; const float* row_lse; const float* col_coef; const float* col_lse;
+  float* out;            // dA (nsplit == 1) or slabs [nsplit][m][D]
+  int row_blocks, nsplit, blocks_per_split;
+};
+
+constexpr int FBM = 32, FBN = 128, FBK = 32;
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void sim_flash_grad_kernel(const FlashParams p) {
+  using SA = Stage<FBM, FBK, true>;
+  using SB = Stage<FBN, FBK, true>;
+  constexpr int DS_STRIDE = FBM + 1;
+  __shared__ __attribute__((aligned(16))) float lds[FBK * SA::STRIDE + FBK * SB::STRIDE + FBN * DS_STRIDE + 2 * FBM];
+  float* As = lds;
+  float* Bs = As + FBK * SA::STRIDE;
+  float* Ds = Bs + FBK * SB::STRIDE;
+  float* rc_s = Ds + FBN * DS_STRIDE;
+  float* rl_s = rc_s + FBM;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+  const int rb = static_cast<int>(blockIdx.x) % p.row_blocks, z = static_cast<int>(blockIdx.x) / p.row_blocks;
+  const int i0 = rb * FBM;
+  const int c0 = wave * NT * 32;  // first output column of this wave
+  const int nblocks = (p.n + FBN - 1) / FBN;
+  const int jb_lo = z * p.blocks_per_split, jb_hi = min(nblocks, jb_lo + p.blocks_per_split);
+
+  if (tid < FBM) {
+    const bool ok = i0 + tid < p.m;
+    rc_s[tid] = ok ? p.row_coef[i0 + tid] : 0.f;
+    rl_s[tid] = ok ? p.row_lse[i0 + tid] : 0.f;
+  }
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  SA sa; SB sb;
+  const int nk = (p.D + FBK - 1) / FBK;
+#pragma unroll 1
+  for (int jb = jb_lo; jb < jb_hi; ++jb) {
+    const int j0 = jb * FBN;
+    // ---------------- S phase ----------------
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+    sa.load(p.A, p.D, i0, 0, p.m, p.D, p.a_vec);
+    sb.load(p.B, p.D, j0, 0, p.n, p.D, p.b_vec);
+    const int col = j0 + wave * 32 + l31;
+    const bool col_ok = col < p.n;
+    const float ccj = col_ok ? p.col_coef[col] : 0.f;
+    const float clj = col_ok ? p.col_lse[col] : 0.f;
+    sa.store(As); sb.store(Bs);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = (kt + 1 < nk);
+      if (more) {
+        sa.load(p.A, p.D, i0, (kt + 1) * FBK, p.m, p.D, p.a_vec);
+        sb.load(p.B, p.D, j0, (kt + 1) * FBK, p.n, p.D, p.b_vec);
+      }
+      const float* a_base = As + lhi * SA::STRIDE + l31;
+      const float* b_base = Bs + lhi * SB::STRIDE + wave * 32 + l31;
+#pragma unroll
+      for (int kk = 0; kk < FBK; kk += 2)
+        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_base[kk * SA::STRIDE], b_base[kk * SB::STRIDE], sacc, 0, 0, 0);
+      __syncthreads();
+      if (more) {
+        sa.store(As); sb.store(Bs);
+        __syncthreads();
+      }
+    }
+    // ---------------- dS tile -> LDS (k-major: Ds[j_local][row]) ----------------
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rl = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      const int row = i0 + rl;
+      float d = 0.f;
+      if (col_ok && row < p.m) {
+        const float sv = __fmul_rn(p.alpha, sacc[r]);
+        const float rci = rc_s[rl];
+        d = rci * fast_exp(sv - rl_s[rl]) + ccj * fast_exp(sv - clj);
+        if (static_cast<int64_t>(col) == p.diag_offset + row) d -= (rci + ccj);
+      }
+      Ds[(wave * 32 + l31) * DS_STRIDE + rl] = d;
+    }
+    __syncthreads();
+    // ---------------- dA phase ----------------
+    // unconditional loads (a predicated load becomes a branch and forces s_waitcnt vmcnt(0), which would kill the
+    // prefetch): rows beyond n are clamped to n-1 - their dS entries are exactly 0 - and D == 128*NT on this path
+    const float* bcol = p.B + c0 + l31;
+    auto loadb = [&](float (&dst)[2][NT], int s0) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int jr = min(j0 + 2 * (s0 + u) + lhi, p.n - 1);
+        const float* src = bcol + static_cast<int64_t>(jr) * p.D;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) dst[u][t] = src[32 * t];
+      }
+    };
+    auto compute = [&](const float (&src)[2][NT], int s0) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float a = Ds[(2 * (s0 + u) + lhi) * DS_STRIDE + l31];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, src[u][t], acc[t], 0, 0, 0);
+      }
+    };
+    float b0[2][NT], b1[2][NT];
+    loadb(b0, 0);
+#pragma unroll 1
+    for (int s0 = 0; s0 < FBN / 2; s0 += 4) {
+      loadb(b1, s0 + 2);
+      compute(b0, s0);
+      if (s0 + 4 < FBN / 2) loadb(b0, s0 + 4);
+      compute(b1, s0 + 2);
+    }
+    // the next block's S phase has barriers before Ds is rewritten
+  }
+
+  float* out = p.out + (p.nsplit > 1 ? static_cast<int64_t>(z) * p.m * p.D : 0);
+  const float oscale = (p.nsplit > 1) ? 1.f : p.alpha;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = i0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      const int cc = c0 + 32 * t + l31;
+      if (row < p.m) out[static_cast<int64_t>(row) * p.D + cc] = __fmul_rn(oscale, acc[t][r]);
+    }
+}
+
+// dA = alpha * sum_z slab[z] (fixed order), float4-wide; n4 = m*D/4 (D % 4 == 0 on this path)
+__global__ __launch_bounds__(256) void flash_reduce_kernel(const float4* __restrict__ slab, int nsplit, int64_t n4,
+                                                           float alpha, float4* __restrict__ out) {
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += gridDim.x * 256ll) {
+    float4 a = slab[i];
+    for (int zz = 1; zz < nsplit; ++zz) {
+      const float4 b = slab[zz * n4 + i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    out[i] = make_float4(__fmul_rn(alpha, a.x), __fmul_rn(alpha, a.y), __fmul_rn(alpha, a.z), __fmul_rn(alpha, a.w));
+  }
+}
+
+struct FlashPlan { bool ok; int nt, row_blocks, nsplit, blocks_per_split; };
+inline FlashPlan flash_plan(int64_t m, int64_t n, int64_t D) {
+  FlashPlan f{false, 0, 0, 1, 0};
+  if (D > 1024 || D % 128 != 0) return f;        // accumulators hold 32 x D per workgroup, D = 128 * NT
+  f.nt = static_cast<int>(D / 128);
+  f.row_blocks = static_cast<int>((m + FBM - 1) / FBM);
+  const int64_t col_blocks = (n + FBN - 1) / FBN;
+  int64_t ns = (512 + f.row_blocks - 1) / f.row_blocks;   // aim at 2 workgroups per CU
+  if (ns > col_blocks) ns = col_blocks;
+  if (ns < 1) ns = 1;
+  f.blocks_per_split = static_cast<int>((col_blocks + ns - 1) / ns);
+  f.nsplit = static_cast<int>((col_blocks + f.blocks_per_split - 1) / f.blocks_per_split);
+  f.ok = true;
+  return f;
+}
+
 inline bool vec_ok(const float* p, int64_t ld) {
   return (reinterpret_cast<uintptr_t>(p) % 16 == 0) && (ld % 4 == 0);
 }
@@ -482,11 +665,32 @@ extern "C" int dalm_sim_rowstats(const float* A, const float* Bm, int64_t m, int
 }
 
 
+// Which form dalm_sim_grad takes: 1 = flash (no dS panel), 0 = dS panel + NN GEMM (D > 1024 or odd D, or
+// DALM_SIM_GRAD=panel for A/B comparisons).
+static bool use_flash_grad(int64_t m, int64_t n, int64_t D) {
+  static const int forced = [] {
+    const char* e = getenv("DALM_SIM_GRAD");
+    if (!e) return -1;
+    return (e[0] == 'p') ? 0 : 1;
+  }();
+  if (forced == 0) return false;
+  return flash_plan(m, n, D).ok;
+}
+
 extern "C" size_t dalm_sim_grad_workspace_bytes(int64_t m, int64_t n, int64_t D) {
   if (m <= 0 || n <= 0) return 0;
+  if (use_flash_grad(m, n, D)) {
+    const FlashPlan f = flash_plan(m, n, D);
+    return f.nsplit > 1 ? static_cast<size_t>(f.nsplit) * m * D * sizeof(float) : 16;
+  }
   const size_t panel = static_cast<size_t>(m) * static_cast<size_t>(round_up4(n)) * sizeof(float);
   const int sk = sim_splitk(m, n, D);
   return panel * static_cast<size_t>(sk > 1 ? 1 + sk : 1);  // dS panel (+ split-K slabs)
+}
+
+template <int NT>
+static void launch_flash(const FlashParams& p, hipStream_t s) {
+  hipLaunchKernelGGL((sim_flash_grad_kernel<NT>), dim3(static_cast<unsigned>(p.row_blocks * p.nsplit)), dim3(256), 0, s, p);
 }
 
 extern "C" int dalm_sim_grad(const float* A, const float* Bm, int64_t m, int64_t n, int64_t D, float scale,
@@ -500,6 +704,34 @@ extern "C" int dalm_sim_grad(const float* A, const float* Bm, int64_t m, int64_t
   DALM_REQUIRE(ws_bytes >= dalm_sim_grad_workspace_bytes(m, n, D), DALM_E_WORKSPACE, "workspace too small");
   DALM_REQUIRE(reinterpret_cast<uintptr_t>(ws) % 16 == 0, DALM_E_ALIGN, "workspace must be 16-byte aligned");
   hipStream_t s = as_stream(stream);
+  if (use_flash_grad(m, n, D)) {
+    DALM_REQUIRE(reinterpret_cast<uintptr_t>(dA) % 16 == 0, DALM_E_ALIGN, "dA must be 16-byte aligned");
+    const FlashPlan f = flash_plan(m, n, D);
+    FlashParams p{};
+    p.A = A; p.B = Bm; p.m = static_cast<int>(m); p.n = static_cast<int>(n); p.D = static_cast<int>(D);
+    p.alpha = scale; p.a_vec = vec_ok(A, D); p.b_vec = vec_ok(Bm, D); p.diag_offset = diag_offset;
+    p.row_coef = row_coef; p.row_lse = row_lse; p.col_coef = col_coef; p.col_lse = col_lse;
+    p.out = f.nsplit > 1 ? static_cast<float*>(ws) : dA;
+    p.row_blocks = f.row_blocks; p.nsplit = f.nsplit; p.blocks_per_split = f.blocks_per_split;
+    switch (f.nt) {
+      case 1: launch_flash<1>(p, s); break;
+      case 2: launch_flash<2>(p, s); break;
+      case 3: launch_flash<3>(p, s); break;
+      case 4: launch_flash<4>(p, s); break;
+      case 5: launch_flash<5>(p, s); break;
+      case 6: launch_flash<6>(p, s); break;
+      case 7: launch_flash<7>(p, s); break;
+      default: launch_flash<8>(p, s); break;
+    }
+    if (f.nsplit > 1) {
+      const int64_t n4 = m * D / 4;
+      int64_t blocks = (n4 + 255) / 256;
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(flash_reduce_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s,
+                         static_cast<const float4*>(ws), f.nsplit, n4, scale, reinterpret_cast<float4*>(dA));
+    }
+    return check_launch(__func__);
+  }
   const int64_t ldd = round_up4(n);
   float* dS = static_cast<float*>(ws);
   {  // dS panel: recompute S tiles on the MFMA, transform in the epilogue

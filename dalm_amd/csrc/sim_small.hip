@@ -1,0 +1,397 @@
+// K2-K4, small-batch form: the in-batch similarity / contrastive loss at the batch sizes the trainers really
+// use (18 ... a few hundred rows per GPU), where the whole problem is a few MFLOP and everything is latency.
+//
+// Stands in for the same reference lines as sim.hip
+//   dalm/training/utils/train_utils.py:76-88,124   dalm/training/rag_e2e/train_rage2e.py:441-446
+// in THREE launches per step instead of ~10:
+//   small_partial_kernel  S is computed ONCE: 32x32 tiles x split-K over ~256 workgroups; operands go
+//                         global -> registers in MFMA layout (no LDS staging, no barrier in the K loop: the
+//                         K index is permuted identically for both operands, which a dot product allows);
+//                         the 4 waves of a workgroup split its K range and are summed through LDS in fixed
+//                         order; raw partial tiles go to slabs, row-major and (for column stats) transposed
+//   small_stats_kernel    one wave per row of S and per row of S^T: sums the slabs in fixed order, writes S
+//                         (<= 4 MB, L2-resident; reused by the backward), row/column log-sum-exp and diag
+//   small_grad_kernel     dQ = s dS P and dP = s dS^T Q in ONE launch: every workgroup owns a 32x32 tile of an
+//                         output, rebuilds its strip of the closed-form dS from the saved S in LDS, and feeds
+//                         v_mfma_f32_32x32x2_f32 with the other operand straight from global memory
+// Exact f32 throughout (|S| <= 100, see sim.hip).  Deterministic: fixed summation orders, no float atomics.
+// Bound: launch/latency (46 MFLOP and 1.2 MB at 150^2 x 1024); the roofline-relevant similarity kernels are
+// the large-batch ones in sim.hip.
+#include "common.hpp"
+
+namespace dalm {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+__device__ __forceinline__ float4 ld4_guard(const float* p, int nvalid, bool vec_ok) {
+  if (nvalid >= 4 && vec_ok) return *reinterpret_cast<const float4*>(p);
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (nvalid > 0) r.x = p[0];
+  if (nvalid > 1) r.y = p[1];
+  if (nvalid > 2) r.z = p[2];
+  if (nvalid > 3) r.w = p[3];
+  return r;
+}
+
+// C/D layout of v_mfma_f32_32x32x2_f32: acc[r] of lane l is (row = (r&3) + 8*(r>>2) + 4*(l>>5), col = l&31)
+__device__ __forceinline__ int mfma_row(int r, int lhi) { return (r & 3) + 8 * (r >> 2) + 4 * lhi; }
+
+constexpr int RED_STRIDE = 33;
+
+// sums the 4 waves' 32x32 accumulators through LDS (fixed order w = 0..3); afterwards thread t owns tile
+// elements e = t + 256 q.  red: [4][32][33] floats.
+__device__ __forceinline__ void stash_acc(float* red, const f32x16& acc, int wave, int l31, int lhi) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 32 + mfma_row(r, lhi)) * RED_STRIDE + l31] = acc[r];
+}
+__device__ __forceinline__ float red_sum(const float* red, int row, int col) {
+  float s = red[row * RED_STRIDE + col];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) s += red[(w * 32 + row) * RED_STRIDE + col];
+  return s;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// partial tiles.  grid (tiles_m * tiles_n, SK); 256 threads; wave w of slice z contracts
+//   k in [z*k_chunk + w*k_chunk/4, ... + k_chunk/4)   (k_chunk is a multiple of 32)
+// lane (r = l&31, h = l>>5) loads A[i0+r][k+4h .. k+4h+3] and B[j0+r][k+4h .. +3] for k = lo, lo+8, ...;
+// MFMA step t of such a pair multiplies A[.][k+4h+t] with B[.][k+4h+t] over h = 0,1: every k exactly once.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void small_partial_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                            int m, int n, int K, int k_chunk, int tiles_n,
+                                                            int a_vec, int b_vec, float* __restrict__ slab,
+                                                            int ldn, float* __restrict__ slabT, int ldm) {
+  __shared__ float red[4 * 32 * RED_STRIDE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+  const int ti = blockIdx.x / tiles_n, tj = blockIdx.x % tiles_n, z = blockIdx.y;
+  const int i0 = ti * 32, j0 = tj * 32;
+  const int kq = k_chunk >> 2;
+  const int k_lo = z * k_chunk + wave * kq;
+  const int k_hi = min(K, k_lo + kq);
+  const bool arow = (i0 + l31) < m, brow = (j0 + l31) < n;
+  const float* ap = A + static_cast<int64_t>(i0 + l31) * K;
+  const float* bp = B + static_cast<int64_t>(j0 + l31) * K;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k0 = k_lo; k0 < k_hi; k0 += 32) {  // 4 pairs of float4 per operand per round
+    float4 av[4], bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + 8 * u + 4 * lhi;
+      const int nv = k_hi - k;
+      av[u] = ld4_guard(ap + k, arow ? nv : 0, a_vec);
+      bv[u] = ld4_guard(bp + k, brow ? nv : 0, b_vec);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (k0 + 8 * u < k_hi) {  // wave-uniform
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].z, bv[u].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].w, bv[u].w, acc, 0, 0, 0);
+      }
+    }
+  }
+  stash_acc(red, acc, wave, l31, lhi);
+  __syncthreads();
+  float* sl = slab + static_cast<int64_t>(z) * m * ldn;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = tid + 256 * q, row = e >> 5, col = e & 31;
+    if (i0 + row < m && j0 + col < n) sl[static_cast<int64_t>(i0 + row) * ldn + j0 + col] = red_sum(red, row, col);
+  }
+  if (slabT) {
+    float* st = slabT + static_cast<int64_t>(z) * n * ldm;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + 256 * q, col = e >> 5, row = e & 31;
+      if (i0 + row < m && j0 + col < n) st[static_cast<int64_t>(j0 + col) * ldm + i0 + row] = red_sum(red, row, col);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// row statistics of S (blockIdx.y == 0: slab, also writes S and diag) and of S^T (blockIdx.y == 1: slabT).
+// One wave per row; slabs summed in fixed order z = 0..SK-1, then scaled with a separate rounding so that the
+// S read by the backward and the S the statistics saw are the same bits.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float slab_s(const float* __restrict__ p, int64_t slab_stride, int SK, float alpha) {
+  float a = p[0];
+  for (int z = 1; z < SK; ++z) a += p[z * slab_stride];
+  return __fmul_rn(alpha, a);
+}
+
+__global__ __launch_bounds__(256) void small_stats_kernel(const float* __restrict__ slab, int ldn,
+                                                          const float* __restrict__ slabT, int ldm, int SK, int m,
+                                                          int n, float alpha, int64_t diag_offset,
+                                                          float* __restrict__ S, int64_t ldS,
+                                                          float* __restrict__ row_lse, float* __restrict__ diag,
+                                                          float* __restrict__ col_lse) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool cols = blockIdx.y != 0;
+  const int R = cols ? n : m, C = cols ? m : n, ld = cols ? ldm : ldn;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= R) return;
+  const float* base = (cols ? slabT : slab) + static_cast<int64_t>(row) * ld;
+  const int64_t ss = static_cast<int64_t>(R) * ld;
+  float mx = -INFINITY, l = 0.f;
+  if (C <= 512) {  // values stay in registers
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = (c < C) ? slab_s(base + c, ss, SK, alpha) : -INFINITY;
+      mx = fmaxf(mx, v[i]);
+      if (!cols && c < C) {
+        S[static_cast<int64_t>(row) * ldS + c] = v[i];
+        if (static_cast<int64_t>(c) == diag_offset + row) diag[row] = v[i];
+      }
+    }
+    mx = wave_max(mx);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) l += fast_exp(v[i] - mx);  // exp(-inf) = 0 for the padding
+  } else {
+    for (int c = lane; c < C; c += 64) {
+      const float s = slab_s(base + c, ss, SK, alpha);
+      mx = fmaxf(mx, s);
+      if (!cols) {
+        S[static_cast<int64_t>(row) * ldS + c] = s;
+        if (static_cast<int64_t>(c) == diag_offset + row) diag[row] = s;
+      }
+    }
+    mx = wave_max(mx);
+    for (int c = lane; c < C; c += 64) l += fast_exp(slab_s(base + c, ss, SK, alpha) - mx);
+  }
+  l = wave_sum(l);
+  if (lane == 0) (cols ? col_lse : row_lse)[row] = mx + __logf(l);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward from the saved S.  grid (ceil(R/32), ceil(D/32), ndir):
+//   dir 0: dA[i0.., d0..] = alpha * sum_j dS[i][j] Bm[j][d]      (R = m, contraction over n)
+//   dir 1: dB[j0.., d0..] = alpha * sum_i dS[i][j] A[i][d]       (R = n, contraction over m)
+//   dS[i][j] = rc[i] e^{S_ij - rl[i]} + cc[j] e^{S_ij - cl[j]} - [j == off + i] (rc[i] + cc[j])
+// The contraction runs in chunks of 256: the 32 x 256 strip of dS is built in LDS (k-major, stride 33:
+// conflict-free ds_read_b32 fragments), the 4 waves split the chunk and read the other operand's fragments
+// straight from global memory (lane (c,h) reads X[k+h][d0+c]: 128-byte rows, L2-resident), 8 steps in flight.
+// ---------------------------------------------------------------------------------------------------
+constexpr int GK = 256;
+
+__global__ __launch_bounds__(256) void small_grad_kernel(const float* __restrict__ S, int64_t ldS,
+                                                         const float* __restrict__ A, const float* __restrict__ Bm,
+                                                         int m, int n, int D, float alpha, int64_t diag_offset,
+                                                         const float* __restrict__ rc, const float* __restrict__ rl,
+                                                         const float* __restrict__ cc, const float* __restrict__ cl,
+                                                         float* __restrict__ dA, float* __restrict__ dB, int dir0) {
+  __shared__ float Ds[GK * RED_STRIDE];
+  __shared__ float red[4 * 32 * RED_STRIDE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+  const int dir = dir0 + blockIdx.z;
+  const int R = dir ? n : m, Kd = dir ? m : n;
+  const int r0 = blockIdx.x * 32, d0 = blockIdx.y * 32;
+  if (r0 >= R) return;
+  const float* X = dir ? A : Bm;
+  float* out = dir ? dB : dA;
+  const int dcol = d0 + l31;
+  const bool dok = dcol < D;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  for (int k0 = 0; k0 < Kd; k0 += GK) {
+    const int kn = min(GK, Kd - k0);
+    // ---- build the dS strip: Ds[kk][r] = dS(row r0 + r, contraction index k0 + kk) ----
+    if (dir == 0) {
+      const int j = k0 + tid;  // this thread's column of S for all 32 rows
+      const bool jok = tid < kn;
+      const float ccj = jok ? cc[j] : 0.f, clj = jok ? cl[j] : 0.f;
+#pragma unroll 4
+      for (int r = 0; r < 32; ++r) {
+        const int i = r0 + r;
+        float d = 0.f;
+        if (jok && i < m) {
+          const float s = S[static_cast<int64_t>(i) * ldS + j];
+          const float rci = rc[i];
+          d = rci * fast_exp(s - rl[i]) + ccj * fast_exp(s - clj);
+          if (static_cast<int64_t>(j) == diag_offset + i) d -= (rci + ccj);
+        }
+        Ds[tid * RED_STRIDE + r] = d;
+      }
+    } else {
+      const int r = tid & 31, j = r0 + r;
+      const bool jok = j < n;
+      const float ccj = jok ? cc[j] : 0.f, clj = jok ? cl[j] : 0.f;
+#pragma unroll 4
+      for (int q = 0; q < 32; ++q) {
+        const int kk = (tid >> 5) + 8 * q, i = k0 + kk;
+        float d = 0.f;
+        if (jok && kk < kn) {
+          const float s = S[static_cast<int64_t>(i) * ldS + j];
+          const float rci = rc[i];
+          d = rci * fast_exp(s - rl[i]) + ccj * fast_exp(s - clj);
+          if (static_cast<int64_t>(j) == diag_offset + i) d -= (rci + ccj);
+        }
+        Ds[kk * RED_STRIDE + r] = d;
+      }
+    }
+    __syncthreads();
+    // ---- MFMA over this wave's quarter of the chunk, 8 two-wide steps per round ----
+    const int ns = (kn + 1) >> 1;          // two-wide steps in the chunk
+    const int per = (ns + 3) >> 2;
+    const int s_lo = wave * per, s_hi = min(ns, s_lo + per);
+    float bv[8], bn[8];
+    auto load8 = [&](float (&dst)[8], int s0) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int kk = 2 * (s0 + u) + lhi;
+        dst[u] = (s0 + u < s_hi && kk < kn && dok) ? X[static_cast<int64_t>(k0 + kk) * D + dcol] : 0.f;
+      }
+    };
+    if (s_lo < s_hi) load8(bv, s_lo);
+    for (int s0 = s_lo; s0 < s_hi; s0 += 8) {
+      if (s0 + 8 < s_hi) load8(bn, s0 + 8);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (s0 + u < s_hi) {  // wave-uniform
+          const int kk = 2 * (s0 + u) + lhi;
+          const float a = (kk < kn) ? Ds[kk * RED_STRIDE + l31] : 0.f;
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[u], acc, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) bv[u] = bn[u];
+    }
+    __syncthreads();  // Ds is rebuilt by the next chunk
+  }
+  stash_acc(red, acc, wave, l31, lhi);
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = tid + 256 * q, row = e >> 5, col = e & 31;
+    if (r0 + row < R && d0 + col < D)
+      out[static_cast<int64_t>(r0 + row) * D + d0 + col] = __fmul_rn(alpha, red_sum(red, row, col));
+  }
+}
+
+// ---- loss assembly for the RAG-e2e step in one launch (replaces contrastive_finalize + ce_finalize + add) ----
+//   out[1] = L_con = 0.5 (sum_i (lse_r[i]-diag[i]) + sum_j (lse_c[j]-diag[j])) / n_global
+//   doc_lp[i] = diag[i] - lse_r[i]
+//   out[2] = L_gen = (sum_r row_nll[r] - sum_b Nb[b] doc_lp[b]) / M ;  out[0] = L_con + L_gen
+__global__ __launch_bounds__(1024) void rag_loss_finalize_kernel(const float* __restrict__ row_nll, int64_t R,
+                                                                 const float* __restrict__ Nb,
+                                                                 const float* __restrict__ lse_r,
+                                                                 const float* __restrict__ lse_c,
+                                                                 const float* __restrict__ diag, int n_local,
+                                                                 float n_global, const float* __restrict__ stats,
+                                                                 float* __restrict__ out,
+                                                                 float* __restrict__ doc_lp) {
+  __shared__ float red[16];
+  float g = 0.f, c = 0.f;
+  for (int64_t i = threadIdx.x; i < R; i += 1024) g += row_nll[i];
+  for (int i = threadIdx.x; i < n_local; i += 1024) {
+    const float d = diag[i], lp = d - lse_r[i];
+    c += (lse_r[i] - d) + (lse_c[i] - d);
+    g -= Nb[i] * lp;
+    if (doc_lp) doc_lp[i] = lp;
+  }
+  g = block_sum<1024>(g, red);
+  c = block_sum<1024>(c, red);
+  if (threadIdx.x == 0) {
+    const float con = 0.5f * c / n_global, gen = g / stats[0];
+    out[0] = con + gen; out[1] = con; out[2] = gen;
+  }
+}
+
+inline int64_t round_up(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
+
+struct SmallPlan { int sk, k_chunk; int64_t ldn, ldm; };
+inline SmallPlan small_plan(int64_t m, int64_t n, int64_t D) {
+  const int64_t tiles = ((m + 31) / 32) * ((n + 31) / 32);
+  int64_t sk = (256 + tiles - 1) / tiles;
+  const int64_t sk_max = (D + 31) / 32;        // every workgroup gets at least 32 of K (8 per wave)
+  if (sk > 16) sk = 16;
+  if (sk > sk_max) sk = sk_max;
+  if (sk < 1) sk = 1;
+  const int64_t k_chunk = round_up((D + sk - 1) / sk, 32);
+  sk = (D + k_chunk - 1) / k_chunk;
+  return {static_cast<int>(sk), static_cast<int>(k_chunk), round_up(n, 4), round_up(m, 4)};
+}
+inline bool vec16(const float* p, int64_t ld) { return (reinterpret_cast<uintptr_t>(p) % 16 == 0) && (ld % 4 == 0); }
+
+}  // namespace
+}  // namespace dalm
+
+using namespace dalm;
+
+// The small path applies when S (m x n floats) stays L2-sized and the grid of 32x32 tiles is modest.
+extern "C" int dalm_sim_small_supported(int64_t m, int64_t n, int64_t D) {
+  if (m <= 0 || n <= 0 || D <= 0) return 0;
+  if (m > 1024 || n > 8192 || m * n > (1ll << 20) || D > (1 << 20)) return 0;
+  return 1;
+}
+
+extern "C" size_t dalm_sim_small_workspace_bytes(int64_t m, int64_t n, int64_t D, int want_cols) {
+  if (!dalm_sim_small_supported(m, n, D)) return 0;
+  const SmallPlan pl = small_plan(m, n, D);
+  size_t b = static_cast<size_t>(pl.sk) * m * pl.ldn;
+  if (want_cols) b += static_cast<size_t>(pl.sk) * n * pl.ldm;
+  return b * sizeof(float);
+}
+
+extern "C" int dalm_sim_small_fwd(const float* A, const float* Bm, int64_t m, int64_t n, int64_t D, float scale,
+                                  int64_t diag_offset, float* S, int64_t ldS, float* row_lse, float* diag,
+                                  float* col_lse, void* ws, size_t ws_bytes, dalm_stream_t stream) {
+  DALM_REQUIRE(A && Bm && S && row_lse && diag && ws, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(dalm_sim_small_supported(m, n, D), DALM_E_SHAPE, "shape outside the small-batch path (see dalm_sim_small_supported)");
+  DALM_REQUIRE(ldS >= n, DALM_E_SHAPE, "ldS must be >= n");
+  DALM_REQUIRE(diag_offset >= 0 && diag_offset + m <= n, DALM_E_SHAPE, "diag_offset + m must be <= n");
+  const int want_cols = col_lse != nullptr;
+  DALM_REQUIRE(ws_bytes >= dalm_sim_small_workspace_bytes(m, n, D, want_cols), DALM_E_WORKSPACE, "workspace too small");
+  DALM_REQUIRE(reinterpret_cast<uintptr_t>(ws) % 4 == 0, DALM_E_ALIGN, "workspace must be 4-byte aligned");
+  hipStream_t s = as_stream(stream);
+  const SmallPlan pl = small_plan(m, n, D);
+  float* slab = static_cast<float*>(ws);
+  float* slabT = want_cols ? slab + static_cast<size_t>(pl.sk) * m * pl.ldn : nullptr;
+  const int tiles_m = static_cast<int>((m + 31) / 32), tiles_n = static_cast<int>((n + 31) / 32);
+  hipLaunchKernelGGL(small_partial_kernel, dim3(static_cast<unsigned>(tiles_m * tiles_n), static_cast<unsigned>(pl.sk)),
+                     dim3(256), 0, s, A, Bm, static_cast<int>(m), static_cast<int>(n), static_cast<int>(D), pl.k_chunk,
+                     tiles_n, static_cast<int>(vec16(A, D)), static_cast<int>(vec16(Bm, D)), slab,
+                     static_cast<int>(pl.ldn), slabT, static_cast<int>(pl.ldm));
+  const int64_t rmax = want_cols ? (m > n ? m : n) : m;
+  hipLaunchKernelGGL(small_stats_kernel, dim3(static_cast<unsigned>((rmax + 3) / 4), want_cols ? 2u : 1u), dim3(256), 0,
+                     s, slab, static_cast<int>(pl.ldn), slabT, static_cast<int>(pl.ldm), pl.sk, static_cast<int>(m),
+                     static_cast<int>(n), scale, diag_offset, S, ldS, row_lse, diag, col_lse);
+  return check_launch(__func__);
+}
+
+extern "C" int dalm_sim_small_bwd(const float* S, int64_t ldS, const float* A, const float* Bm, int64_t m, int64_t n,
+                                  int64_t D, float scale, int64_t diag_offset, const float* row_coef,
+                                  const float* row_lse, const float* col_coef, const float* col_lse, float* dA,
+                                  float* dB, dalm_stream_t stream) {
+  DALM_REQUIRE(S && A && Bm && row_coef && row_lse && col_coef && col_lse, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(dA || dB, DALM_E_NULL, "at least one of dA / dB is required");
+  DALM_REQUIRE(dalm_sim_small_supported(m, n, D), DALM_E_SHAPE, "shape outside the small-batch path");
+  DALM_REQUIRE(ldS >= n, DALM_E_SHAPE, "ldS must be >= n");
+  const int dir0 = dA ? 0 : 1, ndir = (dA && dB) ? 2 : 1;
+  const int64_t rmax = (ndir == 2) ? (m > n ? m : n) : (dir0 ? n : m);
+  const dim3 grid(static_cast<unsigned>((rmax + 31) / 32), static_cast<unsigned>((D + 31) / 32), static_cast<unsigned>(ndir));
+  hipLaunchKernelGGL(small_grad_kernel, grid, dim3(256), 0, as_stream(stream), S, ldS, A, Bm, static_cast<int>(m),
+                     static_cast<int>(n), static_cast<int>(D), scale, diag_offset, row_coef, row_lse, col_coef, col_lse,
+                     dA, dB, dir0);
+  return check_launch(__func__);
+}
+
+extern "C" int dalm_rag_loss_finalize(const float* row_nll, int64_t num_rows, const float* Nb, const float* row_lse,
+                                      const float* col_lse, const float* diag, int64_t n_local, int64_t n_global,
+                                      const float* stats, float* out, float* doc_lp, dalm_stream_t stream) {
+  DALM_REQUIRE(row_nll && Nb && row_lse && col_lse && diag && stats && out, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(num_rows > 0 && n_local > 0 && n_global >= n_local && n_local <= 0x7fffffffll, DALM_E_SHAPE,
+               "need num_rows>0, 0 < n_local <= n_global");
+  hipLaunchKernelGGL(rag_loss_finalize_kernel, dim3(1), dim3(1024), 0, as_stream(stream), row_nll, num_rows, Nb,
+                     row_lse, col_lse, diag, static_cast<int>(n_local), static_cast<float>(n_global), stats, out, doc_lp);
+  return check_launch(__func__);
+}

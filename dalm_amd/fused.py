@@ -132,6 +132,9 @@ class _ConState:
     diag: torch.Tensor
     offset: int
     n_global: int
+    # small-batch form: the saved S of the rows problem (one GPU: also serves the columns) / the columns problem
+    S_rows: Optional[torch.Tensor] = None
+    S_cols: Optional[torch.Tensor] = None
 
 
 def _contrastive_forward(ops, comm, q, p, scale, q_all=None, p_all=None):
@@ -139,27 +142,45 @@ def _contrastive_forward(ops, comm, q, p, scale, q_all=None, p_all=None):
     p = p.detach().float().contiguous()
     if q.shape != p.shape or q.dim() != 2:
         raise ValueError(f"query/passage embeddings must both be [B,D], got {tuple(q.shape)} / {tuple(p.shape)}")
-    b_l = q.shape[0]
+    b_l, D = q.shape
     offset = comm.rank * b_l
+    if isinstance(comm, LocalComm) and ops.sim_small_supported(b_l, b_l, D):
+        # one GPU at a real batch size: S is computed once, row AND column statistics come out of the same tiles
+        S, lse_r, diag, lse_c = ops.sim_small_fwd(q, p, scale, 0, True)
+        return _ConState(q, p, q, p, lse_r, lse_c, diag, 0, b_l, S_rows=S)
     if p_all is None:
         p_all = comm.all_gather_rows(p)
     if q_all is None:
         q_all = comm.all_gather_rows(q)
-    lse_r, diag = ops.sim_rowstats(q, p_all, scale, offset)
-    lse_c, _ = ops.sim_rowstats(p, q_all, scale, offset)
-    return _ConState(q, p, q_all, p_all, lse_r, lse_c, diag, offset, comm.world_size * b_l)
+    n_g = comm.world_size * b_l
+    S_rows = S_cols = None
+    if ops.sim_small_supported(b_l, n_g, D):
+        S_rows, lse_r, diag, _ = ops.sim_small_fwd(q, p_all, scale, offset, False)
+        S_cols, lse_c, _, _ = ops.sim_small_fwd(p, q_all, scale, offset, False)
+    else:
+        lse_r, diag = ops.sim_rowstats(q, p_all, scale, offset)
+        lse_c, _ = ops.sim_rowstats(p, q_all, scale, offset)
+    return _ConState(q, p, q_all, p_all, lse_r, lse_c, diag, offset, n_g, S_rows=S_rows, S_cols=S_cols)
 
 
 def _contrastive_backward(ops, comm, st: _ConState, scale, a_local, b_local):
     """a: row coefficients (this rank's queries), b: column coefficients (this rank's passages)."""
-    if not isinstance(comm, LocalComm):
+    if isinstance(comm, LocalComm):
+        if st.S_rows is not None:  # one launch: dQ and dP from the saved S
+            return ops.sim_small_bwd(st.S_rows, st.q, st.p, scale, 0, a_local, st.lse_r, b_local, st.lse_c, True, True)
+        lse_r_all, lse_c_all, a_all, b_all = st.lse_r, st.lse_c, a_local, b_local
+    else:
         packed = torch.stack([st.lse_r, st.lse_c, a_local, b_local], dim=1)  # [B_l,4] -> one all-gather
         allv = comm.all_gather_rows(packed)
         lse_r_all, lse_c_all, a_all, b_all = (allv[:, k].contiguous() for k in range(4))
+    if st.S_rows is not None:
+        dq, _ = ops.sim_small_bwd(st.S_rows, st.q, st.p_all, scale, st.offset, a_local, st.lse_r, b_all, lse_c_all, True, False)
     else:
-        lse_r_all, lse_c_all, a_all, b_all = st.lse_r, st.lse_c, a_local, b_local
-    dq = ops.sim_grad(st.q, st.p_all, scale, st.offset, a_local, st.lse_r, b_all, lse_c_all)
-    dp = ops.sim_grad(st.p, st.q_all, scale, st.offset, b_local, st.lse_c, a_all, lse_r_all)
+        dq = ops.sim_grad(st.q, st.p_all, scale, st.offset, a_local, st.lse_r, b_all, lse_c_all)
+    if st.S_cols is not None:
+        dp, _ = ops.sim_small_bwd(st.S_cols, st.p, st.q_all, scale, st.offset, b_local, st.lse_c, a_all, lse_r_all, True, False)
+    else:
+        dp = ops.sim_grad(st.p, st.q_all, scale, st.offset, b_local, st.lse_c, a_all, lse_r_all)
     return dq, dp
 
 
@@ -202,13 +223,12 @@ class _RagE2E(torch.autograd.Function):
         st = _contrastive_forward(ops, comm, q, p, scale,
                                   q_gather.wait() if q_gather is not None else None,
                                   p_gather.wait() if p_gather is not None else None)
-        con, doc_lp = ops.contrastive_finalize(st.lse_r, st.lse_c, st.diag, st.n_global)
         stats, Nb, _Mb = ops.ce_prep(mask, qlen)
         if not isinstance(comm, LocalComm):
             comm.all_reduce_sum_(stats)  # stats[0] = M over the global batch (stats[1] becomes B_g)
         need_grad = logits.requires_grad and fuse_grad
         row_lse, row_nll, dlogits = ops.ce_fwd(logits.detach(), ids, mask, stats, need_grad, inplace_grad)
-        gen = ops.ce_finalize(row_nll, Nb, doc_lp, stats)
+        out3, doc_lp = ops.rag_loss_finalize(row_nll, Nb, st.lse_r, st.lse_c, st.diag, st.n_global, stats)
         ctx.st, ctx.scale, ctx.ops, ctx.comm = st, scale, ops, comm
         ctx.in_dtypes = (q.dtype, p.dtype)
         ctx.fused = need_grad
@@ -217,11 +237,11 @@ class _RagE2E(torch.autograd.Function):
         else:
             ctx.save_for_backward(stats, Nb, logits.detach(), ids, mask, row_lse)
         if aux is not None:
-            aux["contrastive"] = con.reshape(())
-            aux["generator"] = gen.reshape(())
+            aux["contrastive"] = out3[1]
+            aux["generator"] = out3[2]
             aux["doc_logprobs"] = doc_lp
             aux["num_target_tokens"] = stats[0]
-        return (con + gen).reshape(())
+        return out3[0]
 
     @staticmethod
     def backward(ctx, g):
@@ -271,7 +291,6 @@ class _LMHeadRagE2E(torch.autograd.Function):
         st = _contrastive_forward(ops, comm, q, p, scale,
                                   q_gather.wait() if q_gather is not None else None,
                                   p_gather.wait() if p_gather is not None else None)
-        con, doc_lp = ops.contrastive_finalize(st.lse_r, st.lse_c, st.diag, st.n_global)
         stats, Nb, _Mb = ops.ce_prep(mask, qlen)
         if not isinstance(comm, LocalComm):
             comm.all_reduce_sum_(stats)
@@ -292,15 +311,15 @@ class _LMHeadRagE2E(torch.autograd.Function):
             dh[b0:b1] = (dl2 @ w).view(b1 - b0, Tg, H)
             if need_dw:
                 dw.addmm_(dl2.t().float(), hc.float())
-        gen = ops.ce_finalize(row_nll, Nb, doc_lp, stats)
+        out3, doc_lp = ops.rag_loss_finalize(row_nll, Nb, st.lse_r, st.lse_c, st.diag, st.n_global, stats)
         ctx.st, ctx.scale, ctx.ops, ctx.comm = st, scale, ops, comm
         ctx.in_dtypes = (q.dtype, p.dtype, weight.dtype)
         ctx.save_for_backward(stats, Nb, dh, dw if need_dw else stats)
         ctx.need_dw = need_dw
         if aux is not None:
-            aux["contrastive"], aux["generator"] = con.reshape(()), gen.reshape(())
+            aux["contrastive"], aux["generator"] = out3[1], out3[2]
             aux["doc_logprobs"], aux["num_target_tokens"] = doc_lp, stats[0]
-        return (con + gen).reshape(())
+        return out3[0]
 
     @staticmethod
     def backward(ctx, g):

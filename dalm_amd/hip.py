@@ -42,6 +42,13 @@ SIGNATURES = {
     "dalm_gather_nll": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "dalm_marginalize_rows": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp]),
     "dalm_contrastive_finalize": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "dalm_pool_l2norm_fwd_workspace_bytes": (_sz, [_i64, _i64, _i64, _int]),
+    "dalm_pool_l2norm_fwd_ws": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dalm_sim_small_supported": (_int, [_i64, _i64, _i64]),
+    "dalm_sim_small_workspace_bytes": (_sz, [_i64, _i64, _i64, _int]),
+    "dalm_sim_small_fwd": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dalm_sim_small_bwd": (_int, [_vp, _i64, _vp, _vp, _i64, _i64, _i64, _f32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dalm_rag_loss_finalize": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
 }
 
 

@@ -34,8 +34,10 @@ class HipOps:
         emb = torch.empty((B, D), device=dev, dtype=torch.float32)
         norm = torch.empty((B,), device=dev, dtype=torch.float32)
         inv_count = torch.empty((B,), device=dev, dtype=torch.float32)
-        hip.call("dalm_pool_l2norm_fwd", hip.ptr(h), hip.dtype_code(h), hip.ptr(mask), B, T, D, int(normalize),
-                 hip.ptr(emb), hip.ptr(norm), hip.ptr(inv_count), hip.stream())
+        ws_bytes = hip.load().dalm_pool_l2norm_fwd_workspace_bytes(B, T, D, hip.dtype_code(h))
+        ws = torch.empty((ws_bytes // 4,), device=dev, dtype=torch.float32) if ws_bytes else None
+        hip.call("dalm_pool_l2norm_fwd_ws", hip.ptr(h), hip.dtype_code(h), hip.ptr(mask), B, T, D, int(normalize),
+                 hip.ptr(emb), hip.ptr(norm), hip.ptr(inv_count), hip.ptr(ws), ws_bytes, hip.stream())
         return emb, norm, inv_count
 
     def pool_bwd(self, d_emb, emb, norm, inv_count, mask, normalize: bool, T: int, dtype: torch.dtype):
@@ -106,6 +108,53 @@ class HipOps:
                  hip.ptr(row_coef), hip.ptr(row_lse), hip.ptr(col_coef), hip.ptr(col_lse), hip.ptr(dA),
                  hip.ptr(ws), ws_bytes, hip.stream())
         return dA
+
+    # ---- K2-K4, small-batch form: S once, 2 launches forward / 1 launch backward ----------------
+    def sim_small_supported(self, m: int, n: int, D: int) -> bool:
+        return bool(hip.load().dalm_sim_small_supported(int(m), int(n), int(D)))
+
+    def sim_small_fwd(self, A: torch.Tensor, Bm: torch.Tensor, scale: float, diag_offset: int, want_cols: bool):
+        """S = scale*A.B^T (saved), row_lse, diag and (want_cols) col_lse = logsumexp over rows."""
+        dev = hip.require_gpu(A, Bm)
+        A, Bm = hip.as_f32c(A), hip.as_f32c(Bm)
+        m, D = A.shape
+        n = Bm.shape[0]
+        ws_bytes = hip.load().dalm_sim_small_workspace_bytes(m, n, D, int(want_cols))
+        ws = torch.empty((max(ws_bytes, 4) // 4,), device=dev, dtype=torch.float32)
+        S = torch.empty((m, n), device=dev, dtype=torch.float32)
+        row_lse = torch.empty((m,), device=dev, dtype=torch.float32)
+        diag = torch.empty((m,), device=dev, dtype=torch.float32)
+        col_lse = torch.empty((n,), device=dev, dtype=torch.float32) if want_cols else None
+        hip.call("dalm_sim_small_fwd", hip.ptr(A), hip.ptr(Bm), m, n, D, float(scale), int(diag_offset), hip.ptr(S), n,
+                 hip.ptr(row_lse), hip.ptr(diag), hip.ptr(col_lse), hip.ptr(ws), ws_bytes, hip.stream())
+        return S, row_lse, diag, col_lse
+
+    def sim_small_bwd(self, S, A, Bm, scale: float, diag_offset: int, row_coef, row_lse, col_coef, col_lse,
+                      want_dA: bool = True, want_dB: bool = True):
+        """(dA, dB) = (scale dS.B, scale dS^T.A) from the saved S; the closed-form dS of include/dalm_hip.h."""
+        dev = hip.require_gpu(S, A, Bm, row_coef, row_lse, col_coef, col_lse)
+        A, Bm, S = hip.as_f32c(A), hip.as_f32c(Bm), hip.as_f32c(S)
+        row_coef, row_lse = hip.as_f32c(row_coef), hip.as_f32c(row_lse)
+        col_coef, col_lse = hip.as_f32c(col_coef), hip.as_f32c(col_lse)
+        m, D = A.shape
+        n = Bm.shape[0]
+        dA = torch.empty((m, D), device=dev, dtype=torch.float32) if want_dA else None
+        dB = torch.empty((n, D), device=dev, dtype=torch.float32) if want_dB else None
+        hip.call("dalm_sim_small_bwd", hip.ptr(S), S.shape[1], hip.ptr(A), hip.ptr(Bm), m, n, D, float(scale),
+                 int(diag_offset), hip.ptr(row_coef), hip.ptr(row_lse), hip.ptr(col_coef), hip.ptr(col_lse),
+                 hip.ptr(dA), hip.ptr(dB), hip.stream())
+        return dA, dB
+
+    def rag_loss_finalize(self, row_nll, Nb, row_lse, col_lse, diag, n_global: int, stats):
+        """out = [L_con + L_gen, L_con, L_gen], doc_lp - the loss assembly of train_rage2e.py:443-467 in one launch."""
+        dev = hip.require_gpu(row_nll, Nb, row_lse, col_lse, diag, stats)
+        n_local = row_lse.shape[0]
+        out = torch.empty((3,), device=dev, dtype=torch.float32)
+        doc_lp = torch.empty((n_local,), device=dev, dtype=torch.float32)
+        hip.call("dalm_rag_loss_finalize", hip.ptr(row_nll), row_nll.numel(), hip.ptr(Nb), hip.ptr(row_lse),
+                 hip.ptr(col_lse), hip.ptr(diag), n_local, int(n_global), hip.ptr(stats), hip.ptr(out), hip.ptr(doc_lp),
+                 hip.stream())
+        return out, doc_lp
 
     def contrastive_finalize(self, row_lse, col_lse, diag, n_global: int):
         dev = hip.require_gpu(row_lse, col_lse, diag)

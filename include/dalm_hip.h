@@ -63,6 +63,14 @@ int dalm_pool_l2norm_fwd(const void* h, int dtype, const int64_t* mask,
                          int64_t B, int64_t T, int64_t D, int normalize,
                          float* emb, float* norm, float* inv_count,
                          dalm_stream_t stream);
+/* Same, with scratch for the token-sliced form used when B alone cannot occupy the chip (few, long
+ * samples): ws = dalm_pool_l2norm_fwd_workspace_bytes(...) bytes (0 when no slicing is planned; ws may then
+ * be NULL).  dalm_pool_l2norm_fwd == this call with ws = NULL (one workgroup per sample, one launch). */
+size_t dalm_pool_l2norm_fwd_workspace_bytes(int64_t B, int64_t T, int64_t D, int dtype);
+int dalm_pool_l2norm_fwd_ws(const void* h, int dtype, const int64_t* mask,
+                            int64_t B, int64_t T, int64_t D, int normalize,
+                            float* emb, float* norm, float* inv_count,
+                            void* ws, size_t ws_bytes, dalm_stream_t stream);
 /* dh: [B,T,D] (dtype) is fully written (zeros where mask == 0). */
 int dalm_pool_l2norm_bwd(const float* d_emb, const float* emb, const float* norm,
                          const float* inv_count, const int64_t* mask,
@@ -106,13 +114,39 @@ int dalm_sim_rowstats(const float* A, const float* Bm, int64_t m, int64_t n,
  *   dS[i,j] = row_coef[i] exp(S_ij - row_lse[i]) + col_coef[j] exp(S_ij - col_lse[j])
  *             - [j == diag_offset+i] (row_coef[i] + col_coef[j])
  *   dA = scale * dS . B
- * row_* are length m, col_* length n.  ws holds the m x n dS panel. */
+ * row_* are length m, col_* length n.
+ * D a multiple of 128 and <= 1024: flash-style - S tiles are recomputed, transformed and contracted with B
+ * inside one kernel, nothing of size m x n exists; ws only holds per-split partial outputs when m/32 row
+ * blocks cannot fill the chip (<= ~512 row blocks x D floats, 16 bytes otherwise).  Other D: an m x n dS
+ * panel in ws + a second GEMM.  dA and ws must be 16-byte aligned. */
 size_t dalm_sim_grad_workspace_bytes(int64_t m, int64_t n, int64_t D);
 int dalm_sim_grad(const float* A, const float* Bm, int64_t m, int64_t n,
                   int64_t D, float scale, int64_t diag_offset,
                   const float* row_coef, const float* row_lse,
                   const float* col_coef, const float* col_lse, float* dA,
                   void* ws, size_t ws_bytes, dalm_stream_t stream);
+
+/* ---- K2-K4, small-batch form (the batch sizes the trainers really run) ----
+ * Same reference lines as above (train_utils.py:76-88,124; train_rage2e.py:441-446;
+ * train_retriever_only.py:369-374).  For m x n <= 2^20 (m <= 1024, n <= 8192) S is computed ONCE:
+ *   fwd: S[m,n] (saved, ldS >= n), row_lse[m], diag[m] and - when col_lse != NULL -
+ *        col_lse[n] = logsumexp_i S[i,j]     (2 launches: split-K partial tiles, statistics)
+ *   bwd: dA = scale dS . B and/or dB = scale dS^T . A from the saved S (1 launch; pass NULL
+ *        for the output that is not wanted), dS as in dalm_sim_grad.
+ * One GPU: one fwd with col_lse and one bwd with both outputs replace two dalm_sim_rowstats
+ * and two dalm_sim_grad calls (4 computations of S, ~10 launches). */
+int dalm_sim_small_supported(int64_t m, int64_t n, int64_t D);
+size_t dalm_sim_small_workspace_bytes(int64_t m, int64_t n, int64_t D, int want_cols);
+int dalm_sim_small_fwd(const float* A, const float* Bm, int64_t m, int64_t n,
+                       int64_t D, float scale, int64_t diag_offset, float* S,
+                       int64_t ldS, float* row_lse, float* diag, float* col_lse,
+                       void* ws, size_t ws_bytes, dalm_stream_t stream);
+int dalm_sim_small_bwd(const float* S, int64_t ldS, const float* A, const float* Bm,
+                       int64_t m, int64_t n, int64_t D, float scale,
+                       int64_t diag_offset, const float* row_coef,
+                       const float* row_lse, const float* col_coef,
+                       const float* col_lse, float* dA, float* dB,
+                       dalm_stream_t stream);
 
 /* ---- K3 drop-in: get_nt_xent_loss on a materialised square S -----------
  * dalm/training/utils/train_utils.py:80-88 (cross_entropy(S, arange(n)), mean).
@@ -193,6 +227,16 @@ int dalm_contrastive_finalize(const float* row_lse, const float* col_lse,
                               const float* diag, int64_t n_local,
                               int64_t n_global, float* out, float* doc_lp,
                               dalm_stream_t stream);
+
+/* The whole loss assembly of the RAG-e2e step (train_rage2e.py:443-467) in one launch:
+ *   out[1] = L_con (as dalm_contrastive_finalize), doc_lp[i] = diag[i] - row_lse[i] (may be NULL),
+ *   out[2] = L_gen (as dalm_marg_ce_finalize with that doc_lp), out[0] = L_con + L_gen.
+ * Nb, row_lse, col_lse, diag have n_local entries (this rank's rows). */
+int dalm_rag_loss_finalize(const float* row_nll, int64_t num_rows, const float* Nb,
+                           const float* row_lse, const float* col_lse,
+                           const float* diag, int64_t n_local, int64_t n_global,
+                           const float* stats, float* out, float* doc_lp,
+                           dalm_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -180,6 +180,57 @@ def closed_backward(q, p, logits, ids, mask, qlen, scale, fwd: Optional[dict] = 
     return {"dS": dS, "dq": dq, "dp": dp, "dlogits": dlogits}
 
 
+def closed_chunked(q, p, logits, ids, mask, qlen, scale, dlogits_got: Optional[torch.Tensor] = None) -> Dict:
+    """closed_forward + closed_backward at BASELINE's FULL sizes (cfg3: 18x256x32000, cfg5: 18x256x65024) in fp64,
+    one sample at a time so that the [B,Tg,V] fp64 log-probs / gradient never exist (a sample is ~130 MB at
+    V = 65024).  `logits` may be fp32 or bf16 (up-cast exactly, as accelerate does for the reference).  If
+    `dlogits_got` is given its error against the closed-form gradient is accumulated sample by sample:
+    returns dlogits_err = ||got - ref|| / ||ref|| and dlogits_max_err = max|got - ref| / max|ref|."""
+    dt = torch.float64
+    q64, p64 = q.to(dt), p.to(dt)
+    S = scale * (q64 @ p64.t())
+    B = S.shape[0]
+    lse_r, lse_c, d = torch.logsumexp(S, 1), torch.logsumexp(S, 0), S.diag()
+    con = 0.5 * ((lse_r - d).mean() + (lse_c - d).mean())
+    doc_lp = d - lse_r
+    Tg = logits.shape[1]
+    T = Tg - 1
+    m_all = mask[:, 1:].to(dt)
+    M = m_all.sum()
+    cut = _cut_rows(qlen.reshape(-1), T)
+    a = (torch.arange(T).unsqueeze(0) >= cut.unsqueeze(1)).to(dt)
+    Nb = (m_all * a).sum(1)
+    nll_sum = torch.zeros((), dtype=dt)
+    err_sq = ref_sq = torch.zeros((), dtype=dt)
+    max_err = max_ref = 0.0
+    for b in range(B):
+        x = logits[b, :-1, :].to(dt)
+        y = ids[b, 1:]
+        lse = torch.logsumexp(x, dim=1)
+        xy = torch.gather(x, 1, y.unsqueeze(1)).squeeze(1)
+        nll_sum = nll_sum + (m_all[b] * (lse - xy)).sum()
+        if dlogits_got is not None:
+            ref = torch.exp(x - lse.unsqueeze(1))
+            ref[torch.arange(T), y] -= 1.0
+            ref *= (m_all[b] / M).unsqueeze(1)
+            got = dlogits_got[b].to(dt)
+            diff = got[:-1] - ref
+            err_sq = err_sq + (diff * diff).sum() + (got[-1] * got[-1]).sum()   # last position must be exactly 0
+            ref_sq = ref_sq + (ref * ref).sum()
+            max_err = max(max_err, float(diff.abs().max()), float(got[-1].abs().max()))
+            max_ref = max(max_ref, float(ref.abs().max()))
+    gen = (nll_sum - (Nb * doc_lp).sum()) / M
+    eye = torch.eye(B, dtype=dt)
+    soft_r, soft_c = torch.exp(S - lse_r.unsqueeze(1)), torch.exp(S - lse_c.unsqueeze(0))
+    dS = ((soft_r - eye) + (soft_c - eye)) / (2.0 * B) + (Nb / M).unsqueeze(1) * (soft_r - eye)
+    out = {"loss": con + gen, "contrastive": con, "generator": gen, "dq": scale * (dS @ p64), "dp": scale * (dS.t() @ q64),
+           "M": M}
+    if dlogits_got is not None:
+        out["dlogits_err"] = float(torch.sqrt(err_sq / ref_sq))
+        out["dlogits_max_err"] = max_err / max_ref
+    return out
+
+
 # ---------------------------------------------------------------------------
 # OracleOps: the dalm_amd.ops.HipOps interface on CPU tensors (float64 inside).
 # Injected by tests/test_sharded_gloo.py to exercise the world_size>1 host logic
@@ -210,6 +261,29 @@ class OracleOps:
         idx = torch.arange(A.shape[0])
         dS[idx, diag_offset + idx] -= (rc.squeeze(1) + cc.squeeze(0)[diag_offset + idx])
         return (scale * (dS @ B64)).float()
+
+    # small-batch form (mirrors HipOps.sim_small_*: same shape rule so the gloo tests take the same host paths)
+    def sim_small_supported(self, m, n, D):
+        return 0 < m <= 1024 and 0 < n <= 8192 and m * n <= (1 << 20)
+
+    def sim_small_fwd(self, A, Bm, scale, diag_offset, want_cols):
+        S = scale * (A.to(self.dt) @ Bm.to(self.dt).t())
+        idx = torch.arange(A.shape[0])
+        col = torch.logsumexp(S, 0).float() if want_cols else None
+        return S.float(), torch.logsumexp(S, 1).float(), S[idx, diag_offset + idx].float(), col
+
+    def sim_small_bwd(self, S, A, Bm, scale, diag_offset, row_coef, row_lse, col_coef, col_lse, want_dA=True, want_dB=True):
+        A64, B64, S64 = A.to(self.dt), Bm.to(self.dt), S.to(self.dt)
+        rc, cc = row_coef.to(self.dt).unsqueeze(1), col_coef.to(self.dt).unsqueeze(0)
+        dS = rc * torch.exp(S64 - row_lse.to(self.dt).unsqueeze(1)) + cc * torch.exp(S64 - col_lse.to(self.dt).unsqueeze(0))
+        idx = torch.arange(A.shape[0])
+        dS[idx, diag_offset + idx] -= (rc.squeeze(1) + cc.squeeze(0)[diag_offset + idx])
+        return ((scale * (dS @ B64)).float() if want_dA else None, (scale * (dS.t() @ A64)).float() if want_dB else None)
+
+    def rag_loss_finalize(self, row_nll, Nb, row_lse, col_lse, diag, n_global, stats):
+        con, doc_lp = self.contrastive_finalize(row_lse, col_lse, diag, n_global)
+        gen = self.ce_finalize(row_nll, Nb, doc_lp, stats)
+        return torch.cat([con + gen, con, gen]), doc_lp
 
     def contrastive_finalize(self, row_lse, col_lse, diag, n_global):
         r, c, d = row_lse.to(self.dt), col_lse.to(self.dt), diag.to(self.dt)

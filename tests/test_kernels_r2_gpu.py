@@ -1,0 +1,243 @@
+"""GPU parity for the round-2 kernels, all through the C ABI, all against the fp64 oracle on the same seeded inputs:
+small-batch contrastive path (S once: partial tiles -> statistics -> one-launch backward), flash-style similarity
+backward (no dS panel), fused pool + L2-norm forward, one-launch loss assembly, and the FULL-size cfg3 / cfg5
+configurations compared with the oracle itself (not just properties).
+
+Tolerances as in test_hip_parity.py: fp32 loss rel <= 1e-4, gradient norm-rel <= 1e-4 (north-star 1e-3);
+bf16 gradient outputs norm-rel <= 4e-3.
+"""
+import pytest
+import torch
+
+import dalm_oracle as O
+from helpers import norm_rel_err, synth_batch
+from test_hip_parity import BF16_GRAD_NORM_RTOL, GRAD_NORM_RTOL, assert_grad_close, assert_loss_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from dalm_amd import hip
+
+    hip.load()
+    return torch.device("cuda:0")
+
+
+def _problem(m, n, D, off, seed=None):
+    g = torch.Generator().manual_seed(seed if seed is not None else m * 7 + n * 3 + D)
+    A = torch.nn.functional.normalize(torch.randn(m, D, generator=g), dim=1)
+    Bm = torch.nn.functional.normalize(torch.randn(n, D, generator=g), dim=1)
+    Bm[off:off + m] = torch.nn.functional.normalize(A + 0.3 * Bm[off:off + m], dim=1)   # positives stand out, as trained
+    scale = 100.0
+    S = scale * (A.double() @ Bm.double().t())
+    rc, cc = torch.rand(m, generator=g) / m, torch.rand(n, generator=g) / n
+    rl, cl = torch.logsumexp(S, 1), torch.logsumexp(S, 0) + 0.3   # any col_lse >= true one is a valid softmax scale
+    idx = torch.arange(m)
+    dS = rc.double().unsqueeze(1) * torch.exp(S - rl.unsqueeze(1)) + cc.double().unsqueeze(0) * torch.exp(S - cl.unsqueeze(0))
+    dS[idx, off + idx] -= rc.double() + cc.double()[off + idx]
+    return A, Bm, scale, S, rc, rl, cc, cl, dS
+
+
+SMALL = [(18, 18, 1024, 0), (150, 150, 1024, 0), (19, 19, 384, 0), (1, 1, 64, 0), (18, 144, 1024, 36),
+         (150, 1200, 1024, 450), (257, 300, 100, 20), (33, 65, 1030, 7), (600, 600, 768, 0), (1024, 1024, 32, 0)]
+
+
+@pytest.mark.parametrize("m,n,D,off", SMALL)
+def test_small_path_vs_fp64(dev, m, n, D, off):
+    from dalm_amd.ops import default_ops
+
+    ops = default_ops()
+    assert ops.sim_small_supported(m, n, D)
+    A, Bm, scale, S, rc, rl, cc, cl, dS = _problem(m, n, D, off)
+    Sg, row_lse, diag, col_lse = ops.sim_small_fwd(A.to(dev), Bm.to(dev), scale, off, True)
+    idx = torch.arange(m)
+    torch.testing.assert_close(Sg.cpu().double(), S, rtol=1e-6, atol=3e-5)
+    torch.testing.assert_close(row_lse.cpu().double(), rl, rtol=1e-6, atol=3e-5)
+    torch.testing.assert_close(col_lse.cpu().double(), torch.logsumexp(S, 0), rtol=1e-6, atol=3e-5)
+    torch.testing.assert_close(diag.cpu().double(), S[idx, off + idx], rtol=1e-6, atol=3e-5)
+    # rows only (the W > 1 form): same row statistics, no column output
+    S2, row2, diag2, none = ops.sim_small_fwd(A.to(dev), Bm.to(dev), scale, off, False)
+    assert none is None and torch.equal(row2, row_lse) and torch.equal(diag2, diag) and torch.equal(S2, Sg)
+    args = (Sg, A.to(dev), Bm.to(dev), scale, off, rc.to(dev), rl.float().to(dev), cc.to(dev), cl.float().to(dev))
+    dA, dB = ops.sim_small_bwd(*args, True, True)
+    assert_grad_close(dA, scale * (dS @ Bm.double()), 2e-4, "dA")
+    assert_grad_close(dB, scale * (dS.t() @ A.double()), 2e-4, "dB")
+    dA1, n1 = ops.sim_small_bwd(*args, True, False)
+    n2, dB1 = ops.sim_small_bwd(*args, False, True)
+    assert n1 is None and n2 is None and torch.equal(dA1, dA) and torch.equal(dB1, dB)
+
+
+def test_small_path_limits_and_errors(dev):
+    from dalm_amd import hip
+    from dalm_amd.ops import default_ops
+
+    ops = default_ops()
+    assert not ops.sim_small_supported(1025, 1025, 64) and not ops.sim_small_supported(2048, 2048, 1024)
+    assert ops.sim_small_supported(128, 8192, 1024) and not ops.sim_small_supported(129, 8192, 1024)
+    A = torch.randn(4, 8, device=dev)
+    S = torch.empty(4, 4, device=dev)
+    v = torch.empty(4, device=dev)
+    with pytest.raises(ValueError, match="workspace too small"):
+        hip.call("dalm_sim_small_fwd", hip.ptr(A), hip.ptr(A), 4, 4, 8, 1.0, 0, hip.ptr(S), 4, hip.ptr(v), hip.ptr(v),
+                 hip.ptr(v), hip.ptr(S), 4, hip.stream())
+    with pytest.raises(ValueError, match="diag_offset"):
+        ops.sim_small_fwd(A, A[:2], 1.0, 0, True)
+
+
+FLASH = [(1200, 1200, 1024, 0), (150, 1200, 1024, 450), (4096, 4096, 1024, 0), (700, 2304, 128, 1000),
+         (1536, 1536, 256, 0), (333, 5000, 384, 77), (2100, 2100, 768, 0), (40, 130, 512, 3)]
+
+
+@pytest.mark.parametrize("m,n,D,off", FLASH)
+def test_flash_grad_vs_fp64(dev, m, n, D, off):
+    """dalm_sim_grad without a dS panel: same closed form, every split / tail geometry (row tails, column tails,
+    several column splits, one split, NT = 1..8)."""
+    from dalm_amd import hip
+    from dalm_amd.ops import default_ops
+
+    ops = default_ops()
+    A, Bm, scale, S, rc, rl, cc, cl, dS = _problem(m, n, D, off)
+    ws = hip.load().dalm_sim_grad_workspace_bytes(m, n, D)
+    assert ws <= max(16, 1024 * D * 4 * 32), ws   # bounded by ~1k row blocks' worth of partial outputs, never m*n
+    got = ops.sim_grad(A.to(dev), Bm.to(dev), scale, off, rc.to(dev), rl.float().to(dev), cc.to(dev), cl.float().to(dev))
+    assert_grad_close(got, scale * (dS @ Bm.double()), 2e-4, "dA")
+    got2 = ops.sim_grad(A.to(dev), Bm.to(dev), scale, off, rc.to(dev), rl.float().to(dev), cc.to(dev), cl.float().to(dev))
+    assert torch.equal(got, got2)   # deterministic
+
+
+def test_flash_workspace_is_not_m_times_n():
+    from dalm_amd import hip
+
+    lib = hip.load()
+    assert lib.dalm_sim_grad_workspace_bytes(65536, 65536, 1024) == 16            # 2048 row blocks: no split at all
+    assert lib.dalm_sim_grad_workspace_bytes(16384, 16384, 1024) == 16
+    assert lib.dalm_sim_grad_workspace_bytes(4096, 4096, 1024) == 4 * 4096 * 1024 * 4
+    assert lib.dalm_sim_grad_workspace_bytes(4096, 4096, 1000) > 4096 * 4096 * 4 - 1   # odd D keeps the panel form
+
+
+POOL = [(18, 50, 1024), (18, 128, 1024), (150, 128, 1024), (19, 160, 384), (3, 17, 100), (5, 9, 5000),
+        (4, 4096, 1024), (2, 1, 64), (130, 33, 96)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,D", POOL)
+@pytest.mark.parametrize("normalize", [True, False])
+def test_fused_pool_vs_oracle(dev, B, T, D, dtype, normalize):
+    """One-launch pool + norm (and its token-sliced two-launch form at (4,4096,1024)): ragged masks incl. an
+    all-padding sample, left and right padding, integer mask weights, odd / unaligned D."""
+    from dalm_amd.fused import pool_l2norm
+
+    g = torch.Generator().manual_seed(B * 1000 + T + D)
+    h = torch.randn(B, T, D, generator=g).to(dtype)
+    lens = torch.randint(1, T + 1, (B,), generator=g)
+    ar = torch.arange(T).unsqueeze(0)
+    mask = (ar < lens.unsqueeze(1)).long()
+    if B > 1:
+        mask[1] = (ar[0] >= (T - lens[1])).long()      # left padding
+    if B > 2:
+        mask[2] = 0                                      # all padding -> u = 0, |u| = 0 (clamp branches)
+    if B > 3:
+        mask[3, : int(lens[3])] = 2                      # integer weights other than 0/1
+    up = torch.randn(B, D, generator=g)
+    hd = h.to(dev).requires_grad_(True)
+    e = pool_l2norm(hd, mask.to(dev), normalize)
+    (e * up.to(dev)).sum().backward()
+    hh = h.double().requires_grad_(True)
+    ref = O.ref_retrieval_embed(hh, mask, normalize)
+    (ref * up).sum().backward()
+    assert_grad_close(e.detach(), ref.detach(), GRAD_NORM_RTOL, "emb")
+    assert_grad_close(hd.grad, hh.grad, GRAD_NORM_RTOL if dtype == torch.float32 else BF16_GRAD_NORM_RTOL, "dh")
+
+
+def test_rag_loss_finalize_vs_oracle(dev):
+    from dalm_amd.ops import default_ops
+
+    ops, oo = default_ops(), O.OracleOps()
+    g = torch.Generator().manual_seed(4)
+    n_local, R = 37, 37 * 64
+    row_nll = torch.rand(R, generator=g) * 9
+    Nb = torch.randint(0, 50, (n_local,), generator=g).float()
+    lse_r, lse_c = torch.randn(n_local, generator=g) + 5, torch.randn(n_local, generator=g) + 5
+    diag = torch.randn(n_local, generator=g)
+    stats = torch.tensor([1234.0, float(n_local)])
+    out, doc = ops.rag_loss_finalize(*(t.to(dev) for t in (row_nll, Nb, lse_r, lse_c, diag)), 74, stats.to(dev))
+    ref, rdoc = oo.rag_loss_finalize(row_nll, Nb, lse_r, lse_c, diag, 74, stats)
+    torch.testing.assert_close(out.cpu(), ref, rtol=2e-6, atol=1e-6)
+    torch.testing.assert_close(doc.cpu(), rdoc, rtol=1e-6, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------
+# FULL BASELINE sizes against the oracle ("property-tested, not oracle-compared")
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name,V,dtype,inplace", [("cfg3", 32000, torch.float32, False), ("cfg5", 65024, torch.bfloat16, False),
+                                                   ("cfg3-inplace", 32000, torch.float32, True),
+                                                   ("cfg5-inplace", 65024, torch.bfloat16, True)])
+def test_full_size_vs_oracle(dev, name, V, dtype, inplace):
+    """cfg3: 18 x 256 x 32000 fp32 logits; cfg5: 18 x 256 x 65024 bf16 logits (the 1024-thread CE rows), D = 1024,
+    left padding, ragged lengths: loss, dq, dp and EVERY element of dlogits vs closed_chunked (fp64, sample by sample)."""
+    from dalm_amd.fused import rag_e2e_loss
+
+    B, Tg, D = 18, 256, 1024
+    q, p, logits, ids, mask, qlen = synth_batch(31, B, D, Tg, V, pad_side="left", dtype=dtype, logit_gain=2.0)
+    qd, pd = q.to(dev).requires_grad_(True), p.to(dev).requires_grad_(True)
+    ld = logits.to(dev).requires_grad_(True)
+    work = ld * 1.0 if inplace else ld          # a non-leaf buffer the kernel may overwrite with its own gradient
+    aux = {}
+    loss = rag_e2e_loss(qd, pd, work, ids.to(dev), mask.to(dev), qlen.to(dev), 100, inplace_grad=inplace, aux=aux)
+    loss.backward()
+    ref = O.closed_chunked(q, p, logits, ids, mask, qlen, 100.0, dlogits_got=ld.grad.cpu())
+    assert_loss_close(loss, ref["loss"])
+    assert_loss_close(aux["contrastive"], ref["contrastive"])
+    assert_loss_close(aux["generator"], ref["generator"])
+    assert float(aux["num_target_tokens"]) == float(ref["M"])
+    assert_grad_close(qd.grad, ref["dq"], name="dq")
+    assert_grad_close(pd.grad, ref["dp"], name="dp")
+    tol = GRAD_NORM_RTOL if dtype == torch.float32 else BF16_GRAD_NORM_RTOL
+    assert ref["dlogits_err"] <= tol, ref["dlogits_err"]
+    assert ref["dlogits_max_err"] <= 10 * tol, ref["dlogits_max_err"]
+
+
+def test_stream_ce_kernel_inplace_large_vocab(dev):
+    """V > 65536 takes marg_ce_stream_kernel; with the gradient written over the logits the label logit
+    must be read before any store of the row.  131077-wide rows, in place, vs the oracle; repeated to catch the race."""
+    from dalm_amd.fused import rag_e2e_loss
+
+    B, Tg, V, D = 3, 24, 131077, 64
+    q, p, logits, ids, mask, qlen = synth_batch(8, B, D, Tg, V, pad_side="right", logit_gain=3.0)
+    for _ in range(3):
+        ld = logits.to(dev).requires_grad_(True)
+        loss = rag_e2e_loss(q.to(dev), p.to(dev), ld * 1.0, ids.to(dev), mask.to(dev), qlen.to(dev), 100, inplace_grad=True)
+        loss.backward()
+        ref = O.closed_chunked(q, p, logits, ids, mask, qlen, 100.0, dlogits_got=ld.grad.cpu())
+        assert_loss_close(loss, ref["loss"])
+        assert ref["dlogits_err"] <= GRAD_NORM_RTOL
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_lm_head_fused_vs_fp64_oracle(dev, dtype):
+    """rag_e2e_loss_from_hidden (logits never materialised) against the fp64 oracle itself - round 1 only compared
+    it with the materialising HIP path."""
+    from dalm_amd.fused import rag_e2e_loss_from_hidden
+
+    B, Tg, H, V, D = 7, 24, 64, 1000, 32
+    q, p, _, ids, mask, qlen = synth_batch(77, B, D, Tg, V, pad_side="left")
+    g = torch.Generator().manual_seed(5)
+    hidden = torch.randn(B, Tg, H, generator=g).to(dtype)
+    W = (0.2 * torch.randn(V, H, generator=g)).to(dtype)
+    qq, pp = q.to(dev).requires_grad_(True), p.to(dev).requires_grad_(True)
+    hh, ww = hidden.to(dev).requires_grad_(True), W.to(dev).requires_grad_(True)
+    loss = rag_e2e_loss_from_hidden(qq, pp, hh, ww, ids.to(dev), mask.to(dev), qlen.to(dev), 100, chunk_samples=3)
+    loss.backward()
+    h64, w64 = hidden.double().requires_grad_(True), W.double().requires_grad_(True)
+    q64, p64 = q.double().requires_grad_(True), p.double().requires_grad_(True)
+    logits64 = h64 @ w64.t()
+    if dtype == torch.bfloat16:   # the product path rounds the logits to bf16 once (the lm_head's output dtype)
+        logits64 = logits64 + (logits64.detach().to(torch.bfloat16).double() - logits64.detach())
+    ref = O.ref_step_loss(q64, p64, logits64, ids, mask, qlen, 100)
+    ref["loss"].backward()
+    assert_loss_close(loss, ref["loss"], 1e-4 if dtype == torch.float32 else 2e-3)
+    tol = 2e-4 if dtype == torch.float32 else 2e-2
+    for got, want, name in ((qq.grad, q64.grad, "dq"), (pp.grad, p64.grad, "dp"), (hh.grad, h64.grad, "dh"),
+                            (ww.grad, w64.grad, "dW")):
+        assert norm_rel_err(got, want) <= tol, (name, norm_rel_err(got, want))

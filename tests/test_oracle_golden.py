@@ -103,3 +103,21 @@ def test_oracle_ops_consistent_with_closed_form():
     assert abs(float(con) - float(z["ref64_contrastive"])) < 1e-4 * abs(float(z["ref64_contrastive"]))
     assert abs(float(gen) - float(z["ref64_generator"])) < 1e-4 * abs(float(z["ref64_generator"]))
     torch.testing.assert_close(dl.double(), z["ref64_dlogits"], rtol=1e-4, atol=1e-7)
+
+
+def test_closed_chunked_equals_closed_form_and_reference_golden():
+    """closed_chunked (the full-size, sample-at-a-time oracle used by the GPU tests) == closed_forward/backward,
+    and == the reference's own outputs on the golden cases."""
+    import dalm_oracle as O
+    from helpers import LOSS_CASES, load_npz
+
+    for case in LOSS_CASES:
+        z = load_npz(case)
+        if float(z["mask"][:, 1:].sum()) == 0:
+            continue
+        c = O.closed_chunked(z["q"], z["p"], z["logits"], z["ids"], z["mask"], z["qlen"], float(z["scale"]),
+                             dlogits_got=z["ref64_dlogits"])
+        assert abs(float(c["loss"]) - float(z["ref64_loss"])) <= 1e-10 * max(1.0, abs(float(z["ref64_loss"]))), case
+        torch.testing.assert_close(c["dq"], z["ref64_dq"], rtol=1e-9, atol=1e-11)
+        torch.testing.assert_close(c["dp"], z["ref64_dp"], rtol=1e-9, atol=1e-11)
+        assert c["dlogits_err"] <= 1e-10 and c["dlogits_max_err"] <= 1e-10, (case, c["dlogits_err"])

@@ -79,7 +79,26 @@ def bench_sim(m, n, D):
         rc = torch.full((m,), 1.0 / m, device=dev)
         cc = torch.full((n,), 1.0 / n, device=dev)
         med, best = time_fn(lambda: ops.sim_grad(A, Bm, 100.0, 0, rc, rl, cc, cl), iters=10, warmup=3)
-        out["grad(dS+gemm)"] = {"s": med, "TFLOPs": 4.0 * m * n * D / med / 1e12, "frac": 4.0 * m * n * D / med / MFMA_F32_PEAK}
+        out["grad"] = {"s": med, "TFLOPs": 4.0 * m * n * D / med / 1e12, "frac": 4.0 * m * n * D / med / MFMA_F32_PEAK}
+    return out
+
+
+def bench_small(m, n, D, want_cols=True):
+    """Small-batch contrastive path: S once (2 launches), backward 1 launch; latency-bound, reported in us."""
+    ops = default_ops()
+    dev = torch.device("cuda:0")
+    A = torch.nn.functional.normalize(torch.randn(m, D, device=dev), dim=1)
+    Bm = torch.nn.functional.normalize(torch.randn(n, D, device=dev), dim=1)
+    out = {}
+    med, best = time_fn(lambda: ops.sim_small_fwd(A, Bm, 100.0, 0, want_cols), iters=50, warmup=10)
+    out["fwd(partial+stats)"] = {"us": med * 1e6, "best_us": best * 1e6, "TFLOPs": 2.0 * m * n * D / med / 1e12}
+    S, rl, _, cl = ops.sim_small_fwd(A, Bm, 100.0, 0, True)
+    rc = torch.full((m,), 1.0 / m, device=dev)
+    cc = torch.full((n,), 1.0 / n, device=dev)
+    med, best = time_fn(lambda: ops.sim_small_bwd(S, A, Bm, 100.0, 0, rc, rl, cc, cl, True, want_cols), iters=50, warmup=10)
+    nd = 2 if want_cols else 1
+    out["bwd(dQ,dP)" if want_cols else "bwd(dQ)"] = {"us": med * 1e6, "best_us": best * 1e6,
+                                                      "TFLOPs": nd * 2.0 * m * n * D / med / 1e12}
     return out
 
 
@@ -120,7 +139,15 @@ def main():
         # per-rank blocks of the sharded negatives at W = 8: cfg3 (18 x 144) and cfg2 (150 x 1200)
         for m, n in [(18, 144), (150, 1200)]:
             res[f"sim sharded {m}x{n} D1024"] = bench_sim(m, n, 1024)
+    if args.only in ("", "small"):
+        for m, n in [(18, 18), (150, 150), (512, 512)]:
+            res[f"small {m}x{n} D1024 (one GPU: rows+cols)"] = bench_small(m, n, 1024, True)
+        for m, n in [(18, 144), (150, 1200)]:
+            res[f"small sharded {m}x{n} D1024 (rows only)"] = bench_small(m, n, 1024, False)
     if args.only in ("", "pool"):
+        res["pool cfg3 q B18 T50 D1024 bf16"] = bench_pool(18, 50, 1024, torch.bfloat16)
+        res["pool cfg3 p B18 T128 D1024 bf16"] = bench_pool(18, 128, 1024, torch.bfloat16)
+        res["pool cfg2 p B150 T128 D1024 bf16"] = bench_pool(150, 128, 1024, torch.bfloat16)
         res["pool cfg2 q B150 T50 D1024 f32"] = bench_pool(150, 50, 1024, torch.float32)
         res["pool cfg2 p B150 T128 D1024 f32"] = bench_pool(150, 128, 1024, torch.float32)
         res["pool cfg3 p B18 T128 D1024 f32"] = bench_pool(18, 128, 1024, torch.float32)
