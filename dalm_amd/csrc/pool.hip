@@ -156,6 +156,7 @@ __global__ __launch_bounds__(1024) void pool_fused_kernel(const T* __restrict__ 
                                                           float* __restrict__ inv_count, float* __restrict__ part,
                                                           float* __restrict__ part_cnt) {
   constexpr int VEC = HV<T>::VEC;
+  constexpr int TIF = (NCH == 1) ? 8 : 4;   // token rows in flight per group on the fast path (128 B per thread)
   extern __shared__ float lds[];       // [G][Dp] partial sums, then reduction scratch
   __shared__ float red[16];
   __shared__ float cnt_s[16];
@@ -174,29 +175,66 @@ __global__ __launch_bounds__(1024) void pool_fused_kernel(const T* __restrict__ 
 #pragma unroll
     for (int e = 0; e < VEC; ++e) acc[q][e] = 0.f;
   float cnt = 0.f;
-  for (int t0 = t_lo + g; t0 < t_hi; t0 += 4 * G) {
-    int64_t m[4];
+  if (vec_ok) {
+    // Fast path (16-byte aligned rows, D % VEC == 0): UNCONDITIONAL vector loads - a predicated load compiles to a
+    // branch and the compiler then waits with vmcnt(0), which serialises the four rows in flight.  A padded token
+    // is redirected to the slice's first row instead (an L1/L2 hit, no HBM traffic) and its value discarded.
+    const int t_anchor = min(t_lo + g, Tn - 1);
+    for (int t0 = t_lo + g; t0 < t_hi; t0 += TIF * G) {
+      int64_t m[TIF];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) m[u] = (t0 + u * G < t_hi) ? mb[t0 + u * G] : 0;
+      for (int u = 0; u < TIF; ++u) {
+        const int t = t0 + u * G;
+        const int64_t mv = mb[min(t, t_hi - 1)];
+        m[u] = (t < t_hi) ? mv : 0;
+      }
 #pragma unroll
-    for (int q = 0; q < NCH; ++q) {
-      const int d = (q * TPR + c) * VEC;
-      int nvalid = D - d;
-      nvalid = nvalid < 0 ? 0 : (nvalid > VEC ? VEC : nvalid);
-      float x[4][VEC];
+      for (int q = 0; q < NCH; ++q) {
+        const int d = (q * TPR + c) * VEC;
+        const bool dok = d < D;
+        const int dd = dok ? d : 0;
+        float x[TIF][VEC];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (m[u] != 0 && nvalid > 0) HV<T>::load(hb + static_cast<int64_t>(t0 + u * G) * D + d, nvalid, vec_ok, x[u]);
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (m[u] != 0 && nvalid > 0) {
-          const float f = static_cast<float>(m[u]);
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) acc[q][e] = fmaf(f, x[u][e], acc[q][e]);
+        for (int u = 0; u < TIF; ++u) {
+          const int tt = (m[u] != 0) ? (t0 + u * G) : t_anchor;
+          HV<T>::load(hb + static_cast<int64_t>(tt) * D + dd, VEC, true, x[u]);
         }
-    }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) cnt += static_cast<float>(m[u]);
+        for (int u = 0; u < TIF; ++u) {
+          const float f = static_cast<float>(m[u]);
+          const bool use = (m[u] != 0) && dok;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc[q][e] += use ? f * x[u][e] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < TIF; ++u) cnt += static_cast<float>(m[u]);
+    }
+  } else {
+    for (int t0 = t_lo + g; t0 < t_hi; t0 += 4 * G) {
+      int64_t m[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) m[u] = (t0 + u * G < t_hi) ? mb[t0 + u * G] : 0;
+#pragma unroll
+      for (int q = 0; q < NCH; ++q) {
+        const int d = (q * TPR + c) * VEC;
+        int nvalid = D - d;
+        nvalid = nvalid < 0 ? 0 : (nvalid > VEC ? VEC : nvalid);
+        float x[4][VEC];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (m[u] != 0 && nvalid > 0) HV<T>::load(hb + static_cast<int64_t>(t0 + u * G) * D + d, nvalid, false, x[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (m[u] != 0 && nvalid > 0) {
+            const float f = static_cast<float>(m[u]);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[q][e] = fmaf(f, x[u][e], acc[q][e]);
+          }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) cnt += static_cast<float>(m[u]);
+    }
   }
   // ---- combine the G token groups (fixed order) ----
   const int Dp = TPR * VEC * NCH;
@@ -363,7 +401,8 @@ inline PoolPlan pool_plan(int64_t B, int64_t T, int64_t D, int vec) {
   // token slices: only when the batch alone leaves most CUs idle AND a sample is big enough to matter
   const int64_t groups = 1024 / tpr;
   int64_t tz = 1;
-  if (B < 96 && T * D * (16 / vec) > (1 << 20)) {    // > 1 MiB per sample
+  // one CU streams ~50-80 GB/s on its own: slice when a sample is more than a few microseconds of that
+  if (B < 64 && T * D * (16 / vec) >= (384 << 10)) {
     tz = (192 + B - 1) / B;
     const int64_t tz_max = (T + 4 * groups - 1) / (4 * groups);
     if (tz > tz_max) tz = tz_max;

@@ -58,6 +58,7 @@ __device__ __forceinline__ float red_sum(const float* red, int row, int col) {
 // lane (r = l&31, h = l>>5) loads A[i0+r][k+4h .. k+4h+3] and B[j0+r][k+4h .. +3] for k = lo, lo+8, ...;
 // MFMA step t of such a pair multiplies A[.][k+4h+t] with B[.][k+4h+t] over h = 0,1: every k exactly once.
 // ---------------------------------------------------------------------------------------------------
+template <bool FAST>
 __global__ __launch_bounds__(256) void small_partial_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                             int m, int n, int K, int k_chunk, int tiles_n,
                                                             int a_vec, int b_vec, float* __restrict__ slab,
@@ -70,8 +71,8 @@ __global__ __launch_bounds__(256) void small_partial_kernel(const float* __restr
   const int k_lo = z * k_chunk + wave * kq;
   const int k_hi = min(K, k_lo + kq);
   const bool arow = (i0 + l31) < m, brow = (j0 + l31) < n;
-  const float* ap = A + static_cast<int64_t>(i0 + l31) * K;
-  const float* bp = B + static_cast<int64_t>(j0 + l31) * K;
+  const float* ap = A + static_cast<int64_t>(FAST ? min(i0 + l31, m - 1) : i0 + l31) * K;
+  const float* bp = B + static_cast<int64_t>(FAST ? min(j0 + l31, n - 1) : j0 + l31) * K;
 
   f32x16 acc;
 #pragma unroll
@@ -81,9 +82,17 @@ __global__ __launch_bounds__(256) void small_partial_kernel(const float* __restr
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int k = k0 + 8 * u + 4 * lhi;
-      const int nv = k_hi - k;
-      av[u] = ld4_guard(ap + k, arow ? nv : 0, a_vec);
-      bv[u] = ld4_guard(bp + k, brow ? nv : 0, b_vec);
+      if constexpr (FAST) {
+        // K % 8 == 0, 16-byte aligned rows: unconditional loads (rows past m / n are clamped to the last row and
+        // produce tile rows that are never stored; k past the range is clamped and its MFMAs are skipped)
+        const int kc = min(k, K - 4);
+        av[u] = *reinterpret_cast<const float4*>(ap + kc);
+        bv[u] = *reinterpret_cast<const float4*>(bp + kc);
+      } else {
+        const int nv = k_hi - k;
+        av[u] = ld4_guard(ap + k, arow ? nv : 0, a_vec);
+        bv[u] = ld4_guard(bp + k, brow ? nv : 0, b_vec);
+      }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -118,9 +127,18 @@ __global__ __launch_bounds__(256) void small_partial_kernel(const float* __restr
 // One wave per row; slabs summed in fixed order z = 0..SK-1, then scaled with a separate rounding so that the
 // S read by the backward and the S the statistics saw are the same bits.
 // ---------------------------------------------------------------------------------------------------
+constexpr int SK_MAX = 16;
+
+// S value at one position: the SK slab entries are fetched as ONE batch (unconditional, slab index clamped) and
+// summed in fixed order z = 0..SK-1 - a `for z < SK` loop of loads compiles to a serial latency chain
+// (measured: 6-9 us for this kernel at 18..150 rows, all of it waiting).
 __device__ __forceinline__ float slab_s(const float* __restrict__ p, int64_t slab_stride, int SK, float alpha) {
-  float a = p[0];
-  for (int z = 1; z < SK; ++z) a += p[z * slab_stride];
+  float v[SK_MAX];
+#pragma unroll
+  for (int z = 0; z < SK_MAX; ++z) v[z] = p[min(z, SK - 1) * slab_stride];
+  float a = v[0];
+#pragma unroll
+  for (int z = 1; z < SK_MAX; ++z) a += (z < SK) ? v[z] : 0.f;
   return __fmul_rn(alpha, a);
 }
 
@@ -138,32 +156,45 @@ __global__ __launch_bounds__(256) void small_stats_kernel(const float* __restric
   const float* base = (cols ? slabT : slab) + static_cast<int64_t>(row) * ld;
   const int64_t ss = static_cast<int64_t>(R) * ld;
   float mx = -INFINITY, l = 0.f;
-  if (C <= 512) {  // values stay in registers
-    float v[8];
+  if (C <= 256) {  // values stay in registers; chunks past C are skipped wave-uniformly
+    float v[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int c = lane + 64 * i;
-      v[i] = (c < C) ? slab_s(base + c, ss, SK, alpha) : -INFINITY;
+    for (int i = 0; i < 4; ++i) {
+      v[i] = -INFINITY;
+      if (64 * i < C) {
+        const int c = lane + 64 * i;
+        const float sv = slab_s(base + min(c, C - 1), ss, SK, alpha);
+        if (c < C) {
+          v[i] = sv;
+          if (!cols) {
+            S[static_cast<int64_t>(row) * ldS + c] = sv;
+            if (static_cast<int64_t>(c) == diag_offset + row) diag[row] = sv;
+          }
+        }
+      }
       mx = fmaxf(mx, v[i]);
-      if (!cols && c < C) {
-        S[static_cast<int64_t>(row) * ldS + c] = v[i];
-        if (static_cast<int64_t>(c) == diag_offset + row) diag[row] = v[i];
-      }
     }
     mx = wave_max(mx);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) l += fast_exp(v[i] - mx);  // exp(-inf) = 0 for the padding
+    for (int i = 0; i < 4; ++i) l += fast_exp(v[i] - mx);  // exp(-inf) = 0 for the padding
   } else {
-    for (int c = lane; c < C; c += 64) {
-      const float s = slab_s(base + c, ss, SK, alpha);
-      mx = fmaxf(mx, s);
-      if (!cols) {
-        S[static_cast<int64_t>(row) * ldS + c] = s;
-        if (static_cast<int64_t>(c) == diag_offset + row) diag[row] = s;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+      const int c = c0 + lane;
+      const float sv = slab_s(base + min(c, C - 1), ss, SK, alpha);
+      if (c < C) {
+        mx = fmaxf(mx, sv);
+        if (!cols) {
+          S[static_cast<int64_t>(row) * ldS + c] = sv;
+          if (static_cast<int64_t>(c) == diag_offset + row) diag[row] = sv;
+        }
       }
     }
     mx = wave_max(mx);
-    for (int c = lane; c < C; c += 64) l += fast_exp(slab_s(base + c, ss, SK, alpha) - mx);
+    for (int c0 = 0; c0 < C; c0 += 64) {
+      const int c = c0 + lane;
+      const float sv = slab_s(base + min(c, C - 1), ss, SK, alpha);
+      if (c < C) l += fast_exp(sv - mx);
+    }
   }
   l = wave_sum(l);
   if (lane == 0) (cols ? col_lse : row_lse)[row] = mx + __logf(l);
@@ -180,6 +211,11 @@ __global__ __launch_bounds__(256) void small_stats_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------------
 constexpr int GK = 256;
 
+// All loads below are UNCONDITIONAL with clamped indices (a predicated load compiles to a branch plus
+// s_waitcnt vmcnt(0), which serialises what should be one batch in flight); out-of-range entries are zeroed by
+// value.  Vocabulary: "row" = one of the 32 output rows of this workgroup, "k" = contraction index.
+//   dir 0: row = i (query), k = j (passage), S element S[row][k], diag at k == off + row
+//   dir 1: row = j (passage), k = i (query),  S element S[k][row], diag at k == row - off
 __global__ __launch_bounds__(256) void small_grad_kernel(const float* __restrict__ S, int64_t ldS,
                                                          const float* __restrict__ A, const float* __restrict__ Bm,
                                                          int m, int n, int D, float alpha, int64_t diag_offset,
@@ -188,85 +224,96 @@ __global__ __launch_bounds__(256) void small_grad_kernel(const float* __restrict
                                                          float* __restrict__ dA, float* __restrict__ dB, int dir0) {
   __shared__ float Ds[GK * RED_STRIDE];
   __shared__ float red[4 * 32 * RED_STRIDE];
+  __shared__ float rowc_s[32], rowl_s[32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int dir = dir0 + blockIdx.z;
   const int R = dir ? n : m, Kd = dir ? m : n;
   const int r0 = blockIdx.x * 32, d0 = blockIdx.y * 32;
   if (r0 >= R) return;
-  const float* X = dir ? A : Bm;
+  const float* X = dir ? A : Bm;                      // the other operand, [Kd, D]
+  const float* rowc = dir ? cc : rc; const float* rowl = dir ? cl : rl;
+  const float* kc = dir ? rc : cc;   const float* kl = dir ? rl : cl;
   float* out = dir ? dB : dA;
-  const int dcol = d0 + l31;
-  const bool dok = dcol < D;
+  const int dcol = min(d0 + l31, D - 1);
+  const int64_t doff = dir ? -diag_offset : diag_offset;   // diag at k == row + doff
 
+  if (tid < 32) {
+    const int r = min(r0 + tid, R - 1);
+    rowc_s[tid] = rowc[r];
+    rowl_s[tid] = rowl[r];
+  }
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
   for (int k0 = 0; k0 < Kd; k0 += GK) {
     const int kn = min(GK, Kd - k0);
-    // ---- build the dS strip: Ds[kk][r] = dS(row r0 + r, contraction index k0 + kk) ----
-    if (dir == 0) {
-      const int j = k0 + tid;  // this thread's column of S for all 32 rows
-      const bool jok = tid < kn;
-      const float ccj = jok ? cc[j] : 0.f, clj = jok ? cl[j] : 0.f;
-#pragma unroll 4
-      for (int r = 0; r < 32; ++r) {
-        const int i = r0 + r;
-        float d = 0.f;
-        if (jok && i < m) {
-          const float s = S[static_cast<int64_t>(i) * ldS + j];
-          const float rci = rc[i];
-          d = rci * fast_exp(s - rl[i]) + ccj * fast_exp(s - clj);
-          if (static_cast<int64_t>(j) == diag_offset + i) d -= (rci + ccj);
-        }
-        Ds[tid * RED_STRIDE + r] = d;
-      }
-    } else {
-      const int r = tid & 31, j = r0 + r;
-      const bool jok = j < n;
-      const float ccj = jok ? cc[j] : 0.f, clj = jok ? cl[j] : 0.f;
-#pragma unroll 4
-      for (int q = 0; q < 32; ++q) {
-        const int kk = (tid >> 5) + 8 * q, i = k0 + kk;
-        float d = 0.f;
-        if (jok && kk < kn) {
-          const float s = S[static_cast<int64_t>(i) * ldS + j];
-          const float rci = rc[i];
-          d = rci * fast_exp(s - rl[i]) + ccj * fast_exp(s - clj);
-          if (static_cast<int64_t>(j) == diag_offset + i) d -= (rci + ccj);
-        }
-        Ds[kk * RED_STRIDE + r] = d;
-      }
-    }
-    __syncthreads();
-    // ---- MFMA over this wave's quarter of the chunk, 8 two-wide steps per round ----
-    const int ns = (kn + 1) >> 1;          // two-wide steps in the chunk
+    const int ns = (kn + 1) >> 1;          // two-wide MFMA steps in the chunk
     const int per = (ns + 3) >> 2;
     const int s_lo = wave * per, s_hi = min(ns, s_lo + per);
+    // first batch of the other operand's fragments: independent of dS, issued before the strip is built
     float bv[8], bn[8];
     auto load8 = [&](float (&dst)[8], int s0) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int kk = 2 * (s0 + u) + lhi;
-        dst[u] = (s0 + u < s_hi && kk < kn && dok) ? X[static_cast<int64_t>(k0 + kk) * D + dcol] : 0.f;
+        const int kk = min(k0 + 2 * (s0 + u) + lhi, Kd - 1);
+        dst[u] = X[static_cast<int64_t>(kk) * D + dcol];
       }
     };
-    if (s_lo < s_hi) load8(bv, s_lo);
+    load8(bv, s_lo);
+    // ---- build the dS strip: Ds[kk][r] = dS(row r0 + r, k0 + kk), 32 S values per thread in flight ----
+    float sv[32];
+    if (dir == 0) {
+      const int k = min(k0 + tid, Kd - 1);            // this thread's k for all 32 rows
+#pragma unroll
+      for (int r = 0; r < 32; ++r) sv[r] = S[static_cast<int64_t>(min(r0 + r, R - 1)) * ldS + k];
+      const float kcv = kc[k], klv = kl[k];
+      __syncthreads();                                 // rowc_s / rowl_s visible (and Ds free: see loop end)
+#pragma unroll
+      for (int r = 0; r < 32; ++r) {
+        const float rcv = rowc_s[r];
+        float d = rcv * fast_exp(sv[r] - rowl_s[r]) + kcv * fast_exp(sv[r] - klv);
+        if (static_cast<int64_t>(k0 + tid) == r0 + r + doff) d -= (rcv + kcv);
+        Ds[tid * RED_STRIDE + r] = (tid < kn && r0 + r < R) ? d : 0.f;
+      }
+    } else {
+      const int r = tid & 31, kq = tid >> 5;
+      const int row = min(r0 + r, R - 1);
+      float kcv[32], klv[32];
+#pragma unroll
+      for (int q = 0; q < 32; ++q) {
+        const int k = min(k0 + kq + 8 * q, Kd - 1);
+        sv[q] = S[static_cast<int64_t>(k) * ldS + row];
+        kcv[q] = kc[k];
+        klv[q] = kl[k];
+      }
+      __syncthreads();
+      const float rcv = rowc_s[r], rlv = rowl_s[r];
+#pragma unroll
+      for (int q = 0; q < 32; ++q) {
+        const int kk = kq + 8 * q;
+        float d = rcv * fast_exp(sv[q] - rlv) + kcv[q] * fast_exp(sv[q] - klv[q]);
+        if (static_cast<int64_t>(k0 + kk) == r0 + r + doff) d -= (rcv + kcv[q]);
+        Ds[kk * RED_STRIDE + r] = (kk < kn && r0 + r < R) ? d : 0.f;
+      }
+    }
+    __syncthreads();
+    // ---- MFMA over this wave's quarter of the chunk, 8 two-wide steps per round, next round prefetched ----
     for (int s0 = s_lo; s0 < s_hi; s0 += 8) {
       if (s0 + 8 < s_hi) load8(bn, s0 + 8);
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         if (s0 + u < s_hi) {  // wave-uniform
-          const int kk = 2 * (s0 + u) + lhi;
-          const float a = (kk < kn) ? Ds[kk * RED_STRIDE + l31] : 0.f;
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[u], acc, 0, 0, 0);
+          const int kk = min(2 * (s0 + u) + lhi, GK - 1);   // entries at kk >= kn are 0
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ds[kk * RED_STRIDE + l31], bv[u], acc, 0, 0, 0);
         }
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) bv[u] = bn[u];
     }
-    __syncthreads();  // Ds is rebuilt by the next chunk
+    // the barrier after the next chunk's loads (or the one below) orders these Ds reads before its rewrite
   }
+  __syncthreads();
   stash_acc(red, acc, wave, l31, lhi);
   __syncthreads();
 #pragma unroll
@@ -313,7 +360,7 @@ inline SmallPlan small_plan(int64_t m, int64_t n, int64_t D) {
   const int64_t tiles = ((m + 31) / 32) * ((n + 31) / 32);
   int64_t sk = (256 + tiles - 1) / tiles;
   const int64_t sk_max = (D + 31) / 32;        // every workgroup gets at least 32 of K (8 per wave)
-  if (sk > 16) sk = 16;
+  if (sk > SK_MAX) sk = SK_MAX;
   if (sk > sk_max) sk = sk_max;
   if (sk < 1) sk = 1;
   const int64_t k_chunk = round_up((D + sk - 1) / sk, 32);
@@ -357,10 +404,15 @@ extern "C" int dalm_sim_small_fwd(const float* A, const float* Bm, int64_t m, in
   float* slab = static_cast<float*>(ws);
   float* slabT = want_cols ? slab + static_cast<size_t>(pl.sk) * m * pl.ldn : nullptr;
   const int tiles_m = static_cast<int>((m + 31) / 32), tiles_n = static_cast<int>((n + 31) / 32);
-  hipLaunchKernelGGL(small_partial_kernel, dim3(static_cast<unsigned>(tiles_m * tiles_n), static_cast<unsigned>(pl.sk)),
-                     dim3(256), 0, s, A, Bm, static_cast<int>(m), static_cast<int>(n), static_cast<int>(D), pl.k_chunk,
-                     tiles_n, static_cast<int>(vec16(A, D)), static_cast<int>(vec16(Bm, D)), slab,
-                     static_cast<int>(pl.ldn), slabT, static_cast<int>(pl.ldm));
+  const dim3 pgrid(static_cast<unsigned>(tiles_m * tiles_n), static_cast<unsigned>(pl.sk));
+  if (vec16(A, D) && vec16(Bm, D) && D % 8 == 0)
+    hipLaunchKernelGGL(small_partial_kernel<true>, pgrid, dim3(256), 0, s, A, Bm, static_cast<int>(m),
+                       static_cast<int>(n), static_cast<int>(D), pl.k_chunk, tiles_n, 1, 1, slab,
+                       static_cast<int>(pl.ldn), slabT, static_cast<int>(pl.ldm));
+  else
+    hipLaunchKernelGGL(small_partial_kernel<false>, pgrid, dim3(256), 0, s, A, Bm, static_cast<int>(m),
+                       static_cast<int>(n), static_cast<int>(D), pl.k_chunk, tiles_n, static_cast<int>(vec16(A, D)),
+                       static_cast<int>(vec16(Bm, D)), slab, static_cast<int>(pl.ldn), slabT, static_cast<int>(pl.ldm));
   const int64_t rmax = want_cols ? (m > n ? m : n) : m;
   hipLaunchKernelGGL(small_stats_kernel, dim3(static_cast<unsigned>((rmax + 3) / 4), want_cols ? 2u : 1u), dim3(256), 0,
                      s, slab, static_cast<int>(pl.ldn), slabT, static_cast<int>(pl.ldm), pl.sk, static_cast<int>(m),

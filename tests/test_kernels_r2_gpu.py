@@ -28,7 +28,10 @@ def _problem(m, n, D, off, seed=None):
     g = torch.Generator().manual_seed(seed if seed is not None else m * 7 + n * 3 + D)
     A = torch.nn.functional.normalize(torch.randn(m, D, generator=g), dim=1)
     Bm = torch.nn.functional.normalize(torch.randn(n, D, generator=g), dim=1)
-    Bm[off:off + m] = torch.nn.functional.normalize(A + 0.3 * Bm[off:off + m], dim=1)   # positives stand out, as trained
+    # positives stand out (cos ~ 0.55 -> S_ii ~ 55 against ~N(0, 3) negatives), as after some training; the peaked
+    # softmax makes the diagonal term (p_ii - 1) a cancellation, which is where fp32 (ours AND the reference's) loses
+    # digits against this fp64 oracle - hence 5e-4 on the gradients below instead of the usual 1e-4
+    Bm[off:off + m] = torch.nn.functional.normalize(A + 1.5 * Bm[off:off + m], dim=1)
     scale = 100.0
     S = scale * (A.double() @ Bm.double().t())
     rc, cc = torch.rand(m, generator=g) / m, torch.rand(n, generator=g) / n
@@ -61,8 +64,8 @@ def test_small_path_vs_fp64(dev, m, n, D, off):
     assert none is None and torch.equal(row2, row_lse) and torch.equal(diag2, diag) and torch.equal(S2, Sg)
     args = (Sg, A.to(dev), Bm.to(dev), scale, off, rc.to(dev), rl.float().to(dev), cc.to(dev), cl.float().to(dev))
     dA, dB = ops.sim_small_bwd(*args, True, True)
-    assert_grad_close(dA, scale * (dS @ Bm.double()), 2e-4, "dA")
-    assert_grad_close(dB, scale * (dS.t() @ A.double()), 2e-4, "dB")
+    assert_grad_close(dA, scale * (dS @ Bm.double()), 5e-4, "dA")
+    assert_grad_close(dB, scale * (dS.t() @ A.double()), 5e-4, "dB")
     dA1, n1 = ops.sim_small_bwd(*args, True, False)
     n2, dB1 = ops.sim_small_bwd(*args, False, True)
     assert n1 is None and n2 is None and torch.equal(dA1, dA) and torch.equal(dB1, dB)
@@ -101,7 +104,7 @@ def test_flash_grad_vs_fp64(dev, m, n, D, off):
     ws = hip.load().dalm_sim_grad_workspace_bytes(m, n, D)
     assert ws <= max(16, 1024 * D * 4 * 32), ws   # bounded by ~1k row blocks' worth of partial outputs, never m*n
     got = ops.sim_grad(A.to(dev), Bm.to(dev), scale, off, rc.to(dev), rl.float().to(dev), cc.to(dev), cl.float().to(dev))
-    assert_grad_close(got, scale * (dS @ Bm.double()), 2e-4, "dA")
+    assert_grad_close(got, scale * (dS @ Bm.double()), 5e-4, "dA")
     got2 = ops.sim_grad(A.to(dev), Bm.to(dev), scale, off, rc.to(dev), rl.float().to(dev), cc.to(dev), cl.float().to(dev))
     assert torch.equal(got, got2)   # deterministic
 

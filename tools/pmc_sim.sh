@@ -15,7 +15,7 @@ def load(pat):
     for f in glob.glob(pat, recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].replace("(anonymous namespace)::", "")
-            if "gemm_f32_mfma" not in k: continue
+            if "gemm_f32_mfma" not in k and "sim_flash" not in k: continue
             k = re.sub(r"\(.*", "", k).replace("void ", "").replace("dalm::", "")
             grid = int(r["Grid_Size"]) // int(r["Workgroup_Size"])
             agg[(k, grid)][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -31,5 +31,6 @@ for name, pat in (("mfma", "gpurun_out/pmc_sim/mfma/**/*counter_collection.csv")
             line += f"  MFMA busy/(GUI_ACTIVE*1024 SIMDs)={busy/(act*1024):.3f}"
         print(line)
 PY
-f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1); python tools/summarize_rocprof.py "$f" 12 | head -20
+t=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
+python tools/summarize_trace.py "$t" "gemm_f32|flash|rowstats|splitk" 40 > $OUT/per_shape.txt; cat $OUT/per_shape.txt
 find $OUT -name "*kernel_trace.csv" -delete
