@@ -370,42 +370,66 @@ __global__ __launch_bounds__(256) void contrastive_finalize_kernel(const float* 
 // ---------------------------------------------------------------------------------------------------
 // Flash-style backward: dA[m,D] = alpha * dS[m,n] . B[n,D] with dS rebuilt tile by tile - no m x n panel in HBM.
 // A workgroup owns 32 rows of A and ALL D output columns (accumulators: 32 x D f32 = NT 32x32 MFMA tiles per
-// wave, 4 waves side by side over D <= 1024) and walks its share of the column blocks of B, 128 columns at a time:
-//   S phase   S[32 x 128] = A_blk . B_blk^T over K = D, the LDS-staged K loop of gemm_f32_mfma_kernel
-//             (same k order => the same S bits the row statistics saw); each wave one 32x32 tile
+// wave, 4 waves side by side, D = 128*NT <= 1024) and walks its share of the column blocks of B, 128 columns at
+// a time.  The f32 MFMA issues once per 64 cycles per SIMD - slow enough that L2/L1 can feed it DIRECTLY:
+//   S phase   wave w: S[32 x 32] = A_blk . B_cols^T over K = D, both fragments read straight from k-major copies
+//             At[D][m'] / Bt[D][n'] (lane (c,h) reads Xt[2s+h][x0+c]: full 128-byte rows), 16 steps prefetched in
+//             registers; no LDS staging, no barrier, k ascending => the same S bits the row statistics saw
 //   transform dS = rc_i e^{S-rl_i} + cc_j e^{S-cl_j} - [diag](rc_i + cc_j) in registers -> LDS, k-major
 //   dA phase  acc[32 x D] += dS[32 x 128] . B_blk[128 x D]: A-fragments from the dS tile in LDS, B-fragments
-//             straight from global memory (lane (c,h) reads B[j+h][d+c]: full 128-byte rows, L2-resident because the
-//             S phase has just streamed the block), two steps prefetched in registers; no barrier in this phase
-// Both phases issue 512 MFMAs per wave per block at D = 1024.  Column blocks are split over `nsplit` workgroups
-// when m/32 row blocks cannot fill the chip; those write raw partial outputs and flash_reduce_kernel sums them in
-// fixed order (workspace nsplit*m*D floats, bounded by ~512 row blocks worth, never m*n).
+//             straight from the row-major B (lane (c,h) reads B[j+h][d+c]), 4 steps prefetched
+// Two barriers per block (around the dS tile); both phases issue 512 MFMAs per wave per block at D = 1024.
+// The k-major copies are made once per call by transpose_pad_kernel (zero-padded to the tile grid, so the hot
+// loops carry no bounds checks).  Column blocks are split over `nsplit` workgroups when m/32 row blocks cannot
+// fill the chip; those write raw partial outputs and flash_reduce_kernel sums them in fixed order.
+// Workspace: (m' + n') * D floats for the copies + nsplit*m*D for the partials - never m*n.
 // MFMA-bound: 4*m*n*D flop per launch against the 157 TF f32-matrix peak.
 // ---------------------------------------------------------------------------------------------------
 struct FlashParams {
-  const float* A; const float* B;
-  int m, n, D;
+  const float* At; const float* Bt; const float* B;   // At [D][ldm], Bt [D][ldn] (zero-padded), B [n][D]
+  int m, n, D, ldm, ldn;
   float alpha;
-  int a_vec, b_vec;
   int64_t diag_offset;
   const float* row_coef; const float* row_lse; const float* col_coef; const float* col_lse;
   float* out;            // dA (nsplit == 1) or slabs [nsplit][m][D]
   int row_blocks, nsplit, blocks_per_split;
+  int debug_hot;         // timing experiment only (DALM_FLASH_DEBUG=1): every step re-reads the same cached rows
 };
 
-constexpr int FBM = 32, FBN = 128, FBK = 32;
+constexpr int FBM = 32, FBN = 128;
+
+// X [R][K] row-major -> Xt [K][ld] with Xt[k][r] = X[r][k] for r < R, 0 for R <= r < ld.  32x32 tiles through
+// LDS; grid (ld/32, ceil(K/32), 2): blockIdx.z selects (X0 -> Xt0) or (X1 -> Xt1) so both operands go in one launch.
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ X0, int R0, int ld0,
+                                                            float* __restrict__ Xt0, const float* __restrict__ X1,
+                                                            int R1, int ld1, float* __restrict__ Xt1, int K) {
+  __shared__ float tile[32][33];
+  const bool second = blockIdx.z != 0;
+  const float* X = second ? X1 : X0;
+  float* Xt = second ? Xt1 : Xt0;
+  const int R = second ? R1 : R0, ld = second ? ld1 : ld0;
+  const int r0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+  if (r0 >= ld) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = r0 + ty + 8 * q, k = k0 + tx;
+    tile[ty + 8 * q][tx] = (r < R && k < K) ? X[static_cast<int64_t>(r) * K + k] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int k = k0 + ty + 8 * q, r = r0 + tx;
+    if (k < K) Xt[static_cast<int64_t>(k) * ld + r] = tile[tx][ty + 8 * q];
+  }
+}
 
 template <int NT>
 __global__ __launch_bounds__(256, 2) void sim_flash_grad_kernel(const FlashParams p) {
-  using SA = Stage<FBM, FBK, true>;
-  using SB = Stage<FBN, FBK, true>;
   constexpr int DS_STRIDE = FBM + 1;
-  __shared__ __attribute__((aligned(16))) float lds[FBK * SA::STRIDE + FBK * SB::STRIDE + FBN * DS_STRIDE + 2 * FBM];
-  float* As = lds;
-  float* Bs = As + FBK * SA::STRIDE;
-  float* Ds = Bs + FBK * SB::STRIDE;
-  float* rc_s = Ds + FBN * DS_STRIDE;
-  float* rl_s = rc_s + FBM;
+  constexpr int SG = 8;    // S-phase steps per prefetch group (2 dwords each)
+  __shared__ float Ds[FBN * DS_STRIDE];
+  __shared__ float rc_s[FBM], rl_s[FBM];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int rb = static_cast<int>(blockIdx.x) % p.row_blocks, z = static_cast<int>(blockIdx.x) / p.row_blocks;
@@ -415,9 +439,9 @@ __global__ __launch_bounds__(256, 2) void sim_flash_grad_kernel(const FlashParam
   const int jb_lo = z * p.blocks_per_split, jb_hi = min(nblocks, jb_lo + p.blocks_per_split);
 
   if (tid < FBM) {
-    const bool ok = i0 + tid < p.m;
-    rc_s[tid] = ok ? p.row_coef[i0 + tid] : 0.f;
-    rl_s[tid] = ok ? p.row_lse[i0 + tid] : 0.f;
+    const int r = min(i0 + tid, p.m - 1);
+    rc_s[tid] = p.row_coef[r];
+    rl_s[tid] = p.row_lse[r];
   }
 
   f32x16 acc[NT];
@@ -426,68 +450,102 @@ __global__ __launch_bounds__(256, 2) void sim_flash_grad_kernel(const FlashParam
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  SA sa; SB sb;
-  const int nk = (p.D + FBK - 1) / FBK;
+  const int nsteps = p.D / 2;                       // D = 128 * NT: a multiple of 2 * SG
+  // every load below is (wave-uniform row pointer) + (per-lane 32-bit offset): SGPR-base addressing, so a
+  // prefetch group of 32 loads does not hold 32 64-bit VGPR addresses
+  // (buffer_load_dword v, v_off, s[rsrc], s_off offen: the compiler otherwise materialises one 64-bit VGPR address
+  // per load and spills)
+  const __amdgpu_buffer_rsrc_t at_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.At), 0, p.D * p.ldm * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t bt_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Bt), 0, p.D * p.ldn * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, p.n * p.D * 4, 0x00020000);
+  const int a_off = (lhi * p.ldm + i0 + l31) * 4;                       // bytes
+  const int a_step = p.debug_hot ? 0 : 2 * p.ldm * 4, b_step = p.debug_hot ? 0 : 2 * p.ldn * 4;   // bytes per two-wide step
+  const int d_base = (c0 + l31) * 4;                                    // dA phase: column c0 + l31 (+ 32 t)
+
 #pragma unroll 1
   for (int jb = jb_lo; jb < jb_hi; ++jb) {
     const int j0 = jb * FBN;
-    // ---------------- S phase ----------------
-    f32x16 sacc;
+    const int col = j0 + wave * 32 + l31;
+    // ---------------- S phase: LDS-free, register double buffer of SG steps ----------------
+    f32x16 sacc;   // one chain, k ascending: the same S bits the row statistics saw (two chains measured no faster)
 #pragma unroll
     for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-    sa.load(p.A, p.D, i0, 0, p.m, p.D, p.a_vec);
-    sb.load(p.B, p.D, j0, 0, p.n, p.D, p.b_vec);
-    const int col = j0 + wave * 32 + l31;
-    const bool col_ok = col < p.n;
-    const float ccj = col_ok ? p.col_coef[col] : 0.f;
-    const float clj = col_ok ? p.col_lse[col] : 0.f;
-    sa.store(As); sb.store(Bs);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-      const bool more = (kt + 1 < nk);
-      if (more) {
-        sa.load(p.A, p.D, i0, (kt + 1) * FBK, p.m, p.D, p.a_vec);
-        sb.load(p.B, p.D, j0, (kt + 1) * FBK, p.n, p.D, p.b_vec);
-      }
-      const float* a_base = As + lhi * SA::STRIDE + l31;
-      const float* b_base = Bs + lhi * SB::STRIDE + wave * 32 + l31;
+    const int b_off = (lhi * p.ldn + col) * 4;
+    float fa0[SG], fb0[SG], fa1[SG], fb1[SG], fa2[SG], fb2[SG];
+    auto loads = [&](float (&fa)[SG], float (&fb)[SG], int g) {   // group g = steps [g*SG, (g+1)*SG)
 #pragma unroll
-      for (int kk = 0; kk < FBK; kk += 2)
-        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_base[kk * SA::STRIDE], b_base[kk * SB::STRIDE], sacc, 0, 0, 0);
-      __syncthreads();
-      if (more) {
-        sa.store(As); sb.store(Bs);
-        __syncthreads();
+      for (int u = 0; u < SG; ++u) {
+        fa[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(at_rs, a_off, (g * SG + u) * a_step, 0));
+        fb[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bt_rs, b_off, (g * SG + u) * b_step, 0));
       }
+    };
+    auto mfmas = [&](const float (&fa)[SG], const float (&fb)[SG]) {
+#pragma unroll
+      for (int u = 0; u < SG; ++u) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u], fb[u], sacc, 0, 0, 0);
+    };
+    // three register buffers in rotation: every group is requested two groups (16 MFMAs ~ 1000 cycles, about one
+    // L2 round trip under load) before it is consumed; with two buffers (512 cycles) a lone wave sat at 54 % MFMA
+    const int G = nsteps / SG;   // 8 * NT groups
+    loads(fa0, fb0, 0);
+    loads(fa1, fb1, 1);
+    const bool col_ok = col < p.n;
+    const int colc = min(col, p.n - 1);
+    const float ccj = p.col_coef[colc], clj = p.col_lse[colc];
+    // issue order: each MFMA is followed by two of the loads of a later group.  Left alone, hipcc emits the 16 loads
+    // of a group back to back (~10 issue cycles each) and the matrix pipe idles meanwhile - measured 58 % MFMA rate
+    // for a lone wave whether the loads hit the cache or not
+    auto interleave = [&]() {
+#pragma unroll
+      for (int u = 0; u < SG; ++u) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   // 2 VMEM reads
+      }
+    };
+    int g = 0;
+#pragma unroll 1
+    for (; g + 3 <= G; g += 3) {   // branch-free body: loads past the last group are clamped (re-read, unused)
+      loads(fa2, fb2, g + 2);
+      mfmas(fa0, fb0);
+      interleave();
+      loads(fa0, fb0, min(g + 3, G - 1));
+      mfmas(fa1, fb1);
+      interleave();
+      loads(fa1, fb1, min(g + 4, G - 1));
+      mfmas(fa2, fb2);
+      interleave();
     }
+    if (g < G) mfmas(fa0, fb0);
+    if (g + 1 < G) mfmas(fa1, fb1);
+    // first fragments of the dA phase: independent of dS, issued before the barrier
+    float b0[2][NT], b1[2][NT];
+    auto loadb = [&](float (&dst)[2][NT], int s0) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        // lane half h reads row j + h.  Rows past n are clamped onto row n-1 (uniformly: the row offset is an SGPR,
+        // and the h = 1 half drops its +1 when row j is the last one): their dS entries are exactly 0
+        const int ju = p.debug_hot ? 0 : min(j0 + 2 * (s0 + u), p.n - 1);
+        const int hstride = (ju + 1 < p.n) ? p.D * 4 : 0;
+        const int voff = d_base + lhi * hstride;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          dst[u][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rs, voff + 128 * t, ju * p.D * 4, 0));
+      }
+    };
+    loadb(b0, 0);
+    __syncthreads();   // previous block's dA phase has finished reading Ds (and rc_s/rl_s are visible)
     // ---------------- dS tile -> LDS (k-major: Ds[j_local][row]) ----------------
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int rl = (r & 3) + 8 * (r >> 2) + 4 * lhi;
       const int row = i0 + rl;
-      float d = 0.f;
-      if (col_ok && row < p.m) {
-        const float sv = __fmul_rn(p.alpha, sacc[r]);
-        const float rci = rc_s[rl];
-        d = rci * fast_exp(sv - rl_s[rl]) + ccj * fast_exp(sv - clj);
-        if (static_cast<int64_t>(col) == p.diag_offset + row) d -= (rci + ccj);
-      }
-      Ds[(wave * 32 + l31) * DS_STRIDE + rl] = d;
+      const float sv = __fmul_rn(p.alpha, sacc[r]);
+      const float rci = rc_s[rl];
+      float d = rci * fast_exp(sv - rl_s[rl]) + ccj * fast_exp(sv - clj);
+      if (static_cast<int64_t>(col) == p.diag_offset + row) d -= (rci + ccj);
+      Ds[(wave * 32 + l31) * DS_STRIDE + rl] = (col_ok && row < p.m) ? d : 0.f;
     }
     __syncthreads();
     // ---------------- dA phase ----------------
-    // unconditional loads (a predicated load becomes a branch and forces s_waitcnt vmcnt(0), which would kill the
-    // prefetch): rows beyond n are clamped to n-1 - their dS entries are exactly 0 - and D == 128*NT on this path
-    const float* bcol = p.B + c0 + l31;
-    auto loadb = [&](float (&dst)[2][NT], int s0) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int jr = min(j0 + 2 * (s0 + u) + lhi, p.n - 1);
-        const float* src = bcol + static_cast<int64_t>(jr) * p.D;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) dst[u][t] = src[32 * t];
-      }
-    };
     auto compute = [&](const float (&src)[2][NT], int s0) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -496,16 +554,22 @@ __global__ __launch_bounds__(256, 2) void sim_flash_grad_kernel(const FlashParam
         for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, src[u][t], acc[t], 0, 0, 0);
       }
     };
-    float b0[2][NT], b1[2][NT];
-    loadb(b0, 0);
+    auto interleave_da = [&]() {
+#pragma unroll
+      for (int u = 0; u < 2 * NT; ++u) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+      }
+    };
 #pragma unroll 1
-    for (int s0 = 0; s0 < FBN / 2; s0 += 4) {
+    for (int s0 = 0; s0 < FBN / 2; s0 += 4) {   // branch-free: the load past the last step is clamped (unused)
       loadb(b1, s0 + 2);
       compute(b0, s0);
-      if (s0 + 4 < FBN / 2) loadb(b0, s0 + 4);
+      interleave_da();
+      loadb(b0, min(s0 + 4, FBN / 2 - 2));
       compute(b1, s0 + 2);
+      interleave_da();
     }
-    // the next block's S phase has barriers before Ds is rewritten
   }
 
   float* out = p.out + (p.nsplit > 1 ? static_cast<int64_t>(z) * p.m * p.D : 0);
@@ -533,21 +597,39 @@ __global__ __launch_bounds__(256) void flash_reduce_kernel(const float4* __restr
   }
 }
 
-struct FlashPlan { bool ok; int nt, row_blocks, nsplit, blocks_per_split; };
+struct FlashPlan { bool ok; int nt, row_blocks, nsplit, blocks_per_split; int64_t ldm, ldn; };
 inline FlashPlan flash_plan(int64_t m, int64_t n, int64_t D) {
-  FlashPlan f{false, 0, 0, 1, 0};
+  FlashPlan f{false, 0, 0, 1, 0, 0, 0};
   if (D > 1024 || D % 128 != 0) return f;        // accumulators hold 32 x D per workgroup, D = 128 * NT
+  if ((n + 128) * D * 4 >= (1ll << 31) || (m + 32) * D * 4 >= (1ll << 31)) return f;   // 32-bit buffer offsets
   f.nt = static_cast<int>(D / 128);
   f.row_blocks = static_cast<int>((m + FBM - 1) / FBM);
   const int64_t col_blocks = (n + FBN - 1) / FBN;
-  int64_t ns = (512 + f.row_blocks - 1) / f.row_blocks;   // aim at 2 workgroups per CU
-  if (ns > col_blocks) ns = col_blocks;
-  if (ns < 1) ns = 1;
-  f.blocks_per_split = static_cast<int>((col_blocks + ns - 1) / ns);
-  f.nsplit = static_cast<int>((col_blocks + f.blocks_per_split - 1) / f.blocks_per_split);
+  // Column split: cost model fitted to MI355X timings (us).  One workgroup alone on a CU retires a 128-column
+  // block in ~38 us (+ ~5 us of fill/drain), two co-resident ones a pair of blocks in ~66 us (+ ~15 us): two per CU
+  // wins in steady state (4096^2: 4 splits), one per CU wins when a workgroup only has a block or two
+  // (1200^2: 5 splits -> 190 workgroups instead of 10 -> 380 on 256 CUs).  Partial-output traffic is charged at 4 TB/s.
+  double best = 1e30;
+  int64_t best_ns = 1;
+  for (int64_t ns = 1; ns <= col_blocks && ns <= 64; ++ns) {
+    const int64_t bps = (col_blocks + ns - 1) / ns;
+    const int64_t real_ns = (col_blocks + bps - 1) / bps;
+    if (real_ns != ns) continue;
+    const int64_t W = static_cast<int64_t>(f.row_blocks) * ns;
+    double t;
+    if (W <= 256) t = 5.0 + 38.0 * bps;
+    else t = 15.0 + 66.0 * bps * ((W + 511) / 512);
+    if (ns > 1) t += static_cast<double>(ns) * m * D * 8.0 / 4.0e6;
+    if (t < best) { best = t; best_ns = ns; }
+  }
+  f.blocks_per_split = static_cast<int>((col_blocks + best_ns - 1) / best_ns);
+  f.nsplit = static_cast<int>(best_ns);
+  f.ldm = static_cast<int64_t>(f.row_blocks) * FBM;
+  f.ldn = col_blocks * FBN;
   f.ok = true;
   return f;
 }
+inline size_t flash_copy_floats(const FlashPlan& f, int64_t D) { return static_cast<size_t>(D) * (f.ldm + f.ldn); }
 
 inline bool vec_ok(const float* p, int64_t ld) {
   return (reinterpret_cast<uintptr_t>(p) % 16 == 0) && (ld % 4 == 0);
@@ -680,8 +762,8 @@ static bool use_flash_grad(int64_t m, int64_t n, int64_t D) {
 extern "C" size_t dalm_sim_grad_workspace_bytes(int64_t m, int64_t n, int64_t D) {
   if (m <= 0 || n <= 0) return 0;
   if (use_flash_grad(m, n, D)) {
-    const FlashPlan f = flash_plan(m, n, D);
-    return f.nsplit > 1 ? static_cast<size_t>(f.nsplit) * m * D * sizeof(float) : 16;
+    const FlashPlan f = flash_plan(m, n, D);   // k-major operand copies (+ per-split partial outputs)
+    return (flash_copy_floats(f, D) + (f.nsplit > 1 ? static_cast<size_t>(f.nsplit) * m * D : 0)) * sizeof(float);
   }
   const size_t panel = static_cast<size_t>(m) * static_cast<size_t>(round_up4(n)) * sizeof(float);
   const int sk = sim_splitk(m, n, D);
@@ -707,12 +789,21 @@ extern "C" int dalm_sim_grad(const float* A, const float* Bm, int64_t m, int64_t
   if (use_flash_grad(m, n, D)) {
     DALM_REQUIRE(reinterpret_cast<uintptr_t>(dA) % 16 == 0, DALM_E_ALIGN, "dA must be 16-byte aligned");
     const FlashPlan f = flash_plan(m, n, D);
+    float* At = static_cast<float*>(ws);
+    float* Bt = At + static_cast<size_t>(D) * f.ldm;
+    float* slabs = Bt + static_cast<size_t>(D) * f.ldn;
+    const int64_t ldmax = f.ldm > f.ldn ? f.ldm : f.ldn;
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3(static_cast<unsigned>(ldmax / 32), static_cast<unsigned>((D + 31) / 32), 2),
+                       dim3(256), 0, s, A, static_cast<int>(m), static_cast<int>(f.ldm), At, Bm, static_cast<int>(n),
+                       static_cast<int>(f.ldn), Bt, static_cast<int>(D));
     FlashParams p{};
-    p.A = A; p.B = Bm; p.m = static_cast<int>(m); p.n = static_cast<int>(n); p.D = static_cast<int>(D);
-    p.alpha = scale; p.a_vec = vec_ok(A, D); p.b_vec = vec_ok(Bm, D); p.diag_offset = diag_offset;
+    p.At = At; p.Bt = Bt; p.B = Bm; p.m = static_cast<int>(m); p.n = static_cast<int>(n); p.D = static_cast<int>(D);
+    p.ldm = static_cast<int>(f.ldm); p.ldn = static_cast<int>(f.ldn);
+    p.alpha = scale; p.diag_offset = diag_offset;
     p.row_coef = row_coef; p.row_lse = row_lse; p.col_coef = col_coef; p.col_lse = col_lse;
-    p.out = f.nsplit > 1 ? static_cast<float*>(ws) : dA;
+    p.out = f.nsplit > 1 ? slabs : dA;
     p.row_blocks = f.row_blocks; p.nsplit = f.nsplit; p.blocks_per_split = f.blocks_per_split;
+    p.debug_hot = getenv("DALM_FLASH_DEBUG") ? 1 : 0;
     switch (f.nt) {
       case 1: launch_flash<1>(p, s); break;
       case 2: launch_flash<2>(p, s); break;
@@ -728,7 +819,7 @@ extern "C" int dalm_sim_grad(const float* A, const float* Bm, int64_t m, int64_t
       int64_t blocks = (n4 + 255) / 256;
       if (blocks > 2048) blocks = 2048;
       hipLaunchKernelGGL(flash_reduce_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s,
-                         static_cast<const float4*>(ws), f.nsplit, n4, scale, reinterpret_cast<float4*>(dA));
+                         reinterpret_cast<const float4*>(slabs), f.nsplit, n4, scale, reinterpret_cast<float4*>(dA));
     }
     return check_launch(__func__);
   }

@@ -89,7 +89,8 @@ def test_small_path_limits_and_errors(dev):
 
 
 FLASH = [(1200, 1200, 1024, 0), (150, 1200, 1024, 450), (4096, 4096, 1024, 0), (700, 2304, 128, 1000),
-         (1536, 1536, 256, 0), (333, 5000, 384, 77), (2100, 2100, 768, 0), (40, 130, 512, 3)]
+         (1536, 1536, 256, 0), (333, 5000, 384, 77), (2100, 2100, 768, 0), (40, 130, 512, 3), (19, 19, 384, 0),
+         (1, 1, 128, 0), (33, 257, 640, 100), (129, 129, 896, 0)]
 
 
 @pytest.mark.parametrize("m,n,D,off", FLASH)
@@ -102,7 +103,7 @@ def test_flash_grad_vs_fp64(dev, m, n, D, off):
     ops = default_ops()
     A, Bm, scale, S, rc, rl, cc, cl, dS = _problem(m, n, D, off)
     ws = hip.load().dalm_sim_grad_workspace_bytes(m, n, D)
-    assert ws <= max(16, 1024 * D * 4 * 32), ws   # bounded by ~1k row blocks' worth of partial outputs, never m*n
+    assert ws <= (m + n + 160 + 1024 * 32) * D * 4, ws   # operand copies + <= ~1k row blocks of partial outputs, never m*n
     got = ops.sim_grad(A.to(dev), Bm.to(dev), scale, off, rc.to(dev), rl.float().to(dev), cc.to(dev), cl.float().to(dev))
     assert_grad_close(got, scale * (dS @ Bm.double()), 5e-4, "dA")
     got2 = ops.sim_grad(A.to(dev), Bm.to(dev), scale, off, rc.to(dev), rl.float().to(dev), cc.to(dev), cl.float().to(dev))
@@ -110,12 +111,15 @@ def test_flash_grad_vs_fp64(dev, m, n, D, off):
 
 
 def test_flash_workspace_is_not_m_times_n():
+    """k-major operand copies ((m' + n') * D floats - the size of the inputs) + per-split partial outputs (bounded by
+    ~512 row blocks' worth); nothing proportional to m * n."""
     from dalm_amd import hip
 
     lib = hip.load()
-    assert lib.dalm_sim_grad_workspace_bytes(65536, 65536, 1024) == 16            # 2048 row blocks: no split at all
-    assert lib.dalm_sim_grad_workspace_bytes(16384, 16384, 1024) == 16
-    assert lib.dalm_sim_grad_workspace_bytes(4096, 4096, 1024) == 4 * 4096 * 1024 * 4
+    copies = lambda m, n, D: (-(-m // 32) * 32 + -(-n // 128) * 128) * D * 4
+    assert lib.dalm_sim_grad_workspace_bytes(65536, 65536, 1024) == copies(65536, 65536, 1024)   # 2048 row blocks: no split
+    assert lib.dalm_sim_grad_workspace_bytes(16384, 16384, 1024) == copies(16384, 16384, 1024)
+    assert lib.dalm_sim_grad_workspace_bytes(4096, 4096, 1024) <= copies(4096, 4096, 1024) + 8 * 4096 * 1024 * 4
     assert lib.dalm_sim_grad_workspace_bytes(4096, 4096, 1000) > 4096 * 4096 * 4 - 1   # odd D keeps the panel form
 
 
