@@ -31,7 +31,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-import dalm_amd  # noqa: E402,F401  (sets GPU_MAX_HW_QUEUES before the HIP runtime starts - see dalm_amd/__init__.py)
+import dalm_amd  # noqa: E402,F401
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
@@ -40,28 +40,36 @@ A100_README_PAIRS_PER_S = 200000.0 / (7 * 3600.0)  # reference README.md:34-40 (
 CFG = dict(B=18, Tq=50, Tp=128, Tg=256, D=1024, V=32000, logit_scale=100)
 
 
-def build_models(device, dtype, bert_layers=24, llama_layers=32, lora=True):
-    from transformers import BertConfig, BertModel, LlamaConfig, LlamaForCausalLM
+GENERATORS = {
+    # name -> (config factory, vocabulary).  Defaults of the HF configs == the published 7B architectures.
+    "llama-2-7b": (lambda layers: __import__("transformers").LlamaConfig(num_hidden_layers=layers), 32000),
+    "falcon-7b": (lambda layers: __import__("transformers").FalconConfig(num_hidden_layers=layers, hidden_dropout=0.0,
+                                                                          attention_dropout=0.0), 65024),
+}
+
+
+def build_models(device, dtype, bert_layers=24, llama_layers=32, lora=True, generator="llama-2-7b"):
+    from transformers import AutoModelForCausalLM, BertConfig, BertModel
 
     from dalm_amd.models import AutoModelForRagE2E, Mode
 
     bc = BertConfig(hidden_size=1024, num_hidden_layers=bert_layers, num_attention_heads=16, intermediate_size=4096,
                     vocab_size=30522, max_position_embeddings=512)
-    lc = LlamaConfig(num_hidden_layers=llama_layers)  # defaults == Llama-2-7b-hf
+    gc = GENERATORS[generator][0](llama_layers)
     torch.manual_seed(0)  # identical weights on every rank
     with torch.device(device):
         old = torch.get_default_dtype()
         torch.set_default_dtype(dtype)
         try:
             retriever = BertModel(bc)
-            generator = LlamaForCausalLM(lc)
+            gen = AutoModelForCausalLM.from_config(gc)
         finally:
             torch.set_default_dtype(old)
-    return AutoModelForRagE2E.from_modules(retriever, generator, None, None, normalize=True,
+    return AutoModelForRagE2E.from_modules(retriever, gen, None, None, normalize=True,
                                            get_peft=Mode.BOTH if lora else None)
 
 
-def synthetic_batch(device, seed, B=CFG["B"], Tq=CFG["Tq"], Tp=CFG["Tp"], Tg=CFG["Tg"]):
+def synthetic_batch(device, seed, B=CFG["B"], Tq=CFG["Tq"], Tp=CFG["Tp"], Tg=CFG["Tg"], V=CFG["V"]):
     """Token-id level synthetic (Passage, Query, Answer) rows, SURVEY.md section 8(d)."""
     g = torch.Generator().manual_seed(seed)
 
@@ -77,7 +85,7 @@ def synthetic_batch(device, seed, B=CFG["B"], Tq=CFG["Tq"], Tp=CFG["Tp"], Tg=CFG
     batch = {
         "retriever_query_input_ids": ids(B, Tq, 30522), "retriever_query_attention_mask": right_mask(Tq, 5, 15),
         "retriever_passage_input_ids": ids(B, Tp, 30522), "retriever_passage_attention_mask": right_mask(Tp, 30, Tp),
-        "generator_input_input_ids": ids(B, Tg, 32000), "generator_input_attention_mask": gmask,
+        "generator_input_input_ids": ids(B, Tg, V), "generator_input_attention_mask": gmask,
         "query_passage_input_len": (glen.squeeze(1).float() * 0.8).long().clamp(min=1),
     }
     return {k: v.to(device) for k, v in batch.items()}

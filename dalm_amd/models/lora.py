@@ -4,8 +4,10 @@ Mirrors the configuration the reference asks peft for
 (dalm/models/rag_e2e_base_model.py:145-160): r=8, lora_alpha=16, lora_dropout=0.05,
 bias="none", on modules whose name ends in one of `target_modules`
 (key/query/value for BERT-style retrievers, q_proj/v_proj for Llama/Falcon-style models).
-Parameter names follow peft's layout (`base_layer`, `lora_A.default`, `lora_B.default`) so
-adapter checkpoints look familiar.
+Parameter names follow peft's in-memory layout (`base_layer`, `lora_A.default`, `lora_B.default`); adapters are
+written in peft's ON-DISK format (adapter_model.safetensors with `base_model.model.` keys + a full
+adapter_config.json), so `PeftModel.from_pretrained` - what the reference's eval and
+`attach_pre_trained_peft_layers` call - can read them, and adapters trained with the reference load here.
 """
 from __future__ import annotations
 
@@ -73,9 +75,29 @@ def _matches(name: str, targets: Iterable[str]) -> bool:
     return any(leaf == t or name.endswith("." + t) for t in targets)
 
 
+# peft's own per-architecture defaults for models without q_proj / v_proj (TRANSFORMERS_MODELS_TO_LORA_TARGET_MODULES_MAPPING)
+FUSED_QKV_FALLBACK = {"falcon": ["query_key_value"], "gpt_neox": ["query_key_value"], "bloom": ["query_key_value"],
+                      "gpt2": ["c_attn"], "mpt": ["Wqkv"]}
+
+
+def resolve_targets(model: nn.Module, target_modules: List[str]) -> List[str]:
+    """The reference hard-codes q_proj / v_proj for every generator (rag_e2e_base_model.py:61-80); architectures
+    with a fused QKV projection (Falcon - BASELINE config 5) have no such modules and peft would raise.  Fall
+    back to peft's default targets for that architecture instead of failing."""
+    names = [n for n, m in model.named_modules() if isinstance(m, nn.Linear)]
+    if any(_matches(n, target_modules) for n in names):
+        return list(target_modules)
+    mt = getattr(getattr(model, "config", None), "model_type", None)
+    fb = FUSED_QKV_FALLBACK.get(mt)
+    if fb and any(_matches(n, fb) for n in names):
+        return list(fb)
+    return list(target_modules)
+
+
 def inject_lora(model: nn.Module, target_modules: List[str], r: int = 8, lora_alpha: int = 16,
                 lora_dropout: float = 0.05) -> nn.Module:
     """Freeze `model`, wrap every matching nn.Linear in a LoRALinear (trainable A/B only)."""
+    target_modules = resolve_targets(model, target_modules)
     for prm in model.parameters():
         prm.requires_grad_(False)
     replaced = 0
@@ -100,22 +122,82 @@ def has_lora(model: nn.Module) -> bool:
     return any(isinstance(m, LoRALinear) for m in model.modules())
 
 
-def save_adapter(model: nn.Module, path: str) -> None:
+# ---- adapter I/O in peft's on-disk format ---------------------------------------------------------------------
+# The reference saves adapters with peft's save_pretrained (dalm/training/utils/train_utils.py:16-45) and loads them
+# with PeftModel.from_pretrained (train_utils.py:48-73, rag_e2e_base_model.py:113-134, dalm/eval/*).  peft's layout:
+#   adapter_config.json         LoraConfig fields (peft_type, task_type, r, lora_alpha, target_modules, ...)
+#   adapter_model.safetensors   keys "base_model.model.<module path>.lora_A.weight" / ".lora_B.weight"
+#                               (the adapter name "default" is NOT part of the stored key)
+# load_adapter also accepts peft's older adapter_model.bin and this package's round-1 files (raw module paths with
+# ".default" kept) so existing checkpoints keep loading.
+PEFT_PREFIX = "base_model.model."
+ADAPTER_SAFETENSORS = "adapter_model.safetensors"
+
+
+def _to_peft_key(k: str) -> str:
+    return PEFT_PREFIX + k.replace(".lora_A.default.", ".lora_A.").replace(".lora_B.default.", ".lora_B.")
+
+
+def _from_peft_key(k: str) -> str:
+    if k.startswith(PEFT_PREFIX):
+        k = k[len(PEFT_PREFIX):]
+    if ".lora_A.default." in k or ".lora_B.default." in k:
+        return k
+    return k.replace(".lora_A.", ".lora_A.default.").replace(".lora_B.", ".lora_B.default.")
+
+
+def peft_adapter_config(model: nn.Module, task_type: str = None, base_model_name_or_path: str = None) -> Dict:
+    cfg = dict(getattr(model, "_dalm_lora_config", {}))
+    if task_type is None:  # the reference: CAUSAL_LM for generators, FEATURE_EXTRACTION for encoders (:145-160)
+        task_type = "CAUSAL_LM" if hasattr(model, "lm_head") or hasattr(model, "get_output_embeddings") and \
+            model.get_output_embeddings() is not None else "FEATURE_EXTRACTION"
+    if base_model_name_or_path is None:
+        base_model_name_or_path = getattr(getattr(model, "config", None), "_name_or_path", None) or None
+    return {
+        "alpha_pattern": {}, "auto_mapping": None, "base_model_name_or_path": base_model_name_or_path,
+        "bias": cfg.get("bias", "none"), "fan_in_fan_out": False, "inference_mode": True, "init_lora_weights": True,
+        "layers_pattern": None, "layers_to_transform": None, "lora_alpha": cfg.get("lora_alpha", 16),
+        "lora_dropout": cfg.get("lora_dropout", 0.05), "modules_to_save": None, "peft_type": "LORA",
+        "r": cfg.get("r", 8), "rank_pattern": {}, "revision": None,
+        "target_modules": list(cfg.get("target_modules", [])), "task_type": task_type,
+    }
+
+
+def save_adapter(model: nn.Module, path: str, task_type: str = None, base_model_name_or_path: str = None) -> None:
+    """peft-loadable adapter directory (PeftModel.from_pretrained(base, path) reads it)."""
+    from safetensors.torch import save_file
+
     os.makedirs(path, exist_ok=True)
-    torch.save({k: v.detach().cpu() for k, v in lora_state_dict(model).items()}, os.path.join(path, ADAPTER_WEIGHTS))
+    sd = {_to_peft_key(k): v.detach().to("cpu").contiguous() for k, v in lora_state_dict(model).items()}
+    save_file(sd, os.path.join(path, ADAPTER_SAFETENSORS), metadata={"format": "pt"})
     with open(os.path.join(path, ADAPTER_CONFIG), "w") as f:
-        json.dump(getattr(model, "_dalm_lora_config", {}), f, indent=2)
+        json.dump(peft_adapter_config(model, task_type, base_model_name_or_path), f, indent=2, sort_keys=True)
 
 
 def load_adapter(model: nn.Module, path: str) -> nn.Module:
     with open(os.path.join(path, ADAPTER_CONFIG)) as f:
         cfg = json.load(f)
+    if cfg.get("peft_type", "LORA") != "LORA":
+        raise ValueError(f"unsupported peft_type {cfg.get('peft_type')!r} (LoRA adapters only)")
+    targets = cfg["target_modules"]
+    if isinstance(targets, str):
+        targets = [targets]
     if not has_lora(model):
-        inject_lora(model, cfg["target_modules"], cfg.get("r", 8), cfg.get("lora_alpha", 16), cfg.get("lora_dropout", 0.05))
-    sd = torch.load(os.path.join(path, ADAPTER_WEIGHTS), map_location="cpu")
-    missing, unexpected = model.load_state_dict(sd, strict=False)
-    if unexpected:
-        raise RuntimeError(f"unexpected adapter keys: {unexpected[:4]}")
+        inject_lora(model, list(targets), cfg.get("r", 8), cfg.get("lora_alpha", 16), cfg.get("lora_dropout", 0.05))
+    st = os.path.join(path, ADAPTER_SAFETENSORS)
+    if os.path.exists(st):
+        from safetensors.torch import load_file
+
+        raw = load_file(st)
+    else:
+        raw = torch.load(os.path.join(path, ADAPTER_WEIGHTS), map_location="cpu")
+    sd = {_from_peft_key(k): v for k, v in raw.items()}
+    want = set(lora_state_dict(model).keys())
+    unexpected = sorted(set(sd) - want)
+    missing = sorted(want - set(sd))
+    if unexpected or missing:
+        raise RuntimeError(f"adapter at {path} does not match the model: unexpected {unexpected[:3]}, missing {missing[:3]}")
+    model.load_state_dict(sd, strict=False)
     return model
 
 

@@ -22,7 +22,7 @@ def save_submodel(model: torch.nn.Module, path: str) -> None:
 
 
 def load_submodel(model: torch.nn.Module, path: str) -> torch.nn.Module:
-    if os.path.exists(os.path.join(path, lora.ADAPTER_WEIGHTS)):
+    if os.path.exists(os.path.join(path, lora.ADAPTER_CONFIG)):   # a peft-format adapter directory
         return lora.load_adapter(model, path)
     from transformers import AutoModel, AutoModelForCausalLM
 
