@@ -192,12 +192,25 @@ def main():
                     help="graph the tower fwd/bwd and keep collectives eager (the default when --gpus > 1)")
     ap.add_argument("--fuse-lm-head", action="store_true",
                     help="SURVEY 8(f) rank 1: chunked lm_head + CE, the [B,Tg,V] logits are never materialised")
-    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2"],
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg5", "cfg2", "cfg1"],
                     help="cfg3 = RAG-e2e bge-large + Llama-2-7b batch 18 (headline, default); "
-                         "cfg2 = retriever-only bge-large batch 150 (BASELINE.json configs[1])")
+                         "cfg5 = RAG-e2e bge-large + Falcon-7B architecture (V = 65024: the 1024-thread CE rows); "
+                         "cfg2 = retriever-only bge-large batch 150 (BASELINE.json configs[1]); "
+                         "cfg1 = retriever-only bge-small batch 19 (the toy-CSV shape of configs[0])")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"],
+                    help="bf16 = bf16 weights + autocast (default); fp32 = fp32 weights, no autocast "
+                         "(the reference's default precision; quoted beside the bf16 line in DESIGN.md)")
     ap.add_argument("--retriever-layers", type=int, default=24, help=argparse.SUPPRESS)
     ap.add_argument("--generator-layers", type=int, default=32, help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    from dalm_amd.launch import in_distributed_env, spawn_ranks
+
+    if args.gpus > 1 and not in_distributed_env():
+        # `python bench.py --gpus N`: no torchrun needed - spawn one rank per GPU ourselves (RANK / LOCAL_RANK /
+        # WORLD_SIZE / MASTER_ADDR=127.0.0.1), rank 0 prints the JSON line; fewer than N visible GPUs -> exit 2
+        raise SystemExit(spawn_ranks([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], args.gpus))
+    args.hw_queues = dalm_amd.configure_hw_queues(args.gpus)   # before the HIP runtime starts
 
     from dalm_amd import hip
     from dalm_amd.sharded import barrier, init_distributed
@@ -207,16 +220,20 @@ def main():
     from dalm_amd.tuning import enable_tuned_gemms
 
     args.tuned_gemms = enable_tuned_gemms()  # replay-only hipBLASLt/rocBLAS solution table for the tower GEMMs
-    if args.workload == "cfg2":
+    if args.workload in ("cfg2", "cfg1"):
         return main_retriever_only(args)
     comm, dev = init_distributed()
     if dev.type != "cuda":
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     if comm.world_size != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={comm.world_size}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher set WORLD_SIZE={comm.world_size}")
     rank = comm.rank
+    gen_name = "falcon-7b" if args.workload == "cfg5" else "llama-2-7b"
+    V = GENERATORS[gen_name][1]
+    wdtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    autocast = torch.bfloat16 if args.dtype == "bf16" else None
 
-    model = build_models(dev, torch.bfloat16, args.retriever_layers, args.generator_layers)
+    model = build_models(dev, wdtype, args.retriever_layers, args.generator_layers, generator=gen_name)
     model.train()
     params = [p for p in model.parameters() if p.requires_grad]
     from transformers import get_scheduler
@@ -232,15 +249,15 @@ def main():
 
     sched = TensorLRScheduler(opt, 1e-4, mk_sched) if use_graph else mk_sched(opt)
     ops = TimedOps()
-    step = RagE2EStep(model, opt, sched, CFG["logit_scale"], comm=comm, autocast_dtype=torch.bfloat16, ops=ops,
+    step = RagE2EStep(model, opt, sched, CFG["logit_scale"], comm=comm, autocast_dtype=autocast, ops=ops,
                       inplace_grad=True, overlap_towers=not args.no_overlap, fuse_lm_head=args.fuse_lm_head,
                       graph_towers=(args.graph_towers or not isinstance(comm, LocalComm)) and not args.no_graph
                       and not args.graph_collectives,
-                      graph_after=0)
+                      graph_after=0, grad_overlap=not args.graph_collectives)
     if use_graph:
         step = GraphedStep(step)
     # a few distinct pre-staged batches (inputs resident in HBM before the timed region)
-    batches = [synthetic_batch(dev, 100 + 17 * rank + i) for i in range(4)]
+    batches = [synthetic_batch(dev, 100 + 17 * rank + i, V=V) for i in range(4)]
 
     # graphs are captured during the first untimed step; with --warmup 0 one untimed step still runs so that
     # the capture never lands inside the timed region
@@ -275,34 +292,50 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    ranks_seen, backend = 1, "none (one process)"
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        ranks_seen, backend = torch.distributed.get_world_size(), torch.distributed.get_backend()
     if rank == 0:
-        B, Tg, V = CFG["B"], CFG["Tg"], CFG["V"]
+        B, Tg = CFG["B"], CFG["Tg"]
+        el = 2 if args.dtype == "bf16" else 4   # logits element size (bf16 lm_head output / fp32)
         ce_ms = [e[0].elapsed_time(e[1]) for e in ops.events]
         ce_avg_s = (sum(ce_ms) / max(len(ce_ms), 1)) * 1e-3
         lives = [int(e[2]) for e in ops.events]
         alg_bytes = sum((lv + e[3]) * e[4] for lv, e in zip(lives, ops.events)) / max(len(ops.events), 1)  # per launch
         live_rows = sum(lives) / max(len(lives), 1)
-        dense_bytes = 2 * B * (Tg - 1) * V * 2                                # SURVEY 8(d) dense definition, bf16
+        dense_bytes = 2 * B * (Tg - 1) * V * el                               # SURVEY 8(d) dense definition
         achieved = alg_bytes / ce_avg_s / 1e9 if ce_avg_s > 0 else 0.0
-        traffic = None
+        # HBM traffic of that kernel comes from rocprofv3 PMC passes of THIS command (FETCH_SIZE and WRITE_SIZE
+        # cannot share a pass, and counters perturb timing, so they are never collected inside the timed run):
+        # tools/pmc_bench.sh writes profiles/roofline_traffic.json; the value is per launch, FETCH doubled as the
+        # gfx950 guide prescribes.  Only quoted for the workload/dtype it was collected on.
+        traffic, traffic_source = None, None
         tfile = ROOT / "profiles" / "roofline_traffic.json"
         if tfile.exists():
             try:
-                traffic = json.loads(tfile.read_text()).get("bench_marg_ce_bytes_per_launch")
+                tj = json.loads(tfile.read_text())
+                if tj.get("workload", "cfg3") == args.workload and tj.get("dtype", "bf16") == args.dtype:
+                    traffic = tj.get("bench_marg_ce_bytes_per_launch")
+                    traffic_source = tj.get("source", "profiles/roofline_traffic.json (separate rocprofv3 --pmc passes)")
             except Exception:
                 traffic = None
         value = args.gpus * B * args.steps / elapsed
         out = {
-            "metric": "training pairs/sec (global batch) RAG-e2e bge-large+Llama-2-7b",
+            "metric": "training pairs/sec (global batch) RAG-e2e bge-large+" + ("Llama-2-7b" if gen_name == "llama-2-7b" else "Falcon-7B"),
             "value": value, "unit": "pairs/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": (value / A100_README_PAIRS_PER_S) if args.gpus == 1 else None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "cfg3 RAG-e2e: bge-large-en + Llama-2-7b-hf architectures (random init), LoRA r=8 both "
-                                   "towers, per-GPU batch 18, Tq50/Tp128/Tg256, logit_scale 100, Adam, bf16 autocast",
+            "vs_baseline": (value / A100_README_PAIRS_PER_S) if (args.gpus == 1 and args.workload == "cfg3") else None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.workload} RAG-e2e: bge-large-en + {gen_name} architectures (random init, V={V}), "
+                                   "LoRA r=8 both towers, per-GPU batch 18, Tq50/Tp128/Tg256, logit_scale 100, Adam, "
+                                   + ("bf16 weights + autocast" if args.dtype == "bf16" else "fp32 weights, no autocast"),
                        "global_batch": args.gpus * B, "parallelism": f"dp{args.gpus} + sharded in-batch negatives",
+                       "ranks_seen_by_process_group": ranks_seen, "collective_backend": backend + (" (= RCCL)" if backend == "nccl" else ""),
+                       "spawned_by": os.environ.get("TORCHELASTIC_RUN_ID") and "torch.distributed.run" or
+                                     ("dalm_amd.launch (python bench.py --gpus N)" if ranks_seen > 1 else "single process"),
+                       "gpu_max_hw_queues": args.hw_queues,
                        "retriever_layers": args.retriever_layers, "generator_layers": args.generator_layers,
-                       "lm_head": "fused with the CE in sample chunks (no logits tensor)" if args.fuse_lm_head else "logits materialised (bf16)",
+                       "lm_head": "fused with the CE in sample chunks (no logits tensor)" if args.fuse_lm_head else f"logits materialised ({args.dtype})",
                        "tower_gemms": "pre-tuned solution table (dalm_amd/tuning)" if args.tuned_gemms else "library defaults",
                        "launch": ("hipGraph replay of the whole step" if (use_graph and getattr(step, "graph", None) is not None)
                                   else ("hipGraph replay of tower fwd/bwd, eager collectives+loss+optimizer"
@@ -316,16 +349,17 @@ def main():
                        "step_model_tflops": 124.0 + 6.3,
                        "step_frac_of_bf16_mfma_peak": (124.0 + 6.3) / (elapsed / args.steps) / 2500.0,
                        "final_loss": loss_val},
-            "roofline": {"bound": "hbm", "kernel": "marg_ce_row_kernel (fused fwd+grad, bf16 logits)",
+            "roofline": {"bound": "hbm", "kernel": f"marg_ce_row kernel (fused fwd+grad, {args.dtype} logits, V={V})",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "avg_launch_us": ce_avg_s * 1e6, "algorithmic_bytes": alg_bytes,
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "avg_launch_us": ce_avg_s * 1e6, "algorithmic_bytes": alg_bytes,
                          "live_rows_per_launch": live_rows, "dense_rows_per_launch": B * (Tg - 1),
                          "dense_definition_GBps": dense_bytes / ce_avg_s / 1e9 if ce_avg_s > 0 else 0.0,
                          "note": "achieved counts only bytes the launch must move (padded rows are skipped on the read "
                                  "side); the all-ones-mask roofline point is in profiles/ (tools/kernel_bench.py)",
                          "timing": probe_note},
         }
-        if args.gpus == 1 and not args.no_cpu_baseline:
+        if args.gpus == 1 and not args.no_cpu_baseline and args.workload == "cfg3":
             try:
                 out["cpu_baseline"] = cpu_reference_baseline()
             except Exception as e:  # the baseline must never take the GPU number down with it
@@ -349,14 +383,19 @@ def main_retriever_only(args):
     from dalm_amd.training.step import RetrieverStep
 
     comm, dev = init_distributed()
-    B, Tq, Tp = 150, 50, 128
+    small = args.workload == "cfg1"   # bge-small-en: 384 wide, 12 layers, 12 heads; the toy csv has 19 rows (< batch 32)
+    B, Tq, Tp = (19 if small else 150), 50, 128
+    wdtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    autocast = torch.bfloat16 if args.dtype == "bf16" else None
+    layers = min(args.retriever_layers, 12) if small else args.retriever_layers
     torch.manual_seed(0)
     with torch.device(dev):
         old = torch.get_default_dtype()
-        torch.set_default_dtype(torch.bfloat16)
+        torch.set_default_dtype(wdtype)
         try:
-            bert = BertModel(BertConfig(hidden_size=1024, num_hidden_layers=args.retriever_layers, num_attention_heads=16,
-                                        intermediate_size=4096, vocab_size=30522, max_position_embeddings=512))
+            bert = BertModel(BertConfig(hidden_size=384 if small else 1024, num_hidden_layers=layers,
+                                        num_attention_heads=12 if small else 16, intermediate_size=1536 if small else 4096,
+                                        vocab_size=30522, max_position_embeddings=512))
         finally:
             torch.set_default_dtype(old)
     model = AutoModelForSentenceEmbedding.from_modules(bert, None, normalize=True, get_peft=True)
@@ -368,7 +407,7 @@ def main_retriever_only(args):
         return get_scheduler("linear", optimizer=o, num_warmup_steps=0, num_training_steps=100000)
 
     sched = TensorLRScheduler(opt, 1e-4, mk_sched) if use_graph else mk_sched(opt)
-    step = RetrieverStep(model, opt, sched, CFG["logit_scale"], comm=comm, autocast_dtype=torch.bfloat16,
+    step = RetrieverStep(model, opt, sched, CFG["logit_scale"], comm=comm, autocast_dtype=autocast,
                          overlap_towers=not args.no_overlap)
     if use_graph:
         step = GraphedStep(step)
@@ -400,11 +439,12 @@ def main_retriever_only(args):
     if comm.rank == 0:
         value = args.gpus * B * args.steps / float(t.item())
         print(json.dumps({
-            "metric": "training pairs/sec (global batch) retriever-only bge-large", "value": value, "unit": "pairs/s",
+            "metric": "training pairs/sec (global batch) retriever-only " + ("bge-small" if small else "bge-large"), "value": value, "unit": "pairs/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * float(t.item()) / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "cfg2 retriever-only: bge-large-en architecture (random init), LoRA r=8 q/k/v, per-GPU batch 150, "
-                                   "Tq50/Tp128, logit_scale 100, Adam, bf16 autocast", "global_batch": args.gpus * B,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.workload} retriever-only: {'bge-small-en' if small else 'bge-large-en'} architecture (random init), "
+                                   f"LoRA r=8 q/k/v, per-GPU batch {B}, Tq50/Tp128, logit_scale 100, Adam, {args.dtype}",
+                       "global_batch": args.gpus * B,
                        "parallelism": f"dp{args.gpus} + sharded in-batch negatives", "final_loss": float(loss),
                        "launch": "hipGraph replay" if (use_graph and getattr(step, "graph", None) is not None) else "eager"}}),
               flush=True)

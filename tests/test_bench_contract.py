@@ -37,3 +37,37 @@ def test_synthetic_batch_matches_cfg3_shapes():
     assert int(m[:, -1].min()) == 1 and 60 <= int(m.sum(1).min())   # left-padded, 60..256 live tokens
     assert abs(bench.A100_README_PAIRS_PER_S - 7.9365) < 1e-3
     assert bench.HBM_PEAK_GBPS == 8000.0
+
+
+def test_bench_self_spawns_and_refuses_clearly_without_enough_gpus():
+    """`python bench.py --gpus N` (the driver's form, no torchrun): bench.py spawns the ranks itself; on a box with
+    fewer GPUs it says so and exits 2 instead of hanging or dying in rendezvous."""
+    import os
+    import subprocess
+
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 8:
+        return
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-400:])
+    assert "8 ranks requested but only" in r.stderr and "GPU(s) are visible" in r.stderr
+    assert r.stdout.strip() == ""                                   # no JSON line pretending to be a result
+
+
+def test_bench_workloads_and_cfg5_shapes():
+    import bench
+
+    src = (ROOT / "bench.py").read_text()
+    for w in ('"cfg3"', '"cfg5"', '"cfg2"', '"cfg1"', '"--dtype"', '"fp32"', "ranks_seen_by_process_group", "traffic_source"):
+        assert w in src, w
+    assert bench.GENERATORS["falcon-7b"][1] == 65024 and bench.GENERATORS["llama-2-7b"][1] == 32000
+    fc = bench.GENERATORS["falcon-7b"][0](32)
+    assert (fc.hidden_size, fc.num_hidden_layers, fc.num_attention_heads, fc.vocab_size) == (4544, 32, 71, 65024)
+    lc = bench.GENERATORS["llama-2-7b"][0](32)
+    assert (lc.hidden_size, lc.num_hidden_layers, lc.intermediate_size, lc.vocab_size) == (4096, 32, 11008, 32000)
+    b = bench.synthetic_batch(torch.device("cpu"), 0, V=65024)
+    assert int(b["generator_input_input_ids"].max()) > 32000 and int(b["generator_input_input_ids"].max()) < 65024
+    # a tiny cfg5-architecture model assembles (LoRA lands on Falcon's fused query_key_value)
+    m = bench.build_models(torch.device("cpu"), torch.float32, bert_layers=1, llama_layers=1, generator="falcon-7b")
+    assert m.generator_model._dalm_lora_config["target_modules"] == ["query_key_value"]

@@ -1,5 +1,6 @@
-"""Two REAL ranks on one MI355X: both processes run the HIP kernels on cuda:0 and exchange through a host-staged
-gloo communicator (RCCL refuses two ranks on one device).  Checks the complete W = 2 path - sharded rows,
+"""Two REAL ranks: (a) on one MI355X both processes run the HIP kernels on cuda:0 and exchange through a host-staged
+gloo communicator (RCCL refuses two ranks on one device); (b) on a box with >= 2 GPUs, one rank per GPU over RCCL -
+the production configuration (skipped on the 1-GPU gpurun boxes, run by the driver's multi-GPU tier).  Checks the complete W = 2 path - sharded rows,
 diag offsets, the two row problems per rank, stats exchange, global token count, summed gradients - against a
 single process at the global batch (reference op sequence, fp64)."""
 import os
@@ -26,17 +27,21 @@ def _free_port() -> int:
     return port
 
 
-def _worker(rank, world, port, out_dir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+def _worker(rank, world, port, out_dir, rccl=False):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
 
     from dalm_amd.fused import TorchDistComm, pool_l2norm, rag_e2e_loss
     from dalm_amd.sharded import GradBucket
     from helpers import synth_batch
 
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda:0")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", rank if rccl else 0)
+    torch.cuda.set_device(dev)
+    if rccl:   # one rank per GPU, the real thing: RCCL collectives, side-stream gathers, overlapped grad buckets
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     class HostStagedComm(TorchDistComm):
         def all_gather_rows(self, t):
@@ -48,7 +53,7 @@ def _worker(rank, world, port, out_dir):
             t.copy_(h)
             return t
 
-    comm = HostStagedComm()
+    comm = TorchDistComm() if rccl else HostStagedComm()
     B_l, D, Tg, V, T = 5, 64, 24, 1000, 9
     q, p, logits, ids, mask, qlen = synth_batch(7, world * B_l, D, Tg, V, pad_side="left", logit_gain=2.0)
     g = torch.Generator().manual_seed(3)
@@ -64,18 +69,26 @@ def _worker(rank, world, port, out_dir):
     loss = rag_e2e_loss(qe, pe, lg, ids[sl].to(dev), mask[sl].to(dev), qlen[sl].to(dev), 100, comm=comm)
     loss.backward()
     bucket.all_reduce()
-    torch.save({"loss_share": loss.detach().cpu(), "dw": w.grad.detach().cpu().clone(), "dlogits": lg.grad.cpu()},
+    torch.cuda.synchronize()
+    torch.save({"loss_share": loss.detach().cpu(), "dw": w.grad.detach().cpu().clone(), "dlogits": lg.grad.cpu(),
+                "ranks_seen": dist.get_world_size(), "backend": dist.get_backend(), "device": str(dev)},
                os.path.join(out_dir, f"r{rank}.pt"))
     dist.destroy_process_group()
 
 
-def test_two_gpu_ranks_equal_one_process_at_global_batch(tmp_path):
+@pytest.mark.parametrize("rccl", [False, True], ids=["one-gpu-host-staged-gloo", "two-gpus-rccl"])
+def test_two_gpu_ranks_equal_one_process_at_global_batch(tmp_path, rccl):
     import dalm_oracle as O
     from helpers import synth_batch
 
+    if rccl and torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs: one RCCL rank per device (the 1-GPU variant of this test covers the host logic)")
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), rccl), nprocs=world, join=True)
     res = [torch.load(tmp_path / f"r{r}.pt") for r in range(world)]
+    if rccl:
+        assert [r["ranks_seen"] for r in res] == [2, 2] and res[0]["backend"] == "nccl"
+        assert {r["device"] for r in res} == {"cuda:0", "cuda:1"}
 
     B_l, D, Tg, V, T = 5, 64, 24, 1000, 9
     q, p, logits, ids, mask, qlen = synth_batch(7, world * B_l, D, Tg, V, pad_side="left", logit_gain=2.0)
