@@ -329,9 +329,103 @@ def main_step_golden() -> None:
     print("step_golden.json", losses)
 
 
+def tiny_bge_small(vocab: int):
+    """bge-small-en's width (384, 12 heads) at 2 layers: built from a fixed seed on CPU, so the weights are
+    reproduced on the GPU box without committing 4 MB of safetensors; the golden records a checksum."""
+    from transformers import BertConfig, BertModel
+
+    torch.manual_seed(4321)
+    return BertModel(BertConfig(hidden_size=384, num_hidden_layers=2, num_attention_heads=12, intermediate_size=256,
+                                vocab_size=vocab, max_position_embeddings=64, hidden_dropout_prob=0.0,
+                                attention_probs_dropout_prob=0.0))
+
+
+def retriever_rows(n=19):
+    """n synthetic (Question, Abstract) rows over the committed word-level vocabulary (the toy csv of the reference
+    has 19 rows and the default batch is 32, so one partial batch of 19 is what configs[0] really trains on)."""
+    import json
+    import random
+
+    base = json.loads((OUT / "host_golden.json").read_text())["rows"]
+    words = sorted({w for col in base.values() for t in col for w in t.split()})
+    rnd = random.Random(1234)
+    return {"Question": [" ".join(rnd.choice(words) for _ in range(rnd.randint(3, 9))) for _ in range(n)],
+            "Abstract": [" ".join(rnd.choice(words) for _ in range(rnd.randint(8, 30))) for _ in range(n)]}
+
+
+def main_retriever_step_golden() -> None:
+    """a12, retriever-only: the reference's step body (train_retriever_only.py:365-379) with the reference's own
+    AutoModelForSentenceEmbedding (retriever_only_base_model.py) and preprocess_dataset, on a bge-small-width
+    model, batches of 19 / 7 / 19 / 12 / 19 rows, dropout 0, fp32, Adam + linear schedule."""
+    import json
+    import tempfile
+
+    from transformers import AutoModel, PreTrainedTokenizerFast, get_scheduler
+
+    tu, m_rag, du = import_reference()
+    stub = types.ModuleType("peft")
+    for name in ("LoraConfig", "PeftModel", "TaskType", "get_peft_model"):
+        setattr(stub, name, type(name, (), {}))
+    sys.modules["peft"] = stub
+    sys.path.insert(0, str(REF))
+    try:
+        import dalm.models.retriever_only_base_model as m_ret
+        from dalm.training.utils.retriever_only_dataloader_utils import preprocess_dataset as ref_pre_ret
+    finally:
+        sys.modules.pop("peft", None)
+        sys.path.remove(str(REF))
+    tok = PreTrainedTokenizerFast.from_pretrained(str(OUT / "wordlevel_tokenizer"))
+    bert = tiny_bge_small(len(tok))
+    init_sum = float(sum(p.detach().double().abs().sum() for p in bert.parameters()))
+    rows = retriever_rows(19)
+    with tempfile.TemporaryDirectory() as td:
+        bert.save_pretrained(td)
+        tok.save_pretrained(td)
+        # the reference pins device 0 (device_map={"": 0}, retriever_only_base_model.py:25): strip it on CPU
+        orig = AutoModel.from_pretrained
+
+        def cpu_from_pretrained(*a, **kw):
+            kw.pop("device_map", None)
+            kw.pop("quantization_config", None)
+            return orig(*a, **kw)
+
+        AutoModel.from_pretrained = cpu_from_pretrained
+        try:
+            model = m_ret.AutoModelForSentenceEmbedding(td, use_bnb=False, get_peft=False)
+        finally:
+            AutoModel.from_pretrained = orig
+    enc = ref_pre_ret(rows, model.tokenizer, "Question", "Abstract", 12, 32)
+    full = {k: torch.tensor(v) for k, v in enc.items()}
+    spans = [[0, 19], [0, 7], [0, 19], [5, 17], [0, 19]]
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    sched = get_scheduler("linear", optimizer=opt, num_warmup_steps=0, num_training_steps=20)
+    model.train()
+    losses = []
+    for a, b in spans:
+        batch = {k: v[a:b] for k, v in full.items()}
+        q = model(batch["query_input_ids"], batch["query_attention_mask"])
+        p = model(batch["passage_input_ids"], batch["passage_attention_mask"])
+        logits = tu.get_cosine_sim(q, p, 100)
+        loss = (tu.get_nt_xent_loss(logits) + tu.get_nt_xent_loss(logits.t())) / 2.0
+        loss.backward()
+        opt.step(); sched.step(); model.zero_grad()
+        losses.append(float(loss))
+    # only parameters that received gradients move (the BERT pooler is unused: rag_e2e_base_model.py:93 takes [0])
+    rec = {"losses": losses, "lr": 1e-3, "warmup": 0, "total_steps": 20, "batch_rows": spans, "query_max_len": 12,
+           "passage_max_len": 32, "rows": rows, "init_param_abs_sum": init_sum, "seed": 4321,
+           "final_param_abs_sum": float(sum(p.detach().double().abs().sum() for p in model.parameters())),
+           "pre_ret": {k: v for k, v in enc.items()}}
+    (OUT / "retriever_step_golden.json").write_text(json.dumps(rec, indent=1))
+    print("retriever_step_golden.json", losses)
+
+
 if __name__ == "__main__":
+    if "--retriever-step-only" in sys.argv:
+        main_retriever_step_golden()
+        sys.exit(0)
     if not REF.exists():
         sys.exit("/root/reference not present: golden vectors can only be regenerated in the build container")
     main()
     main_host_goldens()
     main_step_golden()
+    main_retriever_step_golden()

@@ -189,3 +189,119 @@ def test_falcon_architecture_generator_runs_through_the_step():
     step = RagE2EStep(rag, opt, None, 100, autocast_dtype=torch.bfloat16, inplace_grad=True)
     losses = [float(step(batch)) for _ in range(8)]
     assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+
+
+# ---------------------------------------------------------------------------
+# retriever-only (BASELINE configs[0]/[1]): trajectory pinned to the reference's own step body
+# ---------------------------------------------------------------------------
+def _tiny_bge_small(vocab, seed):
+    """Same construction as oracle/make_golden.py::tiny_bge_small (CPU RNG, fixed seed): identical weights."""
+    from transformers import BertConfig, BertModel
+
+    torch.manual_seed(seed)
+    return BertModel(BertConfig(hidden_size=384, num_hidden_layers=2, num_attention_heads=12, intermediate_size=256,
+                                vocab_size=vocab, max_position_embeddings=64, hidden_dropout_prob=0.0,
+                                attention_probs_dropout_prob=0.0))
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_retriever_only_step_trajectory_matches_reference(graph):
+    """5-step loss trajectory + final parameters vs the reference's train_retriever step body
+    (train_retriever_only.py:365-379) run on CPU with the reference's AutoModelForSentenceEmbedding -
+    bge-small width (D = 384), batches of 19 / 7 / 19 / 12 / 19 rows (19 = the toy csv), fp32."""
+    from transformers import PreTrainedTokenizerFast, get_scheduler
+
+    from dalm_amd.models import AutoModelForSentenceEmbedding
+    from dalm_amd.training.graphed import GraphedStep, TensorLRScheduler, make_capturable_adam
+    from dalm_amd.training.step import RetrieverStep
+    from dalm_amd.training.utils.retriever_only_dataloader_utils import preprocess_dataset
+
+    gold = json.loads((G / "retriever_step_golden.json").read_text())
+    tok = PreTrainedTokenizerFast.from_pretrained(str(G / "wordlevel_tokenizer"))
+    bert = _tiny_bge_small(len(tok), gold["seed"])
+    init = float(sum(p.detach().double().abs().sum() for p in bert.parameters()))
+    assert abs(init - gold["init_param_abs_sum"]) <= 1e-9 * gold["init_param_abs_sum"], "seeded weights drifted from the golden's"
+    dev = torch.device("cuda:0")
+    model = AutoModelForSentenceEmbedding.from_modules(bert, tok, normalize=True, get_peft=False).to(dev)
+    model.train()
+    enc = preprocess_dataset(gold["rows"], tok, query_column_name="Question", passage_column_name="Abstract",
+                             query_max_len=gold["query_max_len"], passage_max_len=gold["passage_max_len"])
+    for k, v in gold["pre_ret"].items():     # host preprocessing == the reference's, token for token
+        assert [list(x) for x in enc[k]] == v, k
+    full = {k: torch.tensor(v, device=dev) for k, v in enc.items()}
+    opt = make_capturable_adam(model.parameters(), gold["lr"], dev) if graph else torch.optim.Adam(model.parameters(), lr=gold["lr"])
+
+    def mk(o):
+        return get_scheduler("linear", optimizer=o, num_warmup_steps=gold["warmup"], num_training_steps=gold["total_steps"])
+
+    sched = TensorLRScheduler(opt, gold["lr"], mk) if graph else mk(opt)
+    step = RetrieverStep(model, opt, sched, 100, autocast_dtype=None, overlap_towers=graph)
+    if graph:
+        step = GraphedStep(step, warmup=0)
+    losses = [float(step({k: v[a:b] for k, v in full.items()})) for a, b in gold["batch_rows"]]
+    for got, ref in zip(losses, gold["losses"]):
+        assert abs(got - ref) <= 1e-3 * abs(ref), (losses, gold["losses"])
+    final = float(sum(p.detach().double().abs().sum() for p in model.model.parameters()))
+    assert abs(final - gold["final_param_abs_sum"]) <= 1e-4 * gold["final_param_abs_sum"]
+
+
+def test_train_retriever_end_to_end_at_cfg1_shapes(tmp_path):
+    """The entry point itself at BASELINE configs[0]'s shapes: a 19-row csv (the toy csv has 19 rows), requested
+    batch 32 -> one partial batch of 19 per epoch, bge-small width; reference-default use_bnb=True is served with
+    a warning; checkpoints in the reference's layout (peft-format adapter) and resume."""
+    import csv
+
+    from transformers import PreTrainedTokenizerFast
+
+    from dalm_amd.training.retriever_only.train_retriever_only import train_retriever
+
+    gold = json.loads((G / "retriever_step_golden.json").read_text())
+    tok = PreTrainedTokenizerFast.from_pretrained(str(G / "wordlevel_tokenizer"))
+    mdir = tmp_path / "bge_small_tiny"
+    _tiny_bge_small(len(tok), gold["seed"]).save_pretrained(str(mdir))
+    tok.save_pretrained(str(mdir))
+    path = tmp_path / "toy.csv"
+    with open(path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Question", "Abstract", "Answer"])
+        for q, a in zip(gold["rows"]["Question"], gold["rows"]["Abstract"]):
+            w.writerow([q, a, "x"])
+    out = tmp_path / "out"
+    seen = []
+    with pytest.warns(UserWarning, match="bitsandbytes"):
+        train_retriever(str(mdir), str(path), query_max_len=12, passage_max_len=32, per_device_train_batch_size=32,
+                        learning_rate=1e-3, num_train_epochs=4, output_dir=str(out), checkpointing_steps="epoch",
+                        with_tracking=True, mixed_precision="no", on_step=lambda s, l: seen.append((s, float(l))))
+    assert [s for s, _ in seen] == [1, 2, 3, 4] and seen[-1][1] < seen[0][1]
+    for sub in ("retriever/adapter_config.json", "retriever/adapter_model.safetensors", "epoch_3/trainer_state.pt", "logs"):
+        assert (out / sub).exists(), sub
+    more = []
+    train_retriever(str(mdir), str(path), query_max_len=12, passage_max_len=32, per_device_train_batch_size=32,
+                    learning_rate=1e-3, num_train_epochs=6, output_dir=str(out), resume_from_checkpoint=str(out / "epoch_3"),
+                    with_tracking=False, use_bnb=False, mixed_precision="no", on_step=lambda s, l: more.append((s, float(l))))
+    assert [s for s, _ in more] == [5, 6] and more[0][1] < seen[0][1]
+
+
+def test_bf16_autocast_step_stays_within_stated_tolerance_of_fp32_reference():
+    """The bench line is bf16 (bf16 weights + autocast); every other trajectory test is fp32.  Stated tolerance for the
+    bf16 step against the reference's fp32 CPU trajectory: per-step loss within 3e-2 relative over the 5 golden steps
+    (bf16 has 8 mantissa bits: ~4e-3 per rounding, compounded through two tiny towers and 5 Adam steps; the loss path
+    itself is fp32 on the bf16 values, exactly as accelerate hands fp32 up-casts to the reference's loss code)."""
+    from transformers import get_scheduler
+
+    from dalm_amd.models import AutoModelForRagE2E
+    from dalm_amd.training.step import RagE2EStep
+
+    gold = json.loads((G / "step_golden.json").read_text())
+    dev = torch.device("cuda:0")
+    rag = AutoModelForRagE2E(str(G / "tiny_retriever"), str(G / "tiny_generator")).to(dev)
+    g_tok = rag.generator_tokenizer
+    g_tok.pad_token = g_tok.eos_token
+    rag.train()
+    opt = torch.optim.Adam(rag.parameters(), lr=gold["lr"])
+    sched = get_scheduler("linear", optimizer=opt, num_warmup_steps=gold["warmup"], num_training_steps=gold["total_steps"])
+    step = RagE2EStep(rag, opt, sched, 100, autocast_dtype=torch.bfloat16, inplace_grad=True, overlap_towers=True)
+    losses = [float(step(b)) for b in _batches(rag.retriever_tokenizer, g_tok, gold, dev)]
+    rel = [abs(a - b) / abs(b) for a, b in zip(losses, gold["losses"])]
+    assert max(rel) <= 3e-2, (rel, losses, gold["losses"])
+    assert rel[0] <= 1e-2, rel                       # before any optimizer step: forward rounding only
