@@ -72,3 +72,30 @@ def use_roll_rope(model: torch.nn.Module) -> bool:
         mod._dalm_orig_apply_rotary_pos_emb = mod.apply_rotary_pos_emb
         mod.apply_rotary_pos_emb = _rope_roll
     return True
+
+
+# ---------------------------------------------------------------------------
+# Falcon multi-query attention: make the head split capturable
+# ---------------------------------------------------------------------------
+def _split_heads_sliced(self, fused_qkv: torch.Tensor):
+    """Falcon-7B layout [.., num_heads + 2, head_dim]: queries, then ONE shared key head and ONE shared value head.
+    transformers picks the two shared heads with python-list indices (`x[..., [-2], :]`), which builds an index
+    tensor on the host and copies it to the device on every call - an operation a hipGraph capture refuses.  Plain
+    slices select the same elements (as views) with no host work."""
+    b, t, _ = fused_qkv.shape
+    x = fused_qkv.view(b, t, self.num_heads + 2, self.head_dim)
+    n = self.num_heads
+    return x[..., :n, :], x[..., n:n + 1, :], x[..., n + 1:, :]
+
+
+def use_capturable_falcon_heads(model: torch.nn.Module) -> int:
+    """Patch FalconAttention modules of the 7B flavour (multi_query, old decoder architecture); returns the count."""
+    n = 0
+    for mod in model.modules():
+        if type(mod).__name__ != "FalconAttention":
+            continue
+        if getattr(mod, "new_decoder_architecture", False) or not getattr(mod, "multi_query", False):
+            continue
+        mod._split_heads = types.MethodType(_split_heads_sliced, mod)
+        n += 1
+    return n

@@ -116,9 +116,25 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(s)
         init_adam_state(self.step.optimizer)  # no-op after a warm-up step; essential with warmup == 0
         torch.cuda.synchronize()
+        # manual begin/end instead of `with torch.cuda.graph(g)`: when the body raises (an op the capture refuses),
+        # that context manager's exit raises a second error from capture_end() and never restores the current stream -
+        # every later eager step then runs on a stream stuck in an invalidated capture (seen with HF Falcon's
+        # list-indexed head split: the fall-back step died in dropout's RNG-state lookup)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self.static_loss = self.step(self.static)
+        cs = torch.cuda.Stream()
+        cs.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cs):
+            g.capture_begin()
+            try:
+                self.static_loss = self.step(self.static)
+            except BaseException:
+                try:
+                    g.capture_end()
+                except Exception:
+                    pass
+                raise
+            g.capture_end()
+        torch.cuda.current_stream().wait_stream(cs)
         self.graph, self.key = g, self._key(batch)
 
     def __call__(self, batch) -> torch.Tensor:

@@ -41,10 +41,16 @@ class _StepBase:
             # bucketed all-reduce issued from post-accumulate hooks while the backward is still running
             self.bucket = GradBucket(self.trainable, self.comm, overlap=None if grad_overlap else False)
 
+    # autocast keeps a cache of the low-precision copies of fp32 parameters (here: the LoRA matrices).  Two towers of
+    # the SAME model running on two streams would share those copies without any stream dependency - the second
+    # stream can read a copy the first is still writing (seen as NaN losses under hipGraph replay at the bge-small
+    # shape).  Steps that run one model on two streams therefore turn the cache off.
+    autocast_cache = True
+
     def _autocast(self):
         if self.autocast_dtype is None:
             return contextlib.nullcontext()
-        return torch.autocast("cuda", dtype=self.autocast_dtype)
+        return torch.autocast("cuda", dtype=self.autocast_dtype, cache_enabled=self.autocast_cache)
 
     def _finish(self, loss: torch.Tensor) -> torch.Tensor:
         loss.backward()
@@ -189,6 +195,7 @@ class RetrieverStep(_StepBase):
         super().__init__(*a, **kw)
         # the query pass (Tq = 50) is small next to the passage pass (Tp = 128): run it on its own stream
         self.tower_stream = torch.cuda.Stream() if (overlap_towers and torch.cuda.is_available()) else None
+        self.autocast_cache = self.tower_stream is None   # one model on two streams: no shared cast cache
 
     def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         m = self.model
