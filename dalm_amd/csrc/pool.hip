@@ -312,8 +312,12 @@ __global__ __launch_bounds__(256) void pool_finish_kernel(const float* __restric
   float* row = emb + static_cast<int64_t>(b) * D;
   float ss = 0.f;
   for (int i = threadIdx.x; i < D; i += 256) {
+    float pv[32];   // TZ <= 32: one batch of loads (a `for z < TZ` loop of loads is a serial latency chain)
+#pragma unroll
+    for (int z = 0; z < 32; ++z) pv[z] = part[(static_cast<int64_t>(b) * TZ + min(z, TZ - 1)) * D + i];
     float s = 0.f;
-    for (int z = 0; z < TZ; ++z) s += part[(static_cast<int64_t>(b) * TZ + z) * D + i];
+#pragma unroll
+    for (int z = 0; z < 32; ++z) s += (z < TZ) ? pv[z] : 0.f;
     s /= cden;
     row[i] = s;   // re-read below by the same thread only
     ss = fmaf(s, s, ss);
@@ -402,7 +406,7 @@ inline PoolPlan pool_plan(int64_t B, int64_t T, int64_t D, int vec) {
   const int64_t groups = 1024 / tpr;
   int64_t tz = 1;
   // one CU streams ~50-80 GB/s on its own: slice when a sample is more than a few microseconds of that
-  if (B < 64 && T * D * (16 / vec) >= (384 << 10)) {
+  if (B < 64 && T * D * (16 / vec) >= (1 << 20)) {
     tz = (192 + B - 1) / B;
     const int64_t tz_max = (T + 4 * groups - 1) / (4 * groups);
     if (tz > tz_max) tz = tz_max;

@@ -35,7 +35,7 @@ def main(path, top=40):
         print(f"{k:92s} {c:7d} {t/1e6:10.3f} {t/c/1e3:10.2f} {100*t/total:6.2f}")
     print("# --- dalm kernels ---")
     for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        if "dalm" in k or "marg_ce" in k or "gemm_f32_mfma" in k or "pool_" in k or "rowstats" in k or "l2norm" in k or "ce_" in k or "contrastive" in k:
+        if any(t in k for t in ("dalm", "marg_ce", "gemm_f32_mfma", "pool_", "rowstats", "l2norm", "ce_", "contrastive", "small_", "flash", "rag_loss", "transpose_pad")):
             print(f"{k:92s} {c:7d} {t/1e6:10.3f} {t/c/1e3:10.2f} {100*t/total:6.2f}")
 
 
