@@ -402,7 +402,7 @@ constexpr int FBM = 32, FBN = 128;
 // LDS; grid (ld/32, ceil(K/32), 2): blockIdx.z selects (X0 -> Xt0) or (X1 -> Xt1) so both operands go in one launch.
 __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ X0, int R0, int ld0,
                                                             float* __restrict__ Xt0, const float* __restrict__ X1,
-                                                            int R1, int ld1, float* __restrict__ Xt1, int K) {
+                                                            int R1, int ld1, float* __restrict__ Xt1, int K, int Kpad) {
   __shared__ float tile[32][33];
   const bool second = blockIdx.z != 0;
   const float* X = second ? X1 : X0;
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restr
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int k = k0 + ty + 8 * q, r = r0 + tx;
-    if (k < K) Xt[static_cast<int64_t>(k) * ld + r] = tile[tx][ty + 8 * q];
+    if (k < Kpad) Xt[static_cast<int64_t>(k) * ld + r] = tile[tx][ty + 8 * q];   // rows K..Kpad-1 are zeros
   }
 }
 
@@ -584,6 +584,147 @@ __global__ __launch_bounds__(256, 2) void sim_flash_grad_kernel(const FlashParam
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Streaming row statistics (the forward of the large-batch contrastive loss): the S phase of the kernel above
+// without the dA phase.  A workgroup owns 32*RT rows and walks its share of the 128-column blocks; every wave
+// keeps an online (max, sum-exp) per (row, its column lane) in registers and folds each finished 32x32 S tile into
+// it - no LDS, no barrier until the final reduction over lanes and waves.  RT = 2 row tiles per wave halves the
+// B-fragment loads per MFMA and gives two independent accumulation chains (used once there are enough row blocks).
+// Output: partial (max, sum-exp) per column split, merged by rowstats_merge_kernel; diag[i] = S[i, off + i].
+// MFMA-bound: 2*m*n*D flop per launch.
+// ---------------------------------------------------------------------------------------------------
+struct StreamStatsParams {
+  const float* At; const float* Bt;   // [Kpad][ldm], [Kpad][ldn], zero-padded
+  int m, n, Kpad, ldm, ldn;
+  float alpha;
+  int64_t diag_offset;
+  float* part_m; float* part_l;       // [nsplit][m]
+  float* diag;
+  int row_blocks, nsplit, blocks_per_split;
+};
+
+template <int RT>
+__global__ __launch_bounds__(256, 2) void sim_rowstats_stream_kernel(const StreamStatsParams p) {
+  constexpr int SG = 8;
+  __shared__ float red_m[4][32 * RT], red_l[4][32 * RT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+  const int rb = static_cast<int>(blockIdx.x) % p.row_blocks, z = static_cast<int>(blockIdx.x) / p.row_blocks;
+  const int i0 = rb * 32 * RT;
+  const int nblocks = (p.n + FBN - 1) / FBN;
+  const int jb_lo = z * p.blocks_per_split, jb_hi = min(nblocks, jb_lo + p.blocks_per_split);
+  const __amdgpu_buffer_rsrc_t at_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.At), 0, p.Kpad * p.ldm * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t bt_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Bt), 0, p.Kpad * p.ldn * 4, 0x00020000);
+  const int a_off = (lhi * p.ldm + i0 + l31) * 4;
+  const int a_step = 2 * p.ldm * 4, b_step = 2 * p.ldn * 4;
+  const int G = p.Kpad / (2 * SG);   // Kpad is a multiple of 16
+
+  float rmax[RT][16], rsum[RT][16];
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { rmax[t][r] = -INFINITY; rsum[t][r] = 0.f; }
+
+#pragma unroll 1
+  for (int jb = jb_lo; jb < jb_hi; ++jb) {
+    const int col = jb * FBN + wave * 32 + l31;
+    const int b_off = (lhi * p.ldn + col) * 4;
+    f32x16 sacc[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[t][r] = 0.f;
+    float fa0[RT][SG], fb0[SG], fa1[RT][SG], fb1[SG], fa2[RT][SG], fb2[SG];
+    auto loads = [&](float (&fa)[RT][SG], float (&fb)[SG], int g) {
+#pragma unroll
+      for (int u = 0; u < SG; ++u) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+          fa[t][u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(at_rs, a_off + 128 * t, (g * SG + u) * a_step, 0));
+        fb[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bt_rs, b_off, (g * SG + u) * b_step, 0));
+      }
+    };
+    auto mfmas = [&](const float (&fa)[RT][SG], const float (&fb)[SG]) {
+#pragma unroll
+      for (int u = 0; u < SG; ++u)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) sacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t][u], fb[u], sacc[t], 0, 0, 0);
+    };
+    auto interleave = [&]() {
+#pragma unroll
+      for (int u = 0; u < SG; ++u) {   // RT + 1 loads per RT MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+        if constexpr (RT == 2) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+      }
+    };
+    loads(fa0, fb0, 0);
+    loads(fa1, fb1, min(1, G - 1));
+    int g = 0;
+#pragma unroll 1
+    for (; g + 3 <= G; g += 3) {
+      loads(fa2, fb2, g + 2);
+      mfmas(fa0, fb0);
+      interleave();
+      loads(fa0, fb0, min(g + 3, G - 1));
+      mfmas(fa1, fb1);
+      interleave();
+      loads(fa1, fb1, min(g + 4, G - 1));
+      mfmas(fa2, fb2);
+      interleave();
+    }
+    if (g < G) mfmas(fa0, fb0);
+    if (g + 1 < G) mfmas(fa1, fb1);
+    // ---- fold the finished tile(s) into the online row statistics ----
+    const bool col_ok = col < p.n;
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const float v = col_ok ? __fmul_rn(p.alpha, sacc[t][r]) : -INFINITY;
+        if (col_ok && row < p.m && static_cast<int64_t>(col) == p.diag_offset + row) p.diag[row] = v;
+        const float mn = fmaxf(rmax[t][r], v);
+        if (mn != -INFINITY) rsum[t][r] = rsum[t][r] * fast_exp(rmax[t][r] - mn) + fast_exp(v - mn);
+        rmax[t][r] = mn;
+      }
+  }
+  // ---- reduce over the 32 column lanes of each half, then over the 4 waves ----
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float mx = rmax[t][r], l = rsum[t][r];
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) {
+        const float om = __shfl_xor(mx, off, 64), ol = __shfl_xor(l, off, 64);
+        const float mn = fmaxf(mx, om);
+        l = (mn == -INFINITY) ? 0.f : l * fast_exp(mx - mn) + ol * fast_exp(om - mn);
+        mx = mn;
+      }
+      if (l31 == 0) {
+        const int rl = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        red_m[wave][rl] = mx;
+        red_l[wave][rl] = l;
+      }
+    }
+  __syncthreads();
+  if (tid < 32 * RT && i0 + tid < p.m) {
+    float mx = red_m[0][tid];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) mx = fmaxf(mx, red_m[w][tid]);
+    float l = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+      if (red_m[w][tid] != -INFINITY) l += red_l[w][tid] * fast_exp(red_m[w][tid] - mx);
+    const int64_t pi = static_cast<int64_t>(z) * p.m + i0 + tid;
+    p.part_m[pi] = mx;
+    p.part_l[pi] = l;
+  }
+}
+
 // dA = alpha * sum_z slab[z] (fixed order), float4-wide; n4 = m*D/4 (D % 4 == 0 on this path)
 __global__ __launch_bounds__(256) void flash_reduce_kernel(const float4* __restrict__ slab, int nsplit, int64_t n4,
                                                            float alpha, float4* __restrict__ out) {
@@ -630,6 +771,33 @@ inline FlashPlan flash_plan(int64_t m, int64_t n, int64_t D) {
   return f;
 }
 inline size_t flash_copy_floats(const FlashPlan& f, int64_t D) { return static_cast<size_t>(D) * (f.ldm + f.ldn); }
+
+// Streaming row statistics: used once the problem is MFMA-sized (the small-batch path and the latency-bound
+// split-K form cover everything below); any D (the k-major copies are zero-padded to a multiple of 16).
+struct StreamPlan { bool ok; int rt, row_blocks, nsplit, blocks_per_split; int64_t ldm, ldn, kpad; };
+inline StreamPlan stream_plan(int64_t m, int64_t n, int64_t D) {
+  StreamPlan f{false, 1, 0, 1, 0, 0, 0, 0};
+  static const bool off = getenv("DALM_SIM_ROWSTATS") && getenv("DALM_SIM_ROWSTATS")[0] == 'g';   // "gemm": the LDS-tiled form
+  if (off) return f;
+  if (m * n < 512 * 512 || D < 64) return f;
+  f.kpad = (D + 15) / 16 * 16;
+  if ((n + 128) * f.kpad * 4 >= (1ll << 31) || (m + 64) * f.kpad * 4 >= (1ll << 31)) return f;   // 32-bit buffer offsets
+  static const int force_rt = getenv("DALM_STREAM_RT") ? atoi(getenv("DALM_STREAM_RT")) : 0;
+  f.rt = force_rt ? force_rt : ((m >= 4096) ? 2 : 1);   // measured: 2048^2 86 vs 77 TF, 4096^2 100 vs 107, 16384^2 118 vs 141
+  const int64_t bm = 32 * f.rt;
+  f.row_blocks = static_cast<int>((m + bm - 1) / bm);
+  const int64_t col_blocks = (n + FBN - 1) / FBN;
+  int64_t ns = ((f.rt == 2 ? 512 : 768) + f.row_blocks - 1) / f.row_blocks;      // 2-3 workgroups per CU (by registers)
+  if (ns > col_blocks) ns = col_blocks;
+  if (ns < 1) ns = 1;
+  if (ns > 64) ns = 64;
+  f.blocks_per_split = static_cast<int>((col_blocks + ns - 1) / ns);
+  f.nsplit = static_cast<int>((col_blocks + f.blocks_per_split - 1) / f.blocks_per_split);
+  f.ldm = static_cast<int64_t>(f.row_blocks) * bm;
+  f.ldn = col_blocks * FBN;
+  f.ok = true;
+  return f;
+}
 
 inline bool vec_ok(const float* p, int64_t ld) {
   return (reinterpret_cast<uintptr_t>(p) % 16 == 0) && (ld % 4 == 0);
@@ -711,6 +879,8 @@ extern "C" int dalm_sim_matmul(const float* A, const float* Bm, int64_t m, int64
 
 extern "C" size_t dalm_sim_rowstats_workspace_bytes(int64_t m, int64_t n, int64_t D) {
   if (m <= 0 || n <= 0) return 0;
+  if (const StreamPlan f = stream_plan(m, n, D); f.ok)
+    return (static_cast<size_t>(f.kpad) * (f.ldm + f.ldn) + 2 * static_cast<size_t>(f.nsplit) * m) * sizeof(float);
   const int sk = sim_splitk(m, n, D);
   if (sk > 1) return static_cast<size_t>(sk) * static_cast<size_t>(m) * static_cast<size_t>(round_up4(n)) * sizeof(float);
   return static_cast<size_t>(rowstats_parts(m, n)) * static_cast<size_t>(m) * 2 * sizeof(float);
@@ -725,6 +895,27 @@ extern "C" int dalm_sim_rowstats(const float* A, const float* Bm, int64_t m, int
   DALM_REQUIRE(ws_bytes >= dalm_sim_rowstats_workspace_bytes(m, n, D), DALM_E_WORKSPACE, "workspace too small");
   DALM_REQUIRE(reinterpret_cast<uintptr_t>(ws) % 4 == 0, DALM_E_ALIGN, "workspace must be 4-byte aligned");
   hipStream_t s = as_stream(stream);
+  if (const StreamPlan f = stream_plan(m, n, D); f.ok) {
+    float* At = static_cast<float*>(ws);
+    float* Bt = At + static_cast<size_t>(f.kpad) * f.ldm;
+    float* pm = Bt + static_cast<size_t>(f.kpad) * f.ldn;
+    float* pl = pm + static_cast<size_t>(f.nsplit) * m;
+    const int64_t ldmax = f.ldm > f.ldn ? f.ldm : f.ldn;
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3(static_cast<unsigned>(ldmax / 32), static_cast<unsigned>(f.kpad / 32 + (f.kpad % 32 != 0)), 2),
+                       dim3(256), 0, s, A, static_cast<int>(m), static_cast<int>(f.ldm), At, Bm, static_cast<int>(n),
+                       static_cast<int>(f.ldn), Bt, static_cast<int>(D), static_cast<int>(f.kpad));
+    StreamStatsParams q{};
+    q.At = At; q.Bt = Bt; q.m = static_cast<int>(m); q.n = static_cast<int>(n); q.Kpad = static_cast<int>(f.kpad);
+    q.ldm = static_cast<int>(f.ldm); q.ldn = static_cast<int>(f.ldn); q.alpha = scale; q.diag_offset = diag_offset;
+    q.part_m = pm; q.part_l = pl; q.diag = diag;
+    q.row_blocks = f.row_blocks; q.nsplit = f.nsplit; q.blocks_per_split = f.blocks_per_split;
+    const dim3 grid(static_cast<unsigned>(f.row_blocks * f.nsplit));
+    if (f.rt == 2) hipLaunchKernelGGL((sim_rowstats_stream_kernel<2>), grid, dim3(256), 0, s, q);
+    else hipLaunchKernelGGL((sim_rowstats_stream_kernel<1>), grid, dim3(256), 0, s, q);
+    hipLaunchKernelGGL(rowstats_merge_kernel, dim3(static_cast<unsigned>((m + 255) / 256)), dim3(256), 0, s, pm, pl,
+                       f.nsplit, static_cast<int>(m), row_lse);
+    return check_launch(__func__);
+  }
   const int64_t P = rowstats_parts(m, n);
   GemmParams p{};
   p.A = A; p.lda = D; p.B = Bm; p.ldb = D;
@@ -795,7 +986,7 @@ extern "C" int dalm_sim_grad(const float* A, const float* Bm, int64_t m, int64_t
     const int64_t ldmax = f.ldm > f.ldn ? f.ldm : f.ldn;
     hipLaunchKernelGGL(transpose_pad_kernel, dim3(static_cast<unsigned>(ldmax / 32), static_cast<unsigned>((D + 31) / 32), 2),
                        dim3(256), 0, s, A, static_cast<int>(m), static_cast<int>(f.ldm), At, Bm, static_cast<int>(n),
-                       static_cast<int>(f.ldn), Bt, static_cast<int>(D));
+                       static_cast<int>(f.ldn), Bt, static_cast<int>(D), static_cast<int>(D));
     FlashParams p{};
     p.At = At; p.Bt = Bt; p.B = Bm; p.m = static_cast<int>(m); p.n = static_cast<int>(n); p.D = static_cast<int>(D);
     p.ldm = static_cast<int>(f.ldm); p.ldn = static_cast<int>(f.ldn);

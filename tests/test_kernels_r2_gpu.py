@@ -248,3 +248,24 @@ def test_lm_head_fused_vs_fp64_oracle(dev, dtype):
     for got, want, name in ((qq.grad, q64.grad, "dq"), (pp.grad, p64.grad, "dp"), (hh.grad, h64.grad, "dh"),
                             (ww.grad, w64.grad, "dW")):
         assert norm_rel_err(got, want) <= tol, (name, norm_rel_err(got, want))
+
+
+STREAM = [(1200, 1200, 1024, 0), (600, 900, 100, 17), (4096, 4096, 384, 0), (4101, 4300, 64, 100), (513, 513, 72, 0),
+          (150, 4000, 1024, 1000)]
+
+
+@pytest.mark.parametrize("m,n,D,off", STREAM)
+def test_streaming_rowstats_vs_fp64(dev, m, n, D, off):
+    """dalm_sim_rowstats in its LDS-free streaming form (m*n >= 512^2): any D (zero-padded k-major copies), row and
+    column tails, several column splits, both row-tile variants (two row tiles per wave from 4096 rows), sharded diag
+    offsets.  atol 2e-4 on |S| ~ 55: the f32 dot products of 1024 terms carry ~1e-4 absolute error there (3e-6 relative)."""
+    from dalm_amd.ops import default_ops
+
+    ops = default_ops()
+    A, Bm, scale, S, *_ = _problem(m, n, D, off)
+    row_lse, diag = ops.sim_rowstats(A.to(dev), Bm.to(dev), scale, off)
+    idx = torch.arange(m)
+    torch.testing.assert_close(row_lse.cpu().double(), torch.logsumexp(S, 1), rtol=1e-6, atol=2e-4)
+    torch.testing.assert_close(diag.cpu().double(), S[idx, off + idx], rtol=1e-6, atol=2e-4)
+    r2, d2 = ops.sim_rowstats(A.to(dev), Bm.to(dev), scale, off)
+    assert torch.equal(r2, row_lse) and torch.equal(d2, diag)
