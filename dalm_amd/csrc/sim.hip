@@ -601,9 +601,12 @@ struct StreamStatsParams {
   float* part_m; float* part_l;       // [nsplit][m]
   float* diag;
   int row_blocks, nsplit, blocks_per_split;
+  // top-k modes
+  float* gmax; int ng;                // MODE_GMAX: gmax[m][ng], one maximum per 32-column group
 };
+enum { MODE_STATS = 0, MODE_GMAX = 1 };
 
-template <int RT>
+template <int RT, int MODE>
 __global__ __launch_bounds__(256, 2) void sim_rowstats_stream_kernel(const StreamStatsParams p) {
   constexpr int SG = 8;
   __shared__ float red_m[4][32 * RT], red_l[4][32 * RT];
@@ -677,20 +680,35 @@ __global__ __launch_bounds__(256, 2) void sim_rowstats_stream_kernel(const Strea
     }
     if (g < G) mfmas(fa0, fb0);
     if (g + 1 < G) mfmas(fa1, fb1);
-    // ---- fold the finished tile(s) into the online row statistics ----
     const bool col_ok = col < p.n;
+    if constexpr (MODE == MODE_STATS) {
+      // ---- fold the finished tile(s) into the online row statistics ----
 #pragma unroll
-    for (int t = 0; t < RT; ++t)
+      for (int t = 0; t < RT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = i0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        const float v = col_ok ? __fmul_rn(p.alpha, sacc[t][r]) : -INFINITY;
-        if (col_ok && row < p.m && static_cast<int64_t>(col) == p.diag_offset + row) p.diag[row] = v;
-        const float mn = fmaxf(rmax[t][r], v);
-        if (mn != -INFINITY) rsum[t][r] = rsum[t][r] * fast_exp(rmax[t][r] - mn) + fast_exp(v - mn);
-        rmax[t][r] = mn;
-      }
+        for (int r = 0; r < 16; ++r) {
+          const int row = i0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          const float v = col_ok ? __fmul_rn(p.alpha, sacc[t][r]) : -INFINITY;
+          if (col_ok && row < p.m && static_cast<int64_t>(col) == p.diag_offset + row) p.diag[row] = v;
+          const float mn = fmaxf(rmax[t][r], v);
+          if (mn != -INFINITY) rsum[t][r] = rsum[t][r] * fast_exp(rmax[t][r] - mn) + fast_exp(v - mn);
+          rmax[t][r] = mn;
+        }
+    } else if constexpr (MODE == MODE_GMAX) {
+      // ---- top-k pass 1: one maximum per (row, 32-column group): 1/32 of the score matrix ----
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = i0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          float v = col_ok ? __fmul_rn(p.alpha, sacc[t][r]) : -INFINITY;
+#pragma unroll
+          for (int off = 16; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+          if (l31 == 0 && row < p.m) p.gmax[static_cast<int64_t>(row) * p.ng + jb * 4 + wave] = v;
+        }
+    }
   }
+  if constexpr (MODE != MODE_STATS) return;
   // ---- reduce over the 32 column lanes of each half, then over the 4 waves ----
 #pragma unroll
   for (int t = 0; t < RT; ++t)
@@ -722,6 +740,117 @@ __global__ __launch_bounds__(256, 2) void sim_rowstats_stream_kernel(const Strea
     const int64_t pi = static_cast<int64_t>(z) * p.m + i0 + tid;
     p.part_m[pi] = mx;
     p.part_l[pi] = l;
+  }
+}
+
+// ---- exact top-k on the streaming kernel (dalm/eval/utils.py:18-68 builds an approximate hnswlib
+// index; here the search is exact and the [Nq, Nc] score matrix never exists) ----
+// The MFMA pass (MODE_GMAX) leaves one maximum per 32 corpus columns.  The k-th largest of a row's group maxima is a
+// lower bound T of its k-th largest score (k distinct scores >= T exist: those maxima), so every top-k member lives in
+// a group whose maximum is >= T - about k groups per row.  topk_threshold_kernel finds T; topk_refine_kernel
+// recomputes only those groups' 32 scores (plain FMA dot products against the k-major corpus copy: ~k*32 of them per
+// query instead of a second pass over the whole corpus), keeps the scores >= T and sorts them (value descending,
+// lower corpus index first on ties: deterministic).
+__global__ __launch_bounds__(256) void topk_threshold_kernel(const float* __restrict__ gmax, int ng, int k,
+                                                             float* __restrict__ thr) {
+  __shared__ float red[4];
+  __shared__ float redc[4];
+  const float* row = gmax + static_cast<int64_t>(blockIdx.x) * ng;
+  float bound = INFINITY;   // values >= bound are already counted
+  int have = 0;
+  float cur = -INFINITY;
+  for (int round = 0; round < k; ++round) {
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < ng; i += 256) {
+      const float v = row[i];
+      if (v < bound) mx = fmaxf(mx, v);
+    }
+    mx = block_max<256>(mx, red);
+    if (mx == -INFINITY) break;
+    float c = 0.f;
+    for (int i = threadIdx.x; i < ng; i += 256) c += (row[i] == mx) ? 1.f : 0.f;
+    c = block_sum<256>(c, redc);
+    cur = mx;
+    have += static_cast<int>(c);
+    bound = mx;
+    if (have >= k) break;
+  }
+  // a few ulps of slack: the refine pass re-evaluates the scores with a VALU fma chain
+  if (threadIdx.x == 0) thr[blockIdx.x] = (have >= k) ? cur - fabsf(cur) * 1e-6f - 1e-30f : -INFINITY;
+}
+
+// one workgroup per query row.  LDS: q[Kpad] | glist[cap] | cand_val[cap] | cand_idx[cap]
+__global__ __launch_bounds__(256) void topk_refine_kernel(const float* __restrict__ At, int ldm, const float* __restrict__ Bt,
+                                                          int ldn, int Kpad, int n, float alpha,
+                                                          const float* __restrict__ gmax, int ng,
+                                                          const float* __restrict__ thr, int cap, int k,
+                                                          float* __restrict__ out_val, int64_t* __restrict__ out_idx,
+                                                          int* __restrict__ overflow) {
+  extern __shared__ float sm[];
+  __shared__ int n_groups, n_cand;
+  __shared__ float red[4];
+  __shared__ int redi[4];
+  float* q = sm;
+  int* glist = reinterpret_cast<int*>(sm + Kpad);
+  float* cv = sm + Kpad + cap;
+  int* ci = reinterpret_cast<int*>(sm + Kpad + 2 * cap);
+  const int row = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) { n_groups = 0; n_cand = 0; }
+  for (int kk = tid; kk < Kpad; kk += 256) q[kk] = At[static_cast<int64_t>(kk) * ldm + row];
+  const float T = thr[row];
+  __syncthreads();
+  for (int g = tid; g < ng; g += 256)
+    if (gmax[static_cast<int64_t>(row) * ng + g] >= T) {
+      const int pos = atomicAdd(&n_groups, 1);
+      if (pos < cap) glist[pos] = g;
+    }
+  __syncthreads();
+  const int total_groups = n_groups;
+  if (total_groups > cap) {   // massive ties: report and let the caller fall back
+    if (tid == 0) atomicAdd(overflow, 1);
+    return;
+  }
+  // half-wave per group: lane c of the half evaluates column g*32 + c
+  const int hw = tid >> 5, c = tid & 31;
+  for (int gi = hw; gi < total_groups; gi += 8) {
+    const int col = glist[gi] * 32 + c;
+    const float* bcol = Bt + min(col, ldn - 1);
+    float s0 = 0.f;
+#pragma unroll 8
+    for (int kk = 0; kk < Kpad; ++kk) s0 = fmaf(q[kk], bcol[static_cast<int64_t>(kk) * ldn], s0);
+    const float v = __fmul_rn(alpha, s0);
+    if (col < n && v >= T) {
+      const int slot = atomicAdd(&n_cand, 1);
+      if (slot < cap) { cv[slot] = v; ci[slot] = col; }
+    }
+  }
+  __syncthreads();
+  const int cnt = n_cand;
+  if (cnt > cap) {
+    if (tid == 0) atomicAdd(overflow, 1);
+    return;
+  }
+  for (int i = cnt + tid; i < cap; i += 256) { cv[i] = -INFINITY; ci[i] = 0x7fffffff; }
+  __syncthreads();
+  for (int j = 0; j < k; ++j) {
+    float mx = -INFINITY;
+    for (int i = tid; i < cap; i += 256) mx = fmaxf(mx, cv[i]);
+    mx = block_max<256>(mx, red);
+    int bi = 0x7fffffff;   // smallest corpus index among the maxima
+    for (int i = tid; i < cap; i += 256) if (cv[i] == mx) bi = min(bi, ci[i]);
+    const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) bi = min(bi, __shfl_xor(bi, off, 64));
+    if (lane == 0) redi[w] = bi;
+    __syncthreads();
+    bi = min(min(redi[0], redi[1]), min(redi[2], redi[3]));
+    __syncthreads();
+    if (tid == 0) {
+      out_val[static_cast<int64_t>(row) * k + j] = mx;
+      out_idx[static_cast<int64_t>(row) * k + j] = (mx == -INFINITY) ? -1 : bi;
+    }
+    for (int i = tid; i < cap; i += 256) if (cv[i] == mx && ci[i] == bi) cv[i] = -INFINITY;
+    __syncthreads();
   }
 }
 
@@ -775,11 +904,11 @@ inline size_t flash_copy_floats(const FlashPlan& f, int64_t D) { return static_c
 // Streaming row statistics: used once the problem is MFMA-sized (the small-batch path and the latency-bound
 // split-K form cover everything below); any D (the k-major copies are zero-padded to a multiple of 16).
 struct StreamPlan { bool ok; int rt, row_blocks, nsplit, blocks_per_split; int64_t ldm, ldn, kpad; };
-inline StreamPlan stream_plan(int64_t m, int64_t n, int64_t D) {
+inline StreamPlan stream_plan(int64_t m, int64_t n, int64_t D, bool always = false) {
   StreamPlan f{false, 1, 0, 1, 0, 0, 0, 0};
   static const bool off = getenv("DALM_SIM_ROWSTATS") && getenv("DALM_SIM_ROWSTATS")[0] == 'g';   // "gemm": the LDS-tiled form
-  if (off) return f;
-  if (m * n < 512 * 512 || D < 64) return f;
+  if (off && !always) return f;
+  if (!always && (m * n < 512 * 512 || D < 64)) return f;
   f.kpad = (D + 15) / 16 * 16;
   if ((n + 128) * f.kpad * 4 >= (1ll << 31) || (m + 64) * f.kpad * 4 >= (1ll << 31)) return f;   // 32-bit buffer offsets
   static const int force_rt = getenv("DALM_STREAM_RT") ? atoi(getenv("DALM_STREAM_RT")) : 0;
@@ -910,8 +1039,8 @@ extern "C" int dalm_sim_rowstats(const float* A, const float* Bm, int64_t m, int
     q.part_m = pm; q.part_l = pl; q.diag = diag;
     q.row_blocks = f.row_blocks; q.nsplit = f.nsplit; q.blocks_per_split = f.blocks_per_split;
     const dim3 grid(static_cast<unsigned>(f.row_blocks * f.nsplit));
-    if (f.rt == 2) hipLaunchKernelGGL((sim_rowstats_stream_kernel<2>), grid, dim3(256), 0, s, q);
-    else hipLaunchKernelGGL((sim_rowstats_stream_kernel<1>), grid, dim3(256), 0, s, q);
+    if (f.rt == 2) hipLaunchKernelGGL((sim_rowstats_stream_kernel<2, MODE_STATS>), grid, dim3(256), 0, s, q);
+    else hipLaunchKernelGGL((sim_rowstats_stream_kernel<1, MODE_STATS>), grid, dim3(256), 0, s, q);
     hipLaunchKernelGGL(rowstats_merge_kernel, dim3(static_cast<unsigned>((m + 255) / 256)), dim3(256), 0, s, pm, pl,
                        f.nsplit, static_cast<int>(m), row_lse);
     return check_launch(__func__);
@@ -1097,5 +1226,69 @@ extern "C" int dalm_contrastive_finalize(const float* row_lse, const float* col_
                "need 0 < n_local <= n_global");
   hipLaunchKernelGGL(contrastive_finalize_kernel, dim3(1), dim3(256), 0, as_stream(stream), row_lse, col_lse,
                      diag, static_cast<int>(n_local), static_cast<float>(n_global), out, doc_lp);
+  return check_launch(__func__);
+}
+
+
+// ---- exact top-k (eval retrieval): scores = scale * Q . C^T, k largest per query, no score matrix -------------
+namespace {
+struct TopkLayout { StreamPlan f; int cap; size_t at, bt, gmax, thr, total; };
+inline TopkLayout topk_layout(int64_t m, int64_t n, int64_t D, int64_t k) {
+  TopkLayout L{};
+  L.f = stream_plan(m, n, D, true);
+  L.cap = static_cast<int>(8 * k + 64);
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 15) / 16 * 16; return at; };
+  L.at = take(static_cast<size_t>(L.f.kpad) * L.f.ldm * 4);
+  L.bt = take(static_cast<size_t>(L.f.kpad) * L.f.ldn * 4);
+  L.gmax = take(static_cast<size_t>(m) * (L.f.ldn / 32) * 4);
+  L.thr = take(static_cast<size_t>(m) * 4);
+  L.total = o;
+  return L;
+}
+}  // namespace
+
+extern "C" size_t dalm_sim_topk_workspace_bytes(int64_t m, int64_t n, int64_t D, int64_t k) {
+  if (m <= 0 || n <= 0 || D <= 0 || k <= 0) return 0;
+  const TopkLayout L = topk_layout(m, n, D, k);
+  return L.f.ok ? L.total : 0;
+}
+
+extern "C" int dalm_sim_topk(const float* Q, const float* C, int64_t m, int64_t n, int64_t D, float scale, int64_t k,
+                             float* out_val, int64_t* out_idx, int* overflow, void* ws, size_t ws_bytes,
+                             dalm_stream_t stream) {
+  DALM_REQUIRE(Q && C && out_val && out_idx && overflow && ws, DALM_E_NULL, "null pointer argument");
+  if (int e = check_gemm_dims(m, n, D, __func__)) return e;
+  DALM_REQUIRE(k > 0 && k <= n && k <= 1024, DALM_E_SHAPE, "need 0 < k <= min(n, 1024)");
+  const TopkLayout L = topk_layout(m, n, D, k);
+  DALM_REQUIRE(L.f.ok, DALM_E_SHAPE, "corpus block too large for 32-bit buffer offsets: search it in blocks of <= 2^19 rows");
+  DALM_REQUIRE(ws_bytes >= L.total, DALM_E_WORKSPACE, "workspace too small");
+  DALM_REQUIRE(reinterpret_cast<uintptr_t>(ws) % 16 == 0, DALM_E_ALIGN, "workspace must be 16-byte aligned");
+  hipStream_t s = as_stream(stream);
+  char* base = static_cast<char*>(ws);
+  float* At = reinterpret_cast<float*>(base + L.at);
+  float* Bt = reinterpret_cast<float*>(base + L.bt);
+  const StreamPlan& f = L.f;
+  const int64_t ldmax = f.ldm > f.ldn ? f.ldm : f.ldn;
+  hipLaunchKernelGGL(transpose_pad_kernel, dim3(static_cast<unsigned>(ldmax / 32), static_cast<unsigned>((f.kpad + 31) / 32), 2),
+                     dim3(256), 0, s, Q, static_cast<int>(m), static_cast<int>(f.ldm), At, C, static_cast<int>(n),
+                     static_cast<int>(f.ldn), Bt, static_cast<int>(D), static_cast<int>(f.kpad));
+  StreamStatsParams q{};
+  q.At = At; q.Bt = Bt; q.m = static_cast<int>(m); q.n = static_cast<int>(n); q.Kpad = static_cast<int>(f.kpad);
+  q.ldm = static_cast<int>(f.ldm); q.ldn = static_cast<int>(f.ldn); q.alpha = scale;
+  q.row_blocks = f.row_blocks; q.nsplit = f.nsplit; q.blocks_per_split = f.blocks_per_split;
+  q.gmax = reinterpret_cast<float*>(base + L.gmax); q.ng = static_cast<int>(f.ldn / 32);
+  float* thr = reinterpret_cast<float*>(base + L.thr);
+  const dim3 grid(static_cast<unsigned>(f.row_blocks * f.nsplit));
+  if (hipError_t e = hipMemsetAsync(overflow, 0, 4, s); e != hipSuccess) return static_cast<int>(e);
+  if (f.rt == 2) hipLaunchKernelGGL((sim_rowstats_stream_kernel<2, MODE_GMAX>), grid, dim3(256), 0, s, q);
+  else hipLaunchKernelGGL((sim_rowstats_stream_kernel<1, MODE_GMAX>), grid, dim3(256), 0, s, q);
+  hipLaunchKernelGGL(topk_threshold_kernel, dim3(static_cast<unsigned>(m)), dim3(256), 0, s, q.gmax, q.ng,
+                     static_cast<int>(k), thr);
+  const size_t lds = (static_cast<size_t>(f.kpad) + 3 * static_cast<size_t>(L.cap)) * 4;
+  DALM_REQUIRE(lds <= 60 * 1024, DALM_E_SHAPE, "D and k too large for the refine kernel's LDS (D + 3*(8k+64) floats <= 15360)");
+  hipLaunchKernelGGL(topk_refine_kernel, dim3(static_cast<unsigned>(m)), dim3(256), lds, s, At, static_cast<int>(f.ldm),
+                     Bt, static_cast<int>(f.ldn), static_cast<int>(f.kpad), static_cast<int>(n), scale, q.gmax, q.ng, thr,
+                     L.cap, static_cast<int>(k), out_val, out_idx, overflow);
   return check_launch(__func__);
 }

@@ -156,6 +156,24 @@ class HipOps:
                  hip.stream())
         return out, doc_lp
 
+    def sim_topk(self, Q: torch.Tensor, Cm: torch.Tensor, k: int, scale: float = 1.0):
+        """(values [m,k] f32, indices [m,k] int64, overflow [1] int32) - exact top-k of scale*Q.Cm^T per row without the
+        score matrix; `overflow` non-zero means a row had too many ties for the candidate buffer (fall back)."""
+        dev = hip.require_gpu(Q, Cm)
+        Q, Cm = hip.as_f32c(Q), hip.as_f32c(Cm)
+        m, D = Q.shape
+        n = Cm.shape[0]
+        ws_bytes = hip.load().dalm_sim_topk_workspace_bytes(m, n, D, int(k))
+        if ws_bytes == 0:
+            raise ValueError("sim_topk: corpus block too large for one call (n*D*4 must stay below 2^31)")
+        ws = torch.empty((ws_bytes // 4,), device=dev, dtype=torch.float32)
+        val = torch.empty((m, k), device=dev, dtype=torch.float32)
+        idx = torch.empty((m, k), device=dev, dtype=torch.int64)
+        ovf = torch.empty((1,), device=dev, dtype=torch.int32)
+        hip.call("dalm_sim_topk", hip.ptr(Q), hip.ptr(Cm), m, n, D, float(scale), int(k), hip.ptr(val), hip.ptr(idx),
+                 hip.ptr(ovf), hip.ptr(ws), ws_bytes, hip.stream())
+        return val, idx, ovf
+
     def contrastive_finalize(self, row_lse, col_lse, diag, n_global: int):
         dev = hip.require_gpu(row_lse, col_lse, diag)
         n_local = row_lse.shape[0]

@@ -16,19 +16,39 @@ import torch
 from .ops import default_ops
 
 
-def exact_topk(query_embs: torch.Tensor, corpus_embs: torch.Tensor, k: int, block: int = 131072, ops=None):
-    """(scores [Nq,k], indices [Nq,k]) of the k largest inner products per query, exact, sorted descending."""
+MAX_FUSED_BLOCK_BYTES = (1 << 31) - (1 << 20)
+
+
+def _topk_materialised(ops, query_embs, blk, k):
+    s = ops.sim_matmul(query_embs, blk, 1.0)                      # [Nq, blk] on the f32 MFMA kernel
+    return torch.topk(s, min(k, s.shape[1]), dim=1)
+
+
+def exact_topk(query_embs: torch.Tensor, corpus_embs: torch.Tensor, k: int, block: int = 262144, ops=None,
+               fused: bool = True):
+    """(scores [Nq,k], indices [Nq,k]) of the k largest inner products per query, exact, sorted descending.
+
+    fused=True: `dalm_sim_topk` per corpus block - the [Nq, block] score matrix never exists (one pass of the
+    streaming MFMA kernel leaves per-32-column maxima; a per-row threshold picks the ~k groups worth re-evaluating); rows with massive ties
+    (device-side overflow flag) make that block fall back to the materialising search.  Blocks are merged with a
+    running top-k."""
     ops = ops or default_ops()
     nq, nc = query_embs.shape[0], corpus_embs.shape[0]
     if k > nc:
         raise ValueError(f"k={k} exceeds the corpus size {nc}")
+    D = corpus_embs.shape[1]
+    block = max(1, min(block, MAX_FUSED_BLOCK_BYTES // (4 * ((D + 15) // 16 * 16)) - 128))
     best_s: Optional[torch.Tensor] = None
     best_i: Optional[torch.Tensor] = None
     for c0 in range(0, nc, block):
         blk = corpus_embs[c0:c0 + block]
-        s = ops.sim_matmul(query_embs, blk, 1.0)                  # [Nq, blk] on the f32 MFMA kernel
-        kk = min(k, s.shape[1])
-        bs, bi = torch.topk(s, kk, dim=1)
+        kk = min(k, blk.shape[0])
+        if fused and kk <= 1024:
+            bs, bi, ovf = ops.sim_topk(query_embs, blk, kk)
+            if int(ovf.item()) != 0:                              # eval path: one host sync per block is fine
+                bs, bi = _topk_materialised(ops, query_embs, blk, kk)
+        else:
+            bs, bi = _topk_materialised(ops, query_embs, blk, kk)
         bi = bi + c0
         if best_s is None:
             best_s, best_i = bs, bi
@@ -65,3 +85,31 @@ def get_nearest_neighbours(k: int, search_index: ExactIndex, query_embeddings: t
     for lab, dist in zip(labels.tolist(), distances.tolist()):
         out.append([(ids_to_cat_dict[l], 1 - d) for l, d in zip(lab, dist) if (1 - d) >= threshold])
     return out
+
+
+# ---------------------------------------------------------------------------
+# retrieval quality metrics of the reference's eval drivers
+# ---------------------------------------------------------------------------
+def calculate_precision_recall(retrieved_items: List, correct_items: List) -> Tuple[float, float]:
+    """dalm/eval/utils.py:68-82: set precision / recall of one query's retrieved list."""
+    got, want = set(retrieved_items), set(correct_items)
+    hit = len(got & want)
+    return hit / len(got), hit / len(want)
+
+
+def evaluate_retrieval(query_embs: torch.Tensor, corpus_embs: torch.Tensor, correct_idx: torch.Tensor, top_k: int = 10,
+                       ops=None) -> Dict[str, float]:
+    """recall / precision / hit-rate as dalm/eval/utils.py:225-272 + eval_retriever_only.py:105-178 compute them (one
+    correct passage per query, `top_k` retrieved, threshold 0), on the exact fused top-k instead of the hnswlib index.
+    `correct_idx[i]` is the corpus row of query i's gold passage."""
+    _, idx = exact_topk(query_embs, corpus_embs, top_k, ops=ops)
+    idx = idx.cpu()
+    correct = correct_idx.cpu()
+    precs, recs, hits = [], [], 0
+    for i in range(idx.shape[0]):
+        p, r = calculate_precision_recall(idx[i].tolist(), [int(correct[i])])
+        precs.append(p)
+        recs.append(r)
+        hits += int(int(correct[i]) in idx[i].tolist())
+    n = max(len(precs), 1)
+    return {"recall": sum(recs) / n, "precision": sum(precs) / n, "hit_rate": hits / n, "top_k": top_k, "queries": n}

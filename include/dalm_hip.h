@@ -228,6 +228,19 @@ int dalm_contrastive_finalize(const float* row_lse, const float* col_lse,
                               int64_t n_global, float* out, float* doc_lp,
                               dalm_stream_t stream);
 
+/* ---- exact inner-product top-k (eval retrieval) ----
+ * Replaces the hnswlib index of dalm/eval/utils.py:18-68 (construct_search_index / knn_query, space "ip") for
+ * corpora that fit the GPU: out_val[m,k] / out_idx[m,k] = the k largest scale * Q[i] . C[j] per query row, sorted
+ * descending (ties: lower corpus index first), exact f32, without materialising the m x n score matrix
+ * (one pass of the streaming MFMA kernel leaves a maximum per 32 corpus columns; a per-row threshold then picks the
+ * ~k groups that can hold top-k members and only those are re-evaluated).  n*D*4 < 2^31 per call
+ * (search larger corpora block by block and merge).  *overflow (device int) is set non-zero when a row had more
+ * than 8k+64 groups or scores >= its threshold (massive ties, or k > n/32): the caller must then fall back to a materialising search. */
+size_t dalm_sim_topk_workspace_bytes(int64_t m, int64_t n, int64_t D, int64_t k);
+int dalm_sim_topk(const float* Q, const float* C, int64_t m, int64_t n, int64_t D,
+                  float scale, int64_t k, float* out_val, int64_t* out_idx,
+                  int* overflow, void* ws, size_t ws_bytes, dalm_stream_t stream);
+
 /* The whole loss assembly of the RAG-e2e step (train_rage2e.py:443-467) in one launch:
  *   out[1] = L_con (as dalm_contrastive_finalize), doc_lp[i] = diag[i] - row_lse[i] (may be NULL),
  *   out[2] = L_gen (as dalm_marg_ce_finalize with that doc_lp), out[0] = L_con + L_gen.

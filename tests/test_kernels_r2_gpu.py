@@ -269,3 +269,63 @@ def test_streaming_rowstats_vs_fp64(dev, m, n, D, off):
     torch.testing.assert_close(diag.cpu().double(), S[idx, off + idx], rtol=1e-6, atol=2e-4)
     r2, d2 = ops.sim_rowstats(A.to(dev), Bm.to(dev), scale, off)
     assert torch.equal(r2, row_lse) and torch.equal(d2, diag)
+
+
+@pytest.mark.parametrize("nq,nc,D,k", [(37, 5000, 96, 10), (300, 70000, 384, 10), (5, 40, 64, 7), (129, 3001, 1024, 1),
+                                        (64, 2000, 100, 100)])
+def test_fused_topk_vs_fp64(dev, nq, nc, D, k):
+    """dalm_sim_topk: exact top-k without the score matrix == fp64 brute force (indices identical, values to f32)."""
+    from dalm_amd.ops import default_ops
+    from dalm_amd.retrieval import exact_topk
+
+    g = torch.Generator().manual_seed(nq + nc)
+    corpus = torch.nn.functional.normalize(torch.randn(nc, D, generator=g), dim=1)
+    queries = torch.nn.functional.normalize(corpus[:nq] + 0.05 * torch.randn(nq, D, generator=g), dim=1)
+    ref = queries.double() @ corpus.double().t()
+    rs, ri = torch.topk(ref, k, dim=1)
+    val, idx, ovf = default_ops().sim_topk(queries.to(dev), corpus.to(dev), k)
+    if k * 32 > nc and nc > 8 * k + 64:
+        # fewer 32-column groups than k: no useful threshold exists, every score is a candidate and the buffer
+        # overflows - flagged, and exact_topk (below) takes the materialising route for that block
+        assert int(ovf) != 0
+    else:
+        assert int(ovf) == 0
+        # identical unless two scores are closer than f32 resolution: compare through the fp64 scores of the picks
+        picked = torch.gather(ref, 1, idx.cpu())
+        torch.testing.assert_close(picked, rs, rtol=0, atol=2e-6)
+        torch.testing.assert_close(val.cpu().double(), rs, rtol=1e-5, atol=2e-6)
+        assert (idx.cpu()[:, 0] == ri[:, 0]).float().mean() > 0.99
+    s2, i2 = exact_topk(queries.to(dev), corpus.to(dev), k, block=1500)      # several blocks -> merges exercised
+    torch.testing.assert_close(torch.gather(ref, 1, i2.cpu()), rs, rtol=0, atol=2e-6)
+
+
+def test_fused_topk_ties_overflow_falls_back(dev):
+    from dalm_amd.ops import default_ops
+    from dalm_amd.retrieval import exact_topk
+
+    corpus = torch.ones(4000, 64) / 8.0          # every score identical: every row overflows the candidate buffer
+    q = torch.ones(3, 64) / 8.0
+    val, idx, ovf = default_ops().sim_topk(q.to(dev), corpus.to(dev), 5)
+    assert int(ovf) != 0
+    s, i = exact_topk(q.to(dev), corpus.to(dev), 5)
+    torch.testing.assert_close(s.cpu(), torch.ones(3, 5), rtol=1e-6, atol=1e-6)
+
+
+def test_recall_hit_rate_on_synthetic_corpus(dev):
+    """The eval quality metrics of the reference (recall / precision / hit-rate, dalm/eval/utils.py:225-272) on a
+    synthetic corpus: queries are noisy copies of their gold passages; vs a brute-force fp64 evaluation."""
+    from dalm_amd.retrieval import evaluate_retrieval
+
+    g = torch.Generator().manual_seed(3)
+    nc, nq, D, k = 20000, 500, 384, 10
+    corpus = torch.nn.functional.normalize(torch.randn(nc, D, generator=g), dim=1)
+    gold = torch.randperm(nc, generator=g)[:nq]
+    noise = torch.linspace(0.05, 3.0, nq).unsqueeze(1)          # from trivially easy to hopeless
+    queries = torch.nn.functional.normalize(corpus[gold] + noise * torch.randn(nq, D, generator=g) / D ** 0.5 * 4, dim=1)
+    res = evaluate_retrieval(queries.to(dev), corpus.to(dev), gold, top_k=k)
+    ref_idx = torch.topk(queries.double() @ corpus.double().t(), k, dim=1).indices
+    hit = (ref_idx == gold.unsqueeze(1)).any(1).double()
+    assert abs(res["hit_rate"] - float(hit.mean())) <= 2.0 / nq
+    assert abs(res["recall"] - float(hit.mean())) <= 2.0 / nq           # one gold passage: recall == hit
+    assert abs(res["precision"] - float(hit.mean()) / k) <= 2.0 / nq / k
+    assert 0.2 < res["hit_rate"] < 1.0
