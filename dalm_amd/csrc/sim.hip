@@ -291,12 +291,24 @@ __global__ __launch_bounds__(256) void rowstats_merge_kernel(const float* __rest
                                                              float* __restrict__ row_lse) {
   const int row = blockIdx.x * 256 + threadIdx.x;
   if (row >= M) return;
-  float m = -INFINITY;
-  for (int q = 0; q < P; ++q) m = fmaxf(m, part_m[static_cast<int64_t>(q) * M + row]);
-  float l = 0.f;
-  for (int q = 0; q < P; ++q) {
-    const float pm = part_m[static_cast<int64_t>(q) * M + row];
-    if (pm != -INFINITY) l += part_l[static_cast<int64_t>(q) * M + row] * fast_exp(pm - m);
+  // partials are fetched 8 at a time (clamped, unconditional): a `for q < P` loop of loads is a serial latency chain
+  float m = -INFINITY, l = 0.f;
+  for (int q0 = 0; q0 < P; q0 += 8) {
+    float pm[8], pl[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t o = static_cast<int64_t>(min(q0 + u, P - 1)) * M + row;
+      pm[u] = part_m[o];
+      pl[u] = part_l[o];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (q0 + u < P && pm[u] != -INFINITY) {   // online merge in fixed order q = 0..P-1
+        const float mn = fmaxf(m, pm[u]);
+        l = l * fast_exp(m - mn) + pl[u] * fast_exp(pm[u] - mn);
+        m = mn;
+      }
+    }
   }
   row_lse[row] = m + __logf(l);
 }

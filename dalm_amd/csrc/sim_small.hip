@@ -192,7 +192,8 @@ __global__ __launch_bounds__(256) void small_stats_kernel(const float* __restric
     mx = wave_max(mx);
     for (int c0 = 0; c0 < C; c0 += 64) {
       const int c = c0 + lane;
-      const float sv = slab_s(base + min(c, C - 1), ss, SK, alpha);
+      // rows: this lane wrote S[row][c] in the first pass (own writes are visible to the thread) - one load instead of SK
+      const float sv = cols ? slab_s(base + min(c, C - 1), ss, SK, alpha) : S[static_cast<int64_t>(row) * ldS + min(c, C - 1)];
       if (c < C) l += fast_exp(sv - mx);
     }
   }

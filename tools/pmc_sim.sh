@@ -15,7 +15,7 @@ def load(pat):
     for f in glob.glob(pat, recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].replace("(anonymous namespace)::", "")
-            if "gemm_f32_mfma" not in k and "sim_flash" not in k: continue
+            if not any(t in k for t in ("gemm_f32_mfma", "sim_flash", "sim_rowstats_stream")): continue
             k = re.sub(r"\(.*", "", k).replace("void ", "").replace("dalm::", "")
             grid = int(r["Grid_Size"]) // int(r["Workgroup_Size"])
             agg[(k, grid)][r["Counter_Name"]].append(float(r["Counter_Value"]))
