@@ -14,7 +14,7 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = CSRC / "libdalm_hip.so"
-SOURCES = ["lib.hip", "ce.hip", "sim.hip", "sim_small.hip", "pool.hip"]
+SOURCES = ["lib.hip", "ce.hip", "sim.hip", "sim_small.hip", "pool.hip", "comm.hip"]
 HEADERS = [CSRC / "common.hpp", CSRC.parent.parent / "include" / "dalm_hip.h"]
 ARCH = "gfx950"
 
@@ -46,7 +46,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
             print("[dalm_amd build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
         objs.append(str(obj))
-    cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", str(LIB)]
+    cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-ldl", "-o", str(LIB)]
     if verbose:
         print("[dalm_amd build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

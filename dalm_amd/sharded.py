@@ -36,6 +36,13 @@ def init_distributed(backend: Optional[str] = None):
     import torch.distributed as dist
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available() and os.environ.get("DALM_NATIVE_COMM", "0") == "1":
+        # opt-in: the library's own RCCL binding (dalm_comm_*), no torch.distributed process group at all
+        from .comm import NativeRcclComm
+
+        dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev)
+        return NativeRcclComm(), dev
     if torch.cuda.is_available():
         dev = torch.device("cuda", local_rank)
         torch.cuda.set_device(dev)
@@ -200,7 +207,13 @@ class GradBucket:
 
 
 def barrier(comm) -> None:
-    if not isinstance(comm, LocalComm):
-        import torch.distributed as dist
+    if isinstance(comm, LocalComm):
+        return
+    import torch.distributed as dist
 
+    if dist.is_available() and dist.is_initialized():
         dist.barrier()
+    else:   # native communicator: a 1-float all-reduce + host sync is the barrier
+        t = torch.zeros(1, device=torch.device("cuda", torch.cuda.current_device()))
+        comm.all_reduce_sum_(t)
+        torch.cuda.current_stream().synchronize()

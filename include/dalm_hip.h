@@ -251,6 +251,27 @@ int dalm_rag_loss_finalize(const float* row_nll, int64_t num_rows, const float* 
                            const float* stats, float* out, float* doc_lp,
                            dalm_stream_t stream);
 
+/* ---- dalm_comm_*: the collectives of the sharded in-batch negatives, on RCCL, owned by the library ----
+ * Stands in for what the reference gets from accelerate/DDP (train_rage2e.py:416-418,471), plus the embedding
+ * all-gathers the reference does not have (it uses rank-local negatives).  One process per GPU.  RCCL is bound at
+ * run time (dlopen: the copy already in the process, else /opt/rocm/lib/librccl.so).  Collectives are enqueued on
+ * a side HIP stream owned by the communicator; order them against your own streams with
+ *   dalm_comm_wait_stream(c, producer)   - the comm stream waits for work already queued on `producer`
+ *   dalm_comm_stream_wait(c, consumer)   - `consumer` waits for the collectives already queued
+ * (hipEvents; nothing blocks the host).  Bootstrap: rank 0 calls dalm_comm_unique_id and ships the 128 bytes to
+ * the other ranks (file, store, env); every rank then calls dalm_comm_init.  Errors: negative = argument,
+ * 999 = RCCL not loadable, 1000 + ncclResult_t, other positive = hipError_t. */
+typedef struct dalm_comm dalm_comm_t;
+int dalm_comm_unique_id(void* id128);
+int dalm_comm_init(dalm_comm_t** out, const void* id128, int rank, int world, int device);
+int dalm_comm_destroy(dalm_comm_t* c);
+int dalm_comm_rank(const dalm_comm_t* c);
+int dalm_comm_world(const dalm_comm_t* c);
+int dalm_comm_wait_stream(dalm_comm_t* c, dalm_stream_t producer);
+int dalm_comm_stream_wait(dalm_comm_t* c, dalm_stream_t consumer);
+int dalm_comm_allgather(dalm_comm_t* c, const void* send, void* recv, size_t bytes_per_rank);
+int dalm_comm_allreduce_sum_f32(dalm_comm_t* c, float* buf, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -329,3 +329,36 @@ def test_recall_hit_rate_on_synthetic_corpus(dev):
     assert abs(res["recall"] - float(hit.mean())) <= 2.0 / nq           # one gold passage: recall == hit
     assert abs(res["precision"] - float(hit.mean()) / k) <= 2.0 / nq / k
     assert 0.2 < res["hit_rate"] < 1.0
+
+
+def test_native_rccl_communicator_one_rank(dev, tmp_path, monkeypatch):
+    """dalm_comm_*: the library's own RCCL binding (dlopen'd at run time).  One rank on this box: unique id, init, an
+    all-gather and a SUM all-reduce on the communicator's side stream with event ordering against torch's stream, and
+    the sharded loss through it == the single-process loss.  (>= 2 GPUs: tests/test_sharded_two_ranks_gpu.py.)"""
+    from dalm_amd.comm import NativeRcclComm
+    from dalm_amd.fused import rag_e2e_loss
+
+    monkeypatch.setenv("DALM_COMM_ID_FILE", str(tmp_path / "id"))
+    comm = NativeRcclComm(rank=0, world_size=1, device=0)
+    try:
+        x = torch.randn(7, 33, device=dev)
+        y = comm.all_gather_rows(x * 2.0)              # producer kernel on torch's stream, gather on the comm stream
+        z = y + 1.0                                    # consumer on torch's stream again
+        torch.testing.assert_close(z, x * 2.0 + 1.0)
+        g = torch.arange(1000, device=dev, dtype=torch.float32)
+        comm.all_reduce_sum_(g)
+        torch.testing.assert_close(g, torch.arange(1000, device=dev, dtype=torch.float32))
+        q, p, logits, ids, mask, qlen = synth_batch(2, 6, 64, 16, 500)
+        args = [t.to(dev) for t in (q, p, logits, ids, mask, qlen)]
+        a = [args[0].clone().requires_grad_(True), args[1].clone().requires_grad_(True), args[2].clone().requires_grad_(True)]
+        b = [args[0].clone().requires_grad_(True), args[1].clone().requires_grad_(True), args[2].clone().requires_grad_(True)]
+        la = rag_e2e_loss(a[0], a[1], a[2], *args[3:], 100)
+        lb = rag_e2e_loss(b[0], b[1], b[2], *args[3:], 100, comm=comm)     # the W > 1 code path (two row problems, stats exchange)
+        la.backward(); lb.backward()
+        assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(la))
+        for u, v in zip(a, b):
+            assert norm_rel_err(v.grad, u.grad) <= 1e-5
+        with pytest.raises(TypeError):
+            comm.all_reduce_sum_(torch.zeros(3, device=dev, dtype=torch.bfloat16))
+    finally:
+        comm.close()

@@ -38,7 +38,10 @@ def _worker(rank, world, port, out_dir, rccl=False):
 
     dev = torch.device("cuda", rank if rccl else 0)
     torch.cuda.set_device(dev)
-    if rccl:   # one rank per GPU, the real thing: RCCL collectives, side-stream gathers, overlapped grad buckets
+    native = rccl == "native"
+    if native:     # the library's own RCCL binding: no torch.distributed process group at all
+        os.environ["DALM_COMM_ID_FILE"] = os.path.join(out_dir, "rccl.id")
+    elif rccl:     # one rank per GPU, the real thing: RCCL collectives, side-stream gathers, overlapped grad buckets
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -53,7 +56,12 @@ def _worker(rank, world, port, out_dir, rccl=False):
             t.copy_(h)
             return t
 
-    comm = TorchDistComm() if rccl else HostStagedComm()
+    if native:
+        from dalm_amd.comm import NativeRcclComm
+
+        comm = NativeRcclComm(rank=rank, world_size=world, device=rank)
+    else:
+        comm = TorchDistComm() if rccl else HostStagedComm()
     B_l, D, Tg, V, T = 5, 64, 24, 1000, 9
     q, p, logits, ids, mask, qlen = synth_batch(7, world * B_l, D, Tg, V, pad_side="left", logit_gain=2.0)
     g = torch.Generator().manual_seed(3)
@@ -71,12 +79,15 @@ def _worker(rank, world, port, out_dir, rccl=False):
     bucket.all_reduce()
     torch.cuda.synchronize()
     torch.save({"loss_share": loss.detach().cpu(), "dw": w.grad.detach().cpu().clone(), "dlogits": lg.grad.cpu(),
-                "ranks_seen": dist.get_world_size(), "backend": dist.get_backend(), "device": str(dev)},
+                "ranks_seen": comm.world_size, "backend": "dalm_comm" if native else dist.get_backend(), "device": str(dev)},
                os.path.join(out_dir, f"r{rank}.pt"))
-    dist.destroy_process_group()
+    if native:
+        comm.close()
+    else:
+        dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("rccl", [False, True], ids=["one-gpu-host-staged-gloo", "two-gpus-rccl"])
+@pytest.mark.parametrize("rccl", [False, True, "native"], ids=["one-gpu-host-staged-gloo", "two-gpus-rccl", "two-gpus-dalm_comm"])
 def test_two_gpu_ranks_equal_one_process_at_global_batch(tmp_path, rccl):
     import dalm_oracle as O
     from helpers import synth_batch
@@ -87,7 +98,7 @@ def test_two_gpu_ranks_equal_one_process_at_global_batch(tmp_path, rccl):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), rccl), nprocs=world, join=True)
     res = [torch.load(tmp_path / f"r{r}.pt") for r in range(world)]
     if rccl:
-        assert [r["ranks_seen"] for r in res] == [2, 2] and res[0]["backend"] == "nccl"
+        assert [r["ranks_seen"] for r in res] == [2, 2] and res[0]["backend"] == ("dalm_comm" if rccl == "native" else "nccl")
         assert {r["device"] for r in res} == {"cuda:0", "cuda:1"}
 
     B_l, D, Tg, V, T = 5, 64, 24, 1000, 9
