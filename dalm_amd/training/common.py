@@ -54,15 +54,24 @@ class ShardedBatches:
     staging buffer, and the host->device copy of batch i+1 is issued on a copy stream while step i runs
     (the reference tokenises to python lists and collates + copies synchronously every step)."""
 
-    def __init__(self, dataset, batch_size: int, rank: int, world: int, seed: int, columns: List[str]):
+    def __init__(self, dataset, batch_size: int, rank: int, world: int, seed: int, columns: List[str], *,
+                 bucket_by: Optional[str] = None, trim: Optional[Dict[str, Any]] = None):
+        """dataset: a tokenised `datasets.Dataset` or a dict of int tensors/arrays (e.g. `shards.load_token_shards`).
+        bucket_by: name of an attention-mask column - batches are formed from rows of similar length (opt-in: it changes
+        which rows share a batch, i.e. the in-batch negatives; the reference batches at random).
+        trim: kwargs of `shards.trim_batch` - all-padding columns are dropped on the host before the copy (opt-in:
+        shapes then vary from batch to batch; loss-preserving, see shards.py)."""
         self.B, self.rank, self.world, self.seed = batch_size, rank, world, seed
         self.columns = columns
-        self.n = len(dataset)
+        self.n = len(dataset[columns[0]]) if isinstance(dataset, dict) else len(dataset)
         pin = torch.cuda.is_available()
         self.data: Dict[str, torch.Tensor] = {}
         for k in columns:
-            t = torch.as_tensor(dataset[k], dtype=torch.int64).contiguous()
+            # int32 on the host (half the memory and PCIe bytes); int64 again on the device
+            t = torch.as_tensor(dataset[k]).to(torch.int32).contiguous()
             self.data[k] = t.pin_memory() if pin else t
+        self.bucket_by, self.trim = bucket_by, trim
+        self._lengths = (self.data[bucket_by] != 0).sum(dim=1) if bucket_by else None
         n = self.n
         if world == 1:
             self.num_batches = math.ceil(n / batch_size)
@@ -83,8 +92,19 @@ class ShardedBatches:
         return perm[pos + self.rank * b: pos + (self.rank + 1) * b]
 
     def _stage(self, rows: torch.Tensor, device: torch.device):
-        if device.type != "cuda":
-            return {k: v.index_select(0, rows) for k, v in self.data.items()}, None
+        if device.type != "cuda" or self.trim:
+            host = {k: v.index_select(0, rows) for k, v in self.data.items()}
+            if self.trim:
+                from .shards import trim_batch
+
+                host = trim_batch(host, **self.trim)
+            if device.type != "cuda":
+                return {k: v.long() for k, v in host.items()}, None
+            ev = torch.cuda.Event()
+            with torch.cuda.stream(self._copy_stream):   # shapes vary: per-batch pinned copies instead of fixed staging
+                dev = {k: v.pin_memory().to(device, non_blocking=True).long() for k, v in host.items()}
+                ev.record(self._copy_stream)
+            return dev, ev
         # two persistent pinned staging sets (batch i+1 is staged while batch i's copy may still be in flight);
         # index_select writes straight into the pinned buffer: no per-step pinned allocation
         slot = self._slot = (getattr(self, "_slot", -1) + 1) % 2
@@ -101,14 +121,19 @@ class ShardedBatches:
             for k, v in self.data.items():
                 host = self._staging[slot][k][:n]
                 torch.index_select(v, 0, rows, out=host)
-                dev[k] = host.to(device, non_blocking=True)
+                dev[k] = host.to(device, non_blocking=True).long()
             ev.record(self._copy_stream)
         self._staging_free[slot] = ev
         return dev, ev
 
     def epoch(self, epoch: int, device: torch.device, skip: int = 0) -> Iterable[Dict[str, torch.Tensor]]:
         g = torch.Generator().manual_seed(self.seed + epoch)
-        perm = torch.randperm(self.n, generator=g)
+        if self.bucket_by:
+            from .shards import bucketed_order
+
+            perm = bucketed_order(self._lengths, self.B * self.world, g)
+        else:
+            perm = torch.randperm(self.n, generator=g)
         order = list(range(skip, self.num_batches))
         nxt = self._stage(self._rows(perm, order[0]), device) if order else None
         for j, i in enumerate(order):

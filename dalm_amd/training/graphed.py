@@ -82,7 +82,7 @@ class TensorLRScheduler:
 
 
 class GraphedStep:
-    def __init__(self, step, warmup: int = 3, eager_steps: int = 0):
+    def __init__(self, step, warmup: int = 3, eager_steps: int = 0, max_graphs: int = 8):
         """warmup: hidden extra steps run on a side stream right before the capture (benchmarks);
         eager_steps: the first N REAL steps are launched eagerly and the capture happens after them
         (trainers: no hidden steps, and every library - hipBLASLt workspaces, GEMM solution lookup,
@@ -90,32 +90,42 @@ class GraphedStep:
         self.step = step
         self.warmup = warmup
         self.eager_steps = eager_steps
+        self.max_graphs = max_graphs
         self.calls = 0
-        self.graph: Optional[torch.cuda.CUDAGraph] = None
-        self.static: Optional[Dict[str, torch.Tensor]] = None
-        self.static_loss: Optional[torch.Tensor] = None
-        self.key: Optional[Tuple] = None
+        # one graph per batch shape (trimmed / bucketed batches come in a handful of lengths); all graphs share ONE
+        # memory pool - they never run concurrently, so their activations can overlay each other
+        self.graphs: Dict[Tuple, Tuple[torch.cuda.CUDAGraph, Dict[str, torch.Tensor], torch.Tensor]] = {}
+        self.pool = None
         self.failed: Optional[str] = None
+        self.replays = 0
+        self.eager_calls = 0
         # the LR scheduler must not be captured: it runs on the host and writes the lr tensor
         self.scheduler = step.lr_scheduler
         step.lr_scheduler = None
+
+    # first captured graph, for callers that only ever see one shape (bench.py, tests)
+    @property
+    def graph(self) -> Optional[torch.cuda.CUDAGraph]:
+        return next(iter(self.graphs.values()))[0] if self.graphs else None
 
     @staticmethod
     def _key(batch) -> Tuple:
         return tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(batch.items()))
 
     def _capture(self, batch) -> None:
-        self.static = {k: v.clone() for k, v in batch.items()}
+        static = {k: v.clone() for k, v in batch.items()}
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):  # warm-up off the default stream, as the capture API asks
             for _ in range(self.warmup):
-                self.step(self.static)
+                self.step(static)
                 if self.scheduler is not None:
                     self.scheduler.step()
         torch.cuda.current_stream().wait_stream(s)
         init_adam_state(self.step.optimizer)  # no-op after a warm-up step; essential with warmup == 0
         torch.cuda.synchronize()
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()
         # manual begin/end instead of `with torch.cuda.graph(g)`: when the body raises (an op the capture refuses),
         # that context manager's exit raises a second error from capture_end() and never restores the current stream -
         # every later eager step then runs on a stream stuck in an invalidated capture (seen with HF Falcon's
@@ -124,9 +134,9 @@ class GraphedStep:
         cs = torch.cuda.Stream()
         cs.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(cs):
-            g.capture_begin()
+            g.capture_begin(pool=self.pool)
             try:
-                self.static_loss = self.step(self.static)
+                static_loss = self.step(static)
             except BaseException:
                 try:
                     g.capture_end()
@@ -135,25 +145,30 @@ class GraphedStep:
                 raise
             g.capture_end()
         torch.cuda.current_stream().wait_stream(cs)
-        self.graph, self.key = g, self._key(batch)
+        self.graphs[self._key(batch)] = (g, static, static_loss)
 
     def __call__(self, batch) -> torch.Tensor:
         self.calls += 1
-        if self.failed is None and self.graph is None and self.calls > self.eager_steps:
+        key = self._key(batch)
+        if (self.failed is None and key not in self.graphs and len(self.graphs) < self.max_graphs
+                and self.calls > self.eager_steps):
             try:
                 self._capture(batch)
                 # the capture itself does not execute the step; fall through to the replay below
             except Exception as e:  # keep training: same kernels, eager launches
                 self.failed = repr(e)
-                self.graph = None
                 torch.cuda.synchronize()
-        if self.graph is not None and self._key(batch) == self.key:
+        hit = self.graphs.get(key)
+        if hit is not None:
+            g, static, static_loss = hit
             for k, v in batch.items():
-                self.static[k].copy_(v, non_blocking=True)
-            self.graph.replay()
-            loss = self.static_loss
+                static[k].copy_(v, non_blocking=True)
+            g.replay()
+            loss = static_loss
+            self.replays += 1
         else:
             loss = self.step(batch)
+            self.eager_calls += 1
         if self.scheduler is not None:
             self.scheduler.step()
         return loss

@@ -61,6 +61,9 @@ FLAGS = [
     # extensions (not in the reference)
     ("mixed_precision", dict(type=_S, default="bf16", choices=["no", "bf16"], help="[ext] autocast dtype of the towers")),
     ("no_hip_graph", dict(action="store_true", help="[ext] launch every step eagerly instead of replaying a hipGraph")),
+    ("token_cache_dir", dict(type=_S, default=None, help="[ext] keep the tokenised dataset as int32 shards here; reused when unchanged")),
+    ("length_bucketing", dict(action="store_true", help="[ext] batch rows of similar generator length together")),
+    ("trim_padding", dict(action="store_true", help="[ext] drop all-padding columns per batch (loss-preserving)")),
 ]
 
 
@@ -102,6 +105,9 @@ def train_e2e(
     *,
     mixed_precision: str = "bf16",
     no_hip_graph: bool = False,
+    token_cache_dir: Optional[str] = None,
+    length_bucketing: bool = False,
+    trim_padding: bool = False,
     rag_model: Optional[AutoModelForRagE2E] = None,
     on_step=None,
 ) -> None:
@@ -132,17 +138,34 @@ def train_e2e(
     r_tok, g_tok = rag_model.retriever_tokenizer, rag_model.generator_tokenizer
     g_tok.pad_token = g_tok.eos_token
     g_tok.add_eos_token = True
-    processed = dataset.map(
-        lambda ex: preprocess_dataset(ex, retriever_tokenizer=r_tok, generator_tokenizer=g_tok,
-                                      query_column_name=query_column_name, passage_column_name=passage_column_name,
-                                      answer_column_name=answer_column_name, query_max_len=query_max_len,
-                                      passage_max_len=passage_max_len, generator_max_len=generator_max_len),
-        batched=True, remove_columns=dataset.column_names, desc="Running tokenizer on dataset", num_proc=1)
     columns = ["retriever_query_input_ids", "retriever_query_attention_mask", "retriever_passage_input_ids",
                "retriever_passage_attention_mask", "generator_input_input_ids", "generator_input_attention_mask",
                "query_passage_input_len"]
+    from .. import shards
+
+    fp = shards.fingerprint(data=getattr(dataset, "_fingerprint", None), rows=len(dataset), r_tok=(type(r_tok).__name__, len(r_tok)),
+                            g_tok=(type(g_tok).__name__, len(g_tok)), cols=(query_column_name, passage_column_name, answer_column_name),
+                            lens=(query_max_len, passage_max_len, generator_max_len))
+    processed = shards.load_token_shards(token_cache_dir, fp) if token_cache_dir else None
+    if processed is None:
+        mapped = dataset.map(
+            lambda ex: preprocess_dataset(ex, retriever_tokenizer=r_tok, generator_tokenizer=g_tok,
+                                          query_column_name=query_column_name, passage_column_name=passage_column_name,
+                                          answer_column_name=answer_column_name, query_max_len=query_max_len,
+                                          passage_max_len=passage_max_len, generator_max_len=generator_max_len),
+            batched=True, remove_columns=dataset.column_names, desc="Running tokenizer on dataset", num_proc=1)
+        processed = {k: mapped[k] for k in columns}
+        if token_cache_dir and is_main:
+            shards.save_token_shards(processed, token_cache_dir, fp)
+    trim = None
+    if trim_padding:
+        trim = dict(groups=[("retriever_query_input_ids", "retriever_query_attention_mask"),
+                            ("retriever_passage_input_ids", "retriever_passage_attention_mask"),
+                            ("generator_input_input_ids", "generator_input_attention_mask")],
+                    qlen_key="query_passage_input_len", qlen_follows="generator_input_attention_mask")
     batches = common.ShardedBatches(processed, per_device_train_batch_size, comm.rank, comm.world_size,
-                                    seed if seed is not None else 0, columns)
+                                    seed if seed is not None else 0, columns,
+                                    bucket_by="generator_input_attention_mask" if length_bucketing else None, trim=trim)
 
     # ---- optimiser / schedule (reference :336-362) ----------------------------------------------
     params = [p for p in rag_model.parameters() if p.requires_grad]
@@ -183,7 +206,7 @@ def train_e2e(
 
     if is_main:
         logger.info("***** Running E2E training *****  examples=%d epochs=%d per-device batch=%d global batch=%d steps=%d",
-                    len(processed), num_train_epochs, per_device_train_batch_size,
+                    batches.n, num_train_epochs, per_device_train_batch_size,
                     per_device_train_batch_size * comm.world_size, max_train_steps)
     step_fn = RagE2EStep(rag_model, optimizer, scheduler, logit_scale, comm=comm,
                          autocast_dtype=torch.bfloat16 if mixed_precision == "bf16" else None,

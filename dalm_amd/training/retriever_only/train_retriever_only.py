@@ -50,6 +50,9 @@ FLAGS = [
     ("is_autoregressive", dict(action="store_true", help="Retriever is an autoregressive LM")),
     ("mixed_precision", dict(type=_S, default="bf16", choices=["no", "bf16"], help="[ext] autocast dtype")),
     ("no_hip_graph", dict(action="store_true", help="[ext] launch every step eagerly instead of replaying a hipGraph")),
+    ("token_cache_dir", dict(type=_S, default=None, help="[ext] keep the tokenised dataset as int32 shards here; reused when unchanged")),
+    ("length_bucketing", dict(action="store_true", help="[ext] batch rows of similar passage length together")),
+    ("trim_padding", dict(action="store_true", help="[ext] drop all-padding columns per batch (loss-preserving)")),
 ]
 
 
@@ -88,6 +91,9 @@ def train_retriever(
     *,
     mixed_precision: str = "bf16",
     no_hip_graph: bool = False,
+    token_cache_dir: Optional[str] = None,
+    length_bucketing: bool = False,
+    trim_padding: bool = False,
     model: Optional[AutoModelForSentenceEmbedding] = None,
     on_step=None,
 ) -> None:
@@ -110,16 +116,28 @@ def train_retriever(
     model.to(device)
     tokenizer = model.tokenizer
     dataset = load_dataset(dataset_or_path)
-    processed = dataset.map(
-        lambda ex: preprocess_dataset(ex, tokenizer, query_column_name=query_column_name,
-                                      passage_column_name=passage_column_name, query_max_len=query_max_len,
-                                      passage_max_len=passage_max_len),
-        batched=True, remove_columns=dataset.column_names, desc="Running tokenizer on dataset")
+    columns = ["query_input_ids", "query_attention_mask", "passage_input_ids", "passage_attention_mask"]
+    from .. import shards
+
+    fp = shards.fingerprint(data=getattr(dataset, "_fingerprint", None), rows=len(dataset), tok=(type(tokenizer).__name__, len(tokenizer)),
+                            cols=(query_column_name, passage_column_name), lens=(query_max_len, passage_max_len))
+    processed = shards.load_token_shards(token_cache_dir, fp) if token_cache_dir else None
+    if processed is None:
+        mapped = dataset.map(
+            lambda ex: preprocess_dataset(ex, tokenizer, query_column_name=query_column_name,
+                                          passage_column_name=passage_column_name, query_max_len=query_max_len,
+                                          passage_max_len=passage_max_len),
+            batched=True, remove_columns=dataset.column_names, desc="Running tokenizer on dataset")
+        processed = {k: mapped[k] for k in columns}
+        if token_cache_dir and is_main:
+            shards.save_token_shards(processed, token_cache_dir, fp)
     if use_peft and is_main:
         model.print_trainable_parameters()
-    columns = ["query_input_ids", "query_attention_mask", "passage_input_ids", "passage_attention_mask"]
+    trim = dict(groups=[("query_input_ids", "query_attention_mask"), ("passage_input_ids", "passage_attention_mask")]) \
+        if trim_padding else None
     batches = common.ShardedBatches(processed, per_device_train_batch_size, comm.rank, comm.world_size,
-                                    seed if seed is not None else 0, columns)
+                                    seed if seed is not None else 0, columns,
+                                    bucket_by="passage_attention_mask" if length_bucketing else None, trim=trim)
     params = [p for p in model.parameters() if p.requires_grad]
     # one GPU: the whole step is captured once and replayed as a hipGraph (capturable Adam + tensor lr);
     # W > 1 launches eagerly (RCCL collectives stay outside graphs for now)

@@ -439,3 +439,68 @@ def test_lora_falls_back_to_fused_qkv_for_falcon():
     lora.inject_lora(f, ["q_proj", "v_proj"])
     assert f._dalm_lora_config["target_modules"] == ["query_key_value"]
     assert sum(p.requires_grad for p in f.parameters()) == 4
+
+
+def test_token_shards_roundtrip_and_staleness(tmp_path):
+    from dalm_amd.training import shards
+
+    g = torch.Generator().manual_seed(0)
+    cols = {"ids": torch.randint(0, 30000, (1000, 12), generator=g).tolist(),
+            "mask": (torch.rand(1000, 12, generator=g) > 0.3).long().tolist(), "qlen": list(range(1000))}
+    fp = shards.fingerprint(tok=("T", 30000), lens=(12,), rows=1000)
+    assert shards.load_token_shards(str(tmp_path / "c"), fp) is None
+    shards.save_token_shards(cols, str(tmp_path / "c"), fp, rows_per_shard=300)          # 4 shards per column
+    back = shards.load_token_shards(str(tmp_path / "c"), fp)
+    assert back["ids"].dtype == torch.int32 and back["ids"].shape == (1000, 12) and back["qlen"].shape == (1000,)
+    assert back["ids"].tolist() == cols["ids"] and back["qlen"].tolist() == cols["qlen"]
+    assert shards.load_token_shards(str(tmp_path / "c"), shards.fingerprint(tok=("T", 30001), lens=(12,), rows=1000)) is None
+    with pytest.raises(ValueError):
+        shards.save_token_shards({"big": [[2 ** 40]]}, str(tmp_path / "d"), fp)
+
+
+def test_length_bucketing_and_padding_trim():
+    from dalm_amd.training import shards
+    from dalm_amd.training.common import ShardedBatches
+
+    g = torch.Generator().manual_seed(1)
+    N, Tg, Tq, B = 640, 64, 16, 8
+    glen = torch.randint(5, Tg + 1, (N,), generator=g)
+    qlen_tok = torch.randint(2, Tq + 1, (N,), generator=g)
+    ar = torch.arange(Tg).unsqueeze(0)
+    gmask = (ar >= (Tg - glen).unsqueeze(1)).long()                       # generator: left padded
+    qmask = (torch.arange(Tq).unsqueeze(0) < qlen_tok.unsqueeze(1)).long()     # retriever: right padded
+    data = {"g_ids": torch.randint(5, 100, (N, Tg), generator=g) * gmask, "g_mask": gmask,
+            "q_ids": torch.randint(5, 100, (N, Tq), generator=g) * qmask, "q_mask": qmask,
+            "qlen": (glen.float() * 0.7).long().clamp(min=1)}
+    # bucketing: a permutation, deterministic per seed, batches of similar length
+    o1 = shards.bucketed_order(glen, B, torch.Generator().manual_seed(7))
+    o2 = shards.bucketed_order(glen, B, torch.Generator().manual_seed(7))
+    assert torch.equal(o1, o2) and sorted(o1.tolist()) == list(range(N))
+    spread_b = torch.stack([glen[o1[i:i + B]].max() - glen[o1[i:i + B]].min() for i in range(0, N, B)]).float().mean()
+    r = torch.randperm(N, generator=torch.Generator().manual_seed(7))
+    spread_r = torch.stack([glen[r[i:i + B]].max() - glen[r[i:i + B]].min() for i in range(0, N, B)]).float().mean()
+    assert spread_b < 0.25 * spread_r
+    # trimming: only all-padding columns go, in steps of 8; qlen follows the generator axis
+    trim = dict(groups=[("q_ids", "q_mask"), ("g_ids", "g_mask")], qlen_key="qlen", qlen_follows="g_mask")
+    sb = ShardedBatches(data, B, 0, 1, 3, list(data), bucket_by="g_mask", trim=trim)
+    seen = 0
+    for b in sb.epoch(0, torch.device("cpu")):
+        Tb = b["g_mask"].shape[1]
+        assert Tb % 8 == 0 and b["g_ids"].shape == b["g_mask"].shape and b["g_mask"].dtype == torch.int64
+        assert int(b["g_mask"].sum(1).max()) >= Tb - 8 or Tb == 8           # 1..8 leading pad columns stay
+        assert bool((b["g_mask"][:, -1] == 1).all())                         # left padding kept its alignment
+        assert b["q_mask"].shape[1] % 8 == 0 and bool((b["q_mask"][:, 0] == 1).all())
+        seen += b["g_ids"].shape[0]
+    assert seen == N
+    # the shift of qlen: same tokens receive the doc term before and after trimming
+    rows = o1[:B]
+    full = {k: v[rows] for k, v in data.items()}
+    cut = shards.trim_batch(full, **trim)
+    lo = Tg - cut["g_mask"].shape[1]
+    for i in range(B):
+        before = [t for t in range(Tg - 1) if t >= int(full["qlen"][i]) - 1 and int(full["g_mask"][i, t + 1])]
+        after = [t + lo for t in range(cut["g_mask"].shape[1] - 1) if t >= int(cut["qlen"][i]) - 1 and int(cut["g_mask"][i, t + 1])]
+        assert before == after
+    # an all-padding batch is left alone
+    z = {"g_ids": torch.zeros(2, 16, dtype=torch.long), "g_mask": torch.zeros(2, 16, dtype=torch.long)}
+    assert shards.trim_batch(z, [("g_ids", "g_mask")])["g_mask"].shape == (2, 16)

@@ -305,3 +305,64 @@ def test_bf16_autocast_step_stays_within_stated_tolerance_of_fp32_reference():
     rel = [abs(a - b) / abs(b) for a, b in zip(losses, gold["losses"])]
     assert max(rel) <= 3e-2, (rel, losses, gold["losses"])
     assert rel[0] <= 1e-2, rel                       # before any optimizer step: forward rounding only
+
+
+def test_padding_trim_preserves_the_step_and_graphs_are_cached_per_shape():
+    """dropping all-padding columns (and shifting query_passage_input_len by the leading columns
+    removed) leaves loss and parameter update unchanged - checked through the real step on the golden models with
+    extra padding added on both sides - and GraphedStep keeps one hipGraph per batch shape in a shared pool."""
+    from transformers import get_scheduler
+
+    from dalm_amd.models import AutoModelForRagE2E
+    from dalm_amd.training import shards
+    from dalm_amd.training.graphed import GraphedStep, TensorLRScheduler, make_capturable_adam
+    from dalm_amd.training.step import RagE2EStep
+
+    gold = json.loads((G / "step_golden.json").read_text())
+    dev = torch.device("cuda:0")
+
+    def run(trim, graph):
+        rag = AutoModelForRagE2E(str(G / "tiny_retriever"), str(G / "tiny_generator")).to(dev)
+        g_tok = rag.generator_tokenizer
+        g_tok.pad_token = g_tok.eos_token
+        rag.train()
+        opt = make_capturable_adam(rag.parameters(), gold["lr"], dev) if graph else torch.optim.Adam(rag.parameters(), lr=gold["lr"])
+        mk = lambda o: get_scheduler("linear", optimizer=o, num_warmup_steps=0, num_training_steps=20)   # noqa: E731
+        sched = TensorLRScheduler(opt, gold["lr"], mk) if graph else mk(opt)
+        step = RagE2EStep(rag, opt, sched, 100, autocast_dtype=None, inplace_grad=True, overlap_towers=graph)
+        if graph:
+            step = GraphedStep(step, warmup=0)
+        losses = []
+        pad_id = g_tok.pad_token_id
+        for i, b in enumerate(_batches(rag.retriever_tokenizer, g_tok, gold, dev)):
+            # widen: 16 (then 8) extra left-pad columns on the generator side, 8 extra right-pad columns on the retriever
+            # side -> two different trimmed shapes over the run
+            extra = 16 if i % 2 == 0 else 8
+            n = b["generator_input_input_ids"].shape[0]
+            b = dict(b)
+            b["generator_input_input_ids"] = torch.cat([torch.full((n, extra), pad_id, device=dev), b["generator_input_input_ids"]], 1)
+            b["generator_input_attention_mask"] = torch.cat([torch.zeros((n, extra), dtype=torch.long, device=dev), b["generator_input_attention_mask"]], 1)
+            b["query_passage_input_len"] = b["query_passage_input_len"] + extra      # same tokens, wider frame
+            for side in ("query", "passage"):
+                b[f"retriever_{side}_input_ids"] = torch.cat([b[f"retriever_{side}_input_ids"], torch.zeros((n, 8), dtype=torch.long, device=dev)], 1)
+                b[f"retriever_{side}_attention_mask"] = torch.cat([b[f"retriever_{side}_attention_mask"], torch.zeros((n, 8), dtype=torch.long, device=dev)], 1)
+            if trim:
+                b = shards.trim_batch(b, groups=[("retriever_query_input_ids", "retriever_query_attention_mask"),
+                                                 ("retriever_passage_input_ids", "retriever_passage_attention_mask"),
+                                                 ("generator_input_input_ids", "generator_input_attention_mask")],
+                                      qlen_key="query_passage_input_len", qlen_follows="generator_input_attention_mask")
+            losses.append(float(step(b)))
+        final = float(sum(p.detach().double().abs().sum() for p in rag.parameters()))
+        return losses, final, step
+
+    wide, wide_final, _ = run(trim=False, graph=False)
+    cut, cut_final, _ = run(trim=True, graph=False)
+    # (the widened run is not the golden trajectory: with leading pads the reference's shifted-label loss gains the row
+    #  that predicts each sample's first token from the last pad position - trim_batch keeps one pad column for it)
+    for a, b in zip(wide, cut):
+        assert abs(a - b) <= 2e-5 * abs(a), (wide, cut)
+    assert abs(wide_final - cut_final) <= 1e-5 * wide_final
+    gl, gfinal, gstep = run(trim=True, graph=True)
+    assert gstep.failed is None and len(gstep.graphs) >= 2 and gstep.eager_calls == 0, (gstep.failed, len(gstep.graphs), gstep.eager_calls)
+    for a, b in zip(cut, gl):
+        assert abs(a - b) <= 2e-5 * abs(a), (cut, gl)
