@@ -7,6 +7,7 @@ collectives, explicit HIP streams for overlap.
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import logging
 import math
@@ -226,11 +227,125 @@ class Throughput:
         return self.rows / max(time.perf_counter() - self.t0, 1e-9)
 
 
-def save_training_state(path: str, model, optimizer, scheduler, extra: Dict[str, Any], save_models: Callable[[str], None]) -> None:
+# ---------------------------------------------------------------------------
+# checkpoints (SURVEY section 8 f, rank 3): the reference's directory layout (train_rage2e.py:486-524:
+# <output_dir>/{step_N,epoch_N}/{retriever,generator} + accelerate's optimizer/scheduler state), written without
+# stalling the step (async) and, with W > 1, without every rank writing the same bytes (sharded)
+# ---------------------------------------------------------------------------
+def _to_host(obj, stream=None):
+    """Deep copy of a (nested) state dict with every tensor on the host; device tensors are copied on `stream` into
+    pinned memory (non-blocking) so that the training stream never waits for a checkpoint."""
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            host = torch.empty(obj.shape, dtype=obj.dtype, device="cpu", pin_memory=True)
+            with torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext():
+                host.copy_(obj, non_blocking=True)
+            return host
+        return obj.detach().clone()
+    if isinstance(obj, dict):
+        return {k: _to_host(v, stream) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_to_host(v, stream) for v in obj)
+    return obj
+
+
+def shard_optimizer_state(sd: Dict[str, Any], rank: int, world: int) -> Dict[str, Any]:
+    """Data-parallel ranks hold identical optimizer state: rank r keeps every world-th entry of `state` (by sorted key),
+    rank 0 additionally the param_groups.  `merge_optimizer_shards` is the inverse."""
+    keys = sorted(sd["state"].keys())
+    mine = {k: sd["state"][k] for i, k in enumerate(keys) if i % world == rank}
+    return {"state": mine, "param_groups": sd["param_groups"] if rank == 0 else None, "num_state": len(keys)}
+
+
+def merge_optimizer_shards(shards: List[Dict[str, Any]]) -> Dict[str, Any]:
+    state: Dict[Any, Any] = {}
+    groups = None
+    for sh in shards:
+        state.update(sh["state"])
+        if sh.get("param_groups") is not None:
+            groups = sh["param_groups"]
+    want = shards[0].get("num_state")
+    if groups is None or (want is not None and len(state) != want):
+        raise RuntimeError(f"incomplete optimizer shards: {len(state)} of {want} entries, param_groups {'present' if groups else 'missing'}")
+    return {"state": state, "param_groups": groups}
+
+
+class AsyncSaver:
+    """One background writer thread.  `submit(snapshot, write)`: `snapshot()` runs NOW on the caller's thread (device ->
+    pinned host copies enqueued on a side stream, then one event), `write(host_state)` runs on the worker after the
+    event has completed.  At most one checkpoint is in flight: a new submit first waits for the previous one."""
+
+    def __init__(self):
+        import threading
+
+        self._threading = threading
+        self._thread = None
+        self._error: Optional[BaseException] = None
+        self._stream = torch.cuda.Stream() if torch.cuda.is_available() else None
+
+    def submit(self, snapshot: Callable[[Any], Any], write: Callable[[Any], None]) -> None:
+        self.wait()
+        ev = None
+        if self._stream is not None:
+            self._stream.wait_stream(torch.cuda.current_stream())     # the values as of this point of the training stream
+        host_state = snapshot(self._stream)
+        if self._stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(self._stream)
+
+        def work():
+            try:
+                if ev is not None:
+                    ev.synchronize()
+                write(host_state)
+            except BaseException as e:  # surfaced by the next wait()
+                self._error = e
+
+        self._thread = self._threading.Thread(target=work, name="dalm-checkpoint-writer", daemon=False)
+        self._thread.start()
+
+    def wait(self) -> None:
+        if self._thread is not None:
+            self._thread.join()
+            self._thread = None
+        if self._error is not None:
+            e, self._error = self._error, None
+            raise RuntimeError("asynchronous checkpoint write failed") from e
+
+
+def save_training_state(path: str, model, optimizer, scheduler, extra: Dict[str, Any], save_models: Callable[[str], None],
+                        *, rank: int = 0, world: int = 1, saver: Optional[AsyncSaver] = None) -> None:
+    """<path>/{retriever,generator,...} via `save_models` (rank 0), <path>/trainer_state.pt (scheduler, extra, and the
+    optimizer state when world == 1) and, with world > 1, <path>/optimizer-RRRRR-of-WWWWW.pt per rank.  With `saver` the
+    device->host copies are enqueued and the files are written by a background thread (the adapters / models are
+    written synchronously: they go through HF / safetensors writers that read the live tensors)."""
     os.makedirs(path, exist_ok=True)
-    save_models(path)
-    torch.save({"optimizer": optimizer.state_dict(), "scheduler": scheduler.state_dict() if scheduler else None,
-                "extra": extra}, os.path.join(path, "trainer_state.pt"))
+    if rank == 0:
+        save_models(path)
+    sched_sd = scheduler.state_dict() if scheduler else None
+
+    def snapshot(stream):
+        osd = optimizer.state_dict()
+        if world > 1:
+            osd = shard_optimizer_state(osd, rank, world)
+        return _to_host({"optimizer": osd, "scheduler": sched_sd, "extra": dict(extra)}, stream)
+
+    def write(host):
+        if world > 1:
+            torch.save(host["optimizer"], os.path.join(path, f"optimizer-{rank:05d}-of-{world:05d}.pt"))
+            if rank == 0:
+                torch.save({"optimizer": None, "sharded": world, "scheduler": host["scheduler"], "extra": host["extra"]},
+                           os.path.join(path, "trainer_state.pt"))
+        else:
+            torch.save({"optimizer": host["optimizer"], "scheduler": host["scheduler"], "extra": host["extra"]},
+                       os.path.join(path, "trainer_state.pt"))
+
+    if saver is not None:
+        saver.submit(snapshot, write)
+    else:
+        write(snapshot(None))
+        if torch.cuda.is_available():
+            torch.cuda.current_stream().synchronize()
 
 
 def load_training_state(path: str, optimizer, scheduler) -> Dict[str, Any]:
@@ -238,6 +353,13 @@ def load_training_state(path: str, optimizer, scheduler) -> Dict[str, Any]:
     if not os.path.exists(f):
         return {}
     st = torch.load(f, map_location="cpu")
+    if st.get("sharded"):
+        W = int(st["sharded"])
+        files = [os.path.join(path, f"optimizer-{r:05d}-of-{W:05d}.pt") for r in range(W)]
+        missing = [x for x in files if not os.path.exists(x)]
+        if missing:
+            raise FileNotFoundError(f"optimizer shards missing: {missing[:2]}")
+        st["optimizer"] = merge_optimizer_shards([torch.load(x, map_location="cpu") for x in files])
     lr_devices = [g["lr"].device if torch.is_tensor(g["lr"]) else None for g in optimizer.param_groups]
     optimizer.load_state_dict(st["optimizer"])
     for g, dev in zip(optimizer.param_groups, lr_devices):  # a tensor lr (capturable Adam) must stay on its device

@@ -64,6 +64,7 @@ FLAGS = [
     ("token_cache_dir", dict(type=_S, default=None, help="[ext] keep the tokenised dataset as int32 shards here; reused when unchanged")),
     ("length_bucketing", dict(action="store_true", help="[ext] batch rows of similar generator length together")),
     ("trim_padding", dict(action="store_true", help="[ext] drop all-padding columns per batch (loss-preserving)")),
+    ("async_checkpoint", dict(action="store_true", help="[ext] write optimizer/scheduler state from a background thread")),
 ]
 
 
@@ -108,6 +109,7 @@ def train_e2e(
     token_cache_dir: Optional[str] = None,
     length_bucketing: bool = False,
     trim_padding: bool = False,
+    async_checkpoint: bool = False,
     rag_model: Optional[AutoModelForRagE2E] = None,
     on_step=None,
 ) -> None:
@@ -215,6 +217,7 @@ def train_e2e(
     if use_graph:
         step_fn = GraphedStep(step_fn, warmup=0, eager_steps=2)  # partial last batches (other shapes) run eagerly
     meter = common.Throughput()
+    saver = common.AsyncSaver() if async_checkpoint else None
     for epoch in range(starting_epoch, num_train_epochs):
         rag_model.train()
         total_loss = torch.zeros((), device=device)
@@ -231,23 +234,27 @@ def train_e2e(
                 if is_main:
                     logger.info("Step: %d, Loss: %.6f, pairs/s: %.1f", step + 1, float(tl) / (step + 1), meter.rate())
                 tracker.log({"train/loss": float(tl) / (step + 1), "train/pairs_per_sec": meter.rate()}, completed)
-            if isinstance(checkpointing_steps, int) and completed % checkpointing_steps == 0 and output_dir and is_main:
+            if isinstance(checkpointing_steps, int) and completed % checkpointing_steps == 0 and output_dir:
                 common.save_training_state(os.path.join(output_dir, f"step_{completed}"), rag_model, optimizer,
-                                           scheduler, {"completed_steps": completed}, save_models)
+                                           scheduler, {"completed_steps": completed}, save_models,
+                                           rank=comm.rank, world=comm.world_size, saver=saver)
             if completed >= max_train_steps:
                 break
         tl = comm.all_reduce_sum_(total_loss.clone())
         tracker.log({"train/epoch_loss": float(tl) / max(len(batches), 1)}, completed)
         if output_dir is not None:
             barrier(comm)
+            if isinstance(checkpointing_steps, str):
+                common.save_training_state(os.path.join(output_dir, f"epoch_{epoch}"), rag_model, optimizer,
+                                           scheduler, {"completed_steps": completed}, save_models,
+                                           rank=comm.rank, world=comm.world_size, saver=saver)
             if is_main:
-                if isinstance(checkpointing_steps, str):
-                    common.save_training_state(os.path.join(output_dir, f"epoch_{epoch}"), rag_model, optimizer,
-                                               scheduler, {"completed_steps": completed}, save_models)
                 save_models(output_dir)  # <output_dir>/retriever, <output_dir>/generator (reference :508-524)
                 r_tok.save_pretrained(os.path.join(output_dir, "retriever"))
                 g_tok.save_pretrained(os.path.join(output_dir, "generator"))
             barrier(comm)
+    if saver is not None:
+        saver.wait()
     tracker.close()
 
 

@@ -53,6 +53,7 @@ FLAGS = [
     ("token_cache_dir", dict(type=_S, default=None, help="[ext] keep the tokenised dataset as int32 shards here; reused when unchanged")),
     ("length_bucketing", dict(action="store_true", help="[ext] batch rows of similar passage length together")),
     ("trim_padding", dict(action="store_true", help="[ext] drop all-padding columns per batch (loss-preserving)")),
+    ("async_checkpoint", dict(action="store_true", help="[ext] write optimizer/scheduler state from a background thread")),
 ]
 
 
@@ -94,6 +95,7 @@ def train_retriever(
     token_cache_dir: Optional[str] = None,
     length_bucketing: bool = False,
     trim_padding: bool = False,
+    async_checkpoint: bool = False,
     model: Optional[AutoModelForSentenceEmbedding] = None,
     on_step=None,
 ) -> None:
@@ -174,6 +176,7 @@ def train_retriever(
     if use_graph:
         step_fn = GraphedStep(step_fn, warmup=0, eager_steps=2)
     meter = common.Throughput()
+    saver = common.AsyncSaver() if async_checkpoint else None
     for epoch in range(starting_epoch, num_train_epochs):
         model.train()
         total_loss = torch.zeros((), device=device)
@@ -190,22 +193,26 @@ def train_retriever(
                 if is_main:
                     logger.info("Step: %d, Loss: %.6f, pairs/s: %.1f", step + 1, float(tl) / (step + 1), meter.rate())
                 tracker.log({"train/loss": float(tl) / (step + 1), "train/pairs_per_sec": meter.rate()}, completed)
-            if isinstance(checkpointing_steps, int) and completed % checkpointing_steps == 0 and output_dir and is_main:
+            if isinstance(checkpointing_steps, int) and completed % checkpointing_steps == 0 and output_dir:
                 common.save_training_state(os.path.join(output_dir, f"step_{completed}"), model, optimizer, scheduler,
-                                           {"completed_steps": completed}, save_models)
+                                           {"completed_steps": completed}, save_models,
+                                           rank=comm.rank, world=comm.world_size, saver=saver)
             if completed >= max_train_steps:
                 break
         tl = comm.all_reduce_sum_(total_loss.clone())
         tracker.log({"train/epoch_loss": float(tl) / max(len(batches), 1)}, completed)
         if output_dir is not None:
             barrier(comm)
+            if isinstance(checkpointing_steps, str):
+                common.save_training_state(os.path.join(output_dir, f"epoch_{epoch}"), model, optimizer, scheduler,
+                                           {"completed_steps": completed}, save_models,
+                                           rank=comm.rank, world=comm.world_size, saver=saver)
             if is_main:
-                if isinstance(checkpointing_steps, str):
-                    common.save_training_state(os.path.join(output_dir, f"epoch_{epoch}"), model, optimizer, scheduler,
-                                               {"completed_steps": completed}, save_models)
                 save_models(os.path.join(output_dir, "retriever"))
                 tokenizer.save_pretrained(os.path.join(output_dir, "retriever"))
             barrier(comm)
+    if saver is not None:
+        saver.wait()
     tracker.close()
 
 

@@ -173,3 +173,62 @@ def test_launcher_spawns_gloo_ranks(tmp_path):
         no = subprocess.run([sys.executable, "-m", "dalm_amd.launch", "--nproc", "2", str(script), "0"],
                             capture_output=True, text=True, env=env, timeout=300)
         assert no.returncode == 2 and "only 0 GPU(s) are visible" in no.stderr
+
+
+def _ckpt_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+
+    from dalm_amd.training import common
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)                                   # replicas: identical parameters and optimizer state
+    ps = [torch.nn.Parameter(torch.randn(n)) for n in (5, 7, 3, 9, 4)]
+    opt = torch.optim.Adam(ps, lr=1e-3)
+    for _ in range(3):
+        sum((p * p).sum() for p in ps).backward()
+        opt.step(); opt.zero_grad()
+    saver = common.AsyncSaver()
+    common.save_training_state(os.path.join(out_dir, "step_3"), None, opt, None, {"completed_steps": 3},
+                               lambda path: open(os.path.join(path, "models_written_by_rank0"), "w").close(),
+                               rank=rank, world=world, saver=saver)
+    with torch.no_grad():                                  # training moves on while the writer works: the snapshot must not see it
+        for p in ps:
+            p.add_(100.0)
+        for st in opt.state.values():
+            st["exp_avg"].add_(100.0)
+    saver.wait()
+    dist.barrier()
+    if rank == 0:
+        torch.save(opt.state_dict(), os.path.join(out_dir, "live.pt"))
+    dist.destroy_process_group()
+
+
+def test_sharded_async_checkpoint_roundtrip(tmp_path):
+    """SURVEY 8f rank 3: with W ranks every rank writes 1/W of the (replicated) optimizer state from a background thread;
+    loading merges the shards; values are those at submit time, not whatever training did afterwards."""
+    from dalm_amd.training import common
+
+    mp.spawn(_ckpt_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    d = tmp_path / "step_3"
+    assert sorted(p.name for p in d.iterdir()) == ["models_written_by_rank0", "optimizer-00000-of-00002.pt",
+                                                   "optimizer-00001-of-00002.pt", "trainer_state.pt"]
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(n)) for n in (5, 7, 3, 9, 4)]
+    ref = torch.optim.Adam(ps, lr=1e-3)
+    for _ in range(3):
+        sum((p * p).sum() for p in ps).backward()
+        ref.step(); ref.zero_grad()
+    fresh = torch.optim.Adam([torch.nn.Parameter(torch.zeros(n)) for n in (5, 7, 3, 9, 4)], lr=1e-3)
+    extra = common.load_training_state(str(d), fresh, None)
+    assert extra == {"completed_steps": 3}
+    for k, st in ref.state_dict()["state"].items():
+        got = fresh.state_dict()["state"][k]
+        torch.testing.assert_close(got["exp_avg"], st["exp_avg"])
+        torch.testing.assert_close(got["exp_avg_sq"], st["exp_avg_sq"])
+    live = torch.load(tmp_path / "live.pt")                 # sanity: the live state had moved on by +100
+    assert float((live["state"][0]["exp_avg"] - ref.state_dict()["state"][0]["exp_avg"]).mean()) > 99
+    os.remove(d / "optimizer-00001-of-00002.pt")
+    with pytest.raises(FileNotFoundError):
+        common.load_training_state(str(d), fresh, None)

@@ -271,14 +271,17 @@ def test_train_retriever_end_to_end_at_cfg1_shapes(tmp_path):
     with pytest.warns(UserWarning, match="bitsandbytes"):
         train_retriever(str(mdir), str(path), query_max_len=12, passage_max_len=32, per_device_train_batch_size=32,
                         learning_rate=1e-3, num_train_epochs=4, output_dir=str(out), checkpointing_steps="epoch",
-                        with_tracking=True, mixed_precision="no", on_step=lambda s, l: seen.append((s, float(l))))
+                        with_tracking=True, mixed_precision="no", async_checkpoint=True, token_cache_dir=str(tmp_path / "tok"),
+                        on_step=lambda s, l: seen.append((s, float(l))))
     assert [s for s, _ in seen] == [1, 2, 3, 4] and seen[-1][1] < seen[0][1]
+    assert (tmp_path / "tok" / "index.json").exists()          # int32 token shards, reused by the resume run below
     for sub in ("retriever/adapter_config.json", "retriever/adapter_model.safetensors", "epoch_3/trainer_state.pt", "logs"):
         assert (out / sub).exists(), sub
     more = []
     train_retriever(str(mdir), str(path), query_max_len=12, passage_max_len=32, per_device_train_batch_size=32,
                     learning_rate=1e-3, num_train_epochs=6, output_dir=str(out), resume_from_checkpoint=str(out / "epoch_3"),
-                    with_tracking=False, use_bnb=False, mixed_precision="no", on_step=lambda s, l: more.append((s, float(l))))
+                    with_tracking=False, use_bnb=False, mixed_precision="no", token_cache_dir=str(tmp_path / "tok"),
+                    on_step=lambda s, l: more.append((s, float(l))))
     assert [s for s, _ in more] == [5, 6] and more[0][1] < seen[0][1]
 
 
