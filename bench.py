@@ -108,9 +108,9 @@ class TimedOps:
         if not self.enabled:
             return self._ops.ce_fwd(logits, ids, mask, stats, want_grad, inplace)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()  # torch's current stream == the stream the kernel is launched on
-        out = self._ops.ce_fwd(logits, ids, mask, stats, want_grad, inplace)
-        b.record()
+        # recorded inside HipOps.ce_fwd on torch's current stream (== the stream the kernel is launched on), right
+        # around the launch: output allocation and argument marshalling are not inside the interval
+        out = self._ops.ce_fwd(logits, ids, mask, stats, want_grad, inplace, events=(a, b))
         # bytes this launch really has to move: live rows are read once; with want_grad every row of the
         # [B,Tg,V] gradient is written (zeros for masked rows and the last position)
         B, Tg, V = logits.shape

@@ -637,9 +637,11 @@ __global__ __launch_bounds__(256) void gather_nll_kernel(const float* __restrict
 
 __global__ __launch_bounds__(256) void marginalize_rows_kernel(const float* __restrict__ lp, int64_t T,
                                                                int64_t V, const float* __restrict__ doc_lp,
-                                                               int64_t qlen, float* __restrict__ out) {
+                                                               int64_t qlen, const int64_t* __restrict__ qlen_dev,
+                                                               float* __restrict__ out) {
   const int64_t n = T * V;
   const float d = doc_lp[0];
+  if (qlen_dev) qlen = qlen_dev[0];   // the length stays on the device: no host round trip per sample
   // python slice semantics of lp[:qlen-1] / lp[qlen-1:] (train_utils.py:100-103)
   int64_t cut = qlen - 1;
   if (cut < 0) cut = (cut + T < 0) ? 0 : cut + T;
@@ -830,6 +832,18 @@ extern "C" int dalm_marginalize_rows(const float* lp, int64_t T, int64_t V, cons
   int64_t blocks = (T * V + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(marginalize_rows_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
-                     as_stream(stream), lp, T, V, doc_lp, qlen, out);
+                     as_stream(stream), lp, T, V, doc_lp, qlen, static_cast<const int64_t*>(nullptr), out);
+  return check_launch(__func__);
+}
+
+extern "C" int dalm_marginalize_rows_dev(const float* lp, int64_t T, int64_t V, const float* doc_lp,
+                                         const int64_t* qlen_dev, float* out, dalm_stream_t stream) {
+  DALM_REQUIRE(lp && doc_lp && qlen_dev && out, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(T >= 0 && V > 0, DALM_E_SHAPE, "need T>=0, V>0");
+  if (T == 0) return 0;
+  int64_t blocks = (T * V + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(marginalize_rows_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
+                     as_stream(stream), lp, T, V, doc_lp, static_cast<int64_t>(0), qlen_dev, out);
   return check_launch(__func__);
 }

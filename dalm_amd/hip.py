@@ -41,6 +41,7 @@ SIGNATURES = {
     "dalm_doc_logprob_bwd": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _int, _vp]),
     "dalm_gather_nll": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "dalm_marginalize_rows": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp]),
+    "dalm_marginalize_rows_dev": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "dalm_contrastive_finalize": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "dalm_pool_l2norm_fwd_workspace_bytes": (_sz, [_i64, _i64, _i64, _int]),
     "dalm_pool_l2norm_fwd_ws": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -248,8 +248,10 @@ class HipOps:
             logits = logits.contiguous()
         return logits, logits.stride(0), logits.stride(1)
 
-    def ce_fwd(self, logits, ids, mask, stats, want_grad: bool, inplace: bool = False):
-        """One pass over the logits: row_lse, row_nll and (optionally) dlogits for upstream grad 1."""
+    def ce_fwd(self, logits, ids, mask, stats, want_grad: bool, inplace: bool = False, events=None):
+        """One pass over the logits: row_lse, row_nll and (optionally) dlogits for upstream grad 1.
+        events: optional (start, stop) torch.cuda.Event pair recorded on the launch stream immediately around the
+        kernel launch - after the outputs have been allocated - for live roofline timing (bench.py)."""
         dev = hip.require_gpu(logits, ids, mask, stats)
         logits, sb, st = self._logits_view(logits)
         ids, mask = hip.as_i64(ids), hip.as_i64(mask)
@@ -261,8 +263,12 @@ class HipOps:
         dlogits = None
         if want_grad:
             dlogits = logits if inplace else torch.empty_strided(logits.shape, logits.stride(), device=dev, dtype=logits.dtype)
+        if events is not None:
+            events[0].record()
         hip.call("dalm_marg_ce_fwd", hip.ptr(logits), hip.dtype_code(logits), B, Tg, V, sb, st, hip.ptr(ids),
                  hip.ptr(mask), hip.ptr(stats), hip.ptr(row_lse), hip.ptr(row_nll), hip.ptr(dlogits), hip.stream())
+        if events is not None:
+            events[1].record()
         return row_lse, row_nll, dlogits
 
     def ce_bwd(self, logits, ids, mask, stats, row_lse, gscale):
@@ -302,11 +308,17 @@ class HipOps:
         hip.call("dalm_gather_nll", hip.ptr(lp), hip.ptr(labels), R, V, hip.ptr(out), hip.stream())
         return out
 
-    def marginalize_rows(self, lp: torch.Tensor, doc_lp: torch.Tensor, qlen: int) -> torch.Tensor:
+    def marginalize_rows(self, lp: torch.Tensor, doc_lp: torch.Tensor, qlen) -> torch.Tensor:
+        """qlen: python int, or a device tensor (its first element is read by the kernel: no host sync)."""
         dev = hip.require_gpu(lp, doc_lp)
         lp = hip.as_f32c(lp)
         T, V = lp.shape
         out = torch.empty((T, V), device=dev, dtype=torch.float32)
+        if torch.is_tensor(qlen):
+            q = hip.as_i64(qlen.reshape(-1)[:1])
+            hip.call("dalm_marginalize_rows_dev", hip.ptr(lp), T, V, hip.ptr(hip.as_f32c(doc_lp.reshape(-1)[:1])), hip.ptr(q),
+                     hip.ptr(out), hip.stream())
+            return out
         hip.call("dalm_marginalize_rows", hip.ptr(lp), T, V, hip.ptr(hip.as_f32c(doc_lp.reshape(-1)[:1])), int(qlen),
                  hip.ptr(out), hip.stream())
         return out

@@ -50,21 +50,37 @@ class _MarginalizeRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, lp, doc_lp, qlen):
         T = lp.shape[0]
-        cut = qlen - 1
-        if cut < 0:
-            cut = max(cut + T, 0)
-        ctx.cut, ctx.doc_shape = min(cut, T), doc_lp.shape
+        if torch.is_tensor(qlen) and qlen.is_cuda:
+            # the length stays on the device (the reference's loop hands over elements of a device tensor): python-slice
+            # start of lp[qlen-1:] as tensor arithmetic, no .item() / int() round trip per sample
+            cut = qlen.reshape(()).to(torch.int64) - 1
+            cut = torch.where(cut < 0, torch.clamp(cut + T, min=0), cut).clamp(max=T)
+            ctx.save_for_backward(cut)
+            ctx.cut = None
+        else:
+            cut = int(qlen) - 1
+            if cut < 0:
+                cut = max(cut + T, 0)
+            ctx.cut = min(cut, T)
+            qlen = int(qlen)
+        ctx.doc_shape = doc_lp.shape
         return default_ops().marginalize_rows(lp, doc_lp, qlen).to(lp.dtype)
 
     @staticmethod
     def backward(ctx, g):
-        return g, g[ctx.cut:].sum().reshape(ctx.doc_shape).to(g.dtype), None
+        if ctx.cut is None:
+            (cut,) = ctx.saved_tensors
+            rows = (torch.arange(g.shape[0], device=g.device) >= cut).to(g.dtype)
+            d_doc = (g.sum(dim=1) * rows).sum()
+        else:
+            d_doc = g[ctx.cut:].sum()
+        return g, d_doc.reshape(ctx.doc_shape).to(g.dtype), None
 
 
 def marginalize_log_probs(logprobs_logits: torch.Tensor, doc_logprobs: torch.Tensor,
                           query_token_length: torch.Tensor) -> torch.Tensor:
     """rows [qlen-1:] get `+ doc_logprobs` (reference :96-110), one streaming kernel instead of slice/add/cat."""
-    return _MarginalizeRows.apply(logprobs_logits, doc_logprobs, int(query_token_length))
+    return _MarginalizeRows.apply(logprobs_logits, doc_logprobs, query_token_length)
 
 
 def compute_marginalized_loss_from_logits(logits: torch.Tensor, input_tensors: torch.Tensor,

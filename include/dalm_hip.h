@@ -218,6 +218,11 @@ int dalm_gather_nll(const float* lp, const int64_t* labels, int64_t R, int64_t V
 int dalm_marginalize_rows(const float* lp, int64_t T, int64_t V,
                           const float* doc_lp, int64_t qlen, float* out,
                           dalm_stream_t stream);
+/* same with the length read from device memory (qlen_dev[0]): the reference's per-sample loop
+ * (train_utils.py:127-129) hands over elements of a device tensor; no host synchronisation per sample. */
+int dalm_marginalize_rows_dev(const float* lp, int64_t T, int64_t V,
+                              const float* doc_lp, const int64_t* qlen_dev,
+                              float* out, dalm_stream_t stream);
 
 /* contrastive loss assembly (train_rage2e.py:443-446) from row/col statistics:
  *   out[0] = 0.5 ( sum_i (row_lse[i]-diag[i]) + sum_j (col_lse[j]-diag[j]) ) / n_global

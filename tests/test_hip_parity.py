@@ -147,6 +147,18 @@ def test_pieces_get_nll_and_marginalize(dev):
     for ql in (1, 2, 4, 7, 8, 12):
         got = tu.marginalize_log_probs(lp[0], doc, torch.tensor(ql))
         torch.testing.assert_close(got.cpu(), z[f"marg_q{ql}"].float(), rtol=0, atol=1e-6)
+        # the reference's loop hands over elements of a DEVICE tensor: same result, length never leaves the GPU,
+        # and the doc-term gradient (sum of the upstream gradient over the rows that received it) matches autograd
+        a, d = lp[0].clone().requires_grad_(True), doc.clone().requires_grad_(True)
+        out = tu.marginalize_log_probs(a, d, torch.tensor([ql, 99], device=dev)[0])
+        torch.testing.assert_close(out.detach().cpu(), z[f"marg_q{ql}"].float(), rtol=0, atol=1e-6)
+        up = torch.randn_like(out)
+        (out * up).sum().backward()
+        a2, d2 = lp[0].clone().requires_grad_(True), doc.clone().requires_grad_(True)
+        ref = torch.cat([a2[: ql - 1], a2[ql - 1:] + d2], 0)
+        (ref * up).sum().backward()
+        torch.testing.assert_close(a.grad, a2.grad)
+        torch.testing.assert_close(d.grad, d2.grad, rtol=1e-5, atol=1e-5)
 
 
 # ---------------------------------------------------------------------------
