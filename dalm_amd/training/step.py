@@ -72,7 +72,7 @@ class RagE2EStep(_StepBase):
     """batch keys as produced by preprocess_dataset (rag_e2e_dataloader_utils.py:56-68)."""
 
     def __init__(self, *a, inplace_grad: bool = True, overlap_towers: bool = True, fuse_lm_head: bool = False,
-                 lm_head_chunk: int = 6, graph_towers: bool = False, graph_after: int = 2, **kw):
+                 lm_head_chunk: Optional[int] = None, graph_towers: bool = False, graph_after: int = 2, **kw):
         super().__init__(*a, **kw)
         self.inplace_grad = inplace_grad
         # SURVEY 8(f) rank 1 (optional): run the decoder without its lm_head and let the loss consume the

@@ -1,0 +1,62 @@
+"""SURVEY 8(f) rank 1, measured: lm_head + marginalised CE at the cfg3 / cfg5 shapes, forward + backward to dh,
+(a) logits materialised (hipBLASLt GEMM -> fused CE kernel in place -> hipBLASLt GEMM back) vs
+(b) `rag_e2e_loss_from_hidden` (sample chunks, the [B,Tg,V] logits never exist).
+    python tools/lm_head_bench.py
+"""
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+from kernel_bench import time_fn  # noqa: E402
+
+from dalm_amd.fused import rag_e2e_loss, rag_e2e_loss_from_hidden  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda:0")
+    B, Tg, D = 18, 256, 1024
+    for name, H, V in (("cfg3 Llama-2-7b", 4096, 32000), ("cfg5 Falcon-7B", 4544, 65024)):
+        g = torch.Generator(device="cpu").manual_seed(0)
+        q = torch.nn.functional.normalize(torch.randn(B, D, generator=g), dim=1).to(dev)
+        p = torch.nn.functional.normalize(torch.randn(B, D, generator=g), dim=1).to(dev)
+        hidden = torch.randn(B, Tg, H, generator=g).to(dev, torch.bfloat16)
+        W = (0.02 * torch.randn(V, H, generator=g)).to(dev, torch.bfloat16)
+        ids = torch.randint(0, V, (B, Tg), generator=g).to(dev)
+        lens = torch.randint(60, Tg + 1, (B,), generator=g)
+        mask = (torch.arange(Tg).unsqueeze(0) >= (Tg - lens).unsqueeze(1)).long().to(dev)
+        qlen = (lens.float() * 0.8).long().to(dev)
+
+        def materialised():
+            h = hidden.detach().requires_grad_(True)
+            loss = rag_e2e_loss(q, p, h @ W.t(), ids, mask, qlen, 100, inplace_grad=True)
+            loss.backward()
+            return h.grad
+
+        def chunked(chunk):
+            def f():
+                h = hidden.detach().requires_grad_(True)
+                loss = rag_e2e_loss_from_hidden(q, p, h, W, ids, mask, qlen, 100, chunk_samples=chunk)
+                loss.backward()
+                return h.grad
+            return f
+
+        flops = 2 * 2.0 * B * Tg * H * V          # two GEMMs (logits, dh)
+        print(name, f"B={B} Tg={Tg} H={H} V={V} bf16: 2 GEMMs = {flops / 1e12:.2f} TFLOP")
+        ref = materialised()
+        for label, fn in (("materialised logits", materialised), ("chunked, 6 samples", chunked(6)),
+                          ("chunked, 3 samples", chunked(3)), ("chunked, 18 samples (one chunk)", chunked(18))):
+            torch.cuda.reset_peak_memory_stats()
+            base = torch.cuda.memory_allocated()
+            out = fn()
+            peak = (torch.cuda.max_memory_allocated() - base) / 1e6
+            err = float((out.float() - ref.float()).norm() / ref.float().norm())
+            med, _ = time_fn(fn, iters=10, warmup=3)
+            print(f"   {label:34s} {med * 1e3:7.3f} ms   {flops / med / 1e12:7.1f} TF/s on the GEMM flops   "
+                  f"peak extra memory {peak:8.1f} MB   dh rel diff vs materialised {err:.2e}")
+
+
+if __name__ == "__main__":
+    main()
