@@ -504,3 +504,30 @@ def test_length_bucketing_and_padding_trim():
     # an all-padding batch is left alone
     z = {"g_ids": torch.zeros(2, 16, dtype=torch.long), "g_mask": torch.zeros(2, 16, dtype=torch.long)}
     assert shards.trim_batch(z, [("g_ids", "g_mask")])["g_mask"].shape == (2, 16)
+
+
+def test_hw_queue_setting_is_opt_in(monkeypatch):
+    """importing the package must not touch GPU_MAX_HW_QUEUES; the entry points apply 3 only when an
+    RCCL process group will exist, an explicit setting wins, DALM_HW_QUEUES forces / disables."""
+    import importlib
+    import os
+
+    import dalm_amd
+
+    for k in ("GPU_MAX_HW_QUEUES", "DALM_HW_QUEUES", "DALM_FORCE_DIST", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    importlib.reload(dalm_amd)
+    assert "GPU_MAX_HW_QUEUES" not in os.environ
+    assert dalm_amd.configure_hw_queues(1) == "runtime-default" and "GPU_MAX_HW_QUEUES" not in os.environ
+    assert dalm_amd.configure_hw_queues(8) == "rccl-alive:3" and os.environ["GPU_MAX_HW_QUEUES"] == "3"
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "4")
+    assert dalm_amd.configure_hw_queues(8) == "user:4" and os.environ["GPU_MAX_HW_QUEUES"] == "4"
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES")
+    monkeypatch.setenv("DALM_HW_QUEUES", "0")
+    assert dalm_amd.configure_hw_queues(8) == "runtime-default" and "GPU_MAX_HW_QUEUES" not in os.environ
+    monkeypatch.setenv("DALM_HW_QUEUES", "2")
+    assert dalm_amd.configure_hw_queues(1) == "DALM_HW_QUEUES:2"
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES")
+    monkeypatch.delenv("DALM_HW_QUEUES")
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    assert dalm_amd.configure_hw_queues() == "rccl-alive:3"

@@ -362,3 +362,90 @@ def test_native_rccl_communicator_one_rank(dev, tmp_path, monkeypatch):
             comm.all_reduce_sum_(torch.zeros(3, device=dev, dtype=torch.bfloat16))
     finally:
         comm.close()
+
+
+# ---------------------------------------------------------------------------
+# seeded shape fuzz: every geometry decision of the round-2 kernels (tile tails, split counts, K padding, row-tile
+# variants, token slicing) is driven by the shapes, so a fixed pseudo-random sample of shapes runs through each family
+# ---------------------------------------------------------------------------
+def _fuzz_shapes(seed, count, gen):
+    import random
+
+    rnd = random.Random(seed)
+    return [gen(rnd) for _ in range(count)]
+
+
+SMALL_FUZZ = _fuzz_shapes(11, 14, lambda r: (lambda m, n: (m, n, r.choice([32, 64, 100, 384, 520, 1024]), r.randint(0, n - m)))(
+    *sorted((r.randint(1, 300), r.randint(1, 900)))))
+BIG_FUZZ = _fuzz_shapes(12, 8, lambda r: (lambda m, n: (m, n, r.choice([128, 256, 384, 640, 1024]), r.randint(0, n - m)))(
+    *sorted((r.randint(520, 1800), r.randint(700, 3000)))))
+
+
+@pytest.mark.parametrize("m,n,D,off", SMALL_FUZZ)
+def test_fuzz_small_path(dev, m, n, D, off):
+    from dalm_amd.ops import default_ops
+
+    ops = default_ops()
+    if not ops.sim_small_supported(m, n, D):
+        pytest.skip("outside the small path")
+    A, Bm, scale, S, rc, rl, cc, cl, dS = _problem(m, n, D, off, seed=m * 131 + n)
+    Sg, row_lse, diag, col_lse = ops.sim_small_fwd(A.to(dev), Bm.to(dev), scale, off, True)
+    torch.testing.assert_close(row_lse.cpu().double(), rl, rtol=1e-6, atol=2e-4)
+    torch.testing.assert_close(col_lse.cpu().double(), torch.logsumexp(S, 0), rtol=1e-6, atol=2e-4)
+    dA, dB = ops.sim_small_bwd(Sg, A.to(dev), Bm.to(dev), scale, off, rc.to(dev), rl.float().to(dev), cc.to(dev),
+                               cl.float().to(dev), True, True)
+    assert_grad_close(dA, scale * (dS @ Bm.double()), 5e-4, "dA")
+    assert_grad_close(dB, scale * (dS.t() @ A.double()), 5e-4, "dB")
+
+
+@pytest.mark.parametrize("m,n,D,off", BIG_FUZZ)
+def test_fuzz_streaming_forward_and_flash_backward(dev, m, n, D, off):
+    from dalm_amd.ops import default_ops
+
+    ops = default_ops()
+    A, Bm, scale, S, rc, rl, cc, cl, dS = _problem(m, n, D, off, seed=m * 17 + n)
+    row_lse, diag = ops.sim_rowstats(A.to(dev), Bm.to(dev), scale, off)
+    torch.testing.assert_close(row_lse.cpu().double(), rl, rtol=1e-6, atol=2e-4)
+    torch.testing.assert_close(diag.cpu().double(), S[torch.arange(m), off + torch.arange(m)], rtol=1e-6, atol=2e-4)
+    got = ops.sim_grad(A.to(dev), Bm.to(dev), scale, off, rc.to(dev), rl.float().to(dev), cc.to(dev), cl.float().to(dev))
+    assert_grad_close(got, scale * (dS @ Bm.double()), 5e-4, "dA")
+
+
+POOL_FUZZ = _fuzz_shapes(13, 10, lambda r: (r.randint(1, 40), r.randint(1, 300), r.choice([64, 96, 384, 768, 1024, 1500, 4100])))
+
+
+@pytest.mark.parametrize("B,T,D", POOL_FUZZ)
+def test_fuzz_fused_pool(dev, B, T, D):
+    from dalm_amd.fused import pool_l2norm
+
+    g = torch.Generator().manual_seed(B * 7919 + T * 31 + D)
+    for dtype in (torch.float32, torch.bfloat16):
+        h = torch.randn(B, T, D, generator=g).to(dtype)
+        lens = torch.randint(0, T + 1, (B,), generator=g)           # zero-length (all padding) rows included
+        mask = (torch.arange(T).unsqueeze(0) < lens.unsqueeze(1)).long()
+        hd = h.to(dev).requires_grad_(True)
+        e = pool_l2norm(hd, mask.to(dev), True)
+        up = torch.randn(B, D, generator=g)
+        (e * up.to(dev)).sum().backward()
+        hh = h.double().requires_grad_(True)
+        ref = O.ref_retrieval_embed(hh, mask, True)
+        (ref * up).sum().backward()
+        assert_grad_close(e.detach(), ref.detach(), GRAD_NORM_RTOL, "emb")
+        assert_grad_close(hd.grad, hh.grad, GRAD_NORM_RTOL if dtype == torch.float32 else BF16_GRAD_NORM_RTOL, "dh")
+
+
+TOPK_FUZZ = _fuzz_shapes(14, 6, lambda r: (r.randint(1, 200), r.randint(400, 9000), r.choice([64, 100, 384, 1024]), r.randint(1, 12)))
+
+
+@pytest.mark.parametrize("nq,nc,D,k", TOPK_FUZZ)
+def test_fuzz_fused_topk(dev, nq, nc, D, k):
+    from dalm_amd.retrieval import exact_topk
+
+    g = torch.Generator().manual_seed(nq * 101 + nc)
+    corpus = torch.nn.functional.normalize(torch.randn(nc, D, generator=g), dim=1)
+    queries = torch.nn.functional.normalize(torch.randn(nq, D, generator=g), dim=1)
+    ref = queries.double() @ corpus.double().t()
+    rs, _ = torch.topk(ref, k, dim=1)
+    s, i = exact_topk(queries.to(dev), corpus.to(dev), k)
+    torch.testing.assert_close(torch.gather(ref, 1, i.cpu()), rs, rtol=0, atol=2e-6)
+    assert bool((i.cpu()[:, 1:] != i.cpu()[:, :-1]).all()) if k > 1 else True     # no duplicates in a row
