@@ -65,7 +65,7 @@ def _worker(rank, world, port, mode, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,world", [("e2e", 2), ("contrastive", 2), ("e2e", 3)])
+@pytest.mark.parametrize("mode,world", [("e2e", 2), ("contrastive", 2), ("e2e", 3), ("e2e", 8)])
 def test_ranks_equal_one_process_at_global_batch(tmp_path, mode, world):
     import dalm_oracle as O
     from helpers import synth_batch
