@@ -192,6 +192,8 @@ def main():
                     help="graph the tower fwd/bwd and keep collectives eager (the default when --gpus > 1)")
     ap.add_argument("--fuse-lm-head", action="store_true",
                     help="SURVEY 8(f) rank 1: chunked lm_head + CE, the [B,Tg,V] logits are never materialised")
+    ap.add_argument("--all-rows", action="store_true",
+                    help="with --fuse-lm-head: run the padding rows through the lm_head GEMMs too (sample chunks)")
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg5", "cfg2", "cfg1"],
                     help="cfg3 = RAG-e2e bge-large + Llama-2-7b batch 18 (headline, default); "
                          "cfg5 = RAG-e2e bge-large + Falcon-7B architecture (V = 65024: the 1024-thread CE rows); "
@@ -258,6 +260,14 @@ def main():
         step = GraphedStep(step)
     # a few distinct pre-staged batches (inputs resident in HBM before the timed region)
     batches = [synthetic_batch(dev, 100 + 17 * rank + i, V=V) for i in range(4)]
+    if args.fuse_lm_head and not args.all_rows:
+        # the data loader's job (ShardedBatches(live_rows=...)): list the rows that carry loss while the mask is host memory
+        from dalm_amd.fused import gemm_wave_rows, live_row_index
+
+        for b in batches:
+            idx = live_row_index(b["generator_input_attention_mask"], gemm_wave_rows(V))
+            if idx is not None:
+                b["generator_live_rows"] = idx.to(dev)
 
     # graphs are captured during the first untimed step; with --warmup 0 one untimed step still runs so that
     # the capture never lands inside the timed region
@@ -335,7 +345,9 @@ def main():
                                      ("dalm_amd.launch (python bench.py --gpus N)" if ranks_seen > 1 else "single process"),
                        "gpu_max_hw_queues": args.hw_queues,
                        "retriever_layers": args.retriever_layers, "generator_layers": args.generator_layers,
-                       "lm_head": "fused with the CE in sample chunks (no logits tensor)" if args.fuse_lm_head else f"logits materialised ({args.dtype})",
+                       "lm_head": (("fused with the CE in row chunks over the rows that carry loss (no logits tensor)" if not args.all_rows
+                                    else "fused with the CE in sample chunks (no logits tensor)") if args.fuse_lm_head
+                                   else f"logits materialised ({args.dtype})"),
                        "tower_gemms": "pre-tuned solution table (dalm_amd/tuning)" if args.tuned_gemms else "library defaults",
                        "launch": ("hipGraph replay of the whole step" if (use_graph and getattr(step, "graph", None) is not None)
                                   else ("hipGraph replay of tower fwd/bwd, eager collectives+loss+optimizer"

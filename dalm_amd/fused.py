@@ -285,9 +285,92 @@ def rag_e2e_loss(query_embs, passage_embs, generator_logits, input_ids, attentio
 # A chunk (<= ~100 MB bf16) lives in the 256 MB Infinity Cache between the three passes, so the logits and
 # their gradient stop costing HBM round trips and 2 x B*Tg*V elements of memory.
 # ---------------------------------------------------------------------------
+def gemm_wave_rows(V: int, cus: int = 256, tile: int = 256) -> int:
+    """Row granularity at which a [rows, V] bf16 GEMM fills whole waves of the chip: hipBLASLt runs the lm_head shapes on
+    256 x 256 macro tiles, one per CU per wave, so rows/256 * ceil(V/256) tiles should sit just under a multiple of 256
+    CUs.  V = 32000 (125 column tiles): 512 rows = 250 tiles (0.98 of a wave; 768 rows = 375 tiles needs two waves at 0.73 -
+    measured 828 vs 1245 TF/s); V = 65024 (254 column tiles): 256 rows."""
+    ct = -(-V // tile)
+    for k in range(1, 9):
+        t = k * ct
+        if t / (-(-t // cus) * cus) >= 0.9:
+            return k * tile
+    return tile
+
+
+def live_row_index(attention_mask: torch.Tensor, multiple: int = 256) -> Optional[torch.Tensor]:
+    """HOST-side list of the generator rows that carry loss: flat index b*Tg + t of every (b, t) with t < Tg-1 and
+    attention_mask[b, t+1] != 0 (the shifted-label rows of compute_marginalized_loss_from_logits, reference
+    dalm/training/utils/train_utils.py:113-138), padded with -1 to a multiple of `multiple` (use `gemm_wave_rows(V)`) so
+    that the GEMMs run whole waves and only a few distinct lengths (= hipGraph shapes) occur.  None when no row is live (the degenerate NaN-loss batch keeps the
+    uncompacted path and its NaN gradients) or when compaction would not drop anything.
+    Computed where the mask still lives on the host (data loader / batch staging): the count sets tensor shapes, so
+    reading it from the device would cost a sync per step."""
+    m = attention_mask.detach()
+    if m.is_cuda:
+        m = m.cpu()
+    B, Tg = m.shape
+    live = torch.zeros((B, Tg), dtype=torch.bool)
+    live[:, :-1] = m[:, 1:] != 0
+    rows = live.reshape(-1).nonzero().squeeze(1)
+    R = int(rows.numel())
+    Rp = -(-R // multiple) * multiple
+    if R == 0 or Rp >= B * Tg:
+        return None
+    out = torch.full((Rp,), -1, dtype=torch.int64)
+    out[:R] = rows
+    return out
+
+
+def _row_chunks(rows: int, cap: int, unit: int):
+    """Split `rows` into the fewest chunks of at most `cap` rows, sizes multiples of `unit` (the last takes the remainder)
+    and as even as the unit allows, larger first: 3584 rows, cap 2048, unit 512 -> [2048, 1536]."""
+    cap = max(unit, (cap // unit) * unit)
+    units = -(-rows // unit)
+    n = -(-units // (cap // unit))
+    sizes = [(units // n + (1 if i < units % n else 0)) * unit for i in range(n)]
+    sizes[-1] -= units * unit - rows
+    return [z for z in sizes if z > 0]
+
+
+def _lm_head_live_rows(ops, h, w, ids, mask, stats, live_rows, chunk_rows, dw):
+    """lm_head + marginalised CE + d(hidden) over the live rows only.  Padding rows (38 % of bench.py's cfg3 batch, and
+    whatever padding='max_length' leaves in real data) carry no loss and a zero gradient, so both GEMMs and the CE pass
+    skip them; the CE kernel sees each chunk as one virtual sample [1, n+1, V] whose shifted labels are the chunk's
+    labels (row n is the kernel's always-dead last position), so its code path and numerics are the uncompacted ones."""
+    B, Tg, H = h.shape
+    R, Rp, V = B * Tg, live_rows.numel(), w.shape[0]
+    valid = live_rows >= 0
+    rows = live_rows.clamp_min(0)
+    dst = torch.where(valid, rows, torch.full_like(rows, R))       # padding entries land in a dump row
+    nxt = rows + 1                                                  # live rows have t < Tg-1: same sample
+    ids_c = ids.reshape(-1).index_select(0, nxt)
+    mask_c = mask.reshape(-1).index_select(0, nxt) * valid.to(mask.dtype)
+    hc_all = h.reshape(R, H).index_select(0, rows)
+    dh_c = torch.empty_like(hc_all)
+    nll_c = torch.empty((Rp,), device=h.device, dtype=torch.float32)
+    zero1 = ids_c.new_zeros((1,))
+    r1 = 0
+    for n in _row_chunks(Rp, chunk_rows, gemm_wave_rows(V)):
+        r0, r1 = r1, r1 + n
+        buf = torch.empty((n + 1, V), device=h.device, dtype=h.dtype)
+        torch.mm(hc_all[r0:r1], w.t(), out=buf[:n])
+        ids_v = torch.cat((zero1, ids_c[r0:r1])).view(1, n + 1)
+        mask_v = torch.cat((zero1.to(mask_c.dtype), mask_c[r0:r1])).view(1, n + 1)
+        _lse, nll_v, dl_v = ops.ce_fwd(buf.view(1, n + 1, V), ids_v, mask_v, stats, True, True)
+        nll_c[r0:r1] = nll_v.reshape(-1)[:n]
+        dl2 = dl_v.view(n + 1, V)[:n]
+        torch.mm(dl2, w, out=dh_c[r0:r1])
+        if dw is not None:
+            dw.addmm_(dl2.t().float(), hc_all[r0:r1].float())
+    dh = torch.zeros((R + 1, H), device=h.device, dtype=h.dtype).index_copy_(0, dst, dh_c)[:R].view(B, Tg, H)
+    row_nll = torch.zeros((R + 1,), device=h.device, dtype=torch.float32).index_copy_(0, dst, nll_c)[:R]
+    return dh, row_nll
+
+
 class _LMHeadRagE2E(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, p, hidden, weight, ids, mask, qlen, scale, ops, comm, chunk, q_gather, p_gather, aux):
+    def forward(ctx, q, p, hidden, weight, ids, mask, qlen, scale, ops, comm, chunk, q_gather, p_gather, aux, live_rows=None):
         st = _contrastive_forward(ops, comm, q, p, scale,
                                   q_gather.wait() if q_gather is not None else None,
                                   p_gather.wait() if p_gather is not None else None)
@@ -298,19 +381,22 @@ class _LMHeadRagE2E(torch.autograd.Function):
         h = hidden.detach()
         w = weight.detach().to(h.dtype)
         need_dw = weight.requires_grad
-        dh = torch.empty_like(h)
         dw = torch.zeros(w.shape, device=w.device, dtype=torch.float32) if need_dw else None
-        row_nll = torch.empty((B * Tg,), device=h.device, dtype=torch.float32)
-        for b0 in range(0, B, chunk):
-            b1 = min(B, b0 + chunk)
-            hc = h[b0:b1].reshape(-1, H)
-            logits_c = (hc @ w.t()).view(b1 - b0, Tg, -1)
-            _lse, nll_c, dl_c = ops.ce_fwd(logits_c, ids[b0:b1], mask[b0:b1], stats, True, True)
-            row_nll[b0 * Tg:b1 * Tg] = nll_c
-            dl2 = dl_c.view(-1, dl_c.shape[-1])
-            dh[b0:b1] = (dl2 @ w).view(b1 - b0, Tg, H)
-            if need_dw:
-                dw.addmm_(dl2.t().float(), hc.float())
+        if live_rows is None:
+            dh = torch.empty_like(h)
+            row_nll = torch.empty((B * Tg,), device=h.device, dtype=torch.float32)
+            for b0 in range(0, B, chunk):
+                b1 = min(B, b0 + chunk)
+                hc = h[b0:b1].reshape(-1, H)
+                logits_c = (hc @ w.t()).view(b1 - b0, Tg, -1)
+                _lse, nll_c, dl_c = ops.ce_fwd(logits_c, ids[b0:b1], mask[b0:b1], stats, True, True)
+                row_nll[b0 * Tg:b1 * Tg] = nll_c
+                dl2 = dl_c.view(-1, dl_c.shape[-1])
+                torch.mm(dl2, w, out=dh[b0:b1].view(-1, H))
+                if need_dw:
+                    dw.addmm_(dl2.t().float(), hc.float())
+        else:
+            dh, row_nll = _lm_head_live_rows(ops, h, w, ids, mask, stats, live_rows, chunk * Tg, dw)
         out3, doc_lp = ops.rag_loss_finalize(row_nll, Nb, st.lse_r, st.lse_c, st.diag, st.n_global, stats)
         ctx.st, ctx.scale, ctx.ops, ctx.comm = st, scale, ops, comm
         ctx.in_dtypes = (q.dtype, p.dtype, weight.dtype)
@@ -334,22 +420,26 @@ class _LMHeadRagE2E(torch.autograd.Function):
             a = b + g * Nb / stats[0]
             dq, dp = _contrastive_backward(ops, ctx.comm, st, ctx.scale, a, b)
             dq, dp = dq.to(ctx.in_dtypes[0]), dp.to(ctx.in_dtypes[1])
-        return (dq, dp, dh, dweight) + (None,) * 10
+        return (dq, dp, dh, dweight) + (None,) * 11
 
 
 def rag_e2e_loss_from_hidden(query_embs, passage_embs, hidden_states, lm_head_weight, input_ids, attention_mask,
                              query_token_length, logit_scale, *, comm=None, ops=None,
-                             chunk_samples: Optional[int] = None, q_gather=None, p_gather=None, aux: Optional[dict] = None):
+                             chunk_samples: Optional[int] = None, q_gather=None, p_gather=None, aux: Optional[dict] = None,
+                             live_rows: Optional[torch.Tensor] = None):
     """Same value and gradients as `rag_e2e_loss(q, p, hidden @ W^T, ...)`, without materialising the logits:
     `hidden_states` [B,Tg,H] are the decoder's final (normed) states, `lm_head_weight` [V,H] (no bias).
     chunk_samples=None sizes a chunk's logits to ~100 MB so that it stays in the 256 MB Infinity Cache between its three
-    passes (measured, tools/lm_head_bench.py: cfg3 6 samples 1.94 ms vs 2.63 ms materialised; cfg5 3 samples 5.18 vs 5.79)."""
+    passes (measured, tools/lm_head_bench.py: cfg3 6 samples 1.94 ms vs 2.63 ms materialised; cfg5 3 samples 5.18 vs 5.79).
+    live_rows (from `live_row_index`, host side): only the rows that carry loss go through the two GEMMs and the CE."""
     if chunk_samples is None:
         Tg, V = hidden_states.shape[1], lm_head_weight.shape[0]
-        chunk_samples = max(1, (100 << 20) // max(Tg * V * hidden_states.element_size(), 1))
+        # row chunks of the live-rows path may be a little larger: cfg3 [2048, 1536] rows 1.64 ms vs [1536, 1024, 1024] 1.82 ms
+        budget = (128 << 20) if live_rows is not None else (100 << 20)
+        chunk_samples = max(1, budget // max(Tg * V * hidden_states.element_size(), 1))
     return _LMHeadRagE2E.apply(query_embs, passage_embs, hidden_states, lm_head_weight, input_ids, attention_mask,
                                query_token_length, float(logit_scale), ops or default_ops(), comm or LocalComm(),
-                               int(chunk_samples), q_gather, p_gather, aux)
+                               int(chunk_samples), q_gather, p_gather, aux, live_rows)
 
 
 # ---------------------------------------------------------------------------

@@ -56,12 +56,15 @@ class ShardedBatches:
     (the reference tokenises to python lists and collates + copies synchronously every step)."""
 
     def __init__(self, dataset, batch_size: int, rank: int, world: int, seed: int, columns: List[str], *,
-                 bucket_by: Optional[str] = None, trim: Optional[Dict[str, Any]] = None):
+                 bucket_by: Optional[str] = None, trim: Optional[Dict[str, Any]] = None,
+                 live_rows: Optional[Dict[str, Any]] = None):
         """dataset: a tokenised `datasets.Dataset` or a dict of int tensors/arrays (e.g. `shards.load_token_shards`).
         bucket_by: name of an attention-mask column - batches are formed from rows of similar length (opt-in: it changes
         which rows share a batch, i.e. the in-batch negatives; the reference batches at random).
         trim: kwargs of `shards.trim_batch` - all-padding columns are dropped on the host before the copy (opt-in:
-        shapes then vary from batch to batch; loss-preserving, see shards.py)."""
+        shapes then vary from batch to batch; loss-preserving, see shards.py).
+        live_rows: dict(mask=<generator attention-mask column>, multiple=<row granularity>) - every batch also carries
+        `generator_live_rows` (fused.live_row_index of the host copy of that mask) for the fused lm_head path."""
         self.B, self.rank, self.world, self.seed = batch_size, rank, world, seed
         self.columns = columns
         self.n = len(dataset[columns[0]]) if isinstance(dataset, dict) else len(dataset)
@@ -71,7 +74,7 @@ class ShardedBatches:
             # int32 on the host (half the memory and PCIe bytes); int64 again on the device
             t = torch.as_tensor(dataset[k]).to(torch.int32).contiguous()
             self.data[k] = t.pin_memory() if pin else t
-        self.bucket_by, self.trim = bucket_by, trim
+        self.bucket_by, self.trim, self.live_rows = bucket_by, trim, live_rows
         self._lengths = (self.data[bucket_by] != 0).sum(dim=1) if bucket_by else None
         n = self.n
         if world == 1:
@@ -100,10 +103,13 @@ class ShardedBatches:
 
                 host = trim_batch(host, **self.trim)
             if device.type != "cuda":
-                return {k: v.long() for k, v in host.items()}, None
+                dev = {k: v.long() for k, v in host.items()}
+                self._add_live_rows(dev, host, device)
+                return dev, None
             ev = torch.cuda.Event()
             with torch.cuda.stream(self._copy_stream):   # shapes vary: per-batch pinned copies instead of fixed staging
                 dev = {k: v.pin_memory().to(device, non_blocking=True).long() for k, v in host.items()}
+                self._add_live_rows(dev, host, device)
                 ev.record(self._copy_stream)
             return dev, ev
         # two persistent pinned staging sets (batch i+1 is staged while batch i's copy may still be in flight);
@@ -123,9 +129,20 @@ class ShardedBatches:
                 host = self._staging[slot][k][:n]
                 torch.index_select(v, 0, rows, out=host)
                 dev[k] = host.to(device, non_blocking=True).long()
+            self._add_live_rows(dev, {k: self._staging[slot][k][:n] for k in self.data}, device)
             ev.record(self._copy_stream)
         self._staging_free[slot] = ev
         return dev, ev
+
+    def _add_live_rows(self, dev: Dict[str, torch.Tensor], host: Dict[str, torch.Tensor], device: torch.device) -> None:
+        """The rows of the generator batch that carry loss, listed where the mask is still host memory (no device sync)."""
+        if not self.live_rows:
+            return
+        from ..fused import live_row_index
+
+        idx = live_row_index(host[self.live_rows["mask"]], int(self.live_rows.get("multiple", 256)))
+        if idx is not None:
+            dev["generator_live_rows"] = (idx.pin_memory().to(device, non_blocking=True) if device.type == "cuda" else idx)
 
     def epoch(self, epoch: int, device: torch.device, skip: int = 0) -> Iterable[Dict[str, torch.Tensor]]:
         g = torch.Generator().manual_seed(self.seed + epoch)

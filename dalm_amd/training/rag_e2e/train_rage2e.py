@@ -65,6 +65,7 @@ FLAGS = [
     ("length_bucketing", dict(action="store_true", help="[ext] batch rows of similar generator length together")),
     ("trim_padding", dict(action="store_true", help="[ext] drop all-padding columns per batch (loss-preserving)")),
     ("async_checkpoint", dict(action="store_true", help="[ext] write optimizer/scheduler state from a background thread")),
+    ("fuse_lm_head", dict(action="store_true", help="[ext] lm_head + loss in chunks over the rows that carry loss; the [B,T,V] logits never exist")),
 ]
 
 
@@ -110,6 +111,7 @@ def train_e2e(
     length_bucketing: bool = False,
     trim_padding: bool = False,
     async_checkpoint: bool = False,
+    fuse_lm_head: bool = False,
     rag_model: Optional[AutoModelForRagE2E] = None,
     on_step=None,
 ) -> None:
@@ -165,9 +167,16 @@ def train_e2e(
                             ("retriever_passage_input_ids", "retriever_passage_attention_mask"),
                             ("generator_input_input_ids", "generator_input_attention_mask")],
                     qlen_key="query_passage_input_len", qlen_follows="generator_input_attention_mask")
+    live_rows = None
+    if fuse_lm_head:   # padding rows skip the lm_head GEMMs and the CE
+        from ...fused import gemm_wave_rows
+
+        vocab = rag_model.generator_model.get_output_embeddings().weight.shape[0]
+        live_rows = dict(mask="generator_input_attention_mask", multiple=gemm_wave_rows(vocab))
     batches = common.ShardedBatches(processed, per_device_train_batch_size, comm.rank, comm.world_size,
                                     seed if seed is not None else 0, columns,
-                                    bucket_by="generator_input_attention_mask" if length_bucketing else None, trim=trim)
+                                    bucket_by="generator_input_attention_mask" if length_bucketing else None, trim=trim,
+                                    live_rows=live_rows)
 
     # ---- optimiser / schedule (reference :336-362) ----------------------------------------------
     params = [p for p in rag_model.parameters() if p.requires_grad]
@@ -213,7 +222,7 @@ def train_e2e(
     step_fn = RagE2EStep(rag_model, optimizer, scheduler, logit_scale, comm=comm,
                          autocast_dtype=torch.bfloat16 if mixed_precision == "bf16" else None,
                          # W > 1: graph the tower fwd/bwd, keep collectives + loss + optimizer eager
-                         graph_towers=(not use_graph) and (not no_hip_graph), graph_after=2)
+                         graph_towers=(not use_graph) and (not no_hip_graph), graph_after=2, fuse_lm_head=fuse_lm_head)
     if use_graph:
         step_fn = GraphedStep(step_fn, warmup=0, eager_steps=2)  # partial last batches (other shapes) run eagerly
     meter = common.Throughput()

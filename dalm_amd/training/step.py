@@ -179,7 +179,7 @@ class RagE2EStep(_StepBase):
                                             batch["generator_input_attention_mask"], batch["query_passage_input_len"],
                                             self.logit_scale, comm=self.comm, ops=self.ops,
                                             chunk_samples=self.lm_head_chunk, q_gather=q_gather, p_gather=p_gather,
-                                            aux=self.aux)
+                                            aux=self.aux, live_rows=batch.get("generator_live_rows"))
             return self._finish(loss)
         loss = rag_e2e_loss(q_emb, p_emb, logits, batch["generator_input_input_ids"],
                             batch["generator_input_attention_mask"], batch["query_passage_input_len"],

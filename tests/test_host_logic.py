@@ -531,3 +531,64 @@ def test_hw_queue_setting_is_opt_in(monkeypatch):
     monkeypatch.delenv("DALM_HW_QUEUES")
     monkeypatch.setenv("WORLD_SIZE", "4")
     assert dalm_amd.configure_hw_queues() == "rccl-alive:3"
+
+
+def test_live_row_index_lists_the_shifted_label_rows():
+    """fused.live_row_index: row (b, t) is listed iff t < Tg-1 and mask[b, t+1] != 0 (the rows whose shifted label counts
+    in compute_marginalized_loss_from_logits, reference train_utils.py:113-138); -1 padding to the multiple."""
+    from dalm_amd.fused import _row_chunks, gemm_wave_rows, live_row_index
+
+    mask = torch.tensor([[0, 0, 1, 1, 1, 1], [1, 1, 1, 1, 0, 0], [0, 0, 0, 0, 0, 1]])
+    idx = live_row_index(mask, multiple=4)
+    assert idx.tolist() == [1, 2, 3, 4, 6, 7, 8, 16]   # 8 live rows: exactly two multiples of 4, nothing to pad
+    idx = live_row_index(mask, multiple=5)
+    assert idx.tolist() == [1, 2, 3, 4, 6, 7, 8, 16, -1, -1]
+    assert live_row_index(torch.zeros(2, 6, dtype=torch.long), 4) is None            # no loss anywhere: uncompacted (NaN) path
+    assert live_row_index(torch.ones(2, 6, dtype=torch.long), 4) is None              # 10 live rows pad to 12 = all rows
+    assert gemm_wave_rows(32000) == 512 and gemm_wave_rows(65024) == 256
+    assert _row_chunks(3584, 2048, 512) == [2048, 1536] and _row_chunks(700, 512, 256) == [512, 188]
+    assert sum(_row_chunks(3328, 1536, 256)) == 3328 and max(_row_chunks(3328, 1536, 256)) <= 1536
+
+
+def test_lm_head_live_rows_equals_all_rows_on_the_oracle_ops():
+    """The compacted lm_head path against the all-rows path with the CPU oracle ops (no GPU): same loss and gradients."""
+    from oracle.dalm_oracle import OracleOps
+
+    from dalm_amd.fused import live_row_index, rag_e2e_loss_from_hidden
+
+    B, Tg, H, V, D = 5, 12, 16, 50, 8
+    g = torch.Generator().manual_seed(1)
+    glen = torch.randint(3, Tg + 1, (B, 1), generator=g)
+    mask = (torch.arange(Tg).unsqueeze(0) >= (Tg - glen)).long()
+    ids = torch.randint(0, V, (B, Tg), generator=g)
+    qlen = (glen.squeeze(1).float() * 0.6).long().clamp(min=1)
+    q = torch.nn.functional.normalize(torch.randn(B, D, generator=g), dim=1)
+    p = torch.nn.functional.normalize(torch.randn(B, D, generator=g), dim=1)
+    h, W = torch.randn(B, Tg, H, generator=g), 0.3 * torch.randn(V, H, generator=g)
+    live = live_row_index(mask, multiple=8)
+    assert live is not None and int((live < 0).sum()) > 0
+    res = []
+    for rows in (None, live):
+        qq, pp, hh, ww = [t.clone().requires_grad_(True) for t in (q, p, h, W)]
+        rag_e2e_loss_from_hidden(qq, pp, hh, ww, ids, mask, qlen, 20.0, ops=OracleOps(), chunk_samples=2, live_rows=rows).backward()
+        res.append([qq.grad, pp.grad, hh.grad, ww.grad])
+    for a, b in zip(*res):
+        assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(a.abs().max()))
+
+
+def test_sharded_batches_emit_live_rows():
+    from dalm_amd.fused import live_row_index
+    from dalm_amd.training.common import ShardedBatches
+
+    n, T = 12, 10
+    g = torch.Generator().manual_seed(0)
+    lens = torch.randint(2, 7, (n, 1), generator=g)
+    data = {"generator_input_input_ids": torch.randint(1, 50, (n, T), generator=g),
+            "generator_input_attention_mask": (torch.arange(T).unsqueeze(0) >= (T - lens)).long()}
+    sb = ShardedBatches(data, 4, 0, 1, 0, list(data), live_rows=dict(mask="generator_input_attention_mask", multiple=4))
+    seen = 0
+    for batch in sb.epoch(0, torch.device("cpu")):
+        want = live_row_index(batch["generator_input_attention_mask"], 4)
+        assert want is not None and torch.equal(batch["generator_live_rows"], want)
+        seen += 1
+    assert seen == 3

@@ -449,3 +449,37 @@ def test_fuzz_fused_topk(dev, nq, nc, D, k):
     s, i = exact_topk(queries.to(dev), corpus.to(dev), k)
     torch.testing.assert_close(torch.gather(ref, 1, i.cpu()), rs, rtol=0, atol=2e-6)
     assert bool((i.cpu()[:, 1:] != i.cpu()[:, :-1]).all()) if k > 1 else True     # no duplicates in a row
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_lm_head_over_live_rows_equals_all_rows(dtype):
+    """Row compaction of the fused lm_head path (several row chunks, a ragged last chunk, -1 padding entries): the loss and
+    every gradient equal the all-rows path - dead rows only ever contributed zeros."""
+    from dalm_amd.fused import live_row_index, rag_e2e_loss_from_hidden
+
+    dev = torch.device("cuda:0")
+    B, Tg, H, V, D = 8, 128, 64, 1000, 32
+    g = torch.Generator().manual_seed(3)
+    glen = torch.randint(20, Tg + 1, (B, 1), generator=g)
+    glen[2] = Tg                                       # one sample without padding
+    mask = (torch.arange(Tg).unsqueeze(0) >= (Tg - glen)).long()
+    ids = torch.randint(0, V, (B, Tg), generator=g)
+    qlen = (glen.squeeze(1).float() * 0.7).long().clamp(min=1)
+    q = torch.nn.functional.normalize(torch.randn(B, D, generator=g), dim=1).to(dev)
+    p = torch.nn.functional.normalize(torch.randn(B, D, generator=g), dim=1).to(dev)
+    h = torch.randn(B, Tg, H, generator=g).to(dev, dtype)
+    W = (0.2 * torch.randn(V, H, generator=g)).to(dev, dtype)
+    live = live_row_index(mask, multiple=32)
+    assert live is not None and int((live < 0).sum()) > 0 and live.numel() > 512   # >= 3 chunks of <= 256 rows
+    res = []
+    for rows in (None, live.to(dev)):
+        qq, pp, hh, ww = [t.clone().requires_grad_(True) for t in (q, p, h, W)]
+        loss = rag_e2e_loss_from_hidden(qq, pp, hh, ww, ids.to(dev), mask.to(dev), qlen.to(dev), 100.0, chunk_samples=2,
+                                        live_rows=rows)
+        loss.backward()
+        res.append([loss.detach()] + [t.grad.float() for t in (qq, pp, hh, ww)])
+    tol = 1e-5 if dtype == torch.float32 else 2e-2   # bf16: the dW accumulation order changes with the chunking
+    for a, b in zip(*res):
+        assert float((a - b).abs().max()) <= tol * max(1.0, float(a.abs().max())), (a - b).abs().max()
+    dead = (torch.cat((mask[:, 1:], torch.zeros(B, 1, dtype=mask.dtype)), 1) == 0).to(dev)
+    assert float(res[1][3][dead].abs().max()) == 0.0   # d(hidden) of rows without loss is exactly zero

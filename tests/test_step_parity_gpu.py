@@ -369,3 +369,45 @@ def test_padding_trim_preserves_the_step_and_graphs_are_cached_per_shape():
     assert gstep.failed is None and len(gstep.graphs) >= 2 and gstep.eager_calls == 0, (gstep.failed, len(gstep.graphs), gstep.eager_calls)
     for a, b in zip(cut, gl):
         assert abs(a - b) <= 2e-5 * abs(a), (cut, gl)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_fused_lm_head_over_live_rows_matches_reference_trajectory(graph):
+    """the decoder stops at its hidden states, lm_head + marginalised CE + d(hidden) run only over the rows
+    that carry loss (host-built `generator_live_rows`) - same 5-step trajectory as the reference's materialised logits."""
+    from transformers import get_scheduler
+
+    from dalm_amd.fused import live_row_index
+    from dalm_amd.models import AutoModelForRagE2E
+    from dalm_amd.training.graphed import GraphedStep, TensorLRScheduler, make_capturable_adam
+    from dalm_amd.training.step import RagE2EStep
+
+    gold = json.loads((G / "step_golden.json").read_text())
+    dev = torch.device("cuda:0")
+    rag = AutoModelForRagE2E(str(G / "tiny_retriever"), str(G / "tiny_generator")).to(dev)
+    g_tok = rag.generator_tokenizer
+    g_tok.pad_token = g_tok.eos_token
+    rag.train()
+    opt = make_capturable_adam(rag.parameters(), gold["lr"], dev) if graph else torch.optim.Adam(rag.parameters(), lr=gold["lr"])
+
+    def mk(o):
+        return get_scheduler("linear", optimizer=o, num_warmup_steps=gold["warmup"], num_training_steps=gold["total_steps"])
+
+    sched = TensorLRScheduler(opt, gold["lr"], mk) if graph else mk(opt)
+    step = RagE2EStep(rag, opt, sched, 100, autocast_dtype=None, overlap_towers=graph, fuse_lm_head=True)
+    if graph:
+        step = GraphedStep(step, warmup=0)
+    losses, compacted = [], 0
+    for b in _batches(rag.retriever_tokenizer, g_tok, gold, dev):
+        idx = live_row_index(b["generator_input_attention_mask"], multiple=4)
+        if idx is not None:
+            b = dict(b, generator_live_rows=idx.to(dev))
+            compacted += 1
+        losses.append(float(step(b)))
+    assert compacted >= 3, "the golden batches carry padding: most of them must take the compacted path"
+    if graph:
+        assert step.failed is None and step.graph is not None, step.failed
+    for got, ref in zip(losses, gold["losses"]):
+        assert abs(got - ref) <= 1e-3 * abs(ref), (losses, gold["losses"])
+    final = float(sum(p.detach().abs().sum() for p in rag.parameters()))
+    assert abs(final - gold["final_param_abs_sum"]) <= 1e-4 * gold["final_param_abs_sum"]

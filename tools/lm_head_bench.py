@@ -1,6 +1,7 @@
 """SURVEY 8(f) rank 1, measured: lm_head + marginalised CE at the cfg3 / cfg5 shapes, forward + backward to dh,
 (a) logits materialised (hipBLASLt GEMM -> fused CE kernel in place -> hipBLASLt GEMM back) vs
-(b) `rag_e2e_loss_from_hidden` (sample chunks, the [B,Tg,V] logits never exist).
+(b) `rag_e2e_loss_from_hidden` (sample chunks, the [B,Tg,V] logits never exist),
+(c) the same over the live rows only (`live_row_index`: padding rows skip both GEMMs and the CE).
     python tools/lm_head_bench.py
 """
 import sys
@@ -12,11 +13,14 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 sys.path.insert(0, str(Path(__file__).resolve().parent))
 from kernel_bench import time_fn  # noqa: E402
 
-from dalm_amd.fused import rag_e2e_loss, rag_e2e_loss_from_hidden  # noqa: E402
+from dalm_amd.fused import gemm_wave_rows, live_row_index, rag_e2e_loss, rag_e2e_loss_from_hidden  # noqa: E402
 
 
 def main():
     dev = torch.device("cuda:0")
+    if "--tuned" in sys.argv:   # replay dalm_amd/tuning/tunableop_gfx950.csv, as bench.py and the trainers do
+        from dalm_amd.tuning import enable_tuned_gemms
+        print("tuned GEMM table loaded:", enable_tuned_gemms())
     B, Tg, D = 18, 256, 1024
     for name, H, V in (("cfg3 Llama-2-7b", 4096, 32000), ("cfg5 Falcon-7B", 4544, 65024)):
         g = torch.Generator(device="cpu").manual_seed(0)
@@ -35,19 +39,26 @@ def main():
             loss.backward()
             return h.grad
 
-        def chunked(chunk):
+        live = live_row_index(mask, gemm_wave_rows(V))
+        n_live = int((live >= 0).sum())
+        live = live.to(dev)
+
+        def chunked(chunk, rows=None):
             def f():
                 h = hidden.detach().requires_grad_(True)
-                loss = rag_e2e_loss_from_hidden(q, p, h, W, ids, mask, qlen, 100, chunk_samples=chunk)
+                loss = rag_e2e_loss_from_hidden(q, p, h, W, ids, mask, qlen, 100, chunk_samples=chunk, live_rows=rows)
                 loss.backward()
                 return h.grad
             return f
 
         flops = 2 * 2.0 * B * Tg * H * V          # two GEMMs (logits, dh)
-        print(name, f"B={B} Tg={Tg} H={H} V={V} bf16: 2 GEMMs = {flops / 1e12:.2f} TFLOP")
+        print(name, f"B={B} Tg={Tg} H={H} V={V} bf16: 2 GEMMs = {flops / 1e12:.2f} TFLOP; "
+                    f"{n_live} of {B * Tg} rows carry loss, padded to {live.numel()}")
         ref = materialised()
         for label, fn in (("materialised logits", materialised), ("chunked, 6 samples", chunked(6)),
-                          ("chunked, 3 samples", chunked(3)), ("chunked, 18 samples (one chunk)", chunked(18))):
+                          ("chunked, 3 samples", chunked(3)), ("chunked, 18 samples (one chunk)", chunked(18)),
+                          ("live rows, chunks <= 1536 rows", chunked(6, live)), ("live rows, chunks <= 2048 rows", chunked(8, live)),
+                          ("live rows, chunks <= 1024 rows", chunked(4, live))):
             torch.cuda.reset_peak_memory_stats()
             base = torch.cuda.memory_allocated()
             out = fn()
