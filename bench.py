@@ -324,7 +324,8 @@ def main():
         if tfile.exists():
             try:
                 tj = json.loads(tfile.read_text())
-                if tj.get("workload", "cfg3") == args.workload and tj.get("dtype", "bf16") == args.dtype:
+                if (tj.get("workload", "cfg3") == args.workload and tj.get("dtype", "bf16") == args.dtype
+                        and not args.fuse_lm_head):   # collected on the materialised-logits launch
                     traffic = tj.get("bench_marg_ce_bytes_per_launch")
                     traffic_source = tj.get("source", "profiles/roofline_traffic.json (separate rocprofv3 --pmc passes)")
             except Exception:
