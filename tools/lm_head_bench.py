@@ -22,7 +22,11 @@ def main():
         from dalm_amd.tuning import enable_tuned_gemms
         print("tuned GEMM table loaded:", enable_tuned_gemms())
     B, Tg, D = 18, 256, 1024
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]     # e.g. --only=cfg3 (rocprofv3 runs)
+    arms = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--arms=")]     # substring filter on the arm label
     for name, H, V in (("cfg3 Llama-2-7b", 4096, 32000), ("cfg5 Falcon-7B", 4544, 65024)):
+        if only and not any(name.startswith(o) for o in only):
+            continue
         g = torch.Generator(device="cpu").manual_seed(0)
         q = torch.nn.functional.normalize(torch.randn(B, D, generator=g), dim=1).to(dev)
         p = torch.nn.functional.normalize(torch.randn(B, D, generator=g), dim=1).to(dev)
@@ -59,6 +63,8 @@ def main():
                           ("chunked, 3 samples", chunked(3)), ("chunked, 18 samples (one chunk)", chunked(18)),
                           ("live rows, chunks <= 1536 rows", chunked(6, live)), ("live rows, chunks <= 2048 rows", chunked(8, live)),
                           ("live rows, chunks <= 1024 rows", chunked(4, live))):
+            if arms and not any(a in label for a in arms):
+                continue
             torch.cuda.reset_peak_memory_stats()
             base = torch.cuda.memory_allocated()
             out = fn()
