@@ -4,7 +4,8 @@ library's own RCCL binding (`dalm_comm_*` in include/dalm_hip.h) instead of torc
 Opt-in (`DALM_NATIVE_COMM=1` for the trainers / bench, or construct it directly): the torch.distributed(nccl) path
 stays the default because it is the one that has run on hardware with more than one rank.  Bootstrap without
 torch.distributed: rank 0 asks RCCL for the 128-byte unique id and publishes it through a file next to the
-rendezvous port (`/tmp/dalm_comm_<MASTER_PORT>.id`), the other ranks poll for it.
+rendezvous port (`DALM_COMM_ID_FILE`, which `dalm_amd.launch` sets to a path unique to the launch; under other launchers
+`/tmp/dalm_comm_<MASTER_PORT>.id` - remove a stale one after a crashed job), the other ranks poll for it.
 
 Stream contract: a collective is issued on the communicator's own side stream after that stream has been made to wait
 for torch's CURRENT stream, and the current stream is made to wait for the collective before the call returns - the

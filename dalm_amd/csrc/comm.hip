@@ -43,7 +43,11 @@ Rccl& rccl() {
         x.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (x.handle) break;
       }
-    if (!x.handle) { x.error = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : ""); return x; }
+    if (!x.handle) {
+      const char* why = dlerror();   // a second dlerror() call returns NULL: read it once
+      x.error = std::string("librccl.so not found: ") + (why ? why : "");
+      return x;
+    }
     auto sym = [&](const char* s) { return dlsym(x.handle, s); };
     x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(sym("ncclGetUniqueId"));
     x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(sym("ncclCommInitRank"));
@@ -103,7 +107,14 @@ extern "C" int dalm_comm_init(dalm_comm_t** out, const void* id128, int rank, in
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming);
-  if (e != hipSuccess) { r.CommDestroy(c->comm); delete c; return hip_fail(e, __func__); }
+  if (e != hipSuccess) {
+    r.CommDestroy(c->comm);
+    if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+    if (c->ev_out) (void)hipEventDestroy(c->ev_out);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return hip_fail(e, __func__);
+  }
   *out = c;
   return 0;
 }

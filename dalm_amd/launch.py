@@ -22,6 +22,8 @@ import sys
 import time
 from typing import Dict, List, Optional, Sequence
 
+_LAUNCH_T0 = time.time()
+
 
 def in_distributed_env(env: Optional[Dict[str, str]] = None) -> bool:
     """True when a launcher (torchrun, this module) has already set the rank environment."""
@@ -47,6 +49,9 @@ def rank_env(rank: int, world: int, port: int, base: Optional[Dict[str, str]] = 
                 "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
     # the host driver supports only dmabuf IPC: without this RCCL's cross-process buffer sharing fails
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # rendezvous file of the opt-in native communicator (dalm_amd.comm): unique per launch, so that the id file a
+    # crashed earlier job left behind on the same port can never be picked up
+    env.setdefault("DALM_COMM_ID_FILE", f"/tmp/dalm_comm_{port}_{os.getpid()}_{int(_LAUNCH_T0 * 1000)}.id")
     return env
 
 

@@ -290,7 +290,8 @@ def merge_optimizer_shards(shards: List[Dict[str, Any]]) -> Dict[str, Any]:
 class AsyncSaver:
     """One background writer thread.  `submit(snapshot, write)`: `snapshot()` runs NOW on the caller's thread (device ->
     pinned host copies enqueued on a side stream, then one event), `write(host_state)` runs on the worker after the
-    event has completed.  At most one checkpoint is in flight: a new submit first waits for the previous one."""
+    event has completed.  At most one checkpoint is in flight: a new submit first waits for the previous one.
+    The training stream is made to wait for the copies (GPU-side), never for the file system."""
 
     def __init__(self):
         import threading
@@ -309,6 +310,10 @@ class AsyncSaver:
         if self._stream is not None:
             ev = torch.cuda.Event()
             ev.record(self._stream)
+            # the next optimizer update must not overwrite the state while the copies are still reading it: the
+            # training stream waits for them ON THE GPU (a few ms of PCIe time for LoRA state); the host returns at
+            # once and the file writing stays off the critical path
+            torch.cuda.current_stream().wait_event(ev)
 
         def work():
             try:
@@ -360,9 +365,10 @@ def save_training_state(path: str, model, optimizer, scheduler, extra: Dict[str,
     if saver is not None:
         saver.submit(snapshot, write)
     else:
-        write(snapshot(None))
+        host = snapshot(None)
         if torch.cuda.is_available():
-            torch.cuda.current_stream().synchronize()
+            torch.cuda.current_stream().synchronize()   # the non-blocking copies into pinned memory have landed
+        write(host)
 
 
 def load_training_state(path: str, optimizer, scheduler) -> Dict[str, Any]:
