@@ -499,7 +499,11 @@ extern "C" int dalm_pool_l2norm_bwd(const float* d_emb, const float* emb, const 
   const int vec = (dtype == DALM_F32) ? 4 : 8;
   const int vok = (reinterpret_cast<uintptr_t>(dh) % 16 == 0) && (D % vec == 0);
   const int64_t dc = (D + 64 * vec - 1) / (64 * vec);
-  int64_t tz = (1024 + B * dc - 1) / (B * dc);
+  // token slices: every workgroup first rebuilds du (dot product over D, ~16 scalar loads per lane), so many thin slices
+  // cost more than they spread - measured (tools/kernel_bench.py, hipGraph timing): cfg3 passage bf16 [18,128,1024]
+  // 1044 WGs 12.4 us, 540 WGs 9.2 us, 396 WGs 7.7 us; at B = 150 two slices beat one (17.3 vs 19.2 us bf16)
+  int64_t tz = (384 + B * dc - 1) / (B * dc);
+  if (B * dc < 1024 && T >= 64 && tz < 2) tz = 2;
   const int64_t tz_max = (T + 3) / 4;
   if (tz > tz_max) tz = tz_max;
   if (tz < 1) tz = 1;
