@@ -347,8 +347,14 @@ def _lm_head_live_rows(ops, h, w, ids, mask, stats, live_rows, chunk_rows, dw):
     ids_c = ids.reshape(-1).index_select(0, nxt)
     mask_c = mask.reshape(-1).index_select(0, nxt) * valid.to(mask.dtype)
     hc_all = h.reshape(R, H).index_select(0, rows)
-    dh_c = torch.empty_like(hc_all)
-    nll_c = torch.empty((Rp,), device=h.device, dtype=torch.float32)
+    # results land in [Rp+1]-row buffers whose last row stays zero; the full-size outputs are then ONE gather each through
+    # the inverse map (dead rows -> the zero row) instead of a zero fill plus a scatter (43 -> ~20 us at cfg3)
+    dh_c = torch.empty((Rp + 1, H), device=h.device, dtype=h.dtype)
+    nll_c = torch.empty((Rp + 1,), device=h.device, dtype=torch.float32)
+    dh_c[Rp].zero_()
+    nll_c[Rp].zero_()
+    inv = torch.full((R + 1,), Rp, device=h.device, dtype=torch.int64)
+    inv.scatter_(0, dst, torch.arange(Rp, device=h.device, dtype=torch.int64))   # padding entries land in inv[R] (unused)
     zero1 = ids_c.new_zeros((1,))
     r1 = 0
     for n in _row_chunks(Rp, chunk_rows, gemm_wave_rows(V)):
@@ -363,8 +369,8 @@ def _lm_head_live_rows(ops, h, w, ids, mask, stats, live_rows, chunk_rows, dw):
         torch.mm(dl2, w, out=dh_c[r0:r1])
         if dw is not None:
             dw.addmm_(dl2.t().float(), hc_all[r0:r1].float())
-    dh = torch.zeros((R + 1, H), device=h.device, dtype=h.dtype).index_copy_(0, dst, dh_c)[:R].view(B, Tg, H)
-    row_nll = torch.zeros((R + 1,), device=h.device, dtype=torch.float32).index_copy_(0, dst, nll_c)[:R]
+    dh = dh_c.index_select(0, inv[:R]).view(B, Tg, H)
+    row_nll = nll_c.index_select(0, inv[:R])
     return dh, row_nll
 
 
