@@ -198,16 +198,24 @@ class _RetrievalCall(torch.nn.Module):
 
 
 class _GeneratorCall(torch.nn.Module):
-    def __init__(self, rag_model, autocast_dtype):
+    """hidden_only: stop at the decoder's final (normed) hidden states - the fused lm_head path consumes those."""
+
+    def __init__(self, rag_model, autocast_dtype, hidden_only: bool = False):
         super().__init__()
         self.generator = rag_model.generator_model
         self.autocast_dtype = autocast_dtype
+        self.hidden_only = hidden_only
+
+    def _run(self, input_ids, attention_mask):
+        if self.hidden_only:
+            return self.generator.base_model(input_ids=input_ids, attention_mask=attention_mask)[0]
+        return self.generator(input_ids=input_ids, attention_mask=attention_mask).logits
 
     def forward(self, input_ids, attention_mask):
         if self.autocast_dtype is None:
-            return self.generator(input_ids=input_ids, attention_mask=attention_mask).logits
+            return self._run(input_ids, attention_mask)
         with torch.autocast("cuda", dtype=self.autocast_dtype, cache_enabled=False):
-            return self.generator(input_ids=input_ids, attention_mask=attention_mask).logits
+            return self._run(input_ids, attention_mask)
 
 
 class GraphedTowers:
@@ -216,13 +224,13 @@ class GraphedTowers:
     loss with its stats exchange, the gradient all-reduce - and the optimizer stay eager.  That removes >99 %
     of the per-step launches from the host path while no collective is ever captured; it is what W > 1 uses."""
 
-    def __init__(self, rag_model, autocast_dtype, sample_batch: Dict[str, torch.Tensor]):
+    def __init__(self, rag_model, autocast_dtype, sample_batch: Dict[str, torch.Tensor], hidden_only: bool = False):
         if getattr(rag_model, "retriever_is_autoregressive", False):
             raise NotImplementedError("graphed towers: autoregressive retrievers run eagerly")
         b = sample_batch
         self.key = tuple(tuple(b[k].shape) for k in self.KEYS)
         calls = (_RetrievalCall(rag_model, autocast_dtype), _RetrievalCall(rag_model, autocast_dtype),
-                 _GeneratorCall(rag_model, autocast_dtype))
+                 _GeneratorCall(rag_model, autocast_dtype, hidden_only))
         for c in calls:
             c.train(rag_model.training)
         args = ((b["retriever_passage_input_ids"].clone(), b["retriever_passage_attention_mask"].clone()),

@@ -80,7 +80,7 @@ class RagE2EStep(_StepBase):
         self.fuse_lm_head = fuse_lm_head
         self.lm_head_chunk = lm_head_chunk
         # W > 1: graph the towers (fwd + bwd), keep collectives / loss / optimizer eager (GraphedTowers)
-        self.graph_towers = graph_towers and torch.cuda.is_available() and not fuse_lm_head
+        self.graph_towers = graph_towers and torch.cuda.is_available()
         self.towers = None
         self.towers_failed: Optional[str] = None
         self.calls = 0
@@ -104,7 +104,7 @@ class RagE2EStep(_StepBase):
             from .graphed import GraphedTowers
 
             torch.cuda.synchronize()
-            self.towers = GraphedTowers(self.model, self.autocast_dtype, batch)
+            self.towers = GraphedTowers(self.model, self.autocast_dtype, batch, hidden_only=self.fuse_lm_head)
         except Exception as e:  # same kernels, eager launches
             self.towers_failed = repr(e)
             self.towers = None

@@ -371,7 +371,7 @@ def test_padding_trim_preserves_the_step_and_graphs_are_cached_per_shape():
         assert abs(a - b) <= 2e-5 * abs(a), (cut, gl)
 
 
-@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("graph", [False, True, "towers"])
 def test_fused_lm_head_over_live_rows_matches_reference_trajectory(graph):
     """the decoder stops at its hidden states, lm_head + marginalised CE + d(hidden) run only over the rows
     that carry loss (host-built `generator_live_rows`) - same 5-step trajectory as the reference's materialised logits."""
@@ -388,13 +388,16 @@ def test_fused_lm_head_over_live_rows_matches_reference_trajectory(graph):
     g_tok = rag.generator_tokenizer
     g_tok.pad_token = g_tok.eos_token
     rag.train()
+    towers = graph == "towers"   # tower fwd/bwd as graphs (the generator graph ends at the hidden states), loss eager
+    graph = bool(graph) and not towers
     opt = make_capturable_adam(rag.parameters(), gold["lr"], dev) if graph else torch.optim.Adam(rag.parameters(), lr=gold["lr"])
 
     def mk(o):
         return get_scheduler("linear", optimizer=o, num_warmup_steps=gold["warmup"], num_training_steps=gold["total_steps"])
 
     sched = TensorLRScheduler(opt, gold["lr"], mk) if graph else mk(opt)
-    step = RagE2EStep(rag, opt, sched, 100, autocast_dtype=None, overlap_towers=graph, fuse_lm_head=True)
+    step = RagE2EStep(rag, opt, sched, 100, autocast_dtype=None, overlap_towers=graph or towers, fuse_lm_head=True,
+                      graph_towers=towers, graph_after=0)
     if graph:
         step = GraphedStep(step, warmup=0)
     losses, compacted = [], 0
@@ -407,6 +410,8 @@ def test_fused_lm_head_over_live_rows_matches_reference_trajectory(graph):
     assert compacted >= 3, "the golden batches carry padding: most of them must take the compacted path"
     if graph:
         assert step.failed is None and step.graph is not None, step.failed
+    if towers:
+        assert step.towers_failed is None and step.towers is not None, step.towers_failed
     for got, ref in zip(losses, gold["losses"]):
         assert abs(got - ref) <= 1e-3 * abs(ref), (losses, gold["losses"])
     final = float(sum(p.detach().abs().sum() for p in rag.parameters()))
