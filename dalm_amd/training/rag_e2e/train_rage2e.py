@@ -224,7 +224,9 @@ def train_e2e(
                          # W > 1: graph the tower fwd/bwd, keep collectives + loss + optimizer eager
                          graph_towers=(not use_graph) and (not no_hip_graph), graph_after=2, fuse_lm_head=fuse_lm_head)
     if use_graph:
-        step_fn = GraphedStep(step_fn, warmup=0, eager_steps=2)  # partial last batches (other shapes) run eagerly
+        # partial last batches (other shapes) run eagerly; with live rows the padded row count is part of the shape
+        # (multiples of 256-512 rows: at most B*Tg/256 values), all graphs share one memory pool
+        step_fn = GraphedStep(step_fn, warmup=0, eager_steps=2, max_graphs=24 if fuse_lm_head else 8)
     meter = common.Throughput()
     saver = common.AsyncSaver() if async_checkpoint else None
     for epoch in range(starting_epoch, num_train_epochs):
