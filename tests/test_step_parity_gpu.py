@@ -416,3 +416,31 @@ def test_fused_lm_head_over_live_rows_matches_reference_trajectory(graph):
         assert abs(got - ref) <= 1e-3 * abs(ref), (losses, gold["losses"])
     final = float(sum(p.detach().abs().sum() for p in rag.parameters()))
     assert abs(final - gold["final_param_abs_sum"]) <= 1e-4 * gold["final_param_abs_sum"]
+
+
+def test_train_e2e_with_fused_lm_head_follows_the_default_trainer(tmp_path):
+    """--fuse_lm_head through the trainer entry point (data loader emits the live-row list, one hipGraph per padded row
+    count): the same per-step losses as the default materialised-logits trainer on the same csv and seed."""
+    import csv
+
+    from dalm_amd.training.rag_e2e.train_rage2e import train_e2e
+
+    rows = json.loads((G / "host_golden.json").read_text())["rows"]
+    path = tmp_path / "rows.csv"
+    with open(path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Question", "Abstract", "Answer"])
+        for i in range(12):
+            k = i % 5
+            w.writerow([rows["Question"][k], rows["Abstract"][k], rows["Answer"][k]])
+    runs = {}
+    for fuse in (False, True):
+        losses = []
+        train_e2e(str(path), str(G / "tiny_retriever"), str(G / "tiny_generator"), query_max_len=12, passage_max_len=24,
+                  generator_max_len=40, per_device_train_batch_size=4, learning_rate=1e-3, num_train_epochs=2,
+                  num_warmup_steps=0, output_dir=str(tmp_path / f"out{int(fuse)}"), with_tracking=False, seed=7,
+                  mixed_precision="no", fuse_lm_head=fuse, on_step=lambda s, l: losses.append(float(l)))
+        runs[fuse] = losses
+    assert len(runs[True]) == 6
+    for a, b in zip(runs[False], runs[True]):
+        assert abs(a - b) <= 1e-4 * abs(a), runs
