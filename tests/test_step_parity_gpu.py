@@ -444,3 +444,41 @@ def test_train_e2e_with_fused_lm_head_follows_the_default_trainer(tmp_path):
     assert len(runs[True]) == 6
     for a, b in zip(runs[False], runs[True]):
         assert abs(a - b) <= 1e-4 * abs(a), runs
+
+
+def test_autoregressive_retriever_embedding_matches_the_reference_formula():
+    """a4 with `is_autoregressive=True` (reference retriever_only_base_model.py:43-63): last hidden state of the causal LM,
+    pooled through eos_mask (= the last column for left-padded rows), L2-normalised - forward value and the gradient
+    that reaches the LM's parameters, against the same formula written in plain torch."""
+    from transformers import AutoModelForCausalLM
+
+    from dalm_amd.models.retriever_only_base_model import AutoModelForSentenceEmbedding
+    from dalm_amd.utils import eos_mask
+
+    dev = torch.device("cuda:0")
+    lm = AutoModelForCausalLM.from_pretrained(str(G / "tiny_generator")).to(dev)
+    ours = AutoModelForSentenceEmbedding.from_modules(lm, None, normalize=True, get_peft=False, is_autoregressive=True)
+    g = torch.Generator().manual_seed(5)
+    B, T = 6, 17
+    V = lm.config.vocab_size
+    ids = torch.randint(3, V, (B, T), generator=g).to(dev)
+    lens = torch.randint(2, T + 1, (B, 1), generator=g)
+    lens[0] = T
+    mask = (torch.arange(T).unsqueeze(0) >= (T - lens)).long().to(dev)      # left padded, as the Llama tokenizer pads
+    w = torch.randn(B, lm.config.hidden_size, generator=g).to(dev)
+
+    emb = ours(ids, mask)
+    (emb * w).sum().backward()
+    got = {n: p.grad.clone() for n, p in lm.named_parameters() if p.grad is not None}
+    lm.zero_grad(set_to_none=True)
+
+    h = lm(ids, attention_mask=mask, output_hidden_states=True, return_dict=True).hidden_states[-1]
+    m = eos_mask(mask).unsqueeze(-1).expand(h.size()).float()
+    ref = torch.nn.functional.normalize(torch.sum(h * m, 1) / torch.clamp(m.sum(1), min=1e-9), p=2, dim=1)
+    (ref * w).sum().backward()
+    assert float((emb - ref).detach().abs().max()) <= 1e-5
+    assert got, "no gradient reached the language model"
+    for n, p in lm.named_parameters():
+        if p.grad is not None:
+            scale = max(1.0, float(p.grad.abs().max()))
+            assert float((got[n] - p.grad).abs().max()) <= 2e-5 * scale, n
