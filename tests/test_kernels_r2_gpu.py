@@ -369,10 +369,12 @@ def test_native_rccl_communicator_one_rank(dev, tmp_path, monkeypatch):
 # variants, token slicing) is driven by the shapes, so a fixed pseudo-random sample of shapes runs through each family
 # ---------------------------------------------------------------------------
 def _fuzz_shapes(seed, count, gen):
+    import os
     import random
 
-    rnd = random.Random(seed)
-    return [gen(rnd) for _ in range(count)]
+    # DALM_FUZZ_SEED / DALM_FUZZ_SCALE: other samples / more of them for an occasional soak run (defaults: the fixed sample)
+    rnd = random.Random(seed + 1000 * int(os.environ.get("DALM_FUZZ_SEED", "0")))
+    return [gen(rnd) for _ in range(count * int(os.environ.get("DALM_FUZZ_SCALE", "1")))]
 
 
 SMALL_FUZZ = _fuzz_shapes(11, 14, lambda r: (lambda m, n: (m, n, r.choice([32, 64, 100, 384, 520, 1024]), r.randint(0, n - m)))(
