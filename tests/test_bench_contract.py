@@ -71,3 +71,20 @@ def test_bench_workloads_and_cfg5_shapes():
     # a tiny cfg5-architecture model assembles (LoRA lands on Falcon's fused query_key_value)
     m = bench.build_models(torch.device("cpu"), torch.float32, bert_layers=1, llama_layers=1, generator="falcon-7b")
     assert m.generator_model._dalm_lora_config["target_modules"] == ["query_key_value"]
+
+
+def test_bucketed_data_path_is_opt_in_and_keeps_every_row():
+    """--data-path bucketed (an extra line, never the default): batches of B rows, trimmed widths that vary with the bucket,
+    no live token lost, and fewer generator tokens than the fixed-shape batches."""
+    import bench
+
+    src = (ROOT / "bench.py").read_text()
+    assert 'ap.add_argument("--data-path", default="fixed"' in src
+    bs = bench.bucketed_batches(torch.device("cpu"), 100, 32000, n_batches=6)
+    pool = [bench.synthetic_batch(torch.device("cpu"), 100 + i, V=32000) for i in range(6)]
+    live_in = sum(int(b["generator_input_attention_mask"].sum()) for b in pool)
+    live_out = sum(int(b["generator_input_attention_mask"].sum()) for b in bs)
+    assert live_in == live_out
+    widths = {b["generator_input_input_ids"].shape[1] for b in bs}
+    assert all(b["generator_input_input_ids"].shape[0] == bench.CFG["B"] for b in bs) and len(widths) > 1
+    assert sum(b["generator_input_input_ids"].numel() for b in bs) < 0.85 * 6 * bench.CFG["B"] * bench.CFG["Tg"]
