@@ -7,8 +7,7 @@ For the training loop prefer the fused entry points in dalm_amd.fused
 """
 from __future__ import annotations
 
-import os
-from typing import Dict, List
+from typing import Dict
 
 import torch
 
