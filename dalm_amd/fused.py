@@ -333,7 +333,7 @@ def _row_chunks(rows: int, cap: int, unit: int):
     return [z for z in sizes if z > 0]
 
 
-def _lm_head_live_rows(ops, h, w, ids, mask, stats, live_rows, chunk_rows, dw):
+def _lm_head_live_rows(ops, h, w, ids, mask, stats, live_rows, chunk_rows, dw, need_grad=True):
     """lm_head + marginalised CE + d(hidden) over the live rows only.  Padding rows (38 % of bench.py's cfg3 batch, and
     whatever padding='max_length' leaves in real data) carry no loss and a zero gradient, so both GEMMs and the CE pass
     skip them; the CE kernel sees each chunk as one virtual sample [1, n+1, V] whose shifted labels are the chunk's
@@ -349,9 +349,10 @@ def _lm_head_live_rows(ops, h, w, ids, mask, stats, live_rows, chunk_rows, dw):
     hc_all = h.reshape(R, H).index_select(0, rows)
     # results land in [Rp+1]-row buffers whose last row stays zero; the full-size outputs are then ONE gather each through
     # the inverse map (dead rows -> the zero row) instead of a zero fill plus a scatter (43 -> ~20 us at cfg3)
-    dh_c = torch.empty((Rp + 1, H), device=h.device, dtype=h.dtype)
+    dh_c = torch.empty((Rp + 1, H), device=h.device, dtype=h.dtype) if need_grad else None
     nll_c = torch.empty((Rp + 1,), device=h.device, dtype=torch.float32)
-    dh_c[Rp].zero_()
+    if need_grad:
+        dh_c[Rp].zero_()
     nll_c[Rp].zero_()
     inv = torch.full((R + 1,), Rp, device=h.device, dtype=torch.int64)
     inv.scatter_(0, dst, torch.arange(Rp, device=h.device, dtype=torch.int64))   # padding entries land in inv[R] (unused)
@@ -363,13 +364,15 @@ def _lm_head_live_rows(ops, h, w, ids, mask, stats, live_rows, chunk_rows, dw):
         torch.mm(hc_all[r0:r1], w.t(), out=buf[:n])
         ids_v = torch.cat((zero1, ids_c[r0:r1])).view(1, n + 1)
         mask_v = torch.cat((zero1.to(mask_c.dtype), mask_c[r0:r1])).view(1, n + 1)
-        _lse, nll_v, dl_v = ops.ce_fwd(buf.view(1, n + 1, V), ids_v, mask_v, stats, True, True)
+        _lse, nll_v, dl_v = ops.ce_fwd(buf.view(1, n + 1, V), ids_v, mask_v, stats, need_grad, need_grad)
         nll_c[r0:r1] = nll_v.reshape(-1)[:n]
+        if not need_grad:
+            continue
         dl2 = dl_v.view(n + 1, V)[:n]
         torch.mm(dl2, w, out=dh_c[r0:r1])
         if dw is not None:
             dw.addmm_(dl2.t().float(), hc_all[r0:r1].float())
-    dh = dh_c.index_select(0, inv[:R]).view(B, Tg, H)
+    dh = dh_c.index_select(0, inv[:R]).view(B, Tg, H) if need_grad else None
     row_nll = nll_c.index_select(0, inv[:R])
     return dh, row_nll
 
@@ -388,21 +391,25 @@ class _LMHeadRagE2E(torch.autograd.Function):
         w = weight.detach().to(h.dtype)
         need_dw = weight.requires_grad
         dw = torch.zeros(w.shape, device=w.device, dtype=torch.float32) if need_dw else None
+        # evaluation (torch.no_grad(), or nothing upstream wants a gradient): forward-only CE, no d(hidden) GEMM
+        need_grad = need_dw or any(ctx.needs_input_grad[:3])
         if live_rows is None:
-            dh = torch.empty_like(h)
+            dh = torch.empty_like(h) if need_grad else None
             row_nll = torch.empty((B * Tg,), device=h.device, dtype=torch.float32)
             for b0 in range(0, B, chunk):
                 b1 = min(B, b0 + chunk)
                 hc = h[b0:b1].reshape(-1, H)
                 logits_c = (hc @ w.t()).view(b1 - b0, Tg, -1)
-                _lse, nll_c, dl_c = ops.ce_fwd(logits_c, ids[b0:b1], mask[b0:b1], stats, True, True)
+                _lse, nll_c, dl_c = ops.ce_fwd(logits_c, ids[b0:b1], mask[b0:b1], stats, need_grad, need_grad)
                 row_nll[b0 * Tg:b1 * Tg] = nll_c
+                if not need_grad:
+                    continue
                 dl2 = dl_c.view(-1, dl_c.shape[-1])
                 torch.mm(dl2, w, out=dh[b0:b1].view(-1, H))
                 if need_dw:
                     dw.addmm_(dl2.t().float(), hc.float())
         else:
-            dh, row_nll = _lm_head_live_rows(ops, h, w, ids, mask, stats, live_rows, chunk * Tg, dw)
+            dh, row_nll = _lm_head_live_rows(ops, h, w, ids, mask, stats, live_rows, chunk * Tg, dw, need_grad)
         out3, doc_lp = ops.rag_loss_finalize(row_nll, Nb, st.lse_r, st.lse_c, st.diag, st.n_global, stats)
         ctx.st, ctx.scale, ctx.ops, ctx.comm = st, scale, ops, comm
         ctx.in_dtypes = (q.dtype, p.dtype, weight.dtype)

@@ -574,6 +574,13 @@ def test_lm_head_live_rows_equals_all_rows_on_the_oracle_ops():
         res.append([qq.grad, pp.grad, hh.grad, ww.grad])
     for a, b in zip(*res):
         assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(a.abs().max()))
+    # evaluation: under no_grad the forward-only CE runs and no d(hidden) GEMM - same loss value
+    with torch.no_grad():
+        ev = [float(rag_e2e_loss_from_hidden(q, p, h, W, ids, mask, qlen, 20.0, ops=OracleOps(), chunk_samples=2, live_rows=rows))
+              for rows in (None, live)]
+    qq, pp, hh = [t.clone().requires_grad_(True) for t in (q, p, h)]
+    ref = float(rag_e2e_loss_from_hidden(qq, pp, hh, W, ids, mask, qlen, 20.0, ops=OracleOps(), chunk_samples=2))
+    assert abs(ev[0] - ref) <= 1e-6 * abs(ref) and abs(ev[1] - ref) <= 1e-6 * abs(ref)
 
 
 def test_sharded_batches_emit_live_rows():

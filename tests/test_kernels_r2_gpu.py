@@ -485,3 +485,7 @@ def test_lm_head_over_live_rows_equals_all_rows(dtype):
         assert float((a - b).abs().max()) <= tol * max(1.0, float(a.abs().max())), (a - b).abs().max()
     dead = (torch.cat((mask[:, 1:], torch.zeros(B, 1, dtype=mask.dtype)), 1) == 0).to(dev)
     assert float(res[1][3][dead].abs().max()) == 0.0   # d(hidden) of rows without loss is exactly zero
+    with torch.no_grad():   # evaluation: forward-only CE kernels, no d(hidden) GEMM, same value
+        for rows in (None, live.to(dev)):
+            ev = rag_e2e_loss_from_hidden(q, p, h, W, ids.to(dev), mask.to(dev), qlen.to(dev), 100.0, chunk_samples=2, live_rows=rows)
+            assert abs(float(ev) - float(res[0][0])) <= (1e-5 if dtype == torch.float32 else 2e-3) * abs(float(res[0][0]))
