@@ -579,7 +579,7 @@ def test_lm_head_live_rows_equals_all_rows_on_the_oracle_ops():
         ev = [float(rag_e2e_loss_from_hidden(q, p, h, W, ids, mask, qlen, 20.0, ops=OracleOps(), chunk_samples=2, live_rows=rows))
               for rows in (None, live)]
     qq, pp, hh = [t.clone().requires_grad_(True) for t in (q, p, h)]
-    ref = float(rag_e2e_loss_from_hidden(qq, pp, hh, W, ids, mask, qlen, 20.0, ops=OracleOps(), chunk_samples=2))
+    ref = float(rag_e2e_loss_from_hidden(qq, pp, hh, W, ids, mask, qlen, 20.0, ops=OracleOps(), chunk_samples=2).detach())
     assert abs(ev[0] - ref) <= 1e-6 * abs(ref) and abs(ev[1] - ref) <= 1e-6 * abs(ref)
 
 
