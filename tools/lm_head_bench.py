@@ -55,6 +55,14 @@ def main():
                 return h.grad
             return f
 
+        def evaluate(rows, fused=True):
+            def f():
+                with torch.no_grad():
+                    if fused:
+                        return rag_e2e_loss_from_hidden(q, p, hidden, W, ids, mask, qlen, 100, live_rows=rows)
+                    return rag_e2e_loss(q, p, hidden @ W.t(), ids, mask, qlen, 100)
+            return f
+
         flops = 2 * 2.0 * B * Tg * H * V          # two GEMMs (logits, dh)
         print(name, f"B={B} Tg={Tg} H={H} V={V} bf16: 2 GEMMs = {flops / 1e12:.2f} TFLOP; "
                     f"{n_live} of {B * Tg} rows carry loss, padded to {live.numel()}")
@@ -73,6 +81,12 @@ def main():
             med, _ = time_fn(fn, iters=10, warmup=3)
             print(f"   {label:34s} {med * 1e3:7.3f} ms   {flops / med / 1e12:7.1f} TF/s on the GEMM flops   "
                   f"peak extra memory {peak:8.1f} MB   dh rel diff vs materialised {err:.2e}")
+        if not arms or any("eval" in a for a in arms):
+            lv = [float(evaluate(None, False)()), float(evaluate(None)()), float(evaluate(live)())]
+            for label, fn in (("eval (no_grad): materialised logits", evaluate(None, False)),
+                              ("eval (no_grad): sample chunks", evaluate(None)), ("eval (no_grad): live rows", evaluate(live))):
+                med, _ = time_fn(fn, iters=10, warmup=3)
+                print(f"   {label:38s} {med * 1e3:7.3f} ms   (loss values {lv[0]:.5f} / {lv[1]:.5f} / {lv[2]:.5f})")
 
 
 if __name__ == "__main__":
