@@ -17,6 +17,7 @@ are stored.  The committed .npz files travel to the GPU box; this script and
 from __future__ import annotations
 
 import sys
+import os
 import types
 import zlib
 from pathlib import Path
@@ -25,7 +26,8 @@ import numpy as np
 import torch
 
 REF = Path("/root/reference")
-OUT = Path(__file__).resolve().parent.parent / "tests" / "golden"
+# DALM_GOLDEN_OUT=<dir>: regenerate somewhere else and diff against tests/golden (reproducibility check)
+OUT = Path(os.environ.get("DALM_GOLDEN_OUT") or Path(__file__).resolve().parent.parent / "tests" / "golden")
 
 
 def import_reference():
