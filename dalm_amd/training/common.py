@@ -129,20 +129,36 @@ class ShardedBatches:
                 host = self._staging[slot][k][:n]
                 torch.index_select(v, 0, rows, out=host)
                 dev[k] = host.to(device, non_blocking=True).long()
-            self._add_live_rows(dev, {k: self._staging[slot][k][:n] for k in self.data}, device)
+            self._add_live_rows(dev, {k: self._staging[slot][k][:n] for k in self.data}, device, slot)
             ev.record(self._copy_stream)
         self._staging_free[slot] = ev
         return dev, ev
 
-    def _add_live_rows(self, dev: Dict[str, torch.Tensor], host: Dict[str, torch.Tensor], device: torch.device) -> None:
-        """The rows of the generator batch that carry loss, listed where the mask is still host memory (no device sync)."""
+    def _add_live_rows(self, dev: Dict[str, torch.Tensor], host: Dict[str, torch.Tensor], device: torch.device,
+                       slot: Optional[int] = None) -> None:
+        """The rows of the generator batch that carry loss, listed where the mask is still host memory (no device sync).
+        slot: index of the persistent pinned staging set this batch uses (its previous copy has completed) - the list
+        then goes through a persistent pinned buffer of that slot as well; None: a per-batch pinned copy."""
         if not self.live_rows:
             return
         from ..fused import live_row_index
 
-        idx = live_row_index(host[self.live_rows["mask"]], int(self.live_rows.get("multiple", 256)))
-        if idx is not None:
-            dev["generator_live_rows"] = (idx.pin_memory().to(device, non_blocking=True) if device.type == "cuda" else idx)
+        mask = host[self.live_rows["mask"]]
+        idx = live_row_index(mask, int(self.live_rows.get("multiple", 256)))
+        if idx is None:
+            return
+        if device.type != "cuda":
+            dev["generator_live_rows"] = idx
+            return
+        if slot is None:
+            dev["generator_live_rows"] = idx.pin_memory().to(device, non_blocking=True)
+            return
+        if not hasattr(self, "_live_staging"):
+            cap = self.B * int(self.data[self.live_rows["mask"]].shape[1])
+            self._live_staging = [torch.empty((cap,), dtype=torch.int64).pin_memory() for _ in range(2)]
+        buf = self._live_staging[slot][:idx.numel()]
+        buf.copy_(idx)
+        dev["generator_live_rows"] = buf.to(device, non_blocking=True)
 
     def epoch(self, epoch: int, device: torch.device, skip: int = 0) -> Iterable[Dict[str, torch.Tensor]]:
         g = torch.Generator().manual_seed(self.seed + epoch)
