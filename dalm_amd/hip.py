@@ -52,6 +52,8 @@ SIGNATURES = {
     "dalm_rag_loss_finalize": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "dalm_sim_topk_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "dalm_sim_topk": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dalm_lm_head_lse_workspace_bytes": (_sz, [_i64, _i64]),
+    "dalm_lm_head_lse_fwd": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "dalm_comm_unique_id": (_int, [_vp]),
     "dalm_comm_init": (_int, [C.POINTER(_vp), _vp, _int, _int, _int]),
     "dalm_comm_destroy": (_int, [_vp]),

@@ -174,6 +174,27 @@ class HipOps:
                  hip.ptr(ovf), hip.ptr(ws), ws_bytes, hip.stream())
         return val, idx, ovf
 
+    def lm_head_lse(self, hidden: torch.Tensor, weight: torch.Tensor, labels: torch.Tensor):
+        """(row_lse [R], row_nll [R]) of logits = hidden @ weight^T without the logits: hidden [R,K] bf16, weight [V,K] bf16
+        (both contiguous, K % 64 == 0), labels [R] int64 with negative entries for rows that carry no loss (nll 0).
+        Forward only (evaluation): one bf16 MFMA kernel + a merge of the per-tile (max, sum exp) partials."""
+        dev = hip.require_gpu(hidden, weight, labels)
+        if hidden.dtype != torch.bfloat16 or weight.dtype != torch.bfloat16:
+            raise TypeError("lm_head_lse needs bf16 hidden states and weights")
+        hidden, weight = hidden.contiguous(), weight.contiguous()
+        labels = hip.as_i64(labels).contiguous()
+        R, K = hidden.shape
+        V = weight.shape[0]
+        if weight.shape[1] != K or labels.shape != (R,):
+            raise ValueError(f"shapes: hidden {tuple(hidden.shape)}, weight {tuple(weight.shape)}, labels {tuple(labels.shape)}")
+        ws_bytes = hip.load().dalm_lm_head_lse_workspace_bytes(R, V)
+        ws = torch.empty((ws_bytes // 4,), device=dev, dtype=torch.float32)
+        row_lse = torch.empty((R,), device=dev, dtype=torch.float32)
+        row_nll = torch.empty((R,), device=dev, dtype=torch.float32)
+        hip.call("dalm_lm_head_lse_fwd", hip.ptr(hidden), hip.ptr(weight), hip.ptr(labels), R, V, K, hip.ptr(row_lse),
+                 hip.ptr(row_nll), hip.ptr(ws), ws_bytes, hip.stream())
+        return row_lse, row_nll
+
     def contrastive_finalize(self, row_lse, col_lse, diag, n_global: int):
         dev = hip.require_gpu(row_lse, col_lse, diag)
         n_local = row_lse.shape[0]

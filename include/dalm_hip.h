@@ -246,6 +246,19 @@ int dalm_sim_topk(const float* Q, const float* C, int64_t m, int64_t n, int64_t 
                   float scale, int64_t k, float* out_val, int64_t* out_idx,
                   int* overflow, void* ws, size_t ws_bytes, dalm_stream_t stream);
 
+/* lm_head + log-sum-exp + label gather without the logits (forward / evaluation): replaces
+ *   logits = lm_head(hidden)                         dalm/models/rag_e2e_base_model.py:104-106
+ *   logsumexp over the vocabulary, gather of the label  dalm/training/utils/train_utils.py:113-131
+ * for R rows.  hidden [R,K] and weight [V,K] are contiguous bf16 (K % 64 == 0, 16-byte aligned), labels [R] int64:
+ * a negative label marks a row without loss (row_nll 0), a label >= V gives NaN (torch.gather would raise).
+ * row_lse[r] = log sum_v exp(hidden[r] . weight[v]) (f32 accumulation on the bf16 matrix cores), row_nll[r] = row_lse[r] -
+ * logit of the label.  One bf16 MFMA kernel (128 x 128 tiles reduced in registers) + a merge launch; the backward is not
+ * provided.  Workspace: dalm_lm_head_lse_workspace_bytes(R, V) bytes. */
+size_t dalm_lm_head_lse_workspace_bytes(int64_t R, int64_t V);
+int dalm_lm_head_lse_fwd(const void* hidden, const void* weight, const int64_t* labels, int64_t R,
+                         int64_t V, int64_t K, float* row_lse, float* row_nll, void* ws, size_t ws_bytes,
+                         dalm_stream_t stream);
+
 /* The whole loss assembly of the RAG-e2e step (train_rage2e.py:443-467) in one launch:
  *   out[1] = L_con (as dalm_contrastive_finalize), doc_lp[i] = diag[i] - row_lse[i] (may be NULL),
  *   out[2] = L_gen (as dalm_marg_ce_finalize with that doc_lp), out[0] = L_con + L_gen.

@@ -485,7 +485,39 @@ def test_lm_head_over_live_rows_equals_all_rows(dtype):
         assert float((a - b).abs().max()) <= tol * max(1.0, float(a.abs().max())), (a - b).abs().max()
     dead = (torch.cat((mask[:, 1:], torch.zeros(B, 1, dtype=mask.dtype)), 1) == 0).to(dev)
     assert float(res[1][3][dead].abs().max()) == 0.0   # d(hidden) of rows without loss is exactly zero
+    import os
+
     with torch.no_grad():   # evaluation: forward-only CE kernels, no d(hidden) GEMM, same value
-        for rows in (None, live.to(dev)):
-            ev = rag_e2e_loss_from_hidden(q, p, h, W, ids.to(dev), mask.to(dev), qlen.to(dev), 100.0, chunk_samples=2, live_rows=rows)
-            assert abs(float(ev) - float(res[0][0])) <= (1e-5 if dtype == torch.float32 else 2e-3) * abs(float(res[0][0]))
+        for kern in ("0", "1"):   # "1": through the bf16 MFMA kernel (logits never stored); f32 inputs keep the library path
+            os.environ["DALM_LM_HEAD_KERNEL"] = kern
+            try:
+                for rows in (None, live.to(dev)):
+                    ev = rag_e2e_loss_from_hidden(q, p, h, W, ids.to(dev), mask.to(dev), qlen.to(dev), 100.0, chunk_samples=2,
+                                                  live_rows=rows)
+                    assert abs(float(ev) - float(res[0][0])) <= (1e-5 if dtype == torch.float32 else 2e-3) * abs(float(res[0][0]))
+            finally:
+                os.environ.pop("DALM_LM_HEAD_KERNEL", None)
+
+
+@pytest.mark.parametrize("R,V,K", [(128, 256, 64), (200, 1000, 128), (1, 130, 64), (333, 4099, 512), (640, 32000, 1024),
+                                   (1100, 32000, 256)])   # the last one takes the 256-row tiles
+def test_lm_head_lse_kernel_matches_the_product_in_fp64(dev, R, V, K):
+    """dalm_lm_head_lse_fwd (bf16 MFMA, logits never stored): log-sum-exp and label NLL of hidden @ W^T against the fp64
+    product of the SAME bf16 values - ragged row / vocabulary tails, rows without loss, a label in every 64-column strip."""
+    from dalm_amd.ops import default_ops
+
+    g = torch.Generator().manual_seed(R * 7 + V)
+    h = (0.5 * torch.randn(R, K, generator=g)).to(torch.bfloat16)
+    W = (0.5 * torch.randn(V, K, generator=g)).to(torch.bfloat16)
+    labels = torch.randint(0, V, (R,), generator=g)
+    labels[::5] = -1
+    if R > 3:
+        labels[1], labels[2], labels[3] = 0, V - 1, min(V - 1, 64)
+    lse, nll = default_ops().lm_head_lse(h.to(dev), W.to(dev), labels.to(dev))
+    x = h.double() @ W.double().t()
+    ref_lse = torch.logsumexp(x, dim=1)
+    ref_nll = torch.where(labels >= 0, ref_lse - x.gather(1, labels.clamp_min(0).unsqueeze(1)).squeeze(1), torch.zeros(()).double())
+    # f32 accumulation of exact bf16 products: 1e-5 relative on |x| <= ~K/4
+    tol = 2e-5 * max(1.0, float(x.abs().max()))
+    assert float((lse.cpu().double() - ref_lse).abs().max()) <= tol
+    assert float((nll.cpu().double() - ref_nll).abs().max()) <= tol
