@@ -28,7 +28,7 @@ struct LmParams {
   const unsigned short* H;   // [R, K] bf16
   const unsigned short* W;   // [V, K] bf16
   const int64_t* labels;     // [R]; < 0: row carries no loss
-  int R, V, K, MT, NT;
+  int R, V, K, MT, NT, xcd_order;
   float* pm;                 // [2*NT, R] partial maxima
   float* pl;                 // [2*NT, R] partial sums of exp(x - max)
   float* z;                  // [R] logit of the label
@@ -50,7 +50,16 @@ __global__ __launch_bounds__(256, 2) void lm_head_lse_kernel(const LmParams p) {
   __shared__ int lab_s[LBM];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  const int mt = static_cast<int>(blockIdx.x) % p.MT, nt = static_cast<int>(blockIdx.x) / p.MT;
+  // XCD-aware order: workgroup L runs on XCD L % 8 (own 4 MB L2).  Every XCD gets a contiguous run of tile ids = a range
+  // of vocabulary tiles with all their row tiles, so a 1 MB W tile is pulled into ONE L2 and shared by the row tiles that
+  // use it (plain order: each W tile lands in up to 8 L2s and is shared by < 2 workgroups per XCD).  DALM_LM_HEAD_XCD=0 disables.
+  unsigned wgid = blockIdx.x;
+  if (p.xcd_order) {
+    const unsigned nwg = gridDim.x, L = blockIdx.x;
+    const unsigned q8 = nwg >> 3, r8 = nwg & 7u, xcd = L & 7u;
+    wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (L >> 3);
+  }
+  const int mt = static_cast<int>(wgid) % p.MT, nt = static_cast<int>(wgid) / p.MT;
   const int r0 = mt * LBM, c0 = nt * LBN;
 
   for (int t = tid; t < LBM; t += 256) {
@@ -243,6 +252,8 @@ extern "C" int dalm_lm_head_lse_fwd(const void* hidden, const void* weight, cons
   p.labels = labels;
   p.R = static_cast<int>(R); p.V = static_cast<int>(V); p.K = static_cast<int>(K);
   p.MT = static_cast<int>(MT); p.NT = static_cast<int>(NT);
+  static const char* xcd_env = getenv("DALM_LM_HEAD_XCD");
+  p.xcd_order = xcd_env ? atoi(xcd_env) != 0 : 1;
   float* f = static_cast<float*>(ws);
   p.pm = f;
   p.pl = f + 2 * NT * R;
