@@ -157,7 +157,10 @@ def train_e2e(
                                           query_column_name=query_column_name, passage_column_name=passage_column_name,
                                           answer_column_name=answer_column_name, query_max_len=query_max_len,
                                           passage_max_len=passage_max_len, generator_max_len=generator_max_len),
-            batched=True, remove_columns=dataset.column_names, desc="Running tokenizer on dataset", num_proc=1)
+            # in-process on purpose: the reference passes num_proc=1 (train_rage2e.py:316), which makes `datasets` FORK a
+            # worker - forking a process that already holds a HIP context and its threads crashed the worker now and
+            # then ("One of the subprocesses has abruptly died during map operation")
+            batched=True, remove_columns=dataset.column_names, desc="Running tokenizer on dataset")
         processed = {k: mapped[k] for k in columns}
         if token_cache_dir and is_main:
             shards.save_token_shards(processed, token_cache_dir, fp)
