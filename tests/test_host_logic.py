@@ -599,3 +599,29 @@ def test_sharded_batches_emit_live_rows():
         assert want is not None and torch.equal(batch["generator_live_rows"], want)
         seen += 1
     assert seen == 3
+
+
+def test_live_row_index_and_row_chunks_properties():
+    """Randomised properties: the live-row list is exactly the brute-force set of (b, t) with a live shifted label, sorted,
+    padded with -1 to the multiple; row chunk plans cover the rows exactly with chunks that respect cap and unit."""
+    import random
+
+    from dalm_amd.fused import _row_chunks, live_row_index
+
+    rnd = random.Random(7)
+    for _ in range(60):
+        B, T, mult = rnd.randint(1, 9), rnd.randint(2, 40), rnd.choice([1, 4, 8, 32])
+        mask = torch.tensor([[1 if rnd.random() < 0.6 else 0 for _ in range(T)] for _ in range(B)])
+        want = [b * T + t for b in range(B) for t in range(T - 1) if mask[b, t + 1] != 0]
+        idx = live_row_index(mask, mult)
+        padded = -(-len(want) // mult) * mult
+        if not want or padded >= B * T:
+            assert idx is None
+            continue
+        assert idx.numel() == padded and idx[:len(want)].tolist() == want and bool((idx[len(want):] == -1).all())
+    for _ in range(200):
+        unit = rnd.choice([8, 128, 256, 512])
+        rows, cap = rnd.randint(1, 6000), rnd.randint(1, 5000)
+        plan = _row_chunks(rows, cap, unit)
+        assert sum(plan) == rows and all(z > 0 for z in plan)
+        assert all(z <= max(unit, cap // unit * unit) for z in plan) and all(z % unit == 0 for z in plan[:-1])
