@@ -44,10 +44,20 @@ def _worker(rank, world, port, mode, out_dir):
     q, p, logits, ids, mask, qlen = synth_batch(42, world * B_l, D, Tg, V, pad_side="left", logit_gain=2.0)
     sl = slice(rank * B_l, (rank + 1) * B_l)
     w = torch.nn.Parameter(torch.eye(D) + 0.01 * torch.arange(D * D, dtype=torch.float32).reshape(D, D) / (D * D))
-    bucket = GradBucket([w], comm) if mode == "e2e" else None   # e2e: bucket views; contrastive: flatten path
+    bucket = GradBucket([w], comm) if mode.startswith("e2e") else None   # e2e: bucket views; contrastive: flatten path
     ql, pl = (q[sl] @ w), (p[sl] @ w)          # a shared "tower" parameter, replicated on every rank
     lg = logits[sl].clone().requires_grad_(True)
-    if mode == "e2e":
+    if mode == "e2e_hidden":
+        # the fused lm_head path on every rank, over its own live rows: logits = hidden @ head^T are never formed
+        from dalm_amd.fused import live_row_index, rag_e2e_loss_from_hidden
+
+        g = torch.Generator().manual_seed(7)
+        hidden_all = torch.randn(world * B_l, Tg, 12, generator=g)
+        head = 0.5 * torch.randn(V, 12, generator=g)
+        lg = hidden_all[sl].clone().requires_grad_(True)
+        loss = rag_e2e_loss_from_hidden(ql, pl, lg, head, ids[sl], mask[sl], qlen[sl], 100, comm=comm, ops=ops,
+                                        chunk_samples=2, live_rows=live_row_index(mask[sl], 4))
+    elif mode == "e2e":
         ph = GatherHandle(pl, comm)             # the early all-gather the trainer starts after the passage tower
         loss = rag_e2e_loss(ql, pl, lg, ids[sl], mask[sl], qlen[sl], 100, comm=comm, ops=ops, p_gather=ph)
     else:
@@ -65,7 +75,7 @@ def _worker(rank, world, port, mode, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,world", [("e2e", 2), ("contrastive", 2), ("e2e", 3), ("e2e", 8)])
+@pytest.mark.parametrize("mode,world", [("e2e", 2), ("contrastive", 2), ("e2e", 3), ("e2e", 8), ("e2e_hidden", 2)])
 def test_ranks_equal_one_process_at_global_batch(tmp_path, mode, world):
     import dalm_oracle as O
     from helpers import synth_batch
@@ -79,14 +89,19 @@ def test_ranks_equal_one_process_at_global_batch(tmp_path, mode, world):
     q, p, logits, ids, mask, qlen = synth_batch(42, world * B_l, D, Tg, V, pad_side="left", logit_gain=2.0)
     w = (torch.eye(D) + 0.01 * torch.arange(D * D, dtype=torch.float32).reshape(D, D) / (D * D)).double().requires_grad_(True)
     lg = logits.double().requires_grad_(True)
-    out = O.ref_step_loss(q.double() @ w, p.double() @ w, lg if mode == "e2e" else None, ids, mask, qlen, 100)
+    full = lg
+    if mode == "e2e_hidden":
+        g = torch.Generator().manual_seed(7)
+        lg = torch.randn(world * B_l, Tg, 12, generator=g).double().requires_grad_(True)   # the hidden states
+        full = lg @ (0.5 * torch.randn(V, 12, generator=g)).double().t()
+    out = O.ref_step_loss(q.double() @ w, p.double() @ w, full if mode.startswith("e2e") else None, ids, mask, qlen, 100)
     out["loss"].backward()
 
     assert abs(float(res[0]["loss_total"]) - float(out["loss"])) <= 1e-5 * abs(float(out["loss"]))
     assert abs(sum(float(r["loss_share"]) for r in res) - float(out["loss"])) <= 1e-5 * abs(float(out["loss"]))
     for r in range(world):  # every rank holds the same, fully reduced parameter gradient
         torch.testing.assert_close(res[r]["dw"].double(), w.grad, rtol=2e-4, atol=1e-6)
-    if mode == "e2e":
+    if mode.startswith("e2e"):
         got = torch.cat([res[r]["dlogits"] for r in range(world)]).double()
         torch.testing.assert_close(got, lg.grad, rtol=2e-4, atol=1e-8)
 
