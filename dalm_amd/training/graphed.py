@@ -95,6 +95,7 @@ class GraphedStep:
         # one graph per batch shape (trimmed / bucketed batches come in a handful of lengths); all graphs share ONE
         # memory pool - they never run concurrently, so their activations can overlay each other
         self.graphs: Dict[Tuple, Tuple[torch.cuda.CUDAGraph, Dict[str, torch.Tensor], torch.Tensor]] = {}
+        self._outputs: Dict[Tuple, Tuple[Optional[torch.Tensor], dict]] = {}
         self.pool = None
         self.failed: Optional[str] = None
         self.replays = 0
@@ -107,6 +108,10 @@ class GraphedStep:
     @property
     def graph(self) -> Optional[torch.cuda.CUDAGraph]:
         return next(iter(self.graphs.values()))[0] if self.graphs else None
+
+    @property
+    def grad_norm(self) -> Optional[torch.Tensor]:
+        return getattr(self.step, "grad_norm", None)
 
     @staticmethod
     def _key(batch) -> Tuple:
@@ -146,6 +151,9 @@ class GraphedStep:
             g.capture_end()
         torch.cuda.current_stream().wait_stream(cs)
         self.graphs[self._key(batch)] = (g, static, static_loss)
+        # per-graph views of what the step leaves behind for its caller (each capture allocates its own tensors):
+        # the replay path points the step back at THIS graph's outputs
+        self._outputs[self._key(batch)] = (getattr(self.step, "grad_norm", None), dict(getattr(self.step, "aux", None) or {}))
 
     def __call__(self, batch) -> torch.Tensor:
         self.calls += 1
@@ -166,6 +174,11 @@ class GraphedStep:
             g.replay()
             loss = static_loss
             self.replays += 1
+            gn, aux = self._outputs.get(key, (None, {}))
+            if gn is not None:
+                self.step.grad_norm = gn
+            if aux and isinstance(getattr(self.step, "aux", None), dict):
+                self.step.aux.update(aux)
         else:
             loss = self.step(batch)
             self.eager_calls += 1

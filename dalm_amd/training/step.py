@@ -21,8 +21,12 @@ from ..sharded import GradBucket, allreduce_grads
 
 class _StepBase:
     def __init__(self, model, optimizer, lr_scheduler, logit_scale, comm=None, autocast_dtype=None, ops=None,
-                 grad_overlap: bool = True):
+                 grad_overlap: bool = True, track_grad_norm: bool = False):
         self.model, self.optimizer, self.lr_scheduler = model, optimizer, lr_scheduler
+        # global L2 norm of the (all-reduced) trainable gradients, left on the device in self.grad_norm right before
+        # the optimizer consumes them - the quantity north_star's tolerance is stated on next to the loss
+        self.track_grad_norm = track_grad_norm
+        self.grad_norm: Optional[torch.Tensor] = None
         self.logit_scale = logit_scale
         self.comm = comm or LocalComm()
         self.autocast_dtype = autocast_dtype
@@ -58,6 +62,12 @@ class _StepBase:
             self.bucket.all_reduce()
         else:
             allreduce_grads(self.trainable, self.comm)
+        if self.track_grad_norm:
+            if self.bucket is not None:
+                self.grad_norm = torch.linalg.vector_norm(self.bucket.flat)
+            else:
+                grads = [p.grad for p in self.trainable if p.grad is not None]
+                self.grad_norm = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads)))
         self.optimizer.step()
         if self.lr_scheduler is not None:
             self.lr_scheduler.step()

@@ -300,35 +300,55 @@ def main_step_golden() -> None:
         d = OUT / name
         model.save_pretrained(str(d))
         tok.save_pretrained(str(d))
-    rag = m_rag.AutoModelForRagE2E(str(OUT / "tiny_retriever"), str(OUT / "tiny_generator"))
-    g_tok = rag.generator_tokenizer
-    g_tok.pad_token = g_tok.eos_token
-    enc = ref_pre_e2e(ROWS, rag.retriever_tokenizer, g_tok, "Question", "Abstract", "Answer", 12, 24, 40)
-    full = {k: torch.tensor(v) for k, v in enc.items()}
-    batches = [full, {k: v[:3] for k, v in full.items()}, full, {k: v[1:5] for k, v in full.items()}, full]
-    opt = torch.optim.Adam(rag.parameters(), lr=1e-3)
-    sched = get_scheduler("linear", optimizer=opt, num_warmup_steps=0, num_training_steps=20)
-    rag.train()
-    losses, cons, gens = [], [], []
-    for b in batches:
-        q = rag("retrieval", b["retriever_query_input_ids"], b["retriever_query_attention_mask"])
-        p = rag("retrieval", b["retriever_passage_input_ids"], b["retriever_passage_attention_mask"])
-        S = tu.get_cosine_sim(q, p, 100)
-        con = (tu.get_nt_xent_loss(S) + tu.get_nt_xent_loss(S.t())) / 2.0
-        lg = rag("generation", b["generator_input_input_ids"], b["generator_input_attention_mask"])
-        gen = tu.compute_marginalized_loss_from_logits(lg, b["generator_input_input_ids"],
-                                                       b["generator_input_attention_mask"], S,
-                                                       b["query_passage_input_len"])
-        loss = con + gen
-        loss.backward()
-        opt.step(); sched.step(); rag.zero_grad()
-        losses.append(float(loss)); cons.append(float(con)); gens.append(float(gen))
+    import contextlib
+
+    def run(autocast: bool):
+        """autocast=True: what `accelerate --mixed_precision bf16` gives the reference on this box - the model forward
+        under torch.autocast(bfloat16), its outputs up-cast to fp32 (accelerator.py convert_outputs_to_fp32), the
+        reference's loss code outside autocast on those fp32 values, fp32 master weights."""
+        rag = m_rag.AutoModelForRagE2E(str(OUT / "tiny_retriever"), str(OUT / "tiny_generator"))
+        g_tok = rag.generator_tokenizer
+        g_tok.pad_token = g_tok.eos_token
+        enc = ref_pre_e2e(ROWS, rag.retriever_tokenizer, g_tok, "Question", "Abstract", "Answer", 12, 24, 40)
+        full = {k: torch.tensor(v) for k, v in enc.items()}
+        batches = [full, {k: v[:3] for k, v in full.items()}, full, {k: v[1:5] for k, v in full.items()}, full]
+        opt = torch.optim.Adam(rag.parameters(), lr=1e-3)
+        sched = get_scheduler("linear", optimizer=opt, num_warmup_steps=0, num_training_steps=20)
+        rag.train()
+        ctx = (lambda: torch.autocast("cpu", dtype=torch.bfloat16)) if autocast else contextlib.nullcontext
+        losses, cons, gens, gnorms = [], [], [], []
+        for b in batches:
+            with ctx():
+                q = rag("retrieval", b["retriever_query_input_ids"], b["retriever_query_attention_mask"]).float()
+                p = rag("retrieval", b["retriever_passage_input_ids"], b["retriever_passage_attention_mask"]).float()
+            S = tu.get_cosine_sim(q, p, 100)
+            con = (tu.get_nt_xent_loss(S) + tu.get_nt_xent_loss(S.t())) / 2.0
+            with ctx():
+                lg = rag("generation", b["generator_input_input_ids"], b["generator_input_attention_mask"]).float()
+            gen = tu.compute_marginalized_loss_from_logits(lg, b["generator_input_input_ids"],
+                                                           b["generator_input_attention_mask"], S,
+                                                           b["query_passage_input_len"])
+            loss = con + gen
+            loss.backward()
+            gnorms.append(float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in rag.parameters() if p.grad is not None))))
+            opt.step(); sched.step(); rag.zero_grad()
+            losses.append(float(loss)); cons.append(float(con)); gens.append(float(gen))
+        return rag, losses, cons, gens, gnorms
+
+    rag, losses, cons, gens, gnorms = run(False)
     rec = {"losses": losses, "contrastive": cons, "generator": gens, "lr": 1e-3, "warmup": 0, "total_steps": 20,
            "batch_rows": [[0, 5], [0, 3], [0, 5], [1, 5], [0, 5]], "query_max_len": 12, "passage_max_len": 24,
            "generator_max_len": 40,
-           "final_param_abs_sum": float(sum(p.detach().abs().sum() for p in rag.parameters()))}
+           "final_param_abs_sum": float(sum(p.detach().abs().sum() for p in rag.parameters())),
+           # round 3: global L2 norm of all parameter gradients at every step (before the optimizer consumes them)
+           "grad_norms": gnorms}
+    _, bl, bc, bg, bn = run(True)
+    rec["bf16_autocast"] = {"losses": bl, "contrastive": bc, "generator": bg, "grad_norms": bn,
+                            "how": "reference step body, model forwards under torch.autocast('cpu', bfloat16), outputs "
+                                   "up-cast to fp32, loss code in fp32 outside autocast, fp32 master weights (what "
+                                   "accelerate mixed_precision=bf16 hands the reference)"}
     (OUT / "step_golden.json").write_text(json.dumps(rec, indent=1))
-    print("step_golden.json", losses)
+    print("step_golden.json", losses, "bf16", bl)
 
 
 def tiny_bge_small(vocab: int):
@@ -377,53 +397,164 @@ def main_retriever_step_golden() -> None:
         sys.modules.pop("peft", None)
         sys.path.remove(str(REF))
     tok = PreTrainedTokenizerFast.from_pretrained(str(OUT / "wordlevel_tokenizer"))
-    bert = tiny_bge_small(len(tok))
-    init_sum = float(sum(p.detach().double().abs().sum() for p in bert.parameters()))
     rows = retriever_rows(19)
-    with tempfile.TemporaryDirectory() as td:
-        bert.save_pretrained(td)
-        tok.save_pretrained(td)
-        # the reference pins device 0 (device_map={"": 0}, retriever_only_base_model.py:25): strip it on CPU
-        orig = AutoModel.from_pretrained
-
-        def cpu_from_pretrained(*a, **kw):
-            kw.pop("device_map", None)
-            kw.pop("quantization_config", None)
-            return orig(*a, **kw)
-
-        AutoModel.from_pretrained = cpu_from_pretrained
-        try:
-            model = m_ret.AutoModelForSentenceEmbedding(td, use_bnb=False, get_peft=False)
-        finally:
-            AutoModel.from_pretrained = orig
-    enc = ref_pre_ret(rows, model.tokenizer, "Question", "Abstract", 12, 32)
-    full = {k: torch.tensor(v) for k, v in enc.items()}
     spans = [[0, 19], [0, 7], [0, 19], [5, 17], [0, 19]]
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-    sched = get_scheduler("linear", optimizer=opt, num_warmup_steps=0, num_training_steps=20)
-    model.train()
-    losses = []
-    for a, b in spans:
-        batch = {k: v[a:b] for k, v in full.items()}
-        q = model(batch["query_input_ids"], batch["query_attention_mask"])
-        p = model(batch["passage_input_ids"], batch["passage_attention_mask"])
-        logits = tu.get_cosine_sim(q, p, 100)
-        loss = (tu.get_nt_xent_loss(logits) + tu.get_nt_xent_loss(logits.t())) / 2.0
-        loss.backward()
-        opt.step(); sched.step(); model.zero_grad()
-        losses.append(float(loss))
+
+    def run(autocast: bool):
+        import contextlib
+
+        bert = tiny_bge_small(len(tok))
+        init_sum = float(sum(p.detach().double().abs().sum() for p in bert.parameters()))
+        with tempfile.TemporaryDirectory() as td:
+            bert.save_pretrained(td)
+            tok.save_pretrained(td)
+            # the reference pins device 0 (device_map={"": 0}, retriever_only_base_model.py:25): strip it on CPU
+            orig = AutoModel.from_pretrained
+
+            def cpu_from_pretrained(*a, **kw):
+                kw.pop("device_map", None)
+                kw.pop("quantization_config", None)
+                return orig(*a, **kw)
+
+            AutoModel.from_pretrained = cpu_from_pretrained
+            try:
+                model = m_ret.AutoModelForSentenceEmbedding(td, use_bnb=False, get_peft=False)
+            finally:
+                AutoModel.from_pretrained = orig
+        enc = ref_pre_ret(rows, model.tokenizer, "Question", "Abstract", 12, 32)
+        full = {k: torch.tensor(v) for k, v in enc.items()}
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        sched = get_scheduler("linear", optimizer=opt, num_warmup_steps=0, num_training_steps=20)
+        model.train()
+        ctx = (lambda: torch.autocast("cpu", dtype=torch.bfloat16)) if autocast else contextlib.nullcontext
+        losses, gnorms = [], []
+        for a, b in spans:
+            batch = {k: v[a:b] for k, v in full.items()}
+            with ctx():
+                q = model(batch["query_input_ids"], batch["query_attention_mask"]).float()
+                p = model(batch["passage_input_ids"], batch["passage_attention_mask"]).float()
+            logits = tu.get_cosine_sim(q, p, 100)
+            loss = (tu.get_nt_xent_loss(logits) + tu.get_nt_xent_loss(logits.t())) / 2.0
+            loss.backward()
+            gnorms.append(float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None))))
+            opt.step(); sched.step(); model.zero_grad()
+            losses.append(float(loss))
+        return model, enc, init_sum, losses, gnorms
+
+    model, enc, init_sum, losses, gnorms = run(False)
     # only parameters that received gradients move (the BERT pooler is unused: rag_e2e_base_model.py:93 takes [0])
     rec = {"losses": losses, "lr": 1e-3, "warmup": 0, "total_steps": 20, "batch_rows": spans, "query_max_len": 12,
            "passage_max_len": 32, "rows": rows, "init_param_abs_sum": init_sum, "seed": 4321,
            "final_param_abs_sum": float(sum(p.detach().double().abs().sum() for p in model.parameters())),
-           "pre_ret": {k: v for k, v in enc.items()}}
+           "pre_ret": {k: v for k, v in enc.items()},
+           "grad_norms": gnorms}
+    _, _, _, bl, bn = run(True)
+    rec["bf16_autocast"] = {"losses": bl, "grad_norms": bn}
     (OUT / "retriever_step_golden.json").write_text(json.dumps(rec, indent=1))
-    print("retriever_step_golden.json", losses)
+    print("retriever_step_golden.json", losses, "bf16", bl)
+
+
+def main_realwidth_golden(only=None) -> None:
+    """Round 3: ONE step of the reference's own step body at the REAL widths of BASELINE.json's
+    configs - bge-large (D = 1024), Llama-2-7b (4096, V = 32000), Falcon-7B (4544, V = 65024), batch 18 / 150 - on
+    depth-1 random-init towers built from a CPU seed (oracle/realwidth.py), through the reference's OWN classes
+    (`AutoModelForRagE2E` / `AutoModelForSentenceEmbedding`, get_peft=None: every parameter trains) and loss functions,
+    in fp32 and under bf16 autocast.  Only scalars are committed: losses, the global gradient norm (and its split per
+    tower) and a checksum of the seeded weights."""
+    import contextlib
+    import json
+    import tempfile
+
+    from transformers import AutoModel, PreTrainedTokenizerFast
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    import realwidth as RW
+
+    tu, m_rag, du = import_reference()
+    stub = types.ModuleType("peft")
+    for name in ("LoraConfig", "PeftModel", "TaskType", "get_peft_model"):
+        setattr(stub, name, type(name, (), {}))
+    sys.modules["peft"] = stub
+    sys.path.insert(0, str(REF))
+    try:
+        import dalm.models.retriever_only_base_model as m_ret
+    finally:
+        sys.modules.pop("peft", None)
+        sys.path.remove(str(REF))
+    tok = PreTrainedTokenizerFast.from_pretrained(str(OUT / "wordlevel_tokenizer"))
+    path = OUT / "realwidth_golden.json"
+    out = json.loads(path.read_text()) if (only and path.exists()) else {}
+    for case in RW.CASES:
+        if only and case not in only:
+            continue
+        retriever, generator = RW.build_case(case)
+        rec = {"seed": RW.SEED, "depth": 1, "checksum_retriever": RW.checksum(retriever),
+               "checksum_generator": RW.checksum(generator) if generator is not None else None}
+        batch = RW.synthetic_batch(case)
+        with tempfile.TemporaryDirectory() as td:
+            rdir, gdir = f"{td}/retriever", f"{td}/generator"
+            retriever.save_pretrained(rdir); tok.save_pretrained(rdir)
+            if generator is not None:
+                generator.save_pretrained(gdir); tok.save_pretrained(gdir)
+            del retriever, generator
+            if RW.CASES[case]["generator"] is not None:
+                model = m_rag.AutoModelForRagE2E(rdir, gdir)
+            else:
+                orig = AutoModel.from_pretrained
+
+                def cpu_from_pretrained(*a, **kw):
+                    kw.pop("device_map", None)
+                    kw.pop("quantization_config", None)
+                    return orig(*a, **kw)
+
+                AutoModel.from_pretrained = cpu_from_pretrained
+                try:
+                    model = m_ret.AutoModelForSentenceEmbedding(rdir, use_bnb=False, get_peft=False)
+                finally:
+                    AutoModel.from_pretrained = orig
+        model.train()   # every dropout probability of these configs is 0
+        for tag, autocast in (("fp32", False), ("bf16_autocast", True)):
+            ctx = (lambda: torch.autocast("cpu", dtype=torch.bfloat16)) if autocast else contextlib.nullcontext
+            model.zero_grad()
+            if RW.CASES[case]["generator"] is not None:
+                with ctx():
+                    q = model("retrieval", batch["retriever_query_input_ids"], batch["retriever_query_attention_mask"]).float()
+                    p = model("retrieval", batch["retriever_passage_input_ids"], batch["retriever_passage_attention_mask"]).float()
+                S = tu.get_cosine_sim(q, p, 100)
+                con = (tu.get_nt_xent_loss(S) + tu.get_nt_xent_loss(S.t())) / 2.0
+                with ctx():
+                    lg = model("generation", batch["generator_input_input_ids"], batch["generator_input_attention_mask"]).float()
+                gen = tu.compute_marginalized_loss_from_logits(lg, batch["generator_input_input_ids"],
+                                                               batch["generator_input_attention_mask"], S,
+                                                               batch["query_passage_input_len"])
+                loss = con + gen
+                loss.backward()
+                rec[tag] = {"loss": float(loss), "contrastive": float(con), "generator": float(gen),
+                            "grad_norm": RW.grad_norm(model.parameters()),
+                            "grad_norm_retriever": RW.grad_norm(model.retriever_model.parameters()),
+                            "grad_norm_generator": RW.grad_norm(model.generator_model.parameters())}
+                del lg, S, q, p, loss, gen, con
+            else:
+                with ctx():
+                    q = model(batch["query_input_ids"], batch["query_attention_mask"]).float()
+                    p = model(batch["passage_input_ids"], batch["passage_attention_mask"]).float()
+                S = tu.get_cosine_sim(q, p, 100)
+                loss = (tu.get_nt_xent_loss(S) + tu.get_nt_xent_loss(S.t())) / 2.0
+                loss.backward()
+                rec[tag] = {"loss": float(loss), "grad_norm": RW.grad_norm(model.parameters())}
+            print(case, tag, rec[tag], flush=True)
+        out[case] = rec
+        del model
+    path.write_text(json.dumps(out, indent=1))
+    print("realwidth_golden.json ok")
 
 
 if __name__ == "__main__":
     if "--retriever-step-only" in sys.argv:
         main_retriever_step_golden()
+        sys.exit(0)
+    if "--realwidth-only" in sys.argv:
+        main_realwidth_golden([a for a in sys.argv[1:] if not a.startswith("--")] or None)
         sys.exit(0)
     if not REF.exists():
         sys.exit("/root/reference not present: golden vectors can only be regenerated in the build container")
@@ -431,3 +562,4 @@ if __name__ == "__main__":
     main_host_goldens()
     main_step_golden()
     main_retriever_step_golden()
+    main_realwidth_golden()
