@@ -286,10 +286,9 @@ def test_train_retriever_end_to_end_at_cfg1_shapes(tmp_path):
 
 
 def test_bf16_autocast_step_stays_within_stated_tolerance_of_fp32_reference():
-    """The bench line is bf16 (bf16 weights + autocast); every other trajectory test is fp32.  Stated tolerance for the
-    bf16 step against the reference's fp32 CPU trajectory: per-step loss within 3e-2 relative over the 5 golden steps
-    (bf16 has 8 mantissa bits: ~4e-3 per rounding, compounded through two tiny towers and 5 Adam steps; the loss path
-    itself is fp32 on the bf16 values, exactly as accelerate hands fp32 up-casts to the reference's loss code)."""
+    """Information next to tests/test_step_realwidth_gpu.py (which compares the bf16 step with the reference run UNDER bf16
+    autocast): against the reference's FP32 trajectory the bf16-autocast step stays within 2e-3 relative per-step loss over
+    the 5 golden steps (measured 3e-5; the reference's own bf16-autocast trajectory differs from its fp32 one by 2e-5)."""
     from transformers import get_scheduler
 
     from dalm_amd.models import AutoModelForRagE2E
@@ -306,8 +305,8 @@ def test_bf16_autocast_step_stays_within_stated_tolerance_of_fp32_reference():
     step = RagE2EStep(rag, opt, sched, 100, autocast_dtype=torch.bfloat16, inplace_grad=True, overlap_towers=True)
     losses = [float(step(b)) for b in _batches(rag.retriever_tokenizer, g_tok, gold, dev)]
     rel = [abs(a - b) / abs(b) for a, b in zip(losses, gold["losses"])]
-    assert max(rel) <= 3e-2, (rel, losses, gold["losses"])
-    assert rel[0] <= 1e-2, rel                       # before any optimizer step: forward rounding only
+    assert max(rel) <= 2e-3, (rel, losses, gold["losses"])
+    assert rel[0] <= 1e-3, rel                       # before any optimizer step: forward rounding only
 
 
 def test_padding_trim_preserves_the_step_and_graphs_are_cached_per_shape():

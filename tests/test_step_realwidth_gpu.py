@@ -7,10 +7,11 @@ Two independent checks per configuration, both on depth-1 towers built from a CP
      code in the build container (oracle/make_golden.py::main_realwidth_golden), fp32 and bf16-autocast;
   2. LoRA (the bench's configuration; the image has no peft, so the in-tree injector is used on both sides) vs the
      oracle's `ref_*` restatement run on this host's CPU in fp32.
-Tolerances (north_star: 1e-3 relative in fp32, stated tolerance in bf16):
-  fp32            loss / contrastive / generator / grad-norm  <= 1e-3
-  bf16 autocast   loss / contrastive / generator              <= 5e-3   (vs the reference under CPU bf16 autocast)
-                  grad-norm (global and per tower)            <= 2e-2   (bf16 has 8 mantissa bits; CPU and GPU autocast
+Tolerances asserted here (north_star: 1e-3 relative in fp32, stated tolerance in bf16); measured on MI355X in round 3
+(profiles/r03_realwidth_parity.json): fp32 <= 1e-6 everywhere, bf16 loss <= 4e-6 / gradient norm <= 6e-5 at real width:
+  fp32            loss / contrastive / generator / grad-norm  <= 1e-4
+  bf16 autocast   loss / contrastive / generator              <= 1e-3   (vs the reference under CPU bf16 autocast)
+                  grad-norm (global and per tower)            <= 5e-3   (bf16 has 8 mantissa bits; CPU and GPU autocast
                                                                          round at different operators)
 """
 import copy
@@ -25,7 +26,7 @@ pytestmark = pytest.mark.gpu
 G = Path(__file__).parent / "golden"
 OUT = Path(__file__).resolve().parent.parent / "gpurun_out"
 
-TOL = {"fp32": {"loss": 1e-3, "grad": 1e-3}, "bf16_autocast": {"loss": 5e-3, "grad": 2e-2}}
+TOL = {"fp32": {"loss": 1e-4, "grad": 1e-4}, "bf16_autocast": {"loss": 1e-3, "grad": 5e-3}}
 
 
 def _rel(a, b):
@@ -56,10 +57,23 @@ class _TowerNorms:
         self.norms = {k: RW.grad_norm(ps) for k, ps in self.groups.items()}
 
 
+_BUILT = {}
+
+
+def _build(case):
+    """Seeded towers, built once per session (465 M - 720 M parameters of CPU randn each) and handed out as copies."""
+    import realwidth as RW
+
+    if case not in _BUILT:      # ~5 GB of host memory for the three configurations together
+        _BUILT[case] = RW.build_case(case)
+    r, g = _BUILT[case]
+    return copy.deepcopy(r), copy.deepcopy(g)
+
+
 def _seeded_case(case, gold):
     import realwidth as RW
 
-    retriever, generator = RW.build_case(case)
+    retriever, generator = _build(case)
     cs = RW.checksum(retriever)
     if _rel(cs, gold["checksum_retriever"]) > 1e-9:
         pytest.skip(f"this host's torch CPU RNG does not reproduce the golden's seeded weights ({cs} vs {gold['checksum_retriever']})")
@@ -150,7 +164,7 @@ def test_lora_step_matches_the_oracle_on_this_host_at_real_width(case):
     from dalm_amd.models import AutoModelForRagE2E, AutoModelForSentenceEmbedding, lora
     from dalm_amd.training.step import RagE2EStep, RetrieverStep
 
-    retriever, generator = RW.build_case(case)
+    retriever, generator = _build(case)
     lora.inject_lora(retriever, ["key", "query", "value"], lora_dropout=0.0)
     _randomise_lora_b(retriever, 11)
     if generator is not None:
@@ -202,7 +216,7 @@ def test_lora_step_matches_the_oracle_on_this_host_at_real_width(case):
         ref.update(contrastive=float(out["contrastive"]), generator=float(out["generator"]))
     rel = {k: _rel(got[k], ref[k]) for k in ref}
     _record(f"{case}/lora/fp32_vs_oracle_on_host", {"got": got, "reference": ref, "rel": rel})
-    assert max(rel.values()) <= 1e-3, (rel, got, ref)
+    assert max(rel.values()) <= 1e-4, (rel, got, ref)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -210,9 +224,9 @@ def test_lora_step_matches_the_oracle_on_this_host_at_real_width(case):
 # (fp32 master weights, forward under autocast, fp32 loss code on the up-cast outputs - accelerate's bf16 mode)
 # ---------------------------------------------------------------------------------------------------------------
 def test_bf16_autocast_trajectory_matches_the_reference_under_bf16_autocast():
-    """Stated bf16 tolerance: per-step loss <= 5e-3 relative and per-step gradient norm <= 3e-2 relative against the
-    reference's own bf16-autocast trajectory (step_golden.json["bf16_autocast"]); the earlier 3e-2 bound against the
-    fp32 trajectory is kept in test_step_parity_gpu.py as information only."""
+    """Stated bf16 tolerance: per-step loss <= 2e-3 relative and per-step gradient norm <= 5e-3 relative against the
+    reference's own bf16-autocast trajectory (step_golden.json["bf16_autocast"]) over 5 Adam steps (measured: 2e-5 /
+    8e-5); the bound against the reference's fp32 trajectory lives in test_step_parity_gpu.py."""
     from transformers import get_scheduler
 
     from dalm_amd.models import AutoModelForRagE2E
@@ -239,8 +253,8 @@ def test_bf16_autocast_trajectory_matches_the_reference_under_bf16_autocast():
     rel_fp32 = [_rel(a, b) for a, b in zip(losses, gold["losses"])]
     _record("tiny/e2e/bf16_autocast_trajectory", {"losses": losses, "grad_norms": gnorms, "rel_loss": rel_l,
                                                   "rel_grad_norm": rel_g, "rel_loss_vs_fp32_reference": rel_fp32})
-    assert max(rel_l) <= 5e-3, (rel_l, losses, ref["losses"])
-    assert max(rel_g) <= 3e-2, (rel_g, gnorms, ref["grad_norms"])
+    assert max(rel_l) <= 2e-3, (rel_l, losses, ref["losses"])
+    assert max(rel_g) <= 5e-3, (rel_g, gnorms, ref["grad_norms"])
 
 
 @pytest.mark.parametrize("graph", [False, True])
@@ -293,7 +307,7 @@ def test_retriever_only_trajectory_matches_the_reference_gradient_norms_fp32_and
     enc = preprocess_dataset(gold["rows"], tok, query_column_name="Question", passage_column_name="Abstract",
                              query_max_len=gold["query_max_len"], passage_max_len=gold["passage_max_len"])
     full = {k: torch.tensor(v, device=dev) for k, v in enc.items()}
-    for precision, ref, tol_l, tol_g in (("fp32", gold, 1e-3, 1e-3), ("bf16", gold["bf16_autocast"], 5e-3, 3e-2)):
+    for precision, ref, tol_l, tol_g in (("fp32", gold, 1e-3, 1e-3), ("bf16", gold["bf16_autocast"], 2e-3, 5e-3)):
         bert = _tiny_bge_small(len(tok), gold["seed"])
         model = AutoModelForSentenceEmbedding.from_modules(bert, tok, normalize=True, get_peft=False).to(dev)
         model.train()
