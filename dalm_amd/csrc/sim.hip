@@ -763,7 +763,7 @@ __global__ __launch_bounds__(256, 2) void sim_rowstats_stream_kernel(const Strea
 // recomputes only those groups' 32 scores (plain FMA dot products against the k-major corpus copy: ~k*32 of them per
 // query instead of a second pass over the whole corpus), keeps the scores >= T and sorts them (value descending,
 // lower corpus index first on ties: deterministic).
-__global__ __launch_bounds__(256) void topk_threshold_kernel(const float* __restrict__ gmax, int ng, int k,
+__global__ __launch_bounds__(256) void topk_threshold_kernel(const float* __restrict__ gmax, int ng, int k, float abs_slack,
                                                              float* __restrict__ thr) {
   __shared__ float red[4];
   __shared__ float redc[4];
@@ -787,8 +787,10 @@ __global__ __launch_bounds__(256) void topk_threshold_kernel(const float* __rest
     bound = mx;
     if (have >= k) break;
   }
-  // a few ulps of slack: the refine pass re-evaluates the scores with a VALU fma chain
-  if (threadIdx.x == 0) thr[blockIdx.x] = (have >= k) ? cur - fabsf(cur) * 1e-6f - 1e-30f : -INFINITY;
+  // slack: the refine pass re-evaluates the scores with a VALU fma chain (same k order as the MFMA chain, so normally the same
+  // bits).  Relative part for large scores, absolute part (~ 2 eps sqrt(K) |alpha| for O(1)-norm embeddings) for scores near 0,
+  // where a purely relative slack vanishes; a row that still ends up with fewer than k candidates reports overflow (refine).
+  if (threadIdx.x == 0) thr[blockIdx.x] = (have >= k) ? cur - fabsf(cur) * 1e-6f - abs_slack : -INFINITY;
 }
 
 // one workgroup per query row.  LDS: q[Kpad] | glist[cap] | cand_val[cap] | cand_idx[cap]
@@ -838,7 +840,7 @@ __global__ __launch_bounds__(256) void topk_refine_kernel(const float* __restric
   }
   __syncthreads();
   const int cnt = n_cand;
-  if (cnt > cap) {
+  if (cnt > cap || cnt < min(k, n)) {   // too many ties, or a recomputed score slipped under the threshold: caller falls back
     if (tid == 0) atomicAdd(overflow, 1);
     return;
   }
@@ -1260,6 +1262,12 @@ inline TopkLayout topk_layout(int64_t m, int64_t n, int64_t D, int64_t k) {
 }
 }  // namespace
 
+extern "C" int dalm_sim_topk_supported(int64_t D, int64_t k) {
+  if (D <= 0 || k <= 0 || k > 1024) return 0;
+  const size_t kpad = static_cast<size_t>((D + 15) / 16 * 16);       // as stream_plan pads the embedding width
+  return (kpad + 3 * static_cast<size_t>(8 * k + 64)) * 4 <= 60 * 1024;
+}
+
 extern "C" size_t dalm_sim_topk_workspace_bytes(int64_t m, int64_t n, int64_t D, int64_t k) {
   if (m <= 0 || n <= 0 || D <= 0 || k <= 0) return 0;
   const TopkLayout L = topk_layout(m, n, D, k);
@@ -1276,6 +1284,9 @@ extern "C" int dalm_sim_topk(const float* Q, const float* C, int64_t m, int64_t 
   DALM_REQUIRE(L.f.ok, DALM_E_SHAPE, "corpus block too large for 32-bit buffer offsets: search it in blocks of <= 2^19 rows");
   DALM_REQUIRE(ws_bytes >= L.total, DALM_E_WORKSPACE, "workspace too small");
   DALM_REQUIRE(reinterpret_cast<uintptr_t>(ws) % 16 == 0, DALM_E_ALIGN, "workspace must be 16-byte aligned");
+  // validated BEFORE anything is enqueued (dalm_sim_topk_supported is the same test for callers that want to fall back)
+  DALM_REQUIRE(dalm_sim_topk_supported(D, k), DALM_E_SHAPE,
+               "D and k too large for the refine kernel's LDS (padded D + 3*(8k+64) floats <= 15360)");
   hipStream_t s = as_stream(stream);
   char* base = static_cast<char*>(ws);
   float* At = reinterpret_cast<float*>(base + L.at);
@@ -1296,9 +1307,8 @@ extern "C" int dalm_sim_topk(const float* Q, const float* C, int64_t m, int64_t 
   if (f.rt == 2) hipLaunchKernelGGL((sim_rowstats_stream_kernel<2, MODE_GMAX>), grid, dim3(256), 0, s, q);
   else hipLaunchKernelGGL((sim_rowstats_stream_kernel<1, MODE_GMAX>), grid, dim3(256), 0, s, q);
   hipLaunchKernelGGL(topk_threshold_kernel, dim3(static_cast<unsigned>(m)), dim3(256), 0, s, q.gmax, q.ng,
-                     static_cast<int>(k), thr);
+                     static_cast<int>(k), 2.4e-7f * sqrtf(static_cast<float>(f.kpad)) * fabsf(scale), thr);
   const size_t lds = (static_cast<size_t>(f.kpad) + 3 * static_cast<size_t>(L.cap)) * 4;
-  DALM_REQUIRE(lds <= 60 * 1024, DALM_E_SHAPE, "D and k too large for the refine kernel's LDS (D + 3*(8k+64) floats <= 15360)");
   hipLaunchKernelGGL(topk_refine_kernel, dim3(static_cast<unsigned>(m)), dim3(256), lds, s, At, static_cast<int>(f.ldm),
                      Bt, static_cast<int>(f.ldn), static_cast<int>(f.kpad), static_cast<int>(n), scale, q.gmax, q.ng, thr,
                      L.cap, static_cast<int>(k), out_val, out_idx, overflow);

@@ -56,7 +56,7 @@ def rank_env(rank: int, world: int, port: int, base: Optional[Dict[str, str]] = 
 
 
 def spawn_ranks(cmd: Sequence[str], nproc: int, *, require_gpus: bool = True, port: Optional[int] = None,
-                extra_env: Optional[Dict[str, str]] = None, poll_s: float = 0.2) -> int:
+                extra_env: Optional[Dict[str, str]] = None, poll_s: float = 0.2, term_grace_s: float = 10.0) -> int:
     """Run `cmd` nproc times (rank r gets LOCAL_RANK=r -> cuda:r) and return the job's exit code."""
     if nproc < 1:
         raise ValueError("nproc must be >= 1")
@@ -75,6 +75,7 @@ def spawn_ranks(cmd: Sequence[str], nproc: int, *, require_gpus: bool = True, po
         procs.append(subprocess.Popen(list(cmd), env=env, stdout=None if r == 0 else sys.stderr))
     code = 0
     live = set(range(nproc))
+    kill_at: Optional[float] = None      # set at the first failure: ranks still alive after the grace period get SIGKILL
     while live:
         for r in sorted(live):
             rc = procs[r].poll()
@@ -86,15 +87,15 @@ def spawn_ranks(cmd: Sequence[str], nproc: int, *, require_gpus: bool = True, po
                 sys.stderr.write(f"[dalm_amd.launch] rank {r} exited with code {rc}; stopping the other ranks\n")
                 for o in live:
                     procs[o].terminate()
+                kill_at = time.time() + term_grace_s
+        if live and kill_at is not None and time.time() >= kill_at:
+            # a rank stuck inside an RCCL collective or a HIP call never sees SIGTERM: escalate inside the wait loop
+            for o in sorted(live):
+                sys.stderr.write(f"[dalm_amd.launch] rank {o} ignored SIGTERM for {term_grace_s:.0f} s; killing it\n")
+                procs[o].kill()
+            kill_at = time.time() + term_grace_s
         if live:
             time.sleep(poll_s)
-    if code != 0:  # anything that ignored SIGTERM
-        deadline = time.time() + 10.0
-        for p in procs:
-            while p.poll() is None and time.time() < deadline:
-                time.sleep(poll_s)
-            if p.poll() is None:
-                p.kill()
     return code
 
 

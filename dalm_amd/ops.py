@@ -156,9 +156,14 @@ class HipOps:
                  hip.stream())
         return out, doc_lp
 
+    def sim_topk_supported(self, D: int, k: int) -> bool:
+        """Does (embedding width, k) fit the fused search?  (k <= 1024 and the refine kernel's LDS budget.)"""
+        return bool(hip.load().dalm_sim_topk_supported(int(D), int(k)))
+
     def sim_topk(self, Q: torch.Tensor, Cm: torch.Tensor, k: int, scale: float = 1.0):
         """(values [m,k] f32, indices [m,k] int64, overflow [1] int32) - exact top-k of scale*Q.Cm^T per row without the
-        score matrix; `overflow` non-zero means a row had too many ties for the candidate buffer (fall back)."""
+        score matrix; `overflow` non-zero means a row had too many ties for the candidate buffer or ended with fewer than k
+        candidates (fall back to the materialising search)."""
         dev = hip.require_gpu(Q, Cm)
         Q, Cm = hip.as_f32c(Q), hip.as_f32c(Cm)
         m, D = Q.shape

@@ -43,7 +43,7 @@ def exact_topk(query_embs: torch.Tensor, corpus_embs: torch.Tensor, k: int, bloc
     for c0 in range(0, nc, block):
         blk = corpus_embs[c0:c0 + block]
         kk = min(k, blk.shape[0])
-        if fused and kk <= 1024:
+        if fused and ops.sim_topk_supported(D, kk):         # k <= 1024 and (D, k) within the refine kernel's LDS budget
             bs, bi, ovf = ops.sim_topk(query_embs, blk, kk)
             if int(ovf.item()) != 0:                              # eval path: one host sync per block is fine
                 bs, bi = _topk_materialised(ops, query_embs, blk, kk)

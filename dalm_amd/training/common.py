@@ -181,15 +181,15 @@ class ShardedBatches:
 
 
 def effective_grad_accum(gradient_accumulation_steps: int) -> int:
-    """The trainers take one optimizer step per batch.  The reference accepts gradient_accumulation_steps
-    but zeroes the model's gradients after every micro-batch (train_rage2e.py:474), which defeats the
-    accumulation, so there is no reference behaviour worth reproducing for values > 1:
-    the flag is accepted, a warning is logged, and step counting / resume arithmetic use 1 so that every
-    batch of every epoch is consumed and the LR schedule spans all optimizer steps."""
-    if gradient_accumulation_steps and int(gradient_accumulation_steps) > 1:
-        logger.warning("gradient_accumulation_steps=%s is accepted for CLI compatibility only: every batch takes an "
-                       "optimizer step (treated as 1)", gradient_accumulation_steps)
-    return 1
+    """--gradient_accumulation_steps N: the trainers accumulate N micro-batches (each scaled 1/N) per optimizer / scheduler
+    step, so the number of optimizer steps, the LR schedule and the step_N / resume arithmetic are the reference's
+    (ceil(batches / N) steps per epoch).  One deliberate difference: the reference zeroes the model's gradients after
+    every micro-batch (train_rage2e.py:474), which leaves only the LAST micro-batch in each update; here all N count.
+    With N > 1 the whole-step hipGraph is not used (the graph would bake the optimizer step into every replay)."""
+    n = 1 if gradient_accumulation_steps is None else int(gradient_accumulation_steps)
+    if n < 1:
+        raise ValueError("gradient_accumulation_steps must be >= 1")
+    return n
 
 
 def steps_and_epochs(num_batches: int, grad_accum: int, num_train_epochs: int, max_train_steps: Optional[int]):
@@ -352,7 +352,8 @@ class AsyncSaver:
 
 
 def save_training_state(path: str, model, optimizer, scheduler, extra: Dict[str, Any], save_models: Callable[[str], None],
-                        *, rank: int = 0, world: int = 1, saver: Optional[AsyncSaver] = None) -> None:
+                        *, rank: int = 0, world: int = 1, saver: Optional[AsyncSaver] = None,
+                        shard_wait_s: float = 600.0) -> None:
     """<path>/{retriever,generator,...} via `save_models` (rank 0), <path>/trainer_state.pt (scheduler, extra, and the
     optimizer state when world == 1) and, with world > 1, <path>/optimizer-RRRRR-of-WWWWW.pt per rank.  With `saver` the
     device->host copies are enqueued and the files are written by a background thread (the adapters / models are
@@ -368,15 +369,30 @@ def save_training_state(path: str, model, optimizer, scheduler, extra: Dict[str,
             osd = shard_optimizer_state(osd, rank, world)
         return _to_host({"optimizer": osd, "scheduler": sched_sd, "extra": dict(extra)}, stream)
 
+    def atomic_save(obj, name):
+        tmp = os.path.join(path, name + f".tmp{os.getpid()}")
+        torch.save(obj, tmp)
+        os.replace(tmp, os.path.join(path, name))
+
     def write(host):
+        # COMMIT POINT = trainer_state.pt, written last and atomically: every rank renames its optimizer shard into place
+        # first; rank 0 then waits until all W shard files exist before it writes trainer_state.pt - a directory holding
+        # that file is complete, one without it is ignored by parse_resume / load_training_state (crash or early resume)
         if world > 1:
-            torch.save(host["optimizer"], os.path.join(path, f"optimizer-{rank:05d}-of-{world:05d}.pt"))
+            atomic_save(host["optimizer"], f"optimizer-{rank:05d}-of-{world:05d}.pt")
             if rank == 0:
-                torch.save({"optimizer": None, "sharded": world, "scheduler": host["scheduler"], "extra": host["extra"]},
-                           os.path.join(path, "trainer_state.pt"))
+                files = [os.path.join(path, f"optimizer-{r:05d}-of-{world:05d}.pt") for r in range(world)]
+                deadline = time.time() + shard_wait_s
+                while not all(os.path.exists(x) for x in files):
+                    if time.time() > deadline:
+                        raise RuntimeError(f"checkpoint {path}: optimizer shards of other ranks did not appear within "
+                                           f"{shard_wait_s:.0f} s; trainer_state.pt NOT written (checkpoint stays uncommitted)")
+                    time.sleep(0.05)
+                atomic_save({"optimizer": None, "sharded": world, "scheduler": host["scheduler"], "extra": host["extra"]},
+                            "trainer_state.pt")
         else:
-            torch.save({"optimizer": host["optimizer"], "scheduler": host["scheduler"], "extra": host["extra"]},
-                       os.path.join(path, "trainer_state.pt"))
+            atomic_save({"optimizer": host["optimizer"], "scheduler": host["scheduler"], "extra": host["extra"]},
+                        "trainer_state.pt")
 
     if saver is not None:
         saver.submit(snapshot, write)
@@ -390,7 +406,13 @@ def save_training_state(path: str, model, optimizer, scheduler, extra: Dict[str,
 def load_training_state(path: str, optimizer, scheduler) -> Dict[str, Any]:
     f = os.path.join(path, "trainer_state.pt")
     if not os.path.exists(f):
-        return {}
+        import glob
+
+        if glob.glob(os.path.join(path, "optimizer-*-of-*.pt")) or glob.glob(os.path.join(path, "*.tmp*")):
+            # shards without the commit file: the run died (or is still writing) between the shard renames and the commit
+            raise RuntimeError(f"checkpoint {path} was never committed (optimizer shards present, trainer_state.pt missing); "
+                               "resume from the previous step_N / epoch_N directory")
+        return {}      # a checkpoint written by the reference trainer: models / adapters only
     st = torch.load(f, map_location="cpu")
     if st.get("sharded"):
         W = int(st["sharded"])

@@ -63,7 +63,7 @@ FLAGS = [
     ("no_hip_graph", dict(action="store_true", help="[ext] launch every step eagerly instead of replaying a hipGraph")),
     ("token_cache_dir", dict(type=_S, default=None, help="[ext] keep the tokenised dataset as int32 shards here; reused when unchanged")),
     ("length_bucketing", dict(action="store_true", help="[ext] batch rows of similar generator length together")),
-    ("trim_padding", dict(action="store_true", help="[ext] drop all-padding columns per batch (loss-preserving)")),
+    ("trim_padding", dict(action="store_true", help="[ext] drop all-padding columns per batch (exact for real-token rows; the B first-token rows of left-padded generator inputs are approximate, and generators with absolute position embeddings are refused)")),
     ("async_checkpoint", dict(action="store_true", help="[ext] write optimizer/scheduler state from a background thread")),
     ("fuse_lm_head", dict(action="store_true", help="[ext] lm_head + loss in chunks over the rows that carry loss; the [B,T,V] logits never exist")),
 ]
@@ -147,8 +147,14 @@ def train_e2e(
                "query_passage_input_len"]
     from .. import shards
 
-    fp = shards.fingerprint(data=getattr(dataset, "_fingerprint", None), rows=len(dataset), r_tok=(type(r_tok).__name__, len(r_tok)),
-                            g_tok=(type(g_tok).__name__, len(g_tok)), cols=(query_column_name, passage_column_name, answer_column_name),
+    data_id = shards.dataset_identity(dataset)
+    if token_cache_dir and data_id is None:
+        import warnings
+
+        warnings.warn("--token_cache_dir ignored: the dataset carries no content fingerprint, a cache could not be invalidated")
+        token_cache_dir = None
+    fp = shards.fingerprint(data=data_id, rows=len(dataset), r_tok=shards.tokenizer_identity(r_tok),
+                            g_tok=shards.tokenizer_identity(g_tok), cols=(query_column_name, passage_column_name, answer_column_name),
                             lens=(query_max_len, passage_max_len, generator_max_len))
     processed = shards.load_token_shards(token_cache_dir, fp) if token_cache_dir else None
     if processed is None:
@@ -166,6 +172,11 @@ def train_e2e(
             shards.save_token_shards(processed, token_cache_dir, fp)
     trim = None
     if trim_padding:
+        gcfg = rag_model.generator_model.config
+        if getattr(gcfg, "model_type", "") in ("gpt2", "gpt_neo", "opt", "bloom_abs") or (
+                getattr(gcfg, "position_embedding_type", None) == "absolute"):
+            raise ValueError("--trim_padding shifts every token of a left-padded row: it needs a rotary / relative-position "
+                             f"generator (got model_type={getattr(gcfg, 'model_type', None)!r} with absolute positions)")
         trim = dict(groups=[("retriever_query_input_ids", "retriever_query_attention_mask"),
                             ("retriever_passage_input_ids", "retriever_passage_attention_mask"),
                             ("generator_input_input_ids", "generator_input_attention_mask")],
@@ -188,7 +199,7 @@ def train_e2e(
     from ...fused import LocalComm
     from ..graphed import GraphedStep, TensorLRScheduler, make_capturable_adam
 
-    use_graph = isinstance(comm, LocalComm) and not no_hip_graph
+    use_graph = isinstance(comm, LocalComm) and not no_hip_graph and gradient_accumulation_steps == 1
     optimizer = (make_capturable_adam(params, learning_rate, device) if use_graph
                  else torch.optim.Adam(params, lr=learning_rate, fused=True))
     per_epoch, max_train_steps, num_train_epochs = common.steps_and_epochs(
@@ -225,7 +236,8 @@ def train_e2e(
     step_fn = RagE2EStep(rag_model, optimizer, scheduler, logit_scale, comm=comm,
                          autocast_dtype=torch.bfloat16 if mixed_precision == "bf16" else None,
                          # W > 1: graph the tower fwd/bwd, keep collectives + loss + optimizer eager
-                         graph_towers=(not use_graph) and (not no_hip_graph), graph_after=2, fuse_lm_head=fuse_lm_head)
+                         graph_towers=(not use_graph) and (not no_hip_graph), graph_after=2, fuse_lm_head=fuse_lm_head,
+                         grad_accum=gradient_accumulation_steps)
     if use_graph:
         # partial last batches (other shapes) run eagerly; with live rows the padded row count is part of the shape
         # (multiples of 256-512 rows: at most B*Tg/256 values), all graphs share one memory pool
@@ -239,8 +251,10 @@ def train_e2e(
         for step, batch in enumerate(batches.epoch(epoch, device, skip)):
             loss = step_fn(batch)  # rank share of the global-batch loss
             total_loss += loss
-            completed += 1
             meter.add(batch["query_passage_input_len"].shape[0] * comm.world_size)
+            if not getattr(step_fn, "synced", True):
+                continue                  # gradient accumulation: a micro-batch that did not take the optimizer step
+            completed += 1
             if on_step is not None:
                 on_step(completed, loss)
             if (step + 1) % 100 == 0:
@@ -254,6 +268,8 @@ def train_e2e(
                                            rank=comm.rank, world=comm.world_size, saver=saver)
             if completed >= max_train_steps:
                 break
+        if gradient_accumulation_steps > 1 and step_fn.flush():     # pending micro-batches at the end of the epoch
+            completed += 1
         tl = comm.all_reduce_sum_(total_loss.clone())
         tracker.log({"train/epoch_loss": float(tl) / max(len(batches), 1)}, completed)
         if output_dir is not None:

@@ -121,7 +121,13 @@ def train_retriever(
     columns = ["query_input_ids", "query_attention_mask", "passage_input_ids", "passage_attention_mask"]
     from .. import shards
 
-    fp = shards.fingerprint(data=getattr(dataset, "_fingerprint", None), rows=len(dataset), tok=(type(tokenizer).__name__, len(tokenizer)),
+    data_id = shards.dataset_identity(dataset)
+    if token_cache_dir and data_id is None:
+        import warnings
+
+        warnings.warn("--token_cache_dir ignored: the dataset carries no content fingerprint, a cache could not be invalidated")
+        token_cache_dir = None
+    fp = shards.fingerprint(data=data_id, rows=len(dataset), tok=shards.tokenizer_identity(tokenizer),
                             cols=(query_column_name, passage_column_name), lens=(query_max_len, passage_max_len))
     processed = shards.load_token_shards(token_cache_dir, fp) if token_cache_dir else None
     if processed is None:
@@ -146,7 +152,7 @@ def train_retriever(
     from ...fused import LocalComm
     from ..graphed import GraphedStep, TensorLRScheduler, make_capturable_adam
 
-    use_graph = isinstance(comm, LocalComm) and not no_hip_graph
+    use_graph = isinstance(comm, LocalComm) and not no_hip_graph and gradient_accumulation_steps == 1
     optimizer = (make_capturable_adam(params, learning_rate, device) if use_graph
                  else torch.optim.Adam(params, lr=learning_rate, fused=True))
     per_epoch, max_train_steps, num_train_epochs = common.steps_and_epochs(
@@ -172,7 +178,8 @@ def train_retriever(
         starting_epoch, resume_step, completed = common.parse_resume(resume_from_checkpoint, per_epoch, len(batches),
                                                                      gradient_accumulation_steps)
     step_fn = RetrieverStep(model, optimizer, scheduler, logit_scale, comm=comm,
-                            autocast_dtype=torch.bfloat16 if mixed_precision == "bf16" else None)
+                            autocast_dtype=torch.bfloat16 if mixed_precision == "bf16" else None,
+                            grad_accum=gradient_accumulation_steps)
     if use_graph:
         step_fn = GraphedStep(step_fn, warmup=0, eager_steps=2)
     meter = common.Throughput()
@@ -184,8 +191,10 @@ def train_retriever(
         for step, batch in enumerate(batches.epoch(epoch, device, skip)):
             loss = step_fn(batch)
             total_loss += loss
-            completed += 1
             meter.add(batch["query_input_ids"].shape[0] * comm.world_size)
+            if not getattr(step_fn, "synced", True):
+                continue                  # gradient accumulation: a micro-batch that did not take the optimizer step
+            completed += 1
             if on_step is not None:
                 on_step(completed, loss)
             if (step + 1) % 100 == 0:
@@ -199,6 +208,8 @@ def train_retriever(
                                            rank=comm.rank, world=comm.world_size, saver=saver)
             if completed >= max_train_steps:
                 break
+        if gradient_accumulation_steps > 1 and step_fn.flush():     # pending micro-batches at the end of the epoch
+            completed += 1
         tl = comm.all_reduce_sum_(total_loss.clone())
         tracker.log({"train/epoch_loss": float(tl) / max(len(batches), 1)}, completed)
         if output_dir is not None:

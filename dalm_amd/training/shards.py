@@ -33,9 +33,44 @@ INDEX = "index.json"
 
 
 def fingerprint(**what) -> str:
-    """Stable hash of everything that determines the token ids (tokenizer names/sizes, column names, max lengths, rows)."""
-    blob = json.dumps(what, sort_keys=True, default=str).encode()
+    """Stable hash of everything that determines the token ids (tokenizer identities, dataset content fingerprint, column
+    names, max lengths, preprocessing version)."""
+    blob = json.dumps(dict(what, version=PREPROCESS_VERSION), sort_keys=True, default=str).encode()
     return hashlib.sha256(blob).hexdigest()[:32]
+
+
+PREPROCESS_VERSION = "dalm_amd-preprocess-1"   # bump when *_dataloader_utils.preprocess_dataset changes what it emits
+
+
+def tokenizer_identity(tok) -> Dict[str, object]:
+    """What makes two tokenizers produce different ids for the same text: name/path, a hash of the whole vocabulary
+    (Llama-2 and Mistral are both 32000-token LlamaTokenizerFast; cased / retrained BERT vocabularies collide the same way
+    on class name + size), the special tokens, and the padding / eos settings the preprocessing depends on."""
+    try:
+        vocab = tok.get_vocab()
+        h = hashlib.sha256()
+        for k, v in sorted(vocab.items(), key=lambda kv: kv[1]):
+            h.update(f"{v}:{k}\n".encode("utf-8", "surrogatepass"))
+        vocab_hash = h.hexdigest()[:32]
+    except Exception:
+        vocab_hash = None
+    norm = None
+    try:                                  # fast tokenizers: normaliser / pre-tokeniser / post-processor live in tokenizer.json
+        norm = hashlib.sha256(tok.backend_tokenizer.to_str().encode()).hexdigest()[:32]
+    except Exception:
+        pass
+    return {"class": type(tok).__name__, "name_or_path": getattr(tok, "name_or_path", None), "size": len(tok),
+            "vocab": vocab_hash, "pipeline": norm, "special": {k: str(v) for k, v in sorted(tok.special_tokens_map.items())},
+            "pad": (tok.pad_token, tok.pad_token_id, getattr(tok, "padding_side", None)),
+            "truncation_side": getattr(tok, "truncation_side", None),
+            "add_eos_token": getattr(tok, "add_eos_token", None), "add_bos_token": getattr(tok, "add_bos_token", None)}
+
+
+def dataset_identity(dataset) -> Optional[str]:
+    """`datasets` content fingerprint; None when the object has none - callers then do NOT cache (a row count alone would
+    silently reuse stale ids for an edited file of the same length)."""
+    fp = getattr(dataset, "_fingerprint", None)
+    return str(fp) if fp else None
 
 
 def save_token_shards(columns: Dict[str, Sequence], path: str, fp: str, rows_per_shard: int = 1 << 16) -> None:
@@ -112,7 +147,15 @@ def trim_batch(batch: Dict[str, torch.Tensor], groups: Iterable[Tuple[str, str]]
                qlen_follows: Optional[str] = None, multiple: int = 8, min_len: int = 8) -> Dict[str, torch.Tensor]:
     """Drop all-padding columns.  `groups`: (ids_key, mask_key) pairs sharing one time axis; `qlen_key` is shifted by the
     leading columns removed from the `qlen_follows` mask's axis.  Works on host or device tensors (one tiny reduction +
-    two scalars per group; call it on the host copy, before the H2D, to keep the step free of syncs)."""
+    two scalars per group; call it on the host copy, before the H2D, to keep the step free of syncs).
+
+    Exactness: every loss row whose input position is a real token is unchanged.  With LEFT-padded generator inputs each
+    sample also has one live row computed AT a padding position (the row that predicts its first token, m_bt = mask[b,t+1]):
+    a fully masked query row attends uniformly over however many padding keys exist, so removing leading pads changes that
+    row's hidden state - B rows per batch are approximate (measured 2e-5 relative on the step loss with rotary generators,
+    tests/test_step_parity_gpu.py).  Generators with ABSOLUTE position embeddings (gpt2-style) see every token at a
+    different position after a left trim: use trimming with rotary / relative-position generators only (Llama, Falcon,
+    Mistral); right-padded inputs (the retriever side) are exact."""
     out = dict(batch)
     for ids_key, mask_key in groups:
         mask = batch[mask_key]

@@ -21,12 +21,21 @@ from ..sharded import GradBucket, allreduce_grads
 
 class _StepBase:
     def __init__(self, model, optimizer, lr_scheduler, logit_scale, comm=None, autocast_dtype=None, ops=None,
-                 grad_overlap: bool = True, track_grad_norm: bool = False):
+                 grad_overlap: bool = True, track_grad_norm: bool = False, grad_accum: int = 1):
         self.model, self.optimizer, self.lr_scheduler = model, optimizer, lr_scheduler
         # global L2 norm of the (all-reduced) trainable gradients, left on the device in self.grad_norm right before
         # the optimizer consumes them - the quantity north_star's tolerance is stated on next to the loss
         self.track_grad_norm = track_grad_norm
         self.grad_norm: Optional[torch.Tensor] = None
+        # --gradient_accumulation_steps N: N micro-batches (each scaled 1/N, as accelerate scales them) per optimizer /
+        # scheduler step; `synced` tells the trainer whether the call it just made took that step.  The reference zeroes the
+        # model's gradients after EVERY micro-batch (train_rage2e.py:474), so its update only ever sees the last one of the N -
+        # the step COUNT and schedule are the reference's, the dropped micro-batches are not reproduced.
+        self.grad_accum = max(1, int(grad_accum))
+        self._micro = 0
+        self.synced = True
+        if self.grad_accum > 1:
+            grad_overlap = False          # the all-reduce runs once per optimizer step, after the last micro-batch
         self.logit_scale = logit_scale
         self.comm = comm or LocalComm()
         self.autocast_dtype = autocast_dtype
@@ -57,7 +66,27 @@ class _StepBase:
         return torch.autocast("cuda", dtype=self.autocast_dtype, cache_enabled=self.autocast_cache)
 
     def _finish(self, loss: torch.Tensor) -> torch.Tensor:
-        loss.backward()
+        if self.grad_accum > 1:
+            (loss / self.grad_accum).backward()
+            self._micro += 1
+            self.synced = self._micro % self.grad_accum == 0
+            if not self.synced:
+                return loss.detach()
+        else:
+            loss.backward()
+        return self._apply(loss)
+
+    def flush(self) -> bool:
+        """End of an epoch with micro-batches still pending: take the optimizer step on what has accumulated (accelerate
+        syncs on the last batch of the dataloader in the same way).  True when a step was taken."""
+        if self.grad_accum > 1 and self._micro % self.grad_accum != 0:
+            self._micro = 0
+            self.synced = True
+            self._apply(None)
+            return True
+        return False
+
+    def _apply(self, loss: Optional[torch.Tensor]):
         if self.bucket is not None:
             self.bucket.all_reduce()
         else:
@@ -75,7 +104,7 @@ class _StepBase:
             self.bucket.zero()
         else:
             self.model.zero_grad(set_to_none=True)
-        return loss.detach()
+        return loss.detach() if loss is not None else None
 
 
 class RagE2EStep(_StepBase):

