@@ -141,7 +141,179 @@ class TimedOps:
         return out
 
 
-def cpu_reference_baseline(max_seconds=90.0):
+def cpu_loss_path_baseline(batch_cpu, V):
+    """SURVEY 8d level (i), the like-for-like number for what this repo replaces: the reference's LOSS PATH op sequence
+    (oracle ref_*: mean-pool + normalise x2, get_cosine_sim, get_nt_xent_loss x2, compute_marginalized_loss_from_logits),
+    forward + backward in fp32 at the step's full shapes on the host cores - beside `roofline.loss_path_us`."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import dalm_oracle as O
+
+    threads = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(threads)
+    B, Tq, Tp, Tg, D = CFG["B"], CFG["Tq"], CFG["Tp"], CFG["Tg"], CFG["D"]
+    g = torch.Generator().manual_seed(0)
+    hq = torch.randn(B, Tq, D, generator=g, requires_grad=True)
+    hp = torch.randn(B, Tp, D, generator=g, requires_grad=True)
+    logits = torch.randn(B, Tg, V, generator=g, requires_grad=True)
+    best = None
+    for it in range(3):
+        for t in (hq, hp, logits):
+            t.grad = None
+        t0 = time.time()
+        q = O.ref_retrieval_embed(hq, batch_cpu["retriever_query_attention_mask"])
+        p = O.ref_retrieval_embed(hp, batch_cpu["retriever_passage_attention_mask"])
+        out = O.ref_step_loss(q, p, logits, batch_cpu["generator_input_input_ids"], batch_cpu["generator_input_attention_mask"],
+                              batch_cpu["query_passage_input_len"], CFG["logit_scale"])
+        out["loss"].backward()
+        dt = time.time() - t0
+        if it > 0:                       # first pass warms the thread pool / allocator
+            best = dt if best is None else min(best, dt)
+    return {"ms": 1e3 * best, "cores": threads, "kind": "port",
+            "what": f"reference loss-path op sequence (oracle ref_*), fwd+bwd, fp32, [B={B},Tg={Tg},V={V}] logits + pooling of "
+                    f"[{B},{Tq}|{Tp},{D}] token states; min of 2 after a warm-up"}
+
+
+def gpu_loss_path_probe(dev, batch, dtype, V, iters=20):
+    """GPU time of the HIP loss path alone at the step's shapes (pool + normalise x2, similarity / contrastive, marginalised CE
+    with the gradient written in the same pass, finalize, and the backward of all of them down to the token states): tower
+    outputs are random tensors of the right shapes, `iters` forward+backward passes are captured in ONE hipGraph so the host
+    is out of the number.  Returns microseconds per pass."""
+    from dalm_amd.fused import pool_l2norm, rag_e2e_loss
+
+    B, Tq, Tp, Tg, D = CFG["B"], CFG["Tq"], CFG["Tp"], CFG["Tg"], CFG["D"]
+    g = torch.Generator().manual_seed(0)
+    hq = torch.randn(B, Tq, D, generator=g).to(dev, dtype).requires_grad_(True)
+    hp = torch.randn(B, Tp, D, generator=g).to(dev, dtype).requires_grad_(True)
+    logits = torch.randn(B, Tg, V, generator=g).to(dev, dtype).requires_grad_(True)
+
+    def one():
+        q = pool_l2norm(hq, batch["retriever_query_attention_mask"], True)
+        p = pool_l2norm(hp, batch["retriever_passage_attention_mask"], True)
+        loss = rag_e2e_loss(q, p, logits, batch["generator_input_input_ids"], batch["generator_input_attention_mask"],
+                            batch["query_passage_input_len"], CFG["logit_scale"], inplace_grad=True)
+        loss.backward()
+        hq.grad = hp.grad = logits.grad = None
+
+    how = "hipGraph of %d passes" % iters
+    try:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                one()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for _ in range(iters):
+                one()
+        gr.replay()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); gr.replay(); b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b) * 1e3 / iters)
+        us = sorted(ts)[len(ts) // 2]
+    except Exception as e:   # same kernels launched eagerly: the host launch path is then inside the number
+        torch.cuda.synchronize()
+        how = f"eager launches (graph capture failed: {e!r}): includes host launch gaps"
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            one()
+        b.record()
+        torch.cuda.synchronize()
+        us = a.elapsed_time(b) * 1e3 / iters
+    return us, how
+
+
+def collect_ce_traffic(workload, dtype, V, timeout_s=150):
+    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes run NOW, around tools/ce_traffic_probe.py (the
+    same kernel at the bench's shapes and masks): FETCH_SIZE and WRITE_SIZE in separate passes, FETCH doubled as the gfx950
+    guide prescribes.  Returns (bytes or None, source string)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "not collected this run: rocprofv3 not on PATH"
+    B, Tg = CFG["B"], CFG["Tg"]
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="dalm_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
+                   str(ROOT / "tools" / "ce_traffic_probe.py"), "--workload", workload, "--dtype", dtype]
+            try:
+                subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=timeout_s,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            except subprocess.TimeoutExpired:
+                return None, f"not collected this run: rocprofv3 --pmc {counter} pass exceeded {timeout_s} s"
+            got = []
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if (r.get("Counter_Name") == counter and "marg_ce" in r["Kernel_Name"]
+                            and int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1) == B * Tg):
+                        got.append(float(r["Counter_Value"]))
+            if not got:
+                return None, f"not collected this run: no {counter} rows for the CE kernel in the rocprofv3 output"
+            vals[counter] = sum(got) / len(got)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    total = 2.0 * vals["FETCH_SIZE"] * 1024.0 + vals["WRITE_SIZE"] * 1024.0
+    return total, (f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) run by this bench.py invocation around "
+                   f"tools/ce_traffic_probe.py (the same kernel, shapes and masks as the timed step): mean over its launches, "
+                   f"FETCH_SIZE x 2 x 1024 (gfx950 correction) + WRITE_SIZE x 1024 = {2.0 * vals['FETCH_SIZE'] * 1024.0:.4g} + "
+                   f"{vals['WRITE_SIZE'] * 1024.0:.4g} bytes")
+
+
+def step_parity_block(dev, model_cpu, batch_cpu):
+    """One fp32 step of the depth-1 full-width model on the HOST through the reference's op sequence (oracle ref_*) and on
+    the GPU through RagE2EStep, same weights (deep copy), dropout off: loss and global gradient norm, relative."""
+    import copy
+
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import dalm_oracle as O
+    from dalm_amd.training.step import RagE2EStep
+
+    model_cpu.eval()
+    model_cpu.zero_grad()
+    m = model_cpu
+    qh = m.retriever_model(batch_cpu["retriever_query_input_ids"], batch_cpu["retriever_query_attention_mask"])[0]
+    ph = m.retriever_model(batch_cpu["retriever_passage_input_ids"], batch_cpu["retriever_passage_attention_mask"])[0]
+    q = O.ref_retrieval_embed(qh, batch_cpu["retriever_query_attention_mask"])
+    p = O.ref_retrieval_embed(ph, batch_cpu["retriever_passage_attention_mask"])
+    logits = m.generator_model(input_ids=batch_cpu["generator_input_input_ids"],
+                               attention_mask=batch_cpu["generator_input_attention_mask"]).logits
+    out = O.ref_step_loss(q, p, logits, batch_cpu["generator_input_input_ids"], batch_cpu["generator_input_attention_mask"],
+                          batch_cpu["query_passage_input_len"], CFG["logit_scale"])
+    out["loss"].backward()
+    params = [x for x in m.parameters() if x.requires_grad]
+    cpu = {"loss": float(out["loss"].detach()),
+           "grad_norm": float(torch.sqrt(sum((x.grad.double() ** 2).sum() for x in params if x.grad is not None)))}
+    m.zero_grad()
+    g = copy.deepcopy(m).to(dev)
+    g.eval()
+    gp = [x for x in g.parameters() if x.requires_grad]
+    step = RagE2EStep(g, torch.optim.SGD(gp, lr=0.0), None, CFG["logit_scale"], autocast_dtype=None, inplace_grad=True,
+                      overlap_towers=False, track_grad_norm=True)
+    loss = step({k: v.to(dev) for k, v in batch_cpu.items()})
+    gpu = {"loss": float(loss), "grad_norm": float(step.grad_norm)}
+    del g, step
+    torch.cuda.empty_cache()
+    rel = {k: abs(gpu[k] - cpu[k]) / max(abs(cpu[k]), 1e-30) for k in cpu}
+    return {"what": "one fp32 step, depth-1 towers at full cfg3 width (bge-large 1024, Llama-2-7b 4096 / V 32000, LoRA), batch 18, "
+                    "dropout off: HIP loss path + PyTorch-ROCm towers vs the reference op sequence (oracle ref_*) on the host",
+            "host": cpu, "gpu": gpu, "rel": rel, "tolerance": 1e-3, "ok": max(rel.values()) <= 1e-3}
+
+
+def cpu_reference_baseline(max_seconds=90.0, parity_dev=None):
     """Reference CPU path on the host cores, bounded (~25 s): the oracle restatement of the reference's
     loss code at the full cfg3 shapes around the same HF architectures (LoRA, fp32) at depth 1 and
     depth 2 instead of 24 / 32 layers, one step each; the per-layer increment is extrapolated to full
@@ -155,6 +327,7 @@ def cpu_reference_baseline(max_seconds=90.0):
     torch.set_num_threads(threads)
     dev = torch.device("cpu")
     times = {}
+    parity = None
     t_start = time.time()
     for depth in (1, 2):
         model = build_models(dev, torch.float32, bert_layers=depth, llama_layers=depth)
@@ -182,6 +355,11 @@ def cpu_reference_baseline(max_seconds=90.0):
         t0 = time.time()
         step()
         times[depth] = time.time() - t0
+        if depth == 1 and parity_dev is not None:
+            try:        # the weights have taken two Adam steps by now: lora_B is no longer zero, both LoRA factors carry gradient
+                parity = step_parity_block(parity_dev, model, batch)
+            except Exception as e:
+                parity = {"ok": None, "error": repr(e)}
         del model, opt
         if time.time() - t_start > max_seconds:
             break
@@ -197,7 +375,7 @@ def cpu_reference_baseline(max_seconds=90.0):
     else:
         full = times[1] * 30.0
         note = f"depth-1 towers only ({times[1]:.2f} s/step, {threads} threads) x30 (time bound hit before depth 2)"
-    return {"value": CFG["B"] / full, "unit": "training pairs/s", "cores": threads, "kind": "port", "sample": note}
+    return {"value": CFG["B"] / full, "unit": "training pairs/s", "cores": threads, "kind": "port", "sample": note}, parity
 
 
 def main():
@@ -206,6 +384,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the two rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE of the dominant kernel, ~30 s) that fill "
+                         "roofline.traffic")
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-overlap", action="store_true", help="run the retriever towers on the main stream")
     ap.add_argument("--graph-collectives", action="store_true",
@@ -214,10 +395,13 @@ def main():
                     help="graph the tower fwd/bwd and keep collectives eager (the default when --gpus > 1)")
     ap.add_argument("--fuse-lm-head", action="store_true",
                     help="SURVEY 8(f) rank 1: chunked lm_head + CE, the [B,Tg,V] logits are never materialised")
-    ap.add_argument("--data-path", default="fixed", choices=["fixed", "bucketed"],
-                    help="fixed (default, the named configuration): every batch padded to Tq50/Tp128/Tg256; bucketed: the "
-                         "trainer's opt-in --length_bucketing + --trim_padding applied to a pool of synthetic rows "
-                         "(an extra line next to the headline, never the headline)")
+    ap.add_argument("--data-path", default="fixed", choices=["fixed", "bucketed", "loader"],
+                    help="fixed (default, the named configuration): every batch padded to Tq50/Tp128/Tg256 and resident in HBM "
+                         "before the timed region; loader: the same rows fed through the trainer's host data path inside the "
+                         "timed loop (ShardedBatches: int32 pinned columns, one index_select per column into pinned staging, "
+                         "H2D of batch i+1 on a copy stream) - shows what the loader costs the step; bucketed: the trainer's "
+                         "opt-in --length_bucketing + --trim_padding applied to a pool of synthetic rows "
+                         "(extra lines next to the headline, never the headline)")
     ap.add_argument("--all-rows", action="store_true",
                     help="with --fuse-lm-head: run the padding rows through the lm_head GEMMs too (sample chunks)")
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg5", "cfg2", "cfg1"],
@@ -285,8 +469,18 @@ def main():
     if use_graph:
         step = GraphedStep(step, max_graphs=8 if args.data_path == "fixed" else 32)
     # a few distinct pre-staged batches (inputs resident in HBM before the timed region)
+    loader = None
     if args.data_path == "fixed":
         batches = [synthetic_batch(dev, 100 + 17 * rank + i, V=V) for i in range(4)]
+    elif args.data_path == "loader":
+        from dalm_amd.training.common import ShardedBatches
+
+        nb = args.steps + max(args.warmup, 1) + 2
+        pool = [synthetic_batch(torch.device("cpu"), 100 + 17 * rank + i, V=V) for i in range(nb)]
+        rows = {k: torch.cat([b[k] for b in pool]) for k in pool[0]}          # a tokenised dataset of nb * 18 rows
+        loader = ShardedBatches(rows, CFG["B"], 0, 1, 1234, list(rows.keys()))
+        stream = loader.epoch(0, dev, 0)
+        batches = None
     else:
         batches = bucketed_batches(dev, 100 + 17 * rank, V)
         args.warmup = max(args.warmup, len(batches))   # one hipGraph per trimmed shape, all captured before the timed region
@@ -301,21 +495,26 @@ def main():
 
     # graphs are captured during the first untimed step; with --warmup 0 one untimed step still runs so that
     # the capture never lands inside the timed region
+    def next_batch(i):
+        return next(stream) if loader is not None else batches[i % len(batches)]
+
     for i in range(max(args.warmup, 1)):
-        step(batches[i % len(batches)])
+        step(next_batch(i))
     torch.cuda.synchronize()
     barrier(comm)
     graphed = use_graph and getattr(step, "graph", None) is not None
     ops.enabled = not graphed  # HIP events cannot bracket a kernel inside a replayed graph
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss = step(batches[i % len(batches)])
+        loss = step(next_batch(i))
     torch.cuda.synchronize()
     barrier(comm)
     elapsed = time.perf_counter() - t0
     ops.enabled = False
     loss_val = float(loss)
     probe_note = "HIP events around the launch in every timed step"
+    if batches is None:                                   # loader mode: probes below use plain resident batches
+        batches = [synthetic_batch(dev, 100 + 17 * rank + i, V=V) for i in range(4)]
     if graphed:
         # the timed region replays a hipGraph; time the dominant kernel live with HIP events in a few
         # eager launches of the very same step right after it (not part of `value`)
@@ -349,17 +548,18 @@ def main():
         # cannot share a pass, and counters perturb timing, so they are never collected inside the timed run):
         # tools/pmc_bench.sh writes profiles/roofline_traffic.json; the value is per launch, FETCH doubled as the
         # gfx950 guide prescribes.  Only quoted for the workload/dtype it was collected on.
-        traffic, traffic_source = None, None
-        tfile = ROOT / "profiles" / "roofline_traffic.json"
-        if tfile.exists():
+        traffic, traffic_source = None, "not collected this run"
+        if args.gpus == 1 and not args.no_pmc and not args.fuse_lm_head and args.data_path != "bucketed":
             try:
-                tj = json.loads(tfile.read_text())
-                if (tj.get("workload", "cfg3") == args.workload and tj.get("dtype", "bf16") == args.dtype
-                        and not args.fuse_lm_head):   # collected on the materialised-logits launch
-                    traffic = tj.get("bench_marg_ce_bytes_per_launch")
-                    traffic_source = tj.get("source", "profiles/roofline_traffic.json (separate rocprofv3 --pmc passes)")
-            except Exception:
-                traffic = None
+                traffic, traffic_source = collect_ce_traffic(args.workload, args.dtype, V)
+            except Exception as e:
+                traffic, traffic_source = None, f"not collected this run: {e!r}"
+        loss_path_us, loss_path_how = None, None
+        if args.gpus == 1 and not args.fuse_lm_head:
+            try:
+                loss_path_us, loss_path_how = gpu_loss_path_probe(dev, batches[0], torch.bfloat16 if args.dtype == "bf16" else torch.float32, V)
+            except Exception as e:
+                loss_path_how = f"failed: {e!r}"
         value = args.gpus * B * args.steps / elapsed
         out = {
             "metric": "training pairs/sec (global batch) RAG-e2e bge-large+" + ("Llama-2-7b" if gen_name == "llama-2-7b" else "Falcon-7B"),
@@ -372,8 +572,10 @@ def main():
                                    "LoRA r=8 both towers, per-GPU batch 18, Tq50/Tp128/Tg256, logit_scale 100, Adam, "
                                    + ("bf16 weights + autocast" if args.dtype == "bf16" else "fp32 weights, no autocast")
                                    + ("" if args.data_path == "fixed" else
-                                      "; DATA PATH: length-bucketed batches with all-padding columns trimmed (the trainer's opt-in "
-                                      "--length_bucketing --trim_padding), fewer tokens per pair than the named configuration"),
+                                      ("; DATA PATH: batches come through the trainer's host loader inside the timed loop (ShardedBatches: "
+                                       "pinned int32 columns, staged index_select, H2D on a copy stream)" if args.data_path == "loader" else
+                                       "; DATA PATH: length-bucketed batches with all-padding columns trimmed (the trainer's opt-in "
+                                       "--length_bucketing --trim_padding), fewer tokens per pair than the named configuration")),
                        "global_batch": args.gpus * B, "parallelism": f"dp{args.gpus} + sharded in-batch negatives",
                        "ranks_seen_by_process_group": ranks_seen, "collective_backend": backend + (" (= RCCL)" if backend == "nccl" else ""),
                        "spawned_by": os.environ.get("TORCHELASTIC_RUN_ID") and "torch.distributed.run" or
@@ -399,6 +601,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": f"marg_ce_row kernel (fused fwd+grad, {args.dtype} logits, V={V})",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": traffic_source,
+                         "loss_path_us": loss_path_us,
+                         "loss_path_note": (f"whole HIP loss path of one step (pool+normalise x2, similarity/contrastive, fused CE fwd+grad, "
+                                            f"finalize, and their backward) run alone at the step's shapes, {args.dtype} tower outputs: "
+                                            f"{loss_path_how}; beside cpu_baseline.loss_path"),
                          "avg_launch_us": ce_avg_s * 1e6, "algorithmic_bytes": alg_bytes,
                          "live_rows_per_launch": live_rows, "dense_rows_per_launch": B * (Tg - 1),
                          "dense_definition_GBps": dense_bytes / ce_avg_s / 1e9 if ce_avg_s > 0 else 0.0,
@@ -408,10 +614,16 @@ def main():
         }
         if args.gpus == 1 and not args.no_cpu_baseline and args.workload == "cfg3":
             try:
-                out["cpu_baseline"] = cpu_reference_baseline()
+                out["cpu_baseline"], parity = cpu_reference_baseline(parity_dev=dev)
+                if parity is not None:
+                    out["parity"] = parity
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "training pairs/s", "cores": os.cpu_count(),
                                        "kind": "port", "sample": f"failed: {e!r}"}
+            try:
+                out["cpu_baseline"]["loss_path"] = cpu_loss_path_baseline(synthetic_batch(torch.device("cpu"), 100, V=V), V)
+            except Exception as e:
+                out["cpu_baseline"]["loss_path"] = {"ms": None, "what": f"failed: {e!r}"}
         print(json.dumps(out), flush=True)
     barrier(comm)
     if torch.distributed.is_available() and torch.distributed.is_initialized():

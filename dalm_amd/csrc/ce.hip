@@ -609,6 +609,57 @@ __global__ __launch_bounds__(1024) void ce_finalize_kernel(const float* __restri
   if (threadIdx.x == 0) out[0] = s / stats[0];
 }
 
+// ---- finalize with k retrieved contexts per sample (RAG-token marginalisation; the reference is k = 1) ----
+// One workgroup walks the samples in order (B k Tg is a few thousand values): deterministic, no atomics.
+//   part A (rows before the cut of sequence (b,c)):  sum_c sum_{t < cut_bc} row_nll[b,c,t] / k
+//   part B (answer row j of sample b):                -logsumexp_c( doc_lp[b,c] - row_nll[b,c,cut_bc + j] )
+__global__ __launch_bounds__(256) void ce_finalize_topk_kernel(const float* __restrict__ row_nll, int B, int k, int Tg,
+                                                               const int64_t* __restrict__ cut,
+                                                               const float* __restrict__ Nb,
+                                                               const float* __restrict__ doc_lp,
+                                                               const float* __restrict__ stats, float* __restrict__ out,
+                                                               float* __restrict__ weights) {
+  __shared__ float red[4];
+  const float M = stats[0], invk = 1.f / static_cast<float>(k);
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const int nans = static_cast<int>(Nb[b]);
+    for (int c = 0; c < k; ++c) {
+      const int64_t base = (static_cast<int64_t>(b) * k + c) * Tg;
+      const int cu = static_cast<int>(min<int64_t>(max<int64_t>(cut[b * k + c], 0), Tg));
+      for (int t = threadIdx.x; t < Tg; t += 256) {
+        if (t < cu) s += row_nll[base + t] * invk;
+        if (weights) weights[base + t] = (t < cu) ? invk / M : 0.f;
+      }
+    }
+    for (int j = threadIdx.x; j < nans; j += 256) {
+      float mx = -INFINITY;
+      for (int c = 0; c < k; ++c) {
+        const int t = static_cast<int>(cut[b * k + c]) + j;
+        const float v = (t >= 0 && t < Tg) ? doc_lp[b * k + c] - row_nll[(static_cast<int64_t>(b) * k + c) * Tg + t] : -INFINITY;
+        mx = fmaxf(mx, v);
+      }
+      float se = 0.f;
+      for (int c = 0; c < k; ++c) {
+        const int t = static_cast<int>(cut[b * k + c]) + j;
+        if (t >= 0 && t < Tg) se += __expf(doc_lp[b * k + c] - row_nll[(static_cast<int64_t>(b) * k + c) * Tg + t] - mx);
+      }
+      s -= mx + __logf(se);
+      if (weights)
+        for (int c = 0; c < k; ++c) {
+          const int t = static_cast<int>(cut[b * k + c]) + j;
+          if (t >= 0 && t < Tg) {
+            const int64_t at = (static_cast<int64_t>(b) * k + c) * Tg + t;
+            weights[at] = __expf(doc_lp[b * k + c] - row_nll[at] - mx) / se / M;
+          }
+        }
+    }
+    __syncthreads();      // the weights of sample b are complete before the next sample's rows overwrite nothing of it
+  }
+  s = block_sum<256>(s, red);
+  if (threadIdx.x == 0) out[0] = s / M;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void scale_inplace_kernel(T* x, int64_t n, const float* __restrict__ gscale) {
   constexpr int VEC = Elt<T>::VEC;
@@ -811,6 +862,19 @@ extern "C" int dalm_marg_ce_finalize(const float* row_nll, int64_t num_rows, con
   DALM_REQUIRE(num_rows > 0 && B > 0, DALM_E_SHAPE, "need num_rows>0, B>0");
   hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1024), 0, as_stream(stream), row_nll, num_rows, Nb,
                      doc_lp, static_cast<int>(B), stats, out);
+  return check_launch(__func__);
+}
+
+extern "C" int dalm_marg_ce_finalize_topk(const float* row_nll, int64_t B, int64_t k, int64_t Tg, const int64_t* cut,
+                                          const float* Nb, const float* doc_lp, const float* stats, float* out,
+                                          float* weights, dalm_stream_t stream) {
+  DALM_REQUIRE(row_nll && Nb && doc_lp && stats && out, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(B > 0 && k > 0 && Tg > 0 && B * k * Tg < (1ll << 31), DALM_E_SHAPE, "need B, k, Tg > 0");
+  if (k == 1 && !weights)      // the reference's case: the SAME kernel and reduction order as dalm_marg_ce_finalize, bit for bit
+    return dalm_marg_ce_finalize(row_nll, B * Tg, Nb, doc_lp, B, stats, out, stream);
+  DALM_REQUIRE(cut, DALM_E_NULL, "cut is required for k > 1 (or when the weights are asked for)");
+  hipLaunchKernelGGL(ce_finalize_topk_kernel, dim3(1), dim3(256), 0, as_stream(stream), row_nll, static_cast<int>(B),
+                     static_cast<int>(k), static_cast<int>(Tg), cut, Nb, doc_lp, stats, out, weights);
   return check_launch(__func__);
 }
 

@@ -37,6 +37,7 @@ SIGNATURES = {
     "dalm_marg_ce_bwd": (_int, [_vp, _int, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dalm_scale_inplace": (_int, [_vp, _int, _i64, _vp, _vp]),
     "dalm_marg_ce_finalize": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "dalm_marg_ce_finalize_topk": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dalm_doc_logprob_fwd": (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "dalm_doc_logprob_bwd": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _int, _vp]),
     "dalm_gather_nll": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),

@@ -321,6 +321,22 @@ class HipOps:
                  Nb.shape[0], hip.ptr(stats), hip.ptr(out), hip.stream())
         return out
 
+    def ce_finalize_topk(self, row_nll, cut, Nb, doc_lp, stats, want_weights: bool = False):
+        """L_gen with k retrieved contexts per sample (`dalm_marg_ce_finalize_topk`): row_nll [B,k,Tg], cut [B,k] int64,
+        Nb [B], doc_lp [B,k], stats[0] = M.  Returns (out [1], weights [B,k,Tg] or None).  k = 1 without weights is
+        `ce_finalize` bit for bit."""
+        dev = hip.require_gpu(row_nll, Nb, doc_lp, stats)
+        B, k, Tg = row_nll.shape
+        row_nll, doc_lp, Nb = hip.as_f32c(row_nll), hip.as_f32c(doc_lp), hip.as_f32c(Nb)
+        cut = hip.as_i64(cut).contiguous()
+        if doc_lp.shape != (B, k) or cut.shape != (B, k) or Nb.shape != (B,):
+            raise ValueError(f"shapes: row_nll {tuple(row_nll.shape)}, cut {tuple(cut.shape)}, Nb {tuple(Nb.shape)}, doc_lp {tuple(doc_lp.shape)}")
+        out = torch.empty((1,), device=dev, dtype=torch.float32)
+        w = torch.empty((B, k, Tg), device=dev, dtype=torch.float32) if want_weights else None
+        hip.call("dalm_marg_ce_finalize_topk", hip.ptr(row_nll), B, k, Tg, hip.ptr(cut), hip.ptr(Nb), hip.ptr(doc_lp),
+                 hip.ptr(stats), hip.ptr(out), hip.ptr(w) if w is not None else None, hip.stream())
+        return out, w
+
     # ---- get_nll / marginalize_log_probs drop-ins -----------------------------------
     def gather_nll(self, log_probs: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         dev = hip.require_gpu(log_probs, labels)

@@ -202,6 +202,23 @@ int dalm_marg_ce_finalize(const float* row_nll, int64_t num_rows,
                           const float* Nb, const float* doc_lp, int64_t B,
                           const float* stats, float* out, dalm_stream_t stream);
 
+/* The same reduction with a CONTEXT extent k ("marginalisation over top-k passages": the reference is the k = 1 case,
+ * train_utils.py:123-124, and only muses about more at train_rage2e.py:461-462).  Sample b is generated under k retrieved
+ * contexts: row_nll [B,k,Tg] holds, per sequence (b,c), what dalm_marg_ce_fwd leaves (m (lse - x_y) per shifted row);
+ * cut [B,k] = first row of (b,c) that belongs to the answer (qlen - 1, the python slice start of train_utils.py:106);
+ * Nb [B] = live answer rows (the answer text is the same under every context); doc_lp [B,k] = log p(context c | query b);
+ * stats[0] = M = (live rows over all B k sequences) / k.
+ *   out[0] = ( sum_b [ 1/k sum_c sum_{t < cut_bc} row_nll[b,c,t]
+ *                      - sum_{j < Nb_b} logsumexp_c( doc_lp[b,c] - row_nll[b,c,cut_bc + j] ) ] ) / M
+ * (RAG-token: every answer token is marginalised over the contexts; prompt rows, which differ per context, enter with
+ * weight 1/k).  k = 1 with weights == NULL IS dalm_marg_ce_finalize (same kernel, same bits; cut may be NULL).
+ * weights [B,k,Tg] (may be NULL) receives -d out[0] / d(log-prob of the label at that row): 1/(k M) before the cut,
+ * softmax_c(...) / M on answer rows - the per-row factor a backward pass multiplies (softmax - onehot) with. */
+int dalm_marg_ce_finalize_topk(const float* row_nll, int64_t B, int64_t k, int64_t Tg,
+                               const int64_t* cut, const float* Nb, const float* doc_lp,
+                               const float* stats, float* out, float* weights,
+                               dalm_stream_t stream);
+
 /* doc_lp[b] = S[b,b] - logsumexp_j S[b,j] on a materialised S
  * (train_utils.py:124), plus its backward
  *   dS[b,j] += coef[b] * ([j==b] - exp(S_bj - row_lse[b])). */

@@ -231,6 +231,36 @@ def closed_chunked(q, p, logits, ids, mask, qlen, scale, dlogits_got: Optional[t
     return out
 
 
+def closed_gen_loss_topk(label_lp: torch.Tensor, mask: torch.Tensor, cut: torch.Tensor, doc_lp: torch.Tensor) -> Dict:
+    """Generator loss with k retrieved contexts per sample (RAG-token marginalisation; the reference, train_utils.py:113-138,
+    is the k = 1 case and is what pins this function: at k = 1 it must equal `closed_forward`'s generator term).
+    label_lp [B,k,T]: log-prob of the label at every shifted row of sequence (b,c); mask [B,k,T] (m_bt of that sequence);
+    cut [B,k]: first answer row; doc_lp [B,k].  Answer token j of sample b sits at row cut_bc + j of sequence (b,c).
+        L = -( sum_b [ 1/k sum_c sum_{t<cut_bc} m lp  +  sum_j log sum_c exp(doc_lp_bc + lp[b,c,cut_bc+j]) ] ) / M,
+        M = (sum of all masks) / k.
+    Written through PROBABILITIES (sum_c p(c) p(y|c)), not through logsumexp, so that it is an independent statement."""
+    B, k, T = label_lp.shape
+    dt = label_lp.dtype
+    m = mask.to(dt)
+    M = m.sum() / k
+    tot = torch.zeros((), dtype=dt)
+    nans = []
+    for b in range(B):
+        n_b = None
+        for c in range(k):
+            cu = int(cut[b, c])
+            tot = tot + (m[b, c, :cu] * label_lp[b, c, :cu]).sum() / k
+            n_c = int(m[b, c, cu:].sum())
+            assert bool((m[b, c, cu:cu + n_c] == 1).all()), "answer rows must be contiguous and live"
+            assert n_b is None or n_b == n_c, "the answer has the same length under every context"
+            n_b = n_c
+        nans.append(n_b)
+        for j in range(n_b):
+            p = sum(torch.exp(doc_lp[b, c]) * torch.exp(label_lp[b, c, int(cut[b, c]) + j]) for c in range(k))
+            tot = tot + torch.log(p)
+    return {"generator": -tot / M, "M": M, "Nb": torch.tensor(nans, dtype=dt)}
+
+
 # ---------------------------------------------------------------------------
 # OracleOps: the dalm_amd.ops.HipOps interface on CPU tensors (float64 inside).
 # Injected by tests/test_sharded_gloo.py to exercise the world_size>1 host logic

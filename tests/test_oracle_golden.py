@@ -121,3 +121,24 @@ def test_closed_chunked_equals_closed_form_and_reference_golden():
         torch.testing.assert_close(c["dq"], z["ref64_dq"], rtol=1e-9, atol=1e-11)
         torch.testing.assert_close(c["dp"], z["ref64_dp"], rtol=1e-9, atol=1e-11)
         assert c["dlogits_err"] <= 1e-10 and c["dlogits_max_err"] <= 1e-10, (case, c["dlogits_err"])
+
+
+def test_topk_marginalisation_reduces_to_the_reference_at_k1():
+    """`closed_gen_loss_topk` (k retrieved contexts, used to check dalm_marg_ce_finalize_topk) at k = 1 on a reference golden:
+    it must reproduce the generator loss the REFERENCE computed (train_utils.py:113-138)."""
+    import dalm_oracle as O
+    from helpers import load_npz
+
+    for case in ("loss_base_right_pad", "loss_left_pad", "loss_qlen_one", "loss_partial_batch_3"):
+        z = load_npz(case)
+        logits, ids, mask, qlen = z["logits"].double(), z["ids"], z["mask"], z["qlen"]
+        S = z["ref64_S"].double()
+        T = logits.shape[1] - 1
+        lp = torch.log_softmax(logits[:, :-1], dim=2).gather(2, ids[:, 1:].unsqueeze(2)).squeeze(2)
+        cut = O._cut_rows(qlen.reshape(-1), T).clamp(max=T)
+        doc = torch.log_softmax(S, dim=1).diag()
+        m = mask[:, 1:]
+        if not all(bool((m[b, int(cut[b]):int(cut[b]) + int(m[b, int(cut[b]):].sum())] == 1).all()) for b in range(len(cut))):
+            continue      # (left-padded rows whose cut falls into the padding: not the layout this helper states)
+        got = O.closed_gen_loss_topk(lp.unsqueeze(1), m.unsqueeze(1), cut.unsqueeze(1), doc.unsqueeze(1))
+        assert abs(float(got["generator"]) - float(z["ref64_generator"])) <= 1e-12 * abs(float(z["ref64_generator"]))

@@ -152,14 +152,20 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--only", default="")
+    ap.add_argument("--vocab", type=int, default=0,
+                    help="with --only ce: run the B = 18 shapes of this vocabulary size only (PMC passes: one process per V, "
+                         "because the counter CSV cannot tell two launches of one instantiation with the same grid apart)")
     args = ap.parse_args()
     res = {}
     if args.only in ("", "ce"):
-        res["ce cfg3 B18 Tg256 V32000 f32"] = bench_ce(18, 256, 32000, torch.float32)
-        res["ce cfg3 B18 Tg256 V32000 bf16"] = bench_ce(18, 256, 32000, torch.bfloat16)
-        res["ce cfg5 B18 Tg256 V65024 bf16"] = bench_ce(18, 256, 65024, torch.bfloat16)
-        res["ce cfg5 B18 Tg256 V65024 f32"] = bench_ce(18, 256, 65024, torch.float32)
-        res["ce B144 Tg256 V32000 f32 (8x)"] = bench_ce(144, 256, 32000, torch.float32)
+        for name, B, V, dt in (("ce cfg3 B18 Tg256 V32000 f32", 18, 32000, torch.float32),
+                               ("ce cfg3 B18 Tg256 V32000 bf16", 18, 32000, torch.bfloat16),
+                               ("ce cfg5 B18 Tg256 V65024 bf16", 18, 65024, torch.bfloat16),
+                               ("ce cfg5 B18 Tg256 V65024 f32", 18, 65024, torch.float32),
+                               ("ce B144 Tg256 V32000 f32 (8x)", 144, 32000, torch.float32)):
+            if args.vocab and (V != args.vocab or B != 18):
+                continue
+            res[name] = bench_ce(B, 256, V, dt)
     if args.only in ("", "sim"):
         sizes = [(18, 18), (150, 150), (1200, 1200), (4096, 4096), (16384, 16384)]
         if not args.quick:

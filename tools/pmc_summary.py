@@ -1,7 +1,8 @@
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes for the dalm kernels, PER SHAPE.
 
-Launches are grouped by (kernel instantiation, grid): one template instantiation run at several problem sizes is
-never averaged into one number.  FETCH_SIZE / WRITE_SIZE are in KB.  On gfx950 FETCH_SIZE under-reports wide
+Launches are grouped by (kernel instantiation, grid).  Two problem sizes CAN share both (marg_ce_bwd_kernel<bf16_t,256> runs
+grid 4608 at V = 32000 and at V = 65024 - VERDICT r2), and the counter CSV carries no kernel arguments: tools/pmc_ce.sh therefore
+profiles ONE vocabulary size per process and passes it here as --label.  FETCH_SIZE / WRITE_SIZE are in KB.  On gfx950 FETCH_SIZE under-reports wide
 (16 B/lane) coalesced streaming reads by exactly 2x (MI355X_MICROARCH.md, HBM section): the corrected read bytes
 are 2 * FETCH_SIZE * 1024.  WRITE_SIZE is uncalibrated; it is reported raw.
 
@@ -46,10 +47,13 @@ def main():
     ap.add_argument("--workload", default="cfg3")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--source", default=None)
+    ap.add_argument("--label", default=None, help="printed with every line (e.g. V=32000: the counter CSV has no kernel arguments, "
+                                                  "so shapes that share an instantiation AND a grid are profiled in separate processes)")
     a = ap.parse_args()
     fetch = load(f"{a.root}/fetch/**/*counter_collection.csv", "FETCH_SIZE")
     write = load(f"{a.root}/write/**/*counter_collection.csv", "WRITE_SIZE")
-    print("kernel | blocks | launches | FETCH_SIZE KB/launch (raw) | read bytes/launch (x2 gfx950) | WRITE_SIZE KB/launch (raw) | total bytes/launch")
+    lab = f"{a.label} | " if a.label else ""
+    print(("shape | " if a.label else "") + "kernel | blocks | launches | FETCH_SIZE KB/launch (raw) | read bytes/launch (x2 gfx950) | WRITE_SIZE KB/launch (raw) | total bytes/launch")
     best = None
     for k in sorted(set(fetch) | set(write), key=lambda x: (x[0], x[1])):
         fc, fv = fetch.get(k, [0, 0.0])
@@ -57,7 +61,7 @@ def main():
         f1 = fv / fc if fc else 0.0
         w1 = wv / wc if wc else 0.0
         total = 2 * f1 * 1024 + w1 * 1024
-        print(f"{k[0]} | {k[1]} | {fc or wc} | {f1:.1f} | {2 * f1 * 1024:.4g} | {w1:.1f} | {total:.4g}")
+        print(f"{lab}{k[0]} | {k[1]} | {fc or wc} | {f1:.1f} | {2 * f1 * 1024:.4g} | {w1:.1f} | {total:.4g}")
         if "marg_ce" in k[0] and (best is None or total > best[1]):
             best = (k, total, 2 * f1 * 1024, w1 * 1024)
     if a.json and best:
