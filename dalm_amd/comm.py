@@ -1,16 +1,17 @@
 """`NativeRcclComm`: the communicator interface of dalm_amd.fused (all_gather_rows / all_reduce_sum_) on the
 library's own RCCL binding (`dalm_comm_*` in include/dalm_hip.h) instead of torch.distributed.
 
-Opt-in (`DALM_NATIVE_COMM=1` for the trainers / bench, or construct it directly): the torch.distributed(nccl) path
-stays the default because it is the one that has run on hardware with more than one rank.  Bootstrap without
+`DALM_NATIVE_COMM=1` (trainers / bench) or direct construction; the torch.distributed(nccl) path stays the default only
+because it is the one that has run on hardware with more than one rank (no multi-GPU box was available to rounds 1-3).  Bootstrap without
 torch.distributed: rank 0 asks RCCL for the 128-byte unique id and publishes it through a file next to the
 rendezvous port (`DALM_COMM_ID_FILE`, which `dalm_amd.launch` sets to a path unique to the launch; under other launchers
 `/tmp/dalm_comm_<MASTER_PORT>.id` - remove a stale one after a crashed job), the other ranks poll for it.
 
-Stream contract: a collective is issued on the communicator's own side stream after that stream has been made to wait
-for torch's CURRENT stream, and the current stream is made to wait for the collective before the call returns - the
-caller sees stream-ordered semantics (exactly like torch.distributed's nccl ops) while the hardware is free to overlap
-the collective with work on other streams (e.g. `GatherHandle` runs the call under a side torch stream).
+Stream contract: a collective is enqueued on torch's CURRENT stream (`dalm_comm_*_on`): stream-ordered like any kernel
+launch - no library-owned stream, no events, capturable into a hipGraph with the rest of the step.  Overlap is the caller's
+choice of stream (`GatherHandle` runs the call under a side torch stream; the gradient buckets use their communication
+stream).  Round 2 routed every collective through a stream owned by the communicator and measured 214 ms instead of 180 ms
+per step on one GPU: one more HIP stream shifts the stream -> hardware-queue mapping of the whole process.
 """
 from __future__ import annotations
 
@@ -72,20 +73,14 @@ class NativeRcclComm:
         hip.require_gpu(t)
         t = t.contiguous()
         out = torch.empty((self.world_size * t.shape[0],) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
-        cur = hip.stream()
-        hip.call("dalm_comm_wait_stream", self._h, cur)
-        hip.call("dalm_comm_allgather", self._h, hip.ptr(t), hip.ptr(out), t.numel() * t.element_size())
-        hip.call("dalm_comm_stream_wait", self._h, cur)
+        hip.call("dalm_comm_allgather_on", self._h, hip.ptr(t), hip.ptr(out), t.numel() * t.element_size(), hip.stream())
         return out
 
     def all_reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
         hip.require_gpu(t)
         if t.dtype != torch.float32 or not t.is_contiguous():
             raise TypeError("NativeRcclComm.all_reduce_sum_ needs a contiguous float32 tensor")
-        cur = hip.stream()
-        hip.call("dalm_comm_wait_stream", self._h, cur)
-        hip.call("dalm_comm_allreduce_sum_f32", self._h, hip.ptr(t), t.numel())
-        hip.call("dalm_comm_stream_wait", self._h, cur)
+        hip.call("dalm_comm_allreduce_sum_f32_on", self._h, hip.ptr(t), t.numel(), hip.stream())
         return t
 
     def close(self) -> None:

@@ -3,8 +3,9 @@
 // What crosses GPUs per step (the reference's DDP all-reduce is dalm/training/rag_e2e/
 // train_rage2e.py:416-418,471 - it never gathers embeddings): all-gather of the [B_l, D] f32 embeddings, a
 // [B_l,4] stats all-gather, the 1-float token count and the LoRA gradient buckets (SUM).  All of them run on a
-// side HIP stream owned by the communicator; ordering against the caller's streams is explicit
-// (dalm_comm_wait_stream / dalm_comm_stream_wait: hipEvents), so a gather can overlap the other tower.
+// stream the caller names (dalm_comm_*_on: what the Python host code uses - stream-ordered, capturable, no library-owned
+// stream), or on a side HIP stream owned by the communicator with explicit ordering against the caller's streams
+// (dalm_comm_wait_stream / dalm_comm_stream_wait: hipEvents; created on first use), so a gather can overlap the other tower.
 //
 // RCCL is bound at run time (dlopen/dlsym): the copy already loaded in the process (torch ships one) is reused,
 // /opt/rocm/lib/librccl.so is the fallback; libdalm_hip.so itself has no link-time dependency on RCCL.
@@ -12,6 +13,7 @@
 #include "common.hpp"
 #include <dlfcn.h>
 #include <string.h>
+#include <mutex>
 
 namespace {
 
@@ -79,6 +81,9 @@ struct dalm_comm {
   hipStream_t stream = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
   int rank = 0, world = 1, device = 0;
+  // record + wait on the shared event pair is one critical section: the main thread's gathers and the autograd thread's
+  // gradient-bucket hooks may both order themselves against the side stream
+  std::mutex mu;
 };
 
 using namespace dalm;
@@ -104,28 +109,29 @@ extern "C" int dalm_comm_init(dalm_comm_t** out, const void* id128, int rank, in
   ncclUniqueId id;
   memcpy(id.internal, id128, 128);
   if (int rc = r.CommInitRank(&c->comm, world, id, rank); rc != kNcclSuccess) { delete c; return nccl_fail(rc, __func__); }
-  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming);
-  if (e != hipSuccess) {
-    r.CommDestroy(c->comm);
-    if (c->ev_in) (void)hipEventDestroy(c->ev_in);
-    if (c->ev_out) (void)hipEventDestroy(c->ev_out);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
-    delete c;
-    return hip_fail(e, __func__);
-  }
+  // the side stream and its events are created on first use of the side-stream entry points (ensure_side_stream): a
+  // process that only uses the *_on forms never owns an extra HIP stream
   *out = c;
   return 0;
 }
 
+namespace {
+hipError_t ensure_side_stream(dalm_comm* c) {      // call with c->mu held
+  if (c->stream) return hipSuccess;
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming);
+  return e;
+}
+}  // namespace
+
 extern "C" int dalm_comm_destroy(dalm_comm_t* c) {
   if (!c) return 0;
-  hipError_t e = hipStreamSynchronize(c->stream);
+  hipError_t e = c->stream ? hipStreamSynchronize(c->stream) : hipDeviceSynchronize();
   rccl().CommDestroy(c->comm);
-  (void)hipEventDestroy(c->ev_in);
-  (void)hipEventDestroy(c->ev_out);
-  (void)hipStreamDestroy(c->stream);
+  if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+  if (c->ev_out) (void)hipEventDestroy(c->ev_out);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return e == hipSuccess ? 0 : hip_fail(e, __func__);
 }
@@ -136,6 +142,8 @@ extern "C" int dalm_comm_world(const dalm_comm_t* c) { return c ? c->world : -1;
 // the communicator's stream waits for everything queued so far on `producer`
 extern "C" int dalm_comm_wait_stream(dalm_comm_t* c, dalm_stream_t producer) {
   DALM_REQUIRE(c, DALM_E_NULL, "null communicator");
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (hipError_t e = ensure_side_stream(c); e != hipSuccess) return hip_fail(e, __func__);
   if (hipError_t e = hipEventRecord(c->ev_in, as_stream(producer)); e != hipSuccess) return hip_fail(e, __func__);
   if (hipError_t e = hipStreamWaitEvent(c->stream, c->ev_in, 0); e != hipSuccess) return hip_fail(e, __func__);
   return 0;
@@ -143,6 +151,8 @@ extern "C" int dalm_comm_wait_stream(dalm_comm_t* c, dalm_stream_t producer) {
 // `consumer` waits for everything queued so far on the communicator's stream
 extern "C" int dalm_comm_stream_wait(dalm_comm_t* c, dalm_stream_t consumer) {
   DALM_REQUIRE(c, DALM_E_NULL, "null communicator");
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (hipError_t e = ensure_side_stream(c); e != hipSuccess) return hip_fail(e, __func__);
   if (hipError_t e = hipEventRecord(c->ev_out, c->stream); e != hipSuccess) return hip_fail(e, __func__);
   if (hipError_t e = hipStreamWaitEvent(as_stream(consumer), c->ev_out, 0); e != hipSuccess) return hip_fail(e, __func__);
   return 0;
@@ -152,6 +162,8 @@ extern "C" int dalm_comm_stream_wait(dalm_comm_t* c, dalm_stream_t consumer) {
 extern "C" int dalm_comm_allgather(dalm_comm_t* c, const void* send, void* recv, size_t bytes_per_rank) {
   DALM_REQUIRE(c && send && recv, DALM_E_NULL, "null pointer argument");
   if (bytes_per_rank == 0) return 0;
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (hipError_t e = ensure_side_stream(c); e != hipSuccess) return hip_fail(e, __func__);
   if (int rc = rccl().AllGather(send, recv, bytes_per_rank, kNcclInt8, c->comm, c->stream); rc != kNcclSuccess)
     return nccl_fail(rc, __func__);
   return 0;
@@ -161,7 +173,32 @@ extern "C" int dalm_comm_allgather(dalm_comm_t* c, const void* send, void* recv,
 extern "C" int dalm_comm_allreduce_sum_f32(dalm_comm_t* c, float* buf, size_t n) {
   DALM_REQUIRE(c && buf, DALM_E_NULL, "null pointer argument");
   if (n == 0) return 0;
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (hipError_t e = ensure_side_stream(c); e != hipSuccess) return hip_fail(e, __func__);
   if (int rc = rccl().AllReduce(buf, buf, n, kNcclFloat32, kNcclSum, c->comm, c->stream); rc != kNcclSuccess)
+    return nccl_fail(rc, __func__);
+  return 0;
+}
+
+// The same collectives enqueued on a stream of the CALLER's choice (no side stream, no events): stream-ordered like any
+// kernel launch, capturable into the caller's hipGraph, and the caller decides which of its streams overlaps what
+// (round 2 measured the library-owned extra stream at +19 % step time on one GPU: one more stream shifts the
+// stream -> hardware-queue mapping of the whole process).  RCCL serialises operations of one communicator itself.
+extern "C" int dalm_comm_allgather_on(dalm_comm_t* c, const void* send, void* recv, size_t bytes_per_rank,
+                                      dalm_stream_t stream) {
+  DALM_REQUIRE(c && send && recv, DALM_E_NULL, "null pointer argument");
+  if (bytes_per_rank == 0) return 0;
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (int rc = rccl().AllGather(send, recv, bytes_per_rank, kNcclInt8, c->comm, as_stream(stream)); rc != kNcclSuccess)
+    return nccl_fail(rc, __func__);
+  return 0;
+}
+
+extern "C" int dalm_comm_allreduce_sum_f32_on(dalm_comm_t* c, float* buf, size_t n, dalm_stream_t stream) {
+  DALM_REQUIRE(c && buf, DALM_E_NULL, "null pointer argument");
+  if (n == 0) return 0;
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (int rc = rccl().AllReduce(buf, buf, n, kNcclFloat32, kNcclSum, c->comm, as_stream(stream)); rc != kNcclSuccess)
     return nccl_fail(rc, __func__);
   return 0;
 }

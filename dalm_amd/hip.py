@@ -65,6 +65,8 @@ SIGNATURES = {
     "dalm_comm_stream_wait": (_int, [_vp, _vp]),
     "dalm_comm_allgather": (_int, [_vp, _vp, _vp, _sz]),
     "dalm_comm_allreduce_sum_f32": (_int, [_vp, _vp, _sz]),
+    "dalm_comm_allgather_on": (_int, [_vp, _vp, _vp, _sz, _vp]),
+    "dalm_comm_allreduce_sum_f32_on": (_int, [_vp, _vp, _sz, _vp]),
 }
 
 

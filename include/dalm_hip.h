@@ -309,6 +309,11 @@ int dalm_comm_wait_stream(dalm_comm_t* c, dalm_stream_t producer);
 int dalm_comm_stream_wait(dalm_comm_t* c, dalm_stream_t consumer);
 int dalm_comm_allgather(dalm_comm_t* c, const void* send, void* recv, size_t bytes_per_rank);
 int dalm_comm_allreduce_sum_f32(dalm_comm_t* c, float* buf, size_t n);
+/* The same collectives on a stream the CALLER names (its current stream, a side stream of its own, a capturing stream):
+ * stream-ordered like a kernel launch, no library-owned stream or event involved - what dalm_amd.comm.NativeRcclComm
+ * uses.  Safe to call from several host threads (one mutex per communicator around every enqueue / record+wait). */
+int dalm_comm_allgather_on(dalm_comm_t* c, const void* send, void* recv, size_t bytes_per_rank, dalm_stream_t stream);
+int dalm_comm_allreduce_sum_f32_on(dalm_comm_t* c, float* buf, size_t n, dalm_stream_t stream);
 
 #ifdef __cplusplus
 }

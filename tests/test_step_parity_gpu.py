@@ -524,7 +524,8 @@ def test_gradient_accumulation_takes_one_step_per_n_micro_batches():
     assert step.synced and sched.last_epoch == 1
     for d, da, db in zip(delta(rag), *single):
         want = 0.5 * (da + db)
-        assert float((d - want).abs().max()) <= 1e-5 * max(1e-6, float(want.abs().max())) + 1e-9
+        # (the deltas are ~1e-4 on parameters of size ~1: p - start carries ~4e-9 of f32 cancellation error)
+        assert float((d - want).abs().max()) <= 2e-4 * max(1e-6, float(want.abs().max())) + 1e-8
     # a pending micro-batch at the end of an epoch is flushed into a step
     step(A)
     assert not step.synced and step.flush() and sched.last_epoch == 2 and not step.flush()
