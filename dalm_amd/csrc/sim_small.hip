@@ -77,10 +77,13 @@ __global__ __launch_bounds__(256) void small_partial_kernel(const float* __restr
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int k0 = k_lo; k0 < k_hi; k0 += 32) {  // 4 pairs of float4 per operand per round
-    float4 av[4], bv[4];
+  // 4 pairs of float4 per operand per round (32 of K).  Measured and slower on every shape (round 3): 8 pairs per round
+  // (+0.7 ... +1.6 us per call), more split-K workgroups (DALM_SMALL_TARGET 512 - 1024)
+  constexpr int NU = 4;
+  for (int k0 = k_lo; k0 < k_hi; k0 += 8 * NU) {
+    float4 av[NU], bv[NU];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NU; ++u) {
       const int k = k0 + 8 * u + 4 * lhi;
       if constexpr (FAST) {
         // K % 8 == 0, 16-byte aligned rows: unconditional loads (rows past m / n are clamped to the last row and
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(256) void small_partial_kernel(const float* __restr
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NU; ++u) {
       if (k0 + 8 * u < k_hi) {  // wave-uniform
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u].x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u].y, acc, 0, 0, 0);
@@ -201,8 +204,82 @@ __global__ __launch_bounds__(256) void small_stats_kernel(const float* __restric
   if (lane == 0) (cols ? col_lse : row_lse)[row] = mx + __logf(l);
 }
 
+// Rows longer than 256 (the per-rank blocks of a sharded batch: 150 x 1200, 18 x 144 stays above): ONE WORKGROUP per row of
+// S (or of S^T) instead of one wave - 4x the workgroups (150 instead of 38 at 150 x 1200, where the one-wave form took
+// 17 us of pure latency) and every thread's SK x 8 slab loads of a batch are issued together.  Each thread folds its values
+// into an online (max, sum exp) pair; the 256 pairs are combined through LDS in fixed order.
+__global__ __launch_bounds__(256) void small_stats_wide_kernel(const float* __restrict__ slab, int ldn,
+                                                               const float* __restrict__ slabT, int ldm, int SK, int m,
+                                                               int n, float alpha, int64_t diag_offset,
+                                                               float* __restrict__ S, int64_t ldS,
+                                                               float* __restrict__ row_lse, float* __restrict__ diag,
+                                                               float* __restrict__ col_lse) {
+  __shared__ float red[8];
+  const int tid = threadIdx.x;
+  const bool cols = blockIdx.y != 0;
+  const int R = cols ? n : m, C = cols ? m : n, ld = cols ? ldm : ldn;
+  const int row = blockIdx.x;
+  if (row >= R) return;
+  const float* base = (cols ? slabT : slab) + static_cast<int64_t>(row) * ld;
+  const int64_t ss = static_cast<int64_t>(R) * ld;
+  float mx = -INFINITY, l = 0.f;
+  for (int c0 = 0; c0 < C; c0 += 8 * 256) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = c0 + tid + 256 * u;
+      v[u] = slab_s(base + min(c, C - 1), ss, SK, alpha);      // unconditional, clamped: one batch in flight
+    }
+    float bm = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = c0 + tid + 256 * u;
+      if (c < C) {
+        bm = fmaxf(bm, v[u]);
+        if (!cols) {
+          S[static_cast<int64_t>(row) * ldS + c] = v[u];
+          if (static_cast<int64_t>(c) == diag_offset + row) diag[row] = v[u];
+        }
+      } else {
+        v[u] = -INFINITY;
+      }
+    }
+    if (bm > -INFINITY) {
+      const float mn = fmaxf(mx, bm);
+      l *= fast_exp(mx - mn);                                 // exp(-inf) = 0 on the first batch
+#pragma unroll
+      for (int u = 0; u < 8; ++u) l += fast_exp(v[u] - mn);
+      mx = mn;
+    }
+  }
+  const float M = block_max<256>(mx, red);
+  const float L = block_sum<256>((mx == -INFINITY) ? 0.f : l * fast_exp(mx - M), red);
+  if (tid == 0) (cols ? col_lse : row_lse)[row] = M + __logf(L);
+}
+
+// dst[i] = sum_z src[z * stride + i] (fixed order), float4-wide with a scalar tail: combines the contraction slices of
+// small_grad_kernel
+__global__ __launch_bounds__(256) void small_slice_sum_kernel(const float* __restrict__ src, int nsl, int64_t count,
+                                                              float* __restrict__ dst) {
+  const int64_t n4 = count >> 2;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += gridDim.x * 256ll) {
+    float4 a = reinterpret_cast<const float4*>(src)[i];
+    for (int z = 1; z < nsl; ++z) {
+      const float4 b = reinterpret_cast<const float4*>(src + z * count)[i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    reinterpret_cast<float4*>(dst)[i] = a;
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < count; i += 256) {
+      float a = src[i];
+      for (int z = 1; z < nsl; ++z) a += src[z * count + i];
+      dst[i] = a;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
-// backward from the saved S.  grid (ceil(R/32), ceil(D/32), ndir):
+// backward from the saved S.  grid (ceil(R/32), ceil(D/32), ndir * nsl):
 //   dir 0: dA[i0.., d0..] = alpha * sum_j dS[i][j] Bm[j][d]      (R = m, contraction over n)
 //   dir 1: dB[j0.., d0..] = alpha * sum_i dS[i][j] A[i][d]       (R = n, contraction over m)
 //   dS[i][j] = rc[i] e^{S_ij - rl[i]} + cc[j] e^{S_ij - cl[j]} - [j == off + i] (rc[i] + cc[j])
@@ -217,17 +294,25 @@ constexpr int GK = 256;
 // value.  Vocabulary: "row" = one of the 32 output rows of this workgroup, "k" = contraction index.
 //   dir 0: row = i (query), k = j (passage), S element S[row][k], diag at k == off + row
 //   dir 1: row = j (passage), k = i (query),  S element S[k][row], diag at k == row - off
-__global__ __launch_bounds__(256) void small_grad_kernel(const float* __restrict__ S, int64_t ldS,
+__global__ __launch_bounds__(256, 4) void small_grad_kernel(const float* __restrict__ S, int64_t ldS,
                                                          const float* __restrict__ A, const float* __restrict__ Bm,
                                                          int m, int n, int D, float alpha, int64_t diag_offset,
                                                          const float* __restrict__ rc, const float* __restrict__ rl,
                                                          const float* __restrict__ cc, const float* __restrict__ cl,
-                                                         float* __restrict__ dA, float* __restrict__ dB, int dir0) {
+                                                         float* __restrict__ dA, float* __restrict__ dB, int dir0, int nsl,
+                                                         float* __restrict__ slabA, float* __restrict__ slabB) {
+  // the wave-sum scratch of the epilogue (4 x 32 x 33 floats) overlays the dS strip, which is dead by then: 34 KB instead of
+  // 51 KB of LDS per workgroup = 4 resident workgroups per CU (the VGPR limit) instead of 3
   __shared__ float Ds[GK * RED_STRIDE];
-  __shared__ float red[4 * 32 * RED_STRIDE];
+  float* red = Ds;
+  static_assert(GK * RED_STRIDE >= 4 * 32 * RED_STRIDE, "the reduction scratch must fit into the strip");
   __shared__ float rowc_s[32], rowl_s[32];
+  __shared__ float kc_s[GK], kl_s[GK];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
-  const int dir = dir0 + blockIdx.z;
+  // nsl > 1: the contraction is cut into nsl slices of whole 256-chunks, slice z of direction d is block z = d * nsl + slice
+  // and writes its partial tile into slab[slice] - small_slice_sum_kernel adds them in fixed order (the per-rank blocks of a
+  // sharded batch have few row tiles and a long contraction: 150 x 1200 was 160 workgroups x 5 chunks, 30 us of latency)
+  const int dir = dir0 + static_cast<int>(blockIdx.z) / nsl, slice = static_cast<int>(blockIdx.z) % nsl;
   const int R = dir ? n : m, Kd = dir ? m : n;
   const int r0 = blockIdx.x * 32, d0 = blockIdx.y * 32;
   if (r0 >= R) return;
@@ -235,6 +320,9 @@ __global__ __launch_bounds__(256) void small_grad_kernel(const float* __restrict
   const float* rowc = dir ? cc : rc; const float* rowl = dir ? cl : rl;
   const float* kc = dir ? rc : cc;   const float* kl = dir ? rl : cl;
   float* out = dir ? dB : dA;
+  if (nsl > 1) out = (dir ? slabB : slabA) + static_cast<int64_t>(slice) * R * D;
+  const int nchunks = (Kd + GK - 1) / GK, cps = (nchunks + nsl - 1) / nsl;
+  const int k_begin = slice * cps * GK, k_end = min(Kd, (slice + 1) * cps * GK);
   const int dcol = min(d0 + l31, D - 1);
   const int64_t doff = dir ? -diag_offset : diag_offset;   // diag at k == row + doff
 
@@ -247,7 +335,7 @@ __global__ __launch_bounds__(256) void small_grad_kernel(const float* __restrict
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  for (int k0 = 0; k0 < Kd; k0 += GK) {
+  for (int k0 = k_begin; k0 < k_end; k0 += GK) {
     const int kn = min(GK, Kd - k0);
     const int ns = (kn + 1) >> 1;          // two-wide MFMA steps in the chunk
     const int per = (ns + 3) >> 2;
@@ -280,21 +368,23 @@ __global__ __launch_bounds__(256) void small_grad_kernel(const float* __restrict
     } else {
       const int r = tid & 31, kq = tid >> 5;
       const int row = min(r0 + r, R - 1);
-      float kcv[32], klv[32];
 #pragma unroll
       for (int q = 0; q < 32; ++q) {
         const int k = min(k0 + kq + 8 * q, Kd - 1);
         sv[q] = S[static_cast<int64_t>(k) * ldS + row];
-        kcv[q] = kc[k];
-        klv[q] = kl[k];
       }
+      // the chunk's per-k coefficients go through LDS (one value per thread) instead of 2 x 32 registers per thread: the
+      // kernel drops from 189 to ~128 VGPRs = 4 instead of 2 resident workgroups per CU
+      kc_s[tid] = kc[min(k0 + tid, Kd - 1)];
+      kl_s[tid] = kl[min(k0 + tid, Kd - 1)];
       __syncthreads();
       const float rcv = rowc_s[r], rlv = rowl_s[r];
 #pragma unroll
       for (int q = 0; q < 32; ++q) {
         const int kk = kq + 8 * q;
-        float d = rcv * fast_exp(sv[q] - rlv) + kcv[q] * fast_exp(sv[q] - klv[q]);
-        if (static_cast<int64_t>(k0 + kk) == r0 + r + doff) d -= (rcv + kcv[q]);
+        const float kcv = kc_s[kk], klv = kl_s[kk];
+        float d = rcv * fast_exp(sv[q] - rlv) + kcv * fast_exp(sv[q] - klv);
+        if (static_cast<int64_t>(k0 + kk) == r0 + r + doff) d -= (rcv + kcv);
         Ds[kk * RED_STRIDE + r] = (kk < kn && r0 + r < R) ? d : 0.f;
       }
     }
@@ -359,7 +449,8 @@ inline int64_t round_up(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
 struct SmallPlan { int sk, k_chunk; int64_t ldn, ldm; };
 inline SmallPlan small_plan(int64_t m, int64_t n, int64_t D) {
   const int64_t tiles = ((m + 31) / 32) * ((n + 31) / 32);
-  int64_t sk = (256 + tiles - 1) / tiles;
+  static const int64_t target = getenv("DALM_SMALL_TARGET") ? atoi(getenv("DALM_SMALL_TARGET")) : 256;   // workgroups aimed at
+  int64_t sk = (target + tiles - 1) / tiles;
   const int64_t sk_max = (D + 31) / 32;        // every workgroup gets at least 32 of K (8 per wave)
   if (sk > SK_MAX) sk = SK_MAX;
   if (sk > sk_max) sk = sk_max;
@@ -415,9 +506,66 @@ extern "C" int dalm_sim_small_fwd(const float* A, const float* Bm, int64_t m, in
                        static_cast<int>(n), static_cast<int>(D), pl.k_chunk, tiles_n, static_cast<int>(vec16(A, D)),
                        static_cast<int>(vec16(Bm, D)), slab, static_cast<int>(pl.ldn), slabT, static_cast<int>(pl.ldm));
   const int64_t rmax = want_cols ? (m > n ? m : n) : m;
-  hipLaunchKernelGGL(small_stats_kernel, dim3(static_cast<unsigned>((rmax + 3) / 4), want_cols ? 2u : 1u), dim3(256), 0,
-                     s, slab, static_cast<int>(pl.ldn), slabT, static_cast<int>(pl.ldm), pl.sk, static_cast<int>(m),
-                     static_cast<int>(n), scale, diag_offset, S, ldS, row_lse, diag, col_lse);
+  const int64_t cmax = want_cols ? (m > n ? m : n) : n;                  // longest row the statistics pass reduces
+  if (cmax > 256)
+    hipLaunchKernelGGL(small_stats_wide_kernel, dim3(static_cast<unsigned>(rmax), want_cols ? 2u : 1u), dim3(256), 0,
+                       s, slab, static_cast<int>(pl.ldn), slabT, static_cast<int>(pl.ldm), pl.sk, static_cast<int>(m),
+                       static_cast<int>(n), scale, diag_offset, S, ldS, row_lse, diag, col_lse);
+  else
+    hipLaunchKernelGGL(small_stats_kernel, dim3(static_cast<unsigned>((rmax + 3) / 4), want_cols ? 2u : 1u), dim3(256), 0,
+                       s, slab, static_cast<int>(pl.ldn), slabT, static_cast<int>(pl.ldm), pl.sk, static_cast<int>(m),
+                       static_cast<int>(n), scale, diag_offset, S, ldS, row_lse, diag, col_lse);
+  return check_launch(__func__);
+}
+
+namespace {
+// contraction slices of the backward: as many as keep the grid at <= 1024 workgroups, at most one per 256-chunk; only
+// when ONE direction is asked for (the sharded form; with both directions the grid is already two problems wide)
+inline int small_bwd_slices(int64_t m, int64_t n, int64_t D, bool want_dA, bool want_dB) {
+  if (want_dA == want_dB) return 1;
+  const int64_t R = want_dA ? m : n, Kd = want_dA ? n : m;
+  const int64_t blocks = ((R + 31) / 32) * ((D + 31) / 32), chunks = (Kd + GK - 1) / GK;
+  int64_t nsl = blocks > 0 ? 1024 / blocks : 1;
+  if (nsl > chunks) nsl = chunks;
+  return static_cast<int>(nsl < 1 ? 1 : nsl);
+}
+}  // namespace
+
+extern "C" size_t dalm_sim_small_bwd_workspace_bytes(int64_t m, int64_t n, int64_t D, int want_dA, int want_dB) {
+  if (!dalm_sim_small_supported(m, n, D)) return 0;
+  const int nsl = small_bwd_slices(m, n, D, want_dA != 0, want_dB != 0);
+  if (nsl <= 1) return 0;
+  return static_cast<size_t>(nsl) * static_cast<size_t>(want_dA ? m : n) * static_cast<size_t>(D) * sizeof(float);
+}
+
+extern "C" int dalm_sim_small_bwd_ws(const float* S, int64_t ldS, const float* A, const float* Bm, int64_t m, int64_t n,
+                                     int64_t D, float scale, int64_t diag_offset, const float* row_coef,
+                                     const float* row_lse, const float* col_coef, const float* col_lse, float* dA,
+                                     float* dB, void* ws, size_t ws_bytes, dalm_stream_t stream) {
+  DALM_REQUIRE(S && A && Bm && row_coef && row_lse && col_coef && col_lse, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(dA || dB, DALM_E_NULL, "at least one of dA / dB is required");
+  DALM_REQUIRE(dalm_sim_small_supported(m, n, D), DALM_E_SHAPE, "shape outside the small-batch path");
+  DALM_REQUIRE(ldS >= n, DALM_E_SHAPE, "ldS must be >= n");
+  const int dir0 = dA ? 0 : 1, ndir = (dA && dB) ? 2 : 1;
+  int nsl = small_bwd_slices(m, n, D, dA != nullptr, dB != nullptr);
+  const size_t need = dalm_sim_small_bwd_workspace_bytes(m, n, D, dA != nullptr, dB != nullptr);
+  if (nsl > 1 && (!ws || ws_bytes < need || reinterpret_cast<uintptr_t>(ws) % 16 != 0)) nsl = 1;   // no workspace: unsliced form
+  const int64_t rmax = (ndir == 2) ? (m > n ? m : n) : (dir0 ? n : m);
+  const dim3 grid(static_cast<unsigned>((rmax + 31) / 32), static_cast<unsigned>((D + 31) / 32),
+                  static_cast<unsigned>(ndir * nsl));
+  float* slab = static_cast<float*>(ws);
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(small_grad_kernel, grid, dim3(256), 0, s, S, ldS, A, Bm, static_cast<int>(m),
+                     static_cast<int>(n), static_cast<int>(D), scale, diag_offset, row_coef, row_lse, col_coef, col_lse,
+                     dA, dB, dir0, nsl, dA ? slab : nullptr, dA ? nullptr : slab);
+  if (nsl > 1) {
+    const int64_t count = (dA ? m : n) * D;
+    int64_t blocks = (count / 4 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(small_slice_sum_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, slab, nsl, count,
+                       dA ? dA : dB);
+  }
   return check_launch(__func__);
 }
 
@@ -425,17 +573,8 @@ extern "C" int dalm_sim_small_bwd(const float* S, int64_t ldS, const float* A, c
                                   int64_t D, float scale, int64_t diag_offset, const float* row_coef,
                                   const float* row_lse, const float* col_coef, const float* col_lse, float* dA,
                                   float* dB, dalm_stream_t stream) {
-  DALM_REQUIRE(S && A && Bm && row_coef && row_lse && col_coef && col_lse, DALM_E_NULL, "null pointer argument");
-  DALM_REQUIRE(dA || dB, DALM_E_NULL, "at least one of dA / dB is required");
-  DALM_REQUIRE(dalm_sim_small_supported(m, n, D), DALM_E_SHAPE, "shape outside the small-batch path");
-  DALM_REQUIRE(ldS >= n, DALM_E_SHAPE, "ldS must be >= n");
-  const int dir0 = dA ? 0 : 1, ndir = (dA && dB) ? 2 : 1;
-  const int64_t rmax = (ndir == 2) ? (m > n ? m : n) : (dir0 ? n : m);
-  const dim3 grid(static_cast<unsigned>((rmax + 31) / 32), static_cast<unsigned>((D + 31) / 32), static_cast<unsigned>(ndir));
-  hipLaunchKernelGGL(small_grad_kernel, grid, dim3(256), 0, as_stream(stream), S, ldS, A, Bm, static_cast<int>(m),
-                     static_cast<int>(n), static_cast<int>(D), scale, diag_offset, row_coef, row_lse, col_coef, col_lse,
-                     dA, dB, dir0);
-  return check_launch(__func__);
+  return dalm_sim_small_bwd_ws(S, ldS, A, Bm, m, n, D, scale, diag_offset, row_coef, row_lse, col_coef, col_lse, dA, dB,
+                               nullptr, 0, stream);
 }
 
 extern "C" int dalm_rag_loss_finalize(const float* row_nll, int64_t num_rows, const float* Nb, const float* row_lse,

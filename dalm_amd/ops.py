@@ -140,9 +140,11 @@ class HipOps:
         n = Bm.shape[0]
         dA = torch.empty((m, D), device=dev, dtype=torch.float32) if want_dA else None
         dB = torch.empty((n, D), device=dev, dtype=torch.float32) if want_dB else None
-        hip.call("dalm_sim_small_bwd", hip.ptr(S), S.shape[1], hip.ptr(A), hip.ptr(Bm), m, n, D, float(scale),
+        ws_bytes = hip.load().dalm_sim_small_bwd_workspace_bytes(m, n, D, int(want_dA), int(want_dB))
+        ws = torch.empty((ws_bytes // 4,), device=dev, dtype=torch.float32) if ws_bytes else None   # contraction slices
+        hip.call("dalm_sim_small_bwd_ws", hip.ptr(S), S.shape[1], hip.ptr(A), hip.ptr(Bm), m, n, D, float(scale),
                  int(diag_offset), hip.ptr(row_coef), hip.ptr(row_lse), hip.ptr(col_coef), hip.ptr(col_lse),
-                 hip.ptr(dA), hip.ptr(dB), hip.stream())
+                 hip.ptr(dA), hip.ptr(dB), hip.ptr(ws) if ws is not None else None, ws_bytes, hip.stream())
         return dA, dB
 
     def rag_loss_finalize(self, row_nll, Nb, row_lse, col_lse, diag, n_global: int, stats):

@@ -147,6 +147,17 @@ int dalm_sim_small_bwd(const float* S, int64_t ldS, const float* A, const float*
                        const float* row_lse, const float* col_coef,
                        const float* col_lse, float* dA, float* dB,
                        dalm_stream_t stream);
+/* The same backward with a workspace.  When only ONE of dA / dB is asked for (the per-rank block of a sharded batch: few
+ * row tiles, a long contraction - 150 x 1200, 18 x 144) the contraction is cut into slices that run as separate workgroups
+ * and a second launch adds the partial outputs in fixed order; dalm_sim_small_bwd_workspace_bytes() is 0 when the shape is
+ * not sliced.  ws may be NULL (the unsliced form runs); 16-byte aligned otherwise. */
+size_t dalm_sim_small_bwd_workspace_bytes(int64_t m, int64_t n, int64_t D, int want_dA, int want_dB);
+int dalm_sim_small_bwd_ws(const float* S, int64_t ldS, const float* A, const float* Bm,
+                          int64_t m, int64_t n, int64_t D, float scale,
+                          int64_t diag_offset, const float* row_coef,
+                          const float* row_lse, const float* col_coef,
+                          const float* col_lse, float* dA, float* dB,
+                          void* ws, size_t ws_bytes, dalm_stream_t stream);
 
 /* ---- K3 drop-in: get_nt_xent_loss on a materialised square S -----------
  * dalm/training/utils/train_utils.py:80-88 (cross_entropy(S, arange(n)), mean).
