@@ -69,6 +69,10 @@ SIGNATURES = {
     "dalm_comm_allreduce_sum_f32": (_int, [_vp, _vp, _sz]),
     "dalm_comm_allgather_on": (_int, [_vp, _vp, _vp, _sz, _vp]),
     "dalm_comm_allreduce_sum_f32_on": (_int, [_vp, _vp, _sz, _vp]),
+    "dalm_nf4_packed_bytes": (_sz, [_i64]),
+    "dalm_nf4_absmax_count": (_sz, [_i64]),
+    "dalm_nf4_quantize": (_int, [_vp, _int, _i64, _vp, _vp, _vp]),
+    "dalm_nf4_dequantize": (_int, [_vp, _vp, _i64, _int, _vp, _vp]),
 }
 
 

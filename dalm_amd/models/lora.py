@@ -30,7 +30,7 @@ class LoRALinear(nn.Module):
         self.r, self.lora_alpha = r, lora_alpha
         self.scaling = lora_alpha / r
         self.lora_dropout = nn.ModuleDict({"default": nn.Dropout(lora_dropout) if lora_dropout > 0 else nn.Identity()})
-        dev = base.weight.device
+        dev = base.qweight.device if hasattr(base, "qweight") else base.weight.device   # NF4Linear: no resident weight
         self.lora_A = nn.ModuleDict({"default": nn.Linear(base.in_features, r, bias=False, device=dev, dtype=torch.float32)})
         self.lora_B = nn.ModuleDict({"default": nn.Linear(r, base.out_features, bias=False, device=dev, dtype=torch.float32)})
         nn.init.kaiming_uniform_(self.lora_A["default"].weight, a=math.sqrt(5))
@@ -66,8 +66,15 @@ class LoRALinear(nn.Module):
     @torch.no_grad()
     def merge(self) -> nn.Linear:
         delta = (self.lora_B["default"].weight @ self.lora_A["default"].weight) * self.scaling
-        self.base_layer.weight.add_(delta.to(self.base_layer.weight.dtype))
-        return self.base_layer
+        base = self.base_layer
+        if hasattr(base, "to_linear"):      # nf4 base: merge into the dequantised weight (nothing is re-quantised)
+            base = base.to_linear()
+        base.weight.add_(delta.to(base.weight.dtype))
+        return base
+
+
+def _is_linear(m: nn.Module) -> bool:
+    return isinstance(m, nn.Linear) or hasattr(m, "qweight")     # nn.Linear or its nf4 form (models/nf4.py)
 
 
 def _matches(name: str, targets: Iterable[str]) -> bool:
@@ -84,7 +91,7 @@ def resolve_targets(model: nn.Module, target_modules: List[str]) -> List[str]:
     """The reference hard-codes q_proj / v_proj for every generator (rag_e2e_base_model.py:61-80); architectures
     with a fused QKV projection (Falcon - BASELINE config 5) have no such modules and peft would raise.  Fall
     back to peft's default targets for that architecture instead of failing."""
-    names = [n for n, m in model.named_modules() if isinstance(m, nn.Linear)]
+    names = [n for n, m in model.named_modules() if _is_linear(m)]
     if any(_matches(n, target_modules) for n in names):
         return list(target_modules)
     mt = getattr(getattr(model, "config", None), "model_type", None)
@@ -104,7 +111,7 @@ def inject_lora(model: nn.Module, target_modules: List[str], r: int = 8, lora_al
     for parent_name, parent in list(model.named_modules()):
         for child_name, child in list(parent.named_children()):
             full = f"{parent_name}.{child_name}" if parent_name else child_name
-            if isinstance(child, nn.Linear) and _matches(full, target_modules):
+            if _is_linear(child) and _matches(full, target_modules):
                 setattr(parent, child_name, LoRALinear(child, r, lora_alpha, lora_dropout))
                 replaced += 1
     if replaced == 0:

@@ -1,0 +1,141 @@
+"""`use_bnb`: the frozen base weights in 4-bit NormalFloat storage, on the library's own kernels.
+
+The reference passes `BitsAndBytesConfig(load_in_4bit=True, bnb_4bit_quant_type="nf4",
+bnb_4bit_compute_dtype=torch.bfloat16)` to `from_pretrained` (dalm/models/rag_e2e_base_model.py:50-58,137-142;
+retriever_only_base_model.py:23-27,84-90): transformers swaps every `nn.Linear` outside the output head for a
+bitsandbytes `Linear4bit`, which stores blocks of 64 weights as 4-bit NF4 indices + one f32 absmax and, per call, casts
+the activations to bfloat16, dequantises the weight to bfloat16, multiplies, and casts the result back.  bitsandbytes is a
+CUDA library that is not in this image; `NF4Linear` is the same storage format and the same compute recipe on
+`dalm_nf4_quantize` / `dalm_nf4_dequantize` (dalm_amd/csrc/nf4.hip).  The weight is dequantised again in the backward
+pass (only the activation gradient exists - the quantised weight is frozen), so 0.5625 bytes per weight stay resident
+and one [out,in] bf16 scratch is live at a time.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from .. import hip
+
+BLOCK = 64
+COMPUTE_DTYPE = torch.bfloat16
+
+
+def quantize(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[*] f32/bf16/f16 on the GPU -> (packed uint8 [ceil(n/2)], absmax f32 [ceil(n/64)]) over the flattened tensor."""
+    hip.require_gpu(w)
+    if w.dtype not in (torch.float32, torch.bfloat16):
+        w = w.float()
+    w = w.contiguous()
+    n = w.numel()
+    packed = torch.empty((n + 1) // 2, device=w.device, dtype=torch.uint8)
+    absmax = torch.empty((n + BLOCK - 1) // BLOCK, device=w.device, dtype=torch.float32)
+    hip.call("dalm_nf4_quantize", hip.ptr(w), hip.dtype_code(w), n, hip.ptr(packed), hip.ptr(absmax), hip.stream())
+    return packed, absmax
+
+
+def dequantize(packed: torch.Tensor, absmax: torch.Tensor, shape, dtype: torch.dtype = COMPUTE_DTYPE) -> torch.Tensor:
+    hip.require_gpu(packed, absmax)
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("nf4 dequantises to float32 or bfloat16")
+    out = torch.empty(tuple(shape), device=packed.device, dtype=dtype)
+    hip.call("dalm_nf4_dequantize", hip.ptr(packed), hip.ptr(absmax), out.numel(), hip.dtype_code(out), hip.ptr(out),
+             hip.stream())
+    return out
+
+
+class _NF4MatMul(torch.autograd.Function):
+    """y = x . dequant(W)^T with W frozen: nothing but the 4-bit storage is kept for the backward pass."""
+
+    @staticmethod
+    def forward(ctx, x, packed, absmax, shape, bias):
+        w = dequantize(packed, absmax, shape, x.dtype)
+        ctx.save_for_backward(packed, absmax)
+        ctx.shape, ctx.has_bias = shape, bias is not None
+        return torch.nn.functional.linear(x, w, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        packed, absmax = ctx.saved_tensors
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = dy.matmul(dequantize(packed, absmax, ctx.shape, dy.dtype))
+        db = dy.reshape(-1, dy.shape[-1]).sum(0) if ctx.has_bias and ctx.needs_input_grad[4] else None
+        return dx, None, None, None, db
+
+
+class NF4Linear(nn.Module):
+    """`nn.Linear` with the weight held as NF4 (buffers `qweight`, `absmax`); the bias stays in its own dtype."""
+
+    def __init__(self, base: nn.Linear):
+        super().__init__()
+        self.in_features, self.out_features = base.in_features, base.out_features
+        packed, absmax = quantize(base.weight.detach())
+        self.register_buffer("qweight", packed)
+        self.register_buffer("absmax", absmax)
+        self.bias = None if base.bias is None else nn.Parameter(base.bias.detach().clone(), requires_grad=False)
+
+    @property
+    def weight(self) -> torch.Tensor:
+        """The dequantised weight (a fresh bf16 tensor per access) - for code that inspects `.weight` (LoRA merge,
+        device / shape probes); the module never keeps it."""
+        return dequantize(self.qweight, self.absmax, (self.out_features, self.in_features), COMPUTE_DTYPE)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        # bitsandbytes' Linear4bit.forward: activations -> compute dtype, result -> the caller's dtype
+        xin = x if x.dtype == COMPUTE_DTYPE else x.to(COMPUTE_DTYPE)
+        bias = None if self.bias is None else self.bias.to(COMPUTE_DTYPE)
+        y = _NF4MatMul.apply(xin, self.qweight, self.absmax, (self.out_features, self.in_features), bias)
+        return y if y.dtype == x.dtype else y.to(x.dtype)
+
+    def to_linear(self, dtype: torch.dtype = COMPUTE_DTYPE) -> nn.Linear:
+        lin = nn.Linear(self.in_features, self.out_features, bias=self.bias is not None, device=self.qweight.device,
+                        dtype=dtype)
+        with torch.no_grad():
+            lin.weight.copy_(self.weight)
+            if self.bias is not None:
+                lin.bias.copy_(self.bias)
+        lin.requires_grad_(False)
+        return lin
+
+    def extra_repr(self) -> str:
+        return f"in_features={self.in_features}, out_features={self.out_features}, bias={self.bias is not None}, nf4"
+
+
+def modules_kept_in_full_precision(model: nn.Module) -> List[str]:
+    """transformers' `get_keys_to_not_convert` for a 4-bit load: the output head (and whatever is tied to it) stays
+    unquantised; a bare encoder (`AutoModel`) has no head and converts every Linear."""
+    keep = []
+    head = model.get_output_embeddings() if hasattr(model, "get_output_embeddings") else None
+    if head is not None:
+        keep += [n for n, m in model.named_modules() if m is head]
+    return keep
+
+
+def quantize_linears(model: nn.Module, skip: Optional[Iterable[str]] = None) -> int:
+    """Swap every `nn.Linear` of `model` (already on the GPU) outside `skip` for an `NF4Linear`, freeing the original
+    weight as it goes.  Returns the number of converted modules."""
+    skip = set(modules_kept_in_full_precision(model) if skip is None else skip)
+    done = 0
+    for parent_name, parent in list(model.named_modules()):
+        for child_name, child in list(parent.named_children()):
+            full = f"{parent_name}.{child_name}" if parent_name else child_name
+            if type(child) is nn.Linear and full not in skip and full.rsplit(".", 1)[-1] not in skip:
+                setattr(parent, child_name, NF4Linear(child))
+                done += 1
+    if done == 0:
+        raise ValueError("use_bnb: no nn.Linear found to quantise")
+    model._dalm_nf4 = True
+    return done
+
+
+def weight_bytes(model: nn.Module) -> int:
+    """Resident bytes of parameters + buffers (what `use_bnb` is for)."""
+    seen, total = set(), 0
+    for t in list(model.parameters()) + list(model.buffers()):
+        if t.data_ptr() not in seen:
+            seen.add(t.data_ptr())
+            total += t.numel() * t.element_size()
+    return total

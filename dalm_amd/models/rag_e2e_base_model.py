@@ -23,18 +23,37 @@ class Mode(Enum):
     BOTH = "both"
 
 
-_BNB_MSG = ("use_bnb=%r ignored: bitsandbytes nf4 is a CUDA-only dependency outside the accelerated path; the base "
-            "weights stay in their loaded dtype (a 7B model in bf16 is 13 GB of the 288 GB HBM3E), which is what nf4 "
-            "approximates")
+_BNB_MSG = ("use_bnb=%r: %s; the base weights stay in their loaded dtype (a 7B model in bf16 is 13 GB of the 288 GB "
+            "HBM3E)")
 
 
-def warn_bnb_ignored(use_bnb) -> None:
-    """The reference quantises the frozen base weights to nf4 (rag_e2e_base_model.py:137-142) when asked; here the
-    request is served with unquantised weights (strictly more accurate) and a warning, so that default invocations
-    of the reference's signatures (train_retriever has use_bnb=True) run."""
+def nf4_enabled(use_bnb) -> bool:
+    """Whether a `use_bnb` request is served with real nf4 storage (dalm_amd/models/nf4.py).  It needs the GPU library
+    (the quantise / dequantise kernels have no CPU form); `DALM_NF4=0` opts out.  When it cannot be served the request
+    degrades to unquantised weights with a warning, so that default invocations of the reference's signatures
+    (`train_retriever` has use_bnb=True) still run on a box without a GPU."""
+    import os
     import warnings
 
-    warnings.warn(_BNB_MSG % (use_bnb,), stacklevel=3)
+    if not use_bnb:
+        return False
+    if os.environ.get("DALM_NF4", "1") == "0":
+        warnings.warn(_BNB_MSG % (use_bnb, "nf4 switched off by DALM_NF4=0"), stacklevel=3)
+        return False
+    if not torch.cuda.is_available():
+        warnings.warn(_BNB_MSG % (use_bnb, "nf4 storage needs the GPU kernels and no GPU is visible"), stacklevel=3)
+        return False
+    return True
+
+
+def to_nf4(model: torch.nn.Module) -> torch.nn.Module:
+    """The reference's 4-bit load (rag_e2e_base_model.py:50-58,137-142): every Linear outside the output head becomes
+    nf4 storage on the current GPU (transformers places a quantised model there too)."""
+    from . import nf4
+
+    model = model.to(torch.device("cuda", torch.cuda.current_device()))
+    nf4.quantize_linears(model)
+    return model
 
 
 class AutoModelForRagE2E(torch.nn.Module):
@@ -50,8 +69,6 @@ class AutoModelForRagE2E(torch.nn.Module):
         torch_dtype: Optional[torch.dtype] = None,
     ) -> None:
         super().__init__()
-        if use_bnb is not None:
-            warn_bnb_ignored(use_bnb)
         from transformers import AutoModel, AutoModelForCausalLM, AutoTokenizer
 
         kw = {} if torch_dtype is None else {"dtype": torch_dtype}
@@ -59,20 +76,26 @@ class AutoModelForRagE2E(torch.nn.Module):
         generator = AutoModelForCausalLM.from_pretrained(generator_name, trust_remote_code=True, **kw)
         self._assemble(retriever, generator, AutoTokenizer.from_pretrained(retriever_name),
                        AutoTokenizer.from_pretrained(generator_name), normalize, get_peft,
-                       retriever_is_autoregressive)
+                       retriever_is_autoregressive, use_bnb)
 
     @classmethod
     def from_modules(cls, retriever_model, generator_model, retriever_tokenizer=None, generator_tokenizer=None,
                      normalize: bool = True, get_peft: Optional[Mode] = None,
-                     retriever_is_autoregressive: bool = False) -> "AutoModelForRagE2E":
+                     retriever_is_autoregressive: bool = False, use_bnb: Optional[Mode] = None) -> "AutoModelForRagE2E":
         """Build from already-constructed modules (random-init benchmarks, tests)."""
         self = cls.__new__(cls)
         torch.nn.Module.__init__(self)
         self._assemble(retriever_model, generator_model, retriever_tokenizer, generator_tokenizer, normalize,
-                       get_peft, retriever_is_autoregressive)
+                       get_peft, retriever_is_autoregressive, use_bnb)
         return self
 
-    def _assemble(self, retriever, generator, r_tok, g_tok, normalize, get_peft, autoregressive) -> None:
+    def _assemble(self, retriever, generator, r_tok, g_tok, normalize, get_peft, autoregressive, use_bnb=None) -> None:
+        if use_bnb is not None and nf4_enabled(use_bnb):      # quantise first, then adapters on top (reference :50-81)
+            use_bnb = Mode(use_bnb)
+            if use_bnb in (Mode.RETRIEVER, Mode.BOTH):
+                retriever = to_nf4(retriever)
+            if use_bnb in (Mode.GENERATOR, Mode.BOTH):
+                generator = to_nf4(generator)
         self.retriever_model = retriever
         self.generator_model = generator
         self.retriever_tokenizer = r_tok

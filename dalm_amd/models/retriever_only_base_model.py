@@ -10,7 +10,7 @@ from ..fused import pool_l2norm
 from ..utils import eos_mask
 from . import lora
 from .fastpath import use_native_rms_norm
-from .rag_e2e_base_model import warn_bnb_ignored
+from .rag_e2e_base_model import nf4_enabled, to_nf4
 
 
 class AutoModelForSentenceEmbedding(torch.nn.Module):
@@ -18,8 +18,6 @@ class AutoModelForSentenceEmbedding(torch.nn.Module):
                  is_autoregressive: bool = False, *, torch_dtype: Optional[torch.dtype] = None,
                  device: Optional[str] = None) -> None:
         super().__init__()
-        if use_bnb:
-            warn_bnb_ignored(use_bnb)
         from transformers import AutoModel, AutoModelForCausalLM, AutoTokenizer
 
         model_type = AutoModel if not is_autoregressive else AutoModelForCausalLM
@@ -30,17 +28,20 @@ class AutoModelForSentenceEmbedding(torch.nn.Module):
             device = "cuda:0"
         if device is not None:
             model = model.to(device)
-        self._assemble(model, AutoTokenizer.from_pretrained(model_name), normalize, get_peft, is_autoregressive)
+        self._assemble(model, AutoTokenizer.from_pretrained(model_name), normalize, get_peft, is_autoregressive,
+                       use_bnb)
 
     @classmethod
     def from_modules(cls, model, tokenizer=None, normalize: bool = True, get_peft: bool = False,
-                     is_autoregressive: bool = False) -> "AutoModelForSentenceEmbedding":
+                     is_autoregressive: bool = False, use_bnb: bool = False) -> "AutoModelForSentenceEmbedding":
         self = cls.__new__(cls)
         torch.nn.Module.__init__(self)
-        self._assemble(model, tokenizer, normalize, get_peft, is_autoregressive)
+        self._assemble(model, tokenizer, normalize, get_peft, is_autoregressive, use_bnb)
         return self
 
-    def _assemble(self, model, tokenizer, normalize, get_peft, is_autoregressive) -> None:
+    def _assemble(self, model, tokenizer, normalize, get_peft, is_autoregressive, use_bnb=False) -> None:
+        if use_bnb and nf4_enabled(use_bnb):          # the reference's 4-bit load (:23-27), before the adapters
+            model = to_nf4(model)
         self.model = model
         if is_autoregressive:
             use_native_rms_norm(self.model)

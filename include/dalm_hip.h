@@ -326,6 +326,21 @@ int dalm_comm_allreduce_sum_f32(dalm_comm_t* c, float* buf, size_t n);
 int dalm_comm_allgather_on(dalm_comm_t* c, const void* send, void* recv, size_t bytes_per_rank, dalm_stream_t stream);
 int dalm_comm_allreduce_sum_f32_on(dalm_comm_t* c, float* buf, size_t n, dalm_stream_t stream);
 
+/* ---- nf4: 4-bit NormalFloat storage of the frozen base weights (`use_bnb`) ----------------------------------
+ * Replaces what the reference delegates to bitsandbytes through BitsAndBytesConfig(load_in_4bit=True,
+ * bnb_4bit_quant_type="nf4", bnb_4bit_compute_dtype=bfloat16): dalm/models/rag_e2e_base_model.py:137-142,
+ * dalm/models/retriever_only_base_model.py:26,86 (quantise at load; dequantise to the compute dtype in front of every
+ * matmul with a frozen weight).  Blocks of 64 consecutive elements of the flattened weight, one f32 absmax per
+ * block, the 16 NF4 levels of QLoRA (appendix E), two indices per byte with element 2j in the high nibble.
+ *   packed: dalm_nf4_packed_bytes(n) = ceil(n/2) bytes;  absmax: dalm_nf4_absmax_count(n) = ceil(n/64) floats.
+ * `w` / `out`: n elements of `dtype` (DALM_F32 or DALM_BF16), 16-byte aligned.  Streaming kernels: quantise reads
+ * 4n (2n) bytes, dequantise writes 4n (2n) bytes; 0.5625 bytes per weight stay resident. */
+size_t dalm_nf4_packed_bytes(int64_t n);
+size_t dalm_nf4_absmax_count(int64_t n);
+int dalm_nf4_quantize(const void* w, int dtype, int64_t n, uint8_t* packed, float* absmax, dalm_stream_t stream);
+int dalm_nf4_dequantize(const uint8_t* packed, const float* absmax, int64_t n, int dtype, void* out,
+                        dalm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

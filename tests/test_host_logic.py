@@ -152,21 +152,6 @@ def test_lora_injector_matches_reference_config():
                                               intermediate_size=64, vocab_size=50)), ["nope"])
 
 
-def test_use_bnb_warns_and_is_ignored():
-    """The reference's default call (`train_retriever(..., use_bnb=True)`) must run: the nf4 request is served
-    with unquantised weights and a warning (bitsandbytes is CUDA-only)."""
-    from dalm_amd.models.rag_e2e_base_model import warn_bnb_ignored
-
-    with pytest.warns(UserWarning, match="bitsandbytes"):
-        warn_bnb_ignored(True)
-    from dalm_amd.models import AutoModelForSentenceEmbedding
-
-    path = str(GOLDEN / "tiny_retriever")
-    with pytest.warns(UserWarning, match="bitsandbytes"):
-        m = AutoModelForSentenceEmbedding(path, use_bnb=True, get_peft=False, device="cpu")
-    assert m.model is not None
-
-
 def test_grad_accum_keeps_the_references_step_arithmetic():
     """--gradient_accumulation_steps N: N micro-batches per optimizer step, so steps per epoch, the schedule
     length and the step_N resume arithmetic are the reference's (accelerate's) - not N times more steps."""

@@ -148,6 +148,24 @@ def bench_pool(B, T, D, dtype):
     return out
 
 
+def bench_nf4(rows, cols, dtype):
+    """`use_bnb` storage: dequantise one [rows, cols] weight (Llama-2-7b's largest Linear is 11008 x 4096)."""
+    from dalm_amd.models import nf4
+
+    dev = torch.device("cuda:0")
+    w = (torch.randn(rows, cols, device=dev) * 0.02).to(dtype)
+    n = rows * cols
+    el = w.element_size()
+    out = {}
+    med, _ = time_fn(lambda: nf4.quantize(w))
+    b = n * el + n / 2 + n / 16
+    out["quantize"] = {"s": med, "GBps": b / med / 1e9, "frac": b / med / HBM_PEAK}
+    p, a = nf4.quantize(w)
+    med, _ = time_fn(lambda: nf4.dequantize(p, a, (rows, cols), dtype))
+    out["dequantize"] = {"s": med, "GBps": b / med / 1e9, "frac": b / med / HBM_PEAK}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
@@ -188,6 +206,10 @@ def main():
         res["pool cfg2 p B150 T128 D1024 f32"] = bench_pool(150, 128, 1024, torch.float32)
         res["pool cfg3 p B18 T128 D1024 f32"] = bench_pool(18, 128, 1024, torch.float32)
         res["pool B1200 T128 D1024 bf16"] = bench_pool(1200, 128, 1024, torch.bfloat16)
+    if args.only in ("", "nf4"):
+        res["nf4 11008x4096 -> bf16"] = bench_nf4(11008, 4096, torch.bfloat16)
+        res["nf4 4096x4096 -> bf16"] = bench_nf4(4096, 4096, torch.bfloat16)
+        res["nf4 11008x4096 -> f32"] = bench_nf4(11008, 4096, torch.float32)
     for k, v in res.items():
         print(k)
         for kk, vv in v.items():
