@@ -38,7 +38,7 @@ _HELP = {
     "per_device_train_batch_size": "Batch size (per device).",
     "logit_scale": "Logit scale of the contrastive loss.",
     "use_peft": "LoRA fine-tuning (which tower(s)).",
-    "use_bnb": "4-bit quantisation (not available on this build).",
+    "use_bnb": "nf4 storage of the frozen base weights (HIP kernels; needs the GPU).",
     "checkpointing_steps": "Save state every n steps, or 'epoch'.",
     "no_hip_graph": "Launch every step eagerly instead of replaying a hipGraph.",
 }

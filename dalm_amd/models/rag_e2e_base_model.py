@@ -51,7 +51,9 @@ def to_nf4(model: torch.nn.Module) -> torch.nn.Module:
     nf4 storage on the current GPU (transformers places a quantised model there too)."""
     from . import nf4
 
-    model = model.to(torch.device("cuda", torch.cuda.current_device()))
+    where = next(model.parameters()).device
+    if where.type != "cuda":
+        model = model.to(torch.device("cuda", torch.cuda.current_device()))
     nf4.quantize_linears(model)
     return model
 

@@ -56,7 +56,7 @@ FLAGS = [
     ("report_to", dict(type=_S, default="all", help="Tracker name(s); only with --with_tracking")),
     ("sanity_test", dict(action="store_true", help="Unused (kept for CLI compatibility)")),
     ("use_peft", dict(type=Mode, choices=list(Mode), required=False, help="LoRA on generator / retriever / both")),
-    ("use_bnb", dict(type=Mode, choices=list(Mode), help="4-bit quantisation (not available on this build)")),
+    ("use_bnb", dict(type=Mode, choices=list(Mode), help="nf4 storage of the frozen base weights of this tower (HIP kernels; needs the GPU)")),
     ("retriever_is_autoregressive", dict(action="store_true", help="Retriever is an autoregressive LM")),
     # extensions (not in the reference)
     ("mixed_precision", dict(type=_S, default="bf16", choices=["no", "bf16"], help="[ext] autocast dtype of the towers")),

@@ -46,7 +46,7 @@ FLAGS = [
     ("report_to", dict(type=_S, default="all", help="Tracker name(s); only with --with_tracking")),
     ("sanity_test", dict(action="store_true", help="Unused (kept for CLI compatibility)")),
     ("use_peft", dict(action="store_true", help="LoRA on the retriever")),
-    ("use_bnb", dict(action="store_true", help="4-bit quantisation (not available on this build)")),
+    ("use_bnb", dict(action="store_true", help="nf4 storage of the frozen base weights (HIP kernels; needs the GPU)")),
     ("is_autoregressive", dict(action="store_true", help="Retriever is an autoregressive LM")),
     ("mixed_precision", dict(type=_S, default="bf16", choices=["no", "bf16"], help="[ext] autocast dtype")),
     ("no_hip_graph", dict(action="store_true", help="[ext] launch every step eagerly instead of replaying a hipGraph")),
