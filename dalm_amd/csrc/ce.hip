@@ -268,7 +268,8 @@ __global__ __launch_bounds__(BS, (SLOTS * Elt<T>::VEC > 64 ? 3 : 4)) void marg_c
 // unpacked variant (2 rows/CU, time = T_read + T_write) could not do.  exp() is recomputed in the
 // gradient phase instead of being kept in f32 registers (VALU is far from the limit here).
 // ---------------------------------------------------------------------------
-template <int BS, int SLOTS, bool WRITE_GRAD, bool ALIGNED, bool NT = false>
+// NT: cache policy of the two streams - bit 0 = non-temporal loads, bit 1 = non-temporal stores.
+template <int BS, int SLOTS, bool WRITE_GRAD, bool ALIGNED, int NT = 0>
 __global__ __launch_bounds__(BS, 8) void marg_ce_row_bf16_kernel(
     const bf16_t* __restrict__ logits, int64_t stride_b, int64_t stride_t,
     const int64_t* __restrict__ ids, const int64_t* __restrict__ mask, int Tg, int V,
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(BS, 8) void marg_ce_row_bf16_kernel(
     const int slot = k * BS + tid;
     if (slot < nslots) {
       const uint4* src = reinterpret_cast<const uint4*>(abase + static_cast<unsigned>(slot) * 16u);
-      if constexpr (NT) {  // streaming policy: every logit is read exactly once
+      if constexpr (NT & 1) {  // streaming policy: every logit is read exactly once
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
         const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
         raw[k] = make_uint4(t.x, t.y, t.z, t.w);
@@ -382,6 +383,8 @@ __global__ __launch_bounds__(BS, 8) void marg_ce_row_bf16_kernel(
     // softmax = exp(x - lse): a different exponent offset than the sum pass on purpose - with the
     // same expression the compiler CSEs the two passes and keeps all 64 exps live (+64 VGPRs)
     const float nlse = -lse * kLog2e;
+    const bool y_ok = y >= 0 && y < V;
+    const int slot_y = y_ok ? (static_cast<int>(y) + lead) / VEC : -1, e_y = y_ok ? (static_cast<int>(y) + lead) % VEC : 0;
 #pragma unroll
     for (int k = 0; k < SLOTS; ++k) {
       const int slot = k * BS + tid;
@@ -393,10 +396,14 @@ __global__ __launch_bounds__(BS, 8) void marg_ce_row_bf16_kernel(
         g[2 * i] = __builtin_amdgcn_exp2f(fmaf(__uint_as_float(w[i] << 16), kLog2e, nlse)) * coef;
         g[2 * i + 1] = __builtin_amdgcn_exp2f(fmaf(__uint_as_float(w[i] & 0xffff0000u), kLog2e, nlse)) * coef;
       }
+      if (slot == slot_y) {   // the label's element: softmax - 1 (same bits as a separate store of py - coef would write)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) g[e] = (e == e_y) ? g[e] - coef : g[e];
+      }
       bool part = false;
       if constexpr (!ALIGNED) part = (slot == 0 && lead != 0) || (slot == nslots - 1 && tail_partial);
       if (!part) {
-        if constexpr (NT) {
+        if constexpr (NT & 2) {
           typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
           u32x4 o;
           o.x = pack_bf16x2(g[0], g[1]); o.y = pack_bf16x2(g[2], g[3]);
@@ -413,14 +420,6 @@ __global__ __launch_bounds__(BS, 8) void marg_ce_row_bf16_kernel(
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-    }
-    if (y >= 0 && y < V) {
-      const int slot_y = (static_cast<int>(y) + lead) / VEC;
-      if (tid == slot_y % BS) {
-        const float py = __builtin_amdgcn_exp2f(fmaf(xy, kLog2e, nlse)) * coef;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        Elt<T>::put(grow + y, py - coef);
-      }
     }
   }
 }
@@ -726,18 +725,24 @@ void launch_fwd2(const T* logits, int64_t B, int64_t Tg, int64_t V, int64_t sb, 
     hipLaunchKernelGGL((marg_ce_row_kernel<T, 256, S_WIDE, GRAD, ALIGNED>), grid, dim3(256), 0, s, DALM_CE_ARGS);
   else if (sizeof(T) == 2 && !(variant && variant[0] == 'u') && need > 256 * S_SMALL && need <= 1024 * 8) {
     if constexpr (sizeof(T) == 2) {  // packed-register bf16 rows (see marg_ce_row_bf16_kernel)
-      // non-temporal loads + stores are the default (every logit is read once, every gradient written once:
-      // 0.58 -> 0.68 of HBM peak at V=32000, 0.64 -> 0.69 at V=65024); DALM_CE_VARIANT=c keeps the cached policy
-      const bool nt = !(variant && variant[0] == 'c');
+      // cache policy of the read / write streams (DALM_CE_VARIANT=c cached, l nt loads only, w nt stores only, n both)
+      int nt = 3;
+      if (variant && variant[0] == 'c') nt = 0;
+      else if (variant && variant[0] == 'l') nt = 1;
+      else if (variant && variant[0] == 'w') nt = 2;
+#define DALM_CE_BF16(BSZ, P) hipLaunchKernelGGL((marg_ce_row_bf16_kernel<BSZ, 8, GRAD, ALIGNED, P>), grid, dim3(BSZ), 0, s, DALM_CE_ARGS)
+      static const bool wide = getenv("DALM_CE_BS") && atoi(getenv("DALM_CE_BS")) == 1024;   // A/B knob: 16 waves per row
       if (need <= 512 * 4)
         hipLaunchKernelGGL((marg_ce_row_bf16_kernel<512, 4, GRAD, ALIGNED>), grid, dim3(512), 0, s, DALM_CE_ARGS);
-      else if (need <= 512 * 8) {
-        if (nt) hipLaunchKernelGGL((marg_ce_row_bf16_kernel<512, 8, GRAD, ALIGNED, true>), grid, dim3(512), 0, s, DALM_CE_ARGS);
-        else hipLaunchKernelGGL((marg_ce_row_bf16_kernel<512, 8, GRAD, ALIGNED>), grid, dim3(512), 0, s, DALM_CE_ARGS);
+      else if (wide && need <= 1024 * 4) {
+        if (nt == 3) hipLaunchKernelGGL((marg_ce_row_bf16_kernel<1024, 4, GRAD, ALIGNED, 3>), grid, dim3(1024), 0, s, DALM_CE_ARGS);
+        else hipLaunchKernelGGL((marg_ce_row_bf16_kernel<1024, 4, GRAD, ALIGNED, 0>), grid, dim3(1024), 0, s, DALM_CE_ARGS);
+      } else if (need <= 512 * 8) {
+        if (nt == 3) DALM_CE_BF16(512, 3); else if (nt == 2) DALM_CE_BF16(512, 2); else if (nt == 1) DALM_CE_BF16(512, 1); else DALM_CE_BF16(512, 0);
       } else {
-        if (nt) hipLaunchKernelGGL((marg_ce_row_bf16_kernel<1024, 8, GRAD, ALIGNED, true>), grid, dim3(1024), 0, s, DALM_CE_ARGS);
-        else hipLaunchKernelGGL((marg_ce_row_bf16_kernel<1024, 8, GRAD, ALIGNED>), grid, dim3(1024), 0, s, DALM_CE_ARGS);
+        if (nt == 3) DALM_CE_BF16(1024, 3); else if (nt == 2) DALM_CE_BF16(1024, 2); else if (nt == 1) DALM_CE_BF16(1024, 1); else DALM_CE_BF16(1024, 0);
       }
+#undef DALM_CE_BF16
     }
   } else if (need <= 256 * S_SMALL)
     hipLaunchKernelGGL((marg_ce_row_kernel<T, 256, S_SMALL, GRAD, ALIGNED>), grid, dim3(256), 0, s, DALM_CE_ARGS);

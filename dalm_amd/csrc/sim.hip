@@ -618,20 +618,29 @@ struct StreamStatsParams {
 };
 enum { MODE_STATS = 0, MODE_GMAX = 1 };
 
-template <int RT, int MODE>
-__global__ __launch_bounds__(256, 2) void sim_rowstats_stream_kernel(const StreamStatsParams p) {
+// KS > 1 (MODE_STATS, mid-size problems whose 128-column blocks cannot fill the chip): the 4 waves are 4/KS column
+// tiles x KS slices of K; a workgroup then owns 32*RT rows x 128/KS columns per block, the K slices of a tile are summed
+// through LDS in fixed order (slice 0 + 1 + 2 + 3) before the statistics see them - one barrier per column block.
+template <int RT, int MODE, int KS = 1>
+__global__ __launch_bounds__(256, KS > 1 ? 3 : 2) void sim_rowstats_stream_kernel(const StreamStatsParams p) {
+  static_assert(KS == 1 || (MODE == MODE_STATS && RT == 1), "K slices: statistics mode, one row tile");
   constexpr int SG = 8;
+  constexpr int CBN = FBN / KS;       // columns per workgroup and block
   __shared__ float red_m[4][32 * RT], red_l[4][32 * RT];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
-  const int rb = static_cast<int>(blockIdx.x) % p.row_blocks, z = static_cast<int>(blockIdx.x) / p.row_blocks;
-  const int i0 = rb * 32 * RT;
-  const int nblocks = (p.n + FBN - 1) / FBN;
-  const int jb_lo = z * p.blocks_per_split, jb_hi = min(nblocks, jb_lo + p.blocks_per_split);
+  __shared__ float xchg[KS > 1 ? 2 * (4 / KS) * (KS - 1) * 16 * 64 : 1];   // [parity][tile][slice-1][r][lane]
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the K-slice offsets below stay in SGPRs
+  const int ct = wave / KS, kp = wave % KS;
   const __amdgpu_buffer_rsrc_t at_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.At), 0, p.Kpad * p.ldm * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t bt_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Bt), 0, p.Kpad * p.ldn * 4, 0x00020000);
+  const int rb = static_cast<int>(blockIdx.x) % p.row_blocks, z = static_cast<int>(blockIdx.x) / p.row_blocks;
+  const int i0 = rb * 32 * RT;
+  const int nblocks = (p.n + CBN - 1) / CBN;
+  const int jb_lo = z * p.blocks_per_split, jb_hi = min(nblocks, jb_lo + p.blocks_per_split);
   const int a_off = (lhi * p.ldm + i0 + l31) * 4;
   const int a_step = 2 * p.ldm * 4, b_step = 2 * p.ldn * 4;
-  const int G = p.Kpad / (2 * SG);   // Kpad is a multiple of 16
+  const int G = p.Kpad / (2 * SG) / KS;   // groups of 16 k per wave; Kpad is a multiple of 16 * KS
+  const int g0 = kp * G;
 
   float rmax[RT][16], rsum[RT][16];
 #pragma unroll
@@ -641,7 +650,7 @@ __global__ __launch_bounds__(256, 2) void sim_rowstats_stream_kernel(const Strea
 
 #pragma unroll 1
   for (int jb = jb_lo; jb < jb_hi; ++jb) {
-    const int col = jb * FBN + wave * 32 + l31;
+    const int col = jb * CBN + ct * 32 + l31;
     const int b_off = (lhi * p.ldn + col) * 4;
     f32x16 sacc[RT];
 #pragma unroll
@@ -654,8 +663,8 @@ __global__ __launch_bounds__(256, 2) void sim_rowstats_stream_kernel(const Strea
       for (int u = 0; u < SG; ++u) {
 #pragma unroll
         for (int t = 0; t < RT; ++t)
-          fa[t][u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(at_rs, a_off + 128 * t, (g * SG + u) * a_step, 0));
-        fb[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bt_rs, b_off, (g * SG + u) * b_step, 0));
+          fa[t][u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(at_rs, a_off + 128 * t, ((g0 + g) * SG + u) * a_step, 0));
+        fb[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bt_rs, b_off, ((g0 + g) * SG + u) * b_step, 0));
       }
     };
     auto mfmas = [&](const float (&fa)[RT][SG], const float (&fb)[SG]) {
@@ -693,6 +702,24 @@ __global__ __launch_bounds__(256, 2) void sim_rowstats_stream_kernel(const Strea
     if (g < G) mfmas(fa0, fb0);
     if (g + 1 < G) mfmas(fa1, fb1);
     const bool col_ok = col < p.n;
+    if constexpr (KS > 1) {
+      float* xb = xchg + ((jb & 1) * (4 / KS) + ct) * (KS - 1) * 16 * 64;
+      if (kp != 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xb[((kp - 1) * 16 + r) * 64 + lane] = sacc[0][r];
+      }
+      __syncthreads();   // parity double buffer: the next block's writes go to the other half
+      if (kp != 0) continue;
+#pragma unroll
+      for (int q = 0; q < KS - 1; ++q)
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0 += 8) {   // 8 LDS reads in flight at a time (the fragment registers are dead here,
+          __builtin_amdgcn_sched_barrier(0);   // but an unbounded hoist of all 16 (KS - 1) reads spills)
+#pragma unroll
+          for (int r = r0; r < r0 + 8; ++r) sacc[0][r] += xb[(q * 16 + r) * 64 + lane];
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if constexpr (MODE == MODE_STATS) {
       // ---- fold the finished tile(s) into the online row statistics ----
 #pragma unroll
@@ -917,19 +944,30 @@ inline size_t flash_copy_floats(const FlashPlan& f, int64_t D) { return static_c
 
 // Streaming row statistics: used once the problem is MFMA-sized (the small-batch path and the latency-bound
 // split-K form cover everything below); any D (the k-major copies are zero-padded to a multiple of 16).
-struct StreamPlan { bool ok; int rt, row_blocks, nsplit, blocks_per_split; int64_t ldm, ldn, kpad; };
+struct StreamPlan { bool ok; int rt, row_blocks, nsplit, blocks_per_split; int64_t ldm, ldn, kpad; int ks; };
 inline StreamPlan stream_plan(int64_t m, int64_t n, int64_t D, bool always = false) {
-  StreamPlan f{false, 1, 0, 1, 0, 0, 0, 0};
+  StreamPlan f{false, 1, 0, 1, 0, 0, 0, 0, 1};
   static const bool off = getenv("DALM_SIM_ROWSTATS") && getenv("DALM_SIM_ROWSTATS")[0] == 'g';   // "gemm": the LDS-tiled form
   if (off && !always) return f;
   if (!always && (m * n < 512 * 512 || D < 64)) return f;
-  f.kpad = (D + 15) / 16 * 16;
-  if ((n + 128) * f.kpad * 4 >= (1ll << 31) || (m + 64) * f.kpad * 4 >= (1ll << 31)) return f;   // 32-bit buffer offsets
   static const int force_rt = getenv("DALM_STREAM_RT") ? atoi(getenv("DALM_STREAM_RT")) : 0;
+  static const int force_ks = getenv("DALM_STREAM_KS") ? atoi(getenv("DALM_STREAM_KS")) : 0;
   f.rt = force_rt ? force_rt : ((m >= 4096) ? 2 : 1);   // measured: 2048^2 86 vs 77 TF, 4096^2 100 vs 107, 16384^2 118 vs 141
   const int64_t bm = 32 * f.rt;
   f.row_blocks = static_cast<int>((m + bm - 1) / bm);
-  const int64_t col_blocks = (n + FBN - 1) / FBN;
+  // K slices per column tile, for the sizes whose 128-column blocks give the chip only one or two workgroups per CU
+  // (grid = row blocks x column blocks; measured, whole call, us: 768^2 (144) 36.0 / 37.7 / 37.5 for 1 / 2 / 4 slices,
+  // 1200^2 (380) 57.2 / 54.0 / 56.2, 1536^2 (576) 74.3 / 76.4 / 68.1, 2048^2 (1024) 90.8 / 103.6 / 108.2).  What did NOT
+  // move these sizes (profiles/r03_sim_midsize_experiments.txt): 16-byte operand loads from 4-k granule copies (slower),
+  // capping workgroups per CU through LDS padding (slower), XCD rectangles + an L2 warm-up pass (no change).
+  if (!always && f.rt == 1) {
+    const int64_t g128 = static_cast<int64_t>(f.row_blocks) * ((n + 127) / 128);
+    f.ks = (g128 >= 450 && g128 < 640) ? 4 : (g128 >= 300 && g128 < 450) ? 2 : 1;
+    if (force_ks == 1 || force_ks == 2 || force_ks == 4) f.ks = force_ks;
+  }
+  f.kpad = (D + 16 * f.ks - 1) / (16 * f.ks) * (16 * f.ks);
+  if ((n + 128) * f.kpad * 4 >= (1ll << 31) || (m + 64) * f.kpad * 4 >= (1ll << 31)) return f;   // 32-bit buffer offsets
+  const int64_t col_blocks = (n + FBN / f.ks - 1) / (FBN / f.ks);
   int64_t ns = ((f.rt == 2 ? 512 : 768) + f.row_blocks - 1) / f.row_blocks;      // 2-3 workgroups per CU (by registers)
   if (ns > col_blocks) ns = col_blocks;
   if (ns < 1) ns = 1;
@@ -937,7 +975,7 @@ inline StreamPlan stream_plan(int64_t m, int64_t n, int64_t D, bool always = fal
   f.blocks_per_split = static_cast<int>((col_blocks + ns - 1) / ns);
   f.nsplit = static_cast<int>((col_blocks + f.blocks_per_split - 1) / f.blocks_per_split);
   f.ldm = static_cast<int64_t>(f.row_blocks) * bm;
-  f.ldn = col_blocks * FBN;
+  f.ldn = (n + FBN - 1) / FBN * FBN;
   f.ok = true;
   return f;
 }
@@ -1054,6 +1092,8 @@ extern "C" int dalm_sim_rowstats(const float* A, const float* Bm, int64_t m, int
     q.row_blocks = f.row_blocks; q.nsplit = f.nsplit; q.blocks_per_split = f.blocks_per_split;
     const dim3 grid(static_cast<unsigned>(f.row_blocks * f.nsplit));
     if (f.rt == 2) hipLaunchKernelGGL((sim_rowstats_stream_kernel<2, MODE_STATS>), grid, dim3(256), 0, s, q);
+    else if (f.ks == 4) hipLaunchKernelGGL((sim_rowstats_stream_kernel<1, MODE_STATS, 4>), grid, dim3(256), 0, s, q);
+    else if (f.ks == 2) hipLaunchKernelGGL((sim_rowstats_stream_kernel<1, MODE_STATS, 2>), grid, dim3(256), 0, s, q);
     else hipLaunchKernelGGL((sim_rowstats_stream_kernel<1, MODE_STATS>), grid, dim3(256), 0, s, q);
     hipLaunchKernelGGL(rowstats_merge_kernel, dim3(static_cast<unsigned>((m + 255) / 256)), dim3(256), 0, s, pm, pl,
                        f.nsplit, static_cast<int>(m), row_lse);

@@ -260,14 +260,14 @@ def test_lm_head_fused_vs_fp64_oracle(dev, dtype):
 
 
 STREAM = [(1200, 1200, 1024, 0), (600, 900, 100, 17), (4096, 4096, 384, 0), (4101, 4300, 64, 100), (513, 513, 72, 0),
-          (150, 4000, 1024, 1000)]
+          (150, 4000, 1024, 1000), (1199, 1203, 200, 3), (2048, 2048, 128, 0), (1500, 1530, 72, 5)]
 
 
 @pytest.mark.parametrize("m,n,D,off", STREAM)
 def test_streaming_rowstats_vs_fp64(dev, m, n, D, off):
     """dalm_sim_rowstats in its LDS-free streaming form (m*n >= 512^2): any D (zero-padded k-major copies), row and
-    column tails, several column splits, both row-tile variants (two row tiles per wave from 4096 rows), sharded diag
-    offsets.  atol 2e-4 on |S| ~ 55: the f32 dot products of 1024 terms carry ~1e-4 absolute error there (3e-6 relative)."""
+    column tails, several column splits, both row-tile variants (two row tiles per wave from 4096 rows), the 2- and 4-way
+    K-sliced workgroups of mid-size problems (1200^2, 1199 x 1203: 2 slices; 1500 x 1530: 4), sharded diag offsets.  atol 2e-4 on |S| ~ 55: the f32 dot products of 1024 terms carry ~1e-4 absolute error there (3e-6 relative)."""
     from dalm_amd.ops import default_ops
 
     ops = default_ops()

@@ -247,8 +247,9 @@ def test_retriever_only_step_trajectory_matches_reference(graph):
 
 def test_train_retriever_end_to_end_at_cfg1_shapes(tmp_path):
     """The entry point itself at BASELINE configs[0]'s shapes: a 19-row csv (the toy csv has 19 rows), requested
-    batch 32 -> one partial batch of 19 per epoch, bge-small width; reference-default use_bnb=True is served with
-    a warning; checkpoints in the reference's layout (peft-format adapter) and resume."""
+    batch 32 -> one partial batch of 19 per epoch, bge-small width; the reference-default use_bnb=True is served as nf4
+    storage of the frozen Linears (no warning on a GPU box); checkpoints in the reference's layout (peft-format adapter)
+    and resume on the same quantised base."""
     import csv
 
     from transformers import PreTrainedTokenizerFast
@@ -268,11 +269,15 @@ def test_train_retriever_end_to_end_at_cfg1_shapes(tmp_path):
             w.writerow([q, a, "x"])
     out = tmp_path / "out"
     seen = []
-    with pytest.warns(UserWarning, match="bitsandbytes"):
+    import warnings
+
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
         train_retriever(str(mdir), str(path), query_max_len=12, passage_max_len=32, per_device_train_batch_size=32,
                         learning_rate=1e-3, num_train_epochs=4, output_dir=str(out), checkpointing_steps="epoch",
                         with_tracking=True, mixed_precision="no", async_checkpoint=True, token_cache_dir=str(tmp_path / "tok"),
                         on_step=lambda s, l: seen.append((s, float(l))))
+    assert not [w for w in caught if "use_bnb" in str(w.message)], [str(w.message) for w in caught]
     assert [s for s, _ in seen] == [1, 2, 3, 4] and seen[-1][1] < seen[0][1]
     assert (tmp_path / "tok" / "index.json").exists()          # int32 token shards, reused by the resume run below
     for sub in ("retriever/adapter_config.json", "retriever/adapter_model.safetensors", "epoch_3/trainer_state.pt", "logs"):
@@ -280,7 +285,7 @@ def test_train_retriever_end_to_end_at_cfg1_shapes(tmp_path):
     more = []
     train_retriever(str(mdir), str(path), query_max_len=12, passage_max_len=32, per_device_train_batch_size=32,
                     learning_rate=1e-3, num_train_epochs=6, output_dir=str(out), resume_from_checkpoint=str(out / "epoch_3"),
-                    with_tracking=False, use_bnb=False, mixed_precision="no", token_cache_dir=str(tmp_path / "tok"),
+                    with_tracking=False, mixed_precision="no", token_cache_dir=str(tmp_path / "tok"),
                     on_step=lambda s, l: more.append((s, float(l))))
     assert [s for s, _ in more] == [5, 6] and more[0][1] < seen[0][1]
 

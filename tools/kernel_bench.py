@@ -84,6 +84,11 @@ def bench_ce(B, Tg, V, dtype, full_mask=True):
     buf = torch.empty_like(logits)
     med, best = time_fn(lambda: ops.ce_fwd(logits, ids, mask, stats, True))
     out["fwd+grad(fused)"] = {"s": med, "best_s": best, "GBps": 2 * R * V * el / med / 1e9, "frac": 2 * R * V * el / med / HBM_PEAK}
+    # what the training step runs: the gradient overwrites the logits (footprint = one buffer, not two)
+    scratch = logits.clone()
+    med, best = time_fn(lambda: ops.ce_fwd(scratch, ids, mask, stats, True, inplace=True))
+    out["fwd+grad(in place)"] = {"s": med, "best_s": best, "GBps": 2 * R * V * el / med / 1e9, "frac": 2 * R * V * el / med / HBM_PEAK}
+    del scratch
     row_lse, _, _ = ops.ce_fwd(logits, ids, mask, stats, False)
     g = torch.ones(1, device=dev)
     med, best = time_fn(lambda: ops.ce_bwd(logits, ids, mask, stats, row_lse, g))
@@ -173,6 +178,7 @@ def main():
     ap.add_argument("--vocab", type=int, default=0,
                     help="with --only ce: run the B = 18 shapes of this vocabulary size only (PMC passes: one process per V, "
                          "because the counter CSV cannot tell two launches of one instantiation with the same grid apart)")
+    ap.add_argument("--sizes", default="", help="with --only sim: square sizes to run instead of the standard list, e.g. 1200,1536")
     args = ap.parse_args()
     res = {}
     if args.only in ("", "ce"):
@@ -188,10 +194,12 @@ def main():
         sizes = [(18, 18), (150, 150), (1200, 1200), (4096, 4096), (16384, 16384)]
         if not args.quick:
             sizes.append((65536, 65536))
+        if args.sizes:
+            sizes = [(int(x), int(x)) for x in args.sizes.split(",")]
         for m, n in sizes:
             res[f"sim {m}x{n} D1024"] = bench_sim(m, n, 1024)
         # per-rank blocks of the sharded negatives at W = 8: cfg3 (18 x 144) and cfg2 (150 x 1200)
-        for m, n in [(18, 144), (150, 1200)]:
+        for m, n in ([] if args.sizes else [(18, 144), (150, 1200)]):
             res[f"sim sharded {m}x{n} D1024"] = bench_sim(m, n, 1024)
     if args.only in ("", "small"):
         for m, n in [(18, 18), (150, 150), (512, 512)]:
