@@ -48,7 +48,7 @@ GENERATORS = {
 }
 
 
-def build_models(device, dtype, bert_layers=24, llama_layers=32, lora=True, generator="llama-2-7b"):
+def build_models(device, dtype, bert_layers=24, llama_layers=32, lora=True, generator="llama-2-7b", use_bnb=None):
     from transformers import AutoModelForCausalLM, BertConfig, BertModel
 
     from dalm_amd.models import AutoModelForRagE2E, Mode
@@ -66,7 +66,14 @@ def build_models(device, dtype, bert_layers=24, llama_layers=32, lora=True, gene
         finally:
             torch.set_default_dtype(old)
     return AutoModelForRagE2E.from_modules(retriever, gen, None, None, normalize=True,
-                                           get_peft=Mode.BOTH if lora else None)
+                                           get_peft=Mode.BOTH if lora else None,
+                                           use_bnb=Mode(use_bnb) if use_bnb else None)
+
+
+def _resident_weight_bytes(model):
+    from dalm_amd.models import nf4
+
+    return {"retriever": nf4.weight_bytes(model.retriever_model), "generator": nf4.weight_bytes(model.generator_model)}
 
 
 def synthetic_batch(device, seed, B=CFG["B"], Tq=CFG["Tq"], Tp=CFG["Tp"], Tg=CFG["Tg"], V=CFG["V"]):
@@ -415,6 +422,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"],
                     help="bf16 = bf16 weights + autocast (default); fp32 = fp32 weights, no autocast "
                          "(the reference's default precision; quoted beside the bf16 line in DESIGN.md)")
+    ap.add_argument("--use-bnb", default=None, choices=["generator", "retriever", "both"],
+                    help="extra line, not the headline: the reference's use_bnb - frozen base Linears of the named tower(s) "
+                         "held as nf4 (dalm_nf4_* kernels), dequantised to bf16 in front of every GEMM")
     ap.add_argument("--retriever-layers", type=int, default=24, help=argparse.SUPPRESS)
     ap.add_argument("--generator-layers", type=int, default=32, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -450,7 +460,7 @@ def main():
     wdtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     autocast = torch.bfloat16 if args.dtype == "bf16" else None
 
-    model = build_models(dev, wdtype, args.retriever_layers, args.generator_layers, generator=gen_name)
+    model = build_models(dev, wdtype, args.retriever_layers, args.generator_layers, generator=gen_name, use_bnb=args.use_bnb)
     model.train()
     params = [p for p in model.parameters() if p.requires_grad]
     from transformers import get_scheduler
@@ -573,7 +583,7 @@ def main():
             "value": value, "unit": "pairs/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": (value / A100_README_PAIRS_PER_S) if (args.gpus == 1 and args.workload == "cfg3"
-                                                                   and args.data_path == "fixed") else None,
+                                                                   and args.data_path == "fixed" and not args.use_bnb) else None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload} RAG-e2e: bge-large-en + {gen_name} architectures (random init, V={V}), "
                                    "LoRA r=8 both towers, per-GPU batch 18, Tq50/Tp128/Tg256, logit_scale 100, Adam, "
@@ -589,6 +599,9 @@ def main():
                                      ("dalm_amd.launch (python bench.py --gpus N)" if ranks_seen > 1 else "single process"),
                        "gpu_max_hw_queues": args.hw_queues,
                        "retriever_layers": args.retriever_layers, "generator_layers": args.generator_layers,
+                       "use_bnb": (None if not args.use_bnb else
+                                   {"towers": args.use_bnb, "format": "nf4, blocks of 64, f32 absmax, bf16 compute (dalm_nf4_* kernels)",
+                                    "weight_bytes_resident": _resident_weight_bytes(model)}),
                        "lm_head": (("fused with the CE in row chunks over the rows that carry loss (no logits tensor)" if not args.all_rows
                                     else "fused with the CE in sample chunks (no logits tensor)") if args.fuse_lm_head
                                    else f"logits materialised ({args.dtype})"),
