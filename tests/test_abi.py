@@ -63,6 +63,12 @@ def test_argument_errors_are_reported_without_a_gpu(lib):
     assert b"null pointer" in lib.dalm_last_error_string()
     rc = lib.dalm_marg_ce_fwd(None, 0, 1, 2, 3, 6, 3, None, None, None, None, None, None, None)
     assert rc == -1
+    # nf4: sizes of the two stores, and argument errors before any launch
+    assert lib.dalm_nf4_packed_bytes(0) == 0 and lib.dalm_nf4_packed_bytes(64) == 32 and lib.dalm_nf4_packed_bytes(65) == 33
+    assert lib.dalm_nf4_absmax_count(64) == 1 and lib.dalm_nf4_absmax_count(65) == 2
+    assert lib.dalm_nf4_quantize(None, 0, 64, None, None, None) == -1
+    assert lib.dalm_nf4_dequantize(None, None, -1, 0, None, None) == -2
+    assert lib.dalm_nf4_quantize(None, 0, 0, None, None, None) == 0          # nothing to do is not an error
 
 
 def test_product_path_refuses_cpu_tensors():
@@ -74,6 +80,12 @@ def test_product_path_refuses_cpu_tensors():
         tu.get_cosine_sim(q, q, 100)
     with pytest.raises(RuntimeError, match="HIP|MI355X|GPU"):
         tu.get_nt_xent_loss(torch.randn(4, 4))
+    from dalm_amd.models import nf4
+
+    with pytest.raises(RuntimeError, match="HIP|MI355X|GPU"):
+        nf4.quantize(torch.randn(128))
+    with pytest.raises(RuntimeError, match="HIP|MI355X|GPU"):
+        nf4.NF4Linear(torch.nn.Linear(64, 64))
 
 
 def test_package_never_imports_oracle():
