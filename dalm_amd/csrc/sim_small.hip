@@ -78,7 +78,8 @@ __global__ __launch_bounds__(256) void small_partial_kernel(const float* __restr
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   // 4 pairs of float4 per operand per round (32 of K).  Measured and slower on every shape (round 3): 8 pairs per round
-  // (+0.7 ... +1.6 us per call), more split-K workgroups (DALM_SMALL_TARGET 512 - 1024)
+  // (+0.7 ... +1.6 us per call), a wave's whole K range (128 = 4 rounds) in flight before its first MFMA (150 x 1200: 18.9
+  // instead of 17.0 us per call, 512^2: 21.3 instead of 20.5), more split-K workgroups (DALM_SMALL_TARGET 384 - 1024), fewer (128)
   constexpr int NU = 4;
   for (int k0 = k_lo; k0 < k_hi; k0 += 8 * NU) {
     float4 av[NU], bv[NU];
@@ -294,6 +295,7 @@ constexpr int GK = 256;
 // value.  Vocabulary: "row" = one of the 32 output rows of this workgroup, "k" = contraction index.
 //   dir 0: row = i (query), k = j (passage), S element S[row][k], diag at k == off + row
 //   dir 1: row = j (passage), k = i (query),  S element S[k][row], diag at k == row - off
+template <bool LONG>
 __global__ __launch_bounds__(256, 4) void small_grad_kernel(const float* __restrict__ S, int64_t ldS,
                                                          const float* __restrict__ A, const float* __restrict__ Bm,
                                                          int m, int n, int D, float alpha, int64_t diag_offset,
@@ -337,19 +339,29 @@ __global__ __launch_bounds__(256, 4) void small_grad_kernel(const float* __restr
 
   for (int k0 = k_begin; k0 < k_end; k0 += GK) {
     const int kn = min(GK, Kd - k0);
+    // The other operand's fragments (lane (c, h) of step s reads X[k0 + 2s + h][d0 + c]) are independent of dS.
+    //   LONG (contractions longer than 64: 32 two-wide steps per wave): ALL of a wave's fragments are fetched up front - the first half
+    //     before the strip is built (its S loads, the exps and the barrier hide the latency), the second half once the strip's
+    //     32 S values have left their registers (covered by the barrier and the first 16 MFMAs); steps past the chunk's end
+    //     multiply the zero rows of the strip.  Before (round 3 measurement): rounds of 8 steps with the next round fetched
+    //     during the current round's 8 dependent MFMAs = 0.2 us of cover for an L2 round trip, three exposed stalls per
+    //     chunk (512^2: 31.8 -> 28.4 us, 150 x 1200: 20.2 -> 19.1 us per call);
+    //   !LONG (the 18-row batches: one or two steps per wave): the round form - 32 unconditional steps per wave cost
+    //     those shapes 1.1 us.
+    constexpr int SPW = GK / 8;            // LONG: steps per wave
     const int ns = (kn + 1) >> 1;          // two-wide MFMA steps in the chunk
-    const int per = (ns + 3) >> 2;
+    const int per = LONG ? SPW : (ns + 3) >> 2;
     const int s_lo = wave * per, s_hi = min(ns, s_lo + per);
-    // first batch of the other operand's fragments: independent of dS, issued before the strip is built
-    float bv[8], bn[8];
-    auto load8 = [&](float (&dst)[8], int s0) {
+    float bv[LONG ? SPW : 16];
+    auto fetch = [&](int u_lo, int cnt, int s0) {      // bv[u_lo + i] <- fragment of step s0 + i
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int kk = min(k0 + 2 * (s0 + u) + lhi, Kd - 1);
-        dst[u] = X[static_cast<int64_t>(kk) * D + dcol];
+      for (int i = 0; i < cnt; ++i) {
+        const int kk = min(k0 + 2 * (s0 + i) + lhi, Kd - 1);
+        bv[u_lo + i] = X[static_cast<int64_t>(kk) * D + dcol];
       }
     };
-    load8(bv, s_lo);
+    if constexpr (LONG) fetch(0, SPW / 2, s_lo);
+    else fetch(0, 8, s_lo);
     // ---- build the dS strip: Ds[kk][r] = dS(row r0 + r, k0 + kk), 32 S values per thread in flight ----
     float sv[32];
     if (dir == 0) {
@@ -388,19 +400,26 @@ __global__ __launch_bounds__(256, 4) void small_grad_kernel(const float* __restr
         Ds[kk * RED_STRIDE + r] = (kk < kn && r0 + r < R) ? d : 0.f;
       }
     }
+    if constexpr (LONG) fetch(SPW / 2, SPW / 2, s_lo + SPW / 2);   // in flight across the barrier and the first 16 MFMAs
     __syncthreads();
-    // ---- MFMA over this wave's quarter of the chunk, 8 two-wide steps per round, next round prefetched ----
-    for (int s0 = s_lo; s0 < s_hi; s0 += 8) {
-      if (s0 + 8 < s_hi) load8(bn, s0 + 8);
+    // ---- MFMA over this wave's quarter of the chunk ----
+    if constexpr (LONG) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (s0 + u < s_hi) {  // wave-uniform
-          const int kk = min(2 * (s0 + u) + lhi, GK - 1);   // entries at kk >= kn are 0
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ds[kk * RED_STRIDE + l31], bv[u], acc, 0, 0, 0);
+      for (int u = 0; u < SPW; ++u)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ds[(2 * (s_lo + u) + lhi) * RED_STRIDE + l31], bv[u], acc, 0, 0, 0);
+    } else {
+      for (int s0 = s_lo; s0 < s_hi; s0 += 8) {       // 8 steps per round, the next round prefetched into bv[8..15]
+        if (s0 + 8 < s_hi) fetch(8, 8, s0 + 8);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (s0 + u < s_hi) {  // wave-uniform
+            const int kk = min(2 * (s0 + u) + lhi, GK - 1);   // entries at kk >= kn are 0
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ds[kk * RED_STRIDE + l31], bv[u], acc, 0, 0, 0);
+          }
         }
-      }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) bv[u] = bn[u];
+        for (int u = 0; u < 8; ++u) bv[u] = bv[8 + u];
+      }
     }
     // the barrier after the next chunk's loads (or the one below) orders these Ds reads before its rewrite
   }
@@ -555,9 +574,16 @@ extern "C" int dalm_sim_small_bwd_ws(const float* S, int64_t ldS, const float* A
                   static_cast<unsigned>(ndir * nsl));
   float* slab = static_cast<float*>(ws);
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(small_grad_kernel, grid, dim3(256), 0, s, S, ldS, A, Bm, static_cast<int>(m),
-                     static_cast<int>(n), static_cast<int>(D), scale, diag_offset, row_coef, row_lse, col_coef, col_lse,
-                     dA, dB, dir0, nsl, dA ? slab : nullptr, dA ? nullptr : slab);
+  // the shortest contraction among the launched directions decides the form (dir 0 contracts over n, dir 1 over m)
+  const int64_t kd_min = (ndir == 2) ? (m < n ? m : n) : (dir0 ? m : n);
+  if (kd_min > 64)
+    hipLaunchKernelGGL(small_grad_kernel<true>, grid, dim3(256), 0, s, S, ldS, A, Bm, static_cast<int>(m),
+                       static_cast<int>(n), static_cast<int>(D), scale, diag_offset, row_coef, row_lse, col_coef, col_lse,
+                       dA, dB, dir0, nsl, dA ? slab : nullptr, dA ? nullptr : slab);
+  else
+    hipLaunchKernelGGL(small_grad_kernel<false>, grid, dim3(256), 0, s, S, ldS, A, Bm, static_cast<int>(m),
+                       static_cast<int>(n), static_cast<int>(D), scale, diag_offset, row_coef, row_lse, col_coef, col_lse,
+                       dA, dB, dir0, nsl, dA ? slab : nullptr, dA ? nullptr : slab);
   if (nsl > 1) {
     const int64_t count = (dA ? m : n) * D;
     int64_t blocks = (count / 4 + 255) / 256;

@@ -72,10 +72,14 @@ def test_small_path_vs_fp64(dev, m, n, D, off):
     from dalm_amd import hip
 
     for one, both, want_a in ((dA1, dA, 1), (dB1, dB, 0)):
-        if hip.load().dalm_sim_small_bwd_workspace_bytes(m, n, D, want_a, 1 - want_a) == 0:
+        unsliced = hip.load().dalm_sim_small_bwd_workspace_bytes(m, n, D, want_a, 1 - want_a) == 0
+        # the kernel's form (all fragments up front / rounds of 8 steps) follows the shortest contraction of the LAUNCH:
+        # dir 0 contracts over n, dir 1 over m
+        same_form = (min(m, n) > 64) == ((n if want_a else m) > 64)
+        if unsliced and same_form:
             assert torch.equal(one, both)                 # same kernel, same order: same bits
-        else:                                             # one direction of a long contraction runs in slices (fixed order)
-            assert_grad_close(one, both.cpu().double(), 1e-5, "sliced vs unsliced")
+        else:                                             # slices of a long contraction / the other form: fixed order each
+            assert_grad_close(one, both.cpu().double(), 1e-5, "one direction vs both")
     again, _ = ops.sim_small_bwd(*args, True, False)
     assert torch.equal(again, dA1)                        # deterministic either way
 
