@@ -104,31 +104,81 @@ class NF4Linear(nn.Module):
         return f"in_features={self.in_features}, out_features={self.out_features}, bias={self.bias is not None}, nf4"
 
 
-def modules_kept_in_full_precision(model: nn.Module) -> List[str]:
-    """transformers' `get_keys_to_not_convert` for a 4-bit load: the output head (and whatever is tied to it) stays
-    unquantised; a bare encoder (`AutoModel`) has no head and converts every Linear."""
-    keep = []
+def _own_keep_rule(model: nn.Module) -> List[str]:
+    """The output head (and nothing else that is a Linear): what transformers' rule comes to for the architectures of the
+    path - a bare encoder (`AutoModel`) has no head and converts every Linear, a causal LM keeps `lm_head`."""
     head = model.get_output_embeddings() if hasattr(model, "get_output_embeddings") else None
-    if head is not None:
-        keep += [n for n, m in model.named_modules() if m is head]
-    return keep
+    return [] if head is None else [n for n, m in model.named_modules() if m is head]
+
+
+def modules_kept_in_full_precision(model: nn.Module) -> List[str]:
+    """Name patterns of the modules a 4-bit load leaves alone.  The reference passes no `llm_int8_skip_modules`, so
+    transformers decides (`get_keys_to_not_convert`: tied weights, the module of the last parameter, the output embedding);
+    its own function is used when this transformers build has it, `_own_keep_rule` otherwise (tests/test_nf4.py checks
+    that the two convert the same Linears on the golden BERT / Llama / Falcon models)."""
+    try:
+        from transformers.quantizers.base import get_keys_to_not_convert
+    except ImportError:
+        try:
+            from transformers.integrations.bitsandbytes import get_keys_to_not_convert   # transformers 4.x
+        except ImportError:
+            get_keys_to_not_convert = None
+    if get_keys_to_not_convert is not None and hasattr(model, "get_output_embeddings"):
+        try:
+            return list(get_keys_to_not_convert(model))
+        except Exception:       # a model class without the bookkeeping that function reads
+            pass
+    return _own_keep_rule(model)
+
+
+def _skipped(full_name: str, patterns: Iterable[str]) -> bool:
+    """transformers' `should_convert_module`, negated: a pattern is a prefix followed by a dot, a (regex) match from the
+    start of the name, or a suffix of it."""
+    import re
+
+    for key in patterns:
+        try:
+            if re.match(f"{key}\\.", full_name) or re.match(f"{key}", full_name):
+                return True
+        except re.error:
+            pass
+        if full_name.endswith(key):
+            return True
+    return False
 
 
 def quantize_linears(model: nn.Module, skip: Optional[Iterable[str]] = None) -> int:
     """Swap every `nn.Linear` of `model` (already on the GPU) outside `skip` for an `NF4Linear`, freeing the original
     weight as it goes.  Returns the number of converted modules."""
-    skip = set(modules_kept_in_full_precision(model) if skip is None else skip)
+    skip = list(modules_kept_in_full_precision(model) if skip is None else skip)
     done = 0
-    for parent_name, parent in list(model.named_modules()):
-        for child_name, child in list(parent.named_children()):
-            full = f"{parent_name}.{child_name}" if parent_name else child_name
-            if type(child) is nn.Linear and full not in skip and full.rsplit(".", 1)[-1] not in skip:
-                setattr(parent, child_name, NF4Linear(child))
-                done += 1
+    for full, parent, child_name, child in linears_to_convert(model, skip):
+        setattr(parent, child_name, NF4Linear(child))
+        done += 1
     if done == 0:
         raise ValueError("use_bnb: no nn.Linear found to quantise")
     model._dalm_nf4 = True
     return done
+
+
+def _is_plain_linear(m: nn.Module) -> bool:
+    """`nn.Linear` itself, or Falcon's `FalconLinear` (y = x W^T + b spelled as a matmul).  transformers 4.x - the
+    reference pins `transformers>4.35` - converted every `isinstance(module, nn.Linear)`; transformers 5.x narrowed that to
+    the exact type, which would leave a Falcon generator (BASELINE config 5) unquantised.  Other subclasses may override
+    forward and are left alone."""
+    return type(m) is nn.Linear or (isinstance(m, nn.Linear) and type(m).__name__ == "FalconLinear")
+
+
+def linears_to_convert(model: nn.Module, skip: Iterable[str]):
+    """(full name, parent, attribute, module) of every plain Linear outside the skip patterns."""
+    skip = list(skip)
+    out = []
+    for parent_name, parent in list(model.named_modules()):
+        for child_name, child in list(parent.named_children()):
+            full = f"{parent_name}.{child_name}" if parent_name else child_name
+            if _is_plain_linear(child) and not _skipped(full, skip):
+                out.append((full, parent, child_name, child))
+    return out
 
 
 def weight_bytes(model: nn.Module) -> int:

@@ -92,6 +92,41 @@ def test_use_bnb_without_a_gpu_degrades_with_a_warning(monkeypatch):
         assert m.model is not None and not getattr(m.model, "_dalm_nf4", False)
 
 
+def test_which_linears_are_converted_is_transformers_own_rule():
+    """The reference hands the model to transformers' 4-bit loader without `llm_int8_skip_modules`
+    (rag_e2e_base_model.py:50-58): which Linears become 4-bit is transformers' decision.  The installed transformers'
+    own `get_keys_to_not_convert` / `should_convert_module` are what the product calls; the in-tree fallback rule
+    (output head only) converts exactly the same modules on the golden BERT, Llama and a Falcon-architecture model."""
+    import re
+
+    from transformers import AutoModel, AutoModelForCausalLM, FalconConfig
+    from transformers.quantizers.base import get_keys_to_not_convert
+    from transformers.quantizers.quantizers_utils import should_convert_module
+
+    from dalm_amd.models import nf4
+
+    falcon = AutoModelForCausalLM.from_config(FalconConfig(vocab_size=64, hidden_size=64, num_hidden_layers=2,
+                                                           num_attention_heads=4, new_decoder_architecture=False,
+                                                           multi_query=True, parallel_attn=True, bias=False))
+    models = {"bert": AutoModel.from_pretrained(str(G / "tiny_retriever")),
+              "llama": AutoModelForCausalLM.from_pretrained(str(G / "tiny_generator")), "falcon": falcon}
+    for name, m in models.items():
+        theirs = list(get_keys_to_not_convert(m))
+        assert sorted(nf4.modules_kept_in_full_precision(m)) == sorted(theirs), name
+        # transformers 5.x converts `type(module) is nn.Linear` only; 4.x (the reference's `transformers>4.35`) converted
+        # every isinstance - Falcon's FalconLinear included, which the product keeps converting
+        want = [n for n, mod in m.named_modules() if isinstance(mod, torch.nn.Linear) and should_convert_module(n, theirs)]
+        got = [x[0] for x in nf4.linears_to_convert(m, nf4.modules_kept_in_full_precision(m))]
+        own = [x[0] for x in nf4.linears_to_convert(m, nf4._own_keep_rule(m))]
+        assert got == want and own == want and len(want) > 0, (name, set(got) ^ set(want), set(own) ^ set(want))
+        head = m.get_output_embeddings()
+        if head is not None:
+            assert all(not re.fullmatch(r"lm_head", n) for n in want)
+    for n, pats in (("lm_head", ["lm_head"]), ("a.b.c", ["b"]), ("a.b.c", ["a.b"]), ("a.b.c", ["c"]),
+                    ("pooler.dense", ["pooler.dense.bias"]), ("encoder.layer.1.x", ["encoder.layer.*"])):
+        assert nf4._skipped(n, pats) == (not should_convert_module(n, pats)), (n, pats)
+
+
 # ---------------------------------------------------------------- GPU: kernels, module, wrappers
 def _q(w_t):
     from dalm_amd.models import nf4
