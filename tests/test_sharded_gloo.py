@@ -159,6 +159,50 @@ def test_overlapped_grad_buckets_fixed_launch_order(tmp_path):
     assert l0 == l1 == [[2, 1, 0], [2, 1, 0]]
 
 
+def _accum_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+
+    from dalm_amd.fused import TorchDistComm
+    from dalm_amd.training.step import _StepBase
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    model = torch.nn.Linear(4, 3)                                  # same weights on every rank
+    opt = torch.optim.SGD(model.parameters(), lr=0.5)
+    step = _StepBase(model, opt, None, 100, comm=TorchDistComm(), grad_accum=2, track_grad_norm=True)
+    assert step.bucket is not None and step.bucket.overlap is False   # N > 1: ONE all-reduce per optimizer step
+    w0 = model.weight.detach().clone()
+    seen = []
+    for micro in range(4):
+        x = torch.full((2, 4), float(rank + 1 + micro))
+        loss = model(x).sum()
+        step._finish(loss)
+        seen.append((step.synced, model.weight.detach().clone()))
+    torch.save({"seen": seen, "w0": w0, "grad_norm": float(step.grad_norm)}, os.path.join(out_dir, f"acc{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_gradient_accumulation_with_two_ranks_reduces_once_per_optimizer_step(tmp_path):
+    """`--gradient_accumulation_steps 2` at W = 2 (reference: accelerate's accumulate(), train_rage2e.py:431): micro-batch
+    gradients (each scaled 1/N) add up locally, the cross-rank SUM runs once, on the step that takes the update - an
+    all-reduce per micro-batch would count the earlier micro-batches W times."""
+    port = _free_port()
+    mp.spawn(_accum_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "acc0.pt"), torch.load(tmp_path / "acc1.pt")
+    assert [s for s, _ in r0["seen"]] == [False, True, False, True]
+    # d(sum(model(x)))/dW[o, i] = sum_b x[b, i] = 2 * value; optimizer step 1 sees micro 0 + 1 of both ranks, each / 2
+    w = r0["w0"].clone()
+    for first in (0, 2):
+        g = sum(2.0 * float(rank + 1 + micro) / 2.0 for rank in range(2) for micro in (first, first + 1))
+        w = w - 0.5 * g
+        for r in (r0, r1):
+            torch.testing.assert_close(r["seen"][first][1], w + 0.5 * g)      # no update on the first micro-batch
+            torch.testing.assert_close(r["seen"][first + 1][1], w)
+    assert r0["grad_norm"] == r1["grad_norm"] > 0
+
+
 def test_launcher_spawns_gloo_ranks(tmp_path):
     """dalm_amd.launch (the torchrun-free spawner bench.py and the trainers use for N > 1): two CPU ranks
     rendezvous over 127.0.0.1, rank 0 keeps stdout, a failing rank takes the job down with its exit code."""
