@@ -321,9 +321,9 @@ def step_parity_block(dev, model_cpu, batch_cpu):
 
 
 def cpu_reference_baseline(max_seconds=90.0, parity_dev=None):
-    """Reference CPU path on the host cores, bounded (~25 s): the oracle restatement of the reference's
+    """Reference CPU path on the host cores, bounded (~50 s): the oracle restatement of the reference's
     loss code at the full cfg3 shapes around the same HF architectures (LoRA, fp32) at depth 1 and
-    depth 2 instead of 24 / 32 layers, one step each; the per-layer increment is extrapolated to full
+    depth 2 instead of 24 / 32 layers, median of 3 steps each; the per-layer increment is extrapolated to full
     depth.  Threads: min(host cores, 16) - measured on the 256-core GPU-box host, 16 threads is the
     fastest setting for this eager-torch workload (16: 4.9 s, 32: 5.5 s, 64: 6.8 s, 256: 80 s per
     depth-1 step), so this is the CPU path at its best, and `cores` reports the threads used."""
@@ -333,7 +333,7 @@ def cpu_reference_baseline(max_seconds=90.0, parity_dev=None):
     threads = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(threads)
     dev = torch.device("cpu")
-    times = {}
+    times, spread = {}, {}
     parity = None
     t_start = time.time()
     for depth in (1, 2):
@@ -359,9 +359,13 @@ def cpu_reference_baseline(max_seconds=90.0, parity_dev=None):
 
         if depth == 1:
             step()  # warm-up (thread pools, allocator)
-        t0 = time.time()
-        step()
-        times[depth] = time.time() - t0
+        samples = []
+        for _ in range(3):          # median of 3 (one un-repeated step swung 26 % between rounds)
+            t0 = time.time()
+            step()
+            samples.append(time.time() - t0)
+        times[depth] = sorted(samples)[1]
+        spread[depth] = (min(samples), max(samples))
         if depth == 1 and parity_dev is not None:
             try:        # the weights have taken two Adam steps by now: lora_B is no longer zero, both LoRA factors carry gradient
                 parity = step_parity_block(parity_dev, model, batch)
@@ -377,11 +381,14 @@ def cpu_reference_baseline(max_seconds=90.0, parity_dev=None):
         # 12.6 M x 3204 tokens -> 95.8 % / 4.2 %) and scale each share to its true depth (32 / 24)
         full = fixed + delta * (0.958 * 32 + 0.042 * 24)
         note = (f"reference-equivalent CPU step (oracle loss code at full cfg3 shapes + HF towers, LoRA, fp32, "
-                f"{threads} threads): depth 1 = {times[1]:.2f} s, depth 2 = {times[2]:.2f} s per step; per-layer "
-                f"increment extrapolated to 24 BERT / 32 Llama layers -> {full:.1f} s per 18-pair step")
+                f"{threads} threads): median of 3 steps per depth after a warm-up step - depth 1 = {times[1]:.2f} s "
+                f"(min {spread[1][0]:.2f}, max {spread[1][1]:.2f}), depth 2 = {times[2]:.2f} s (min {spread[2][0]:.2f}, max "
+                f"{spread[2][1]:.2f}); per-layer increment extrapolated to 24 BERT / 32 Llama layers -> {full:.1f} s per "
+                f"18-pair step (the extrapolation multiplies the depth-2 minus depth-1 difference by ~32: quote it as +-30 %)")
     else:
         full = times[1] * 30.0
-        note = f"depth-1 towers only ({times[1]:.2f} s/step, {threads} threads) x30 (time bound hit before depth 2)"
+        note = (f"depth-1 towers only (median of 3: {times[1]:.2f} s/step, min {spread[1][0]:.2f}, max {spread[1][1]:.2f}, "
+                f"{threads} threads) x30 (time bound hit before depth 2)")
     return {"value": CFG["B"] / full, "unit": "training pairs/s", "cores": threads, "kind": "port", "sample": note}, parity
 
 
@@ -425,12 +432,28 @@ def main():
     ap.add_argument("--use-bnb", default=None, choices=["generator", "retriever", "both"],
                     help="extra line, not the headline: the reference's use_bnb - frozen base Linears of the named tower(s) "
                          "held as nf4 (dalm_nf4_* kernels), dequantised to bf16 in front of every GEMM")
+    ap.add_argument("--through-trainer", action="store_true",
+                    help="extra line, not the headline: run the TRAINER ENTRY POINT itself (train_e2e; train_retriever for cfg2) at "
+                         "this workload's full size on a synthetic csv - tokenise -> token cache -> ShardedBatches -> GraphedStep "
+                         "(incl. the partial last batch) -> step_N checkpoint -> kill -> --resume_from_checkpoint - and report "
+                         "the trainer's own pairs/s (tools/trainer_bench.py)")
+    ap.add_argument("--trainer-rows", type=int, default=10000, help="rows of the synthetic csv for --through-trainer")
+    ap.add_argument("--bench-line", default=None, help="--through-trainer: file with this workload's bench.py line (ratio)")
     ap.add_argument("--retriever-layers", type=int, default=24, help=argparse.SUPPRESS)
     ap.add_argument("--generator-layers", type=int, default=32, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     from dalm_amd.launch import in_distributed_env, spawn_ranks
 
+    if args.through_trainer:
+        if args.gpus != 1 or args.workload == "cfg1":
+            raise SystemExit("--through-trainer runs on one GPU at cfg3 / cfg5 / cfg2")
+        sys.path.insert(0, str(ROOT / "tools"))
+        import trainer_bench
+
+        argv = ["--workload", args.workload, "--rows", str(args.trainer_rows), "--retriever-layers", str(args.retriever_layers),
+                "--generator-layers", str(args.generator_layers)] + (["--bench-line", args.bench_line] if args.bench_line else [])
+        return trainer_bench.main(argv)
     if args.gpus > 1 and not in_distributed_env():
         # `python bench.py --gpus N`: no torchrun needed - spawn one rank per GPU ourselves (RANK / LOCAL_RANK /
         # WORLD_SIZE / MASTER_ADDR=127.0.0.1), rank 0 prints the JSON line; fewer than N visible GPUs -> exit 2

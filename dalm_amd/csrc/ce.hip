@@ -107,7 +107,9 @@ struct RowWin {
 };
 
 // Write `fill` over one full row (used for masked rows and the t = Tg-1 slot).
-template <typename T, int BS>
+// NTFILL: non-temporal stores (the zero rows of a padded batch are a pure write stream: 110 of the 295 MB written per
+// launch at the bench's masks); measured against cached stores in profiles/r04_ce_row_order.txt.
+template <typename T, int BS, bool NTFILL = false>
 __device__ __forceinline__ void fill_row(T* row, int V, float fill) {
   constexpr int VEC = Elt<T>::VEC;
   RowWin<T> w(row, V);
@@ -117,7 +119,8 @@ __device__ __forceinline__ void fill_row(T* row, int V, float fill) {
   for (int e = 0; e < VEC; ++e) z[e] = fill;
   for (int slot = threadIdx.x; slot < w.nslots; slot += BS) {
     if (!w.partial(slot)) {
-      Elt<T>::store(abase + static_cast<int64_t>(slot) * VEC, z);
+      if constexpr (NTFILL) Elt<T>::store_nt(abase + static_cast<int64_t>(slot) * VEC, z);
+      else Elt<T>::store(abase + static_cast<int64_t>(slot) * VEC, z);
     } else {
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
@@ -126,6 +129,20 @@ __device__ __forceinline__ void fill_row(T* row, int V, float fill) {
       }
     }
   }
+}
+
+// Workgroup -> (b,t) row.  Left-padded samples put a run of write-only rows (padding: the gradient is zeros) in front
+// of a run of read+write rows; with row = blockIdx.x the dispatcher issues them in that order.  `order` permutes which
+// row a workgroup takes (a bijection on [0, B*Tg)), so that both kinds are co-resident on a CU:
+//   0  identity;   -1  sample-interleaved (b = blk % B, t = blk / B);   s > 0  t = (i * s) % Tg inside a sample, gcd(s,Tg)=1
+__device__ __forceinline__ int64_t map_row(unsigned blk, int Tg, int order) {
+  if (order == 0) return blk;
+  if (order < 0) {
+    const unsigned B = gridDim.x / static_cast<unsigned>(Tg);
+    return static_cast<int64_t>(blk % B) * Tg + blk / B;
+  }
+  const unsigned b = blk / static_cast<unsigned>(Tg), i = blk % static_cast<unsigned>(Tg);
+  return static_cast<int64_t>(b) * Tg + (static_cast<uint64_t>(i) * static_cast<unsigned>(order)) % static_cast<unsigned>(Tg);
 }
 
 // ---------------------------------------------------------------------------
@@ -140,10 +157,10 @@ __global__ __launch_bounds__(BS, (SLOTS * Elt<T>::VEC > 64 ? 3 : 4)) void marg_c
     const T* __restrict__ logits, int64_t stride_b, int64_t stride_t,
     const int64_t* __restrict__ ids, const int64_t* __restrict__ mask, int Tg, int V,
     const float* __restrict__ stats, float* __restrict__ row_lse, float* __restrict__ row_nll,
-    T* dlogits) {
+    T* dlogits, int order) {
   constexpr int VEC = Elt<T>::VEC;
   __shared__ float red[BS / kWave];
-  const int64_t row = blockIdx.x;
+  const int64_t row = map_row(blockIdx.x, Tg, order);
   const int b = static_cast<int>(row / Tg), t = static_cast<int>(row % Tg);
   const int tid = threadIdx.x;
   const int64_t off = b * stride_b + t * stride_t;
@@ -268,17 +285,18 @@ __global__ __launch_bounds__(BS, (SLOTS * Elt<T>::VEC > 64 ? 3 : 4)) void marg_c
 // unpacked variant (2 rows/CU, time = T_read + T_write) could not do.  exp() is recomputed in the
 // gradient phase instead of being kept in f32 registers (VALU is far from the limit here).
 // ---------------------------------------------------------------------------
-// NT: cache policy of the two streams - bit 0 = non-temporal loads, bit 1 = non-temporal stores.
+// NT: cache policy of the streams - bit 0 = non-temporal loads, bit 1 = non-temporal stores, bit 2 = non-temporal zero fill
+// of the rows without loss.
 template <int BS, int SLOTS, bool WRITE_GRAD, bool ALIGNED, int NT = 0>
 __global__ __launch_bounds__(BS, 8) void marg_ce_row_bf16_kernel(
     const bf16_t* __restrict__ logits, int64_t stride_b, int64_t stride_t,
     const int64_t* __restrict__ ids, const int64_t* __restrict__ mask, int Tg, int V,
     const float* __restrict__ stats, float* __restrict__ row_lse, float* __restrict__ row_nll,
-    bf16_t* dlogits) {
+    bf16_t* dlogits, int order) {
   using T = bf16_t;
   constexpr int VEC = 8;
   __shared__ float red[BS / kWave];
-  const int64_t row = blockIdx.x;
+  const int64_t row = map_row(blockIdx.x, Tg, order);
   const int b = static_cast<int>(row / Tg), t = static_cast<int>(row % Tg);
   const int tid = threadIdx.x;
   const int64_t off = b * stride_b + t * stride_t;
@@ -289,7 +307,7 @@ __global__ __launch_bounds__(BS, 8) void marg_ce_row_bf16_kernel(
     if (tid == 0) { row_lse[row] = 0.f; row_nll[row] = 0.f; }
     if constexpr (WRITE_GRAD) {
       const float fill = (!last && M == 0.f) ? __builtin_nanf("") : 0.f;
-      fill_row<T, BS>(dlogits + off, V, fill);
+      fill_row<T, BS, (NT & 4) != 0>(dlogits + off, V, fill);
     }
     return;
   }
@@ -434,10 +452,10 @@ __global__ __launch_bounds__(BS) void marg_ce_stream_kernel(
     const T* __restrict__ logits, int64_t stride_b, int64_t stride_t,
     const int64_t* __restrict__ ids, const int64_t* __restrict__ mask, int Tg, int V,
     const float* __restrict__ stats, float* __restrict__ row_lse, float* __restrict__ row_nll,
-    T* dlogits) {
+    T* dlogits, int order) {
   constexpr int VEC = Elt<T>::VEC;
   __shared__ float red[BS / kWave];
-  const int64_t row = blockIdx.x;
+  const int64_t row = map_row(blockIdx.x, Tg, order);
   const int b = static_cast<int>(row / Tg), t = static_cast<int>(row % Tg);
   const int tid = threadIdx.x;
   const int64_t off = b * stride_b + t * stride_t;
@@ -702,6 +720,9 @@ __global__ __launch_bounds__(256) void marginalize_rows_kernel(const float* __re
   }
 }
 
+constexpr int kDefaultRowOrder = 0;     // decided by measurement, see profiles/r04_ce_row_order.txt
+constexpr bool kDefaultNtFill = false;
+
 template <typename T, bool GRAD, bool ALIGNED>
 void launch_fwd2(const T* logits, int64_t B, int64_t Tg, int64_t V, int64_t sb, int64_t st,
                  const int64_t* ids, const int64_t* mask, const float* stats, float* row_lse,
@@ -712,7 +733,21 @@ void launch_fwd2(const T* logits, int64_t B, int64_t Tg, int64_t V, int64_t sb, 
   const int Tgi = static_cast<int>(Tg), Vi = static_cast<int>(V);
   constexpr int S_BIG = 64 / VEC;    // 64 floats per lane: <=128 VGPRs, 4 waves/SIMD
   constexpr int S_SMALL = 16 / VEC;  // 16 floats per lane
-#define DALM_CE_ARGS logits, sb, st, ids, mask, Tgi, Vi, stats, row_lse, row_nll, dlogits
+  // A/B knobs of the write stream (profiles/r04_ce_row_order.txt): DALM_CE_ORDER = 0 identity | i sample-interleaved |
+  // <s> stride inside a sample (made coprime to Tg here); DALM_CE_FILL = c cached zero fill | n non-temporal
+  static const char* order_env = getenv("DALM_CE_ORDER");
+  static const char* fill_env = getenv("DALM_CE_FILL");
+  int order = kDefaultRowOrder;
+  if (order_env) order = (order_env[0] == 'i') ? -1 : atoi(order_env);
+  if (order > 0) {
+    order %= Tgi;
+    auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
+    while (order > 1 && gcd(order, Tgi) != 1) ++order;
+    if (order <= 1) order = 0;
+  }
+  if (!GRAD) order = 0;   // a forward-only launch writes nothing: nothing to interleave
+  const bool nt_fill = fill_env ? fill_env[0] == 'n' : kDefaultNtFill;
+#define DALM_CE_ARGS logits, sb, st, ids, mask, Tgi, Vi, stats, row_lse, row_nll, dlogits, order
   // tuning knob for A/B runs (tools/kernel_bench.py): DALM_CE_VARIANT=stream | t256
   static const char* variant = getenv("DALM_CE_VARIANT");
   constexpr int S_WIDE = 128 / VEC;  // 128 floats per lane, 4 waves per row (fewer barrier participants)
@@ -730,6 +765,7 @@ void launch_fwd2(const T* logits, int64_t B, int64_t Tg, int64_t V, int64_t sb, 
       if (variant && variant[0] == 'c') nt = 0;
       else if (variant && variant[0] == 'l') nt = 1;
       else if (variant && variant[0] == 'w') nt = 2;
+      if (nt == 3 && nt_fill) nt = 7;
 #define DALM_CE_BF16(BSZ, P) hipLaunchKernelGGL((marg_ce_row_bf16_kernel<BSZ, 8, GRAD, ALIGNED, P>), grid, dim3(BSZ), 0, s, DALM_CE_ARGS)
       static const bool wide = getenv("DALM_CE_BS") && atoi(getenv("DALM_CE_BS")) == 1024;   // A/B knob: 16 waves per row
       if (need <= 512 * 4)
@@ -738,9 +774,9 @@ void launch_fwd2(const T* logits, int64_t B, int64_t Tg, int64_t V, int64_t sb, 
         if (nt == 3) hipLaunchKernelGGL((marg_ce_row_bf16_kernel<1024, 4, GRAD, ALIGNED, 3>), grid, dim3(1024), 0, s, DALM_CE_ARGS);
         else hipLaunchKernelGGL((marg_ce_row_bf16_kernel<1024, 4, GRAD, ALIGNED, 0>), grid, dim3(1024), 0, s, DALM_CE_ARGS);
       } else if (need <= 512 * 8) {
-        if (nt == 3) DALM_CE_BF16(512, 3); else if (nt == 2) DALM_CE_BF16(512, 2); else if (nt == 1) DALM_CE_BF16(512, 1); else DALM_CE_BF16(512, 0);
+        if (nt == 7) DALM_CE_BF16(512, 7); else if (nt == 3) DALM_CE_BF16(512, 3); else if (nt == 2) DALM_CE_BF16(512, 2); else if (nt == 1) DALM_CE_BF16(512, 1); else DALM_CE_BF16(512, 0);
       } else {
-        if (nt == 3) DALM_CE_BF16(1024, 3); else if (nt == 2) DALM_CE_BF16(1024, 2); else if (nt == 1) DALM_CE_BF16(1024, 1); else DALM_CE_BF16(1024, 0);
+        if (nt == 7) DALM_CE_BF16(1024, 7); else if (nt == 3) DALM_CE_BF16(1024, 3); else if (nt == 2) DALM_CE_BF16(1024, 2); else if (nt == 1) DALM_CE_BF16(1024, 1); else DALM_CE_BF16(1024, 0);
       }
 #undef DALM_CE_BF16
     }

@@ -40,6 +40,17 @@ def dequantize(packed: torch.Tensor, absmax: torch.Tensor, shape, dtype: torch.d
     hip.require_gpu(packed, absmax)
     if dtype not in (torch.float32, torch.bfloat16):
         raise TypeError("nf4 dequantises to float32 or bfloat16")
+    # the kernel reads raw pointers: a quant state that went through model.half() / .to(bfloat16) would be read as garbage
+    if absmax.dtype != torch.float32 or packed.dtype != torch.uint8:
+        raise TypeError(f"nf4 quant state must stay uint8 / float32 (got {packed.dtype} / {absmax.dtype}): was the module "
+                        "cast with .half() / .to(dtype) through something other than NF4Linear._apply?")
+    if not (absmax.is_contiguous() and packed.is_contiguous()):
+        raise ValueError("nf4 quant state must be contiguous")
+    n = 1
+    for d in shape:
+        n *= int(d)
+    if packed.numel() != (n + 1) // 2 or absmax.numel() != (n + BLOCK - 1) // BLOCK:
+        raise ValueError(f"nf4 quant state does not match shape {tuple(shape)}")
     out = torch.empty(tuple(shape), device=packed.device, dtype=dtype)
     hip.call("dalm_nf4_dequantize", hip.ptr(packed), hip.ptr(absmax), out.numel(), hip.dtype_code(out), hip.ptr(out),
              hip.stream())
@@ -76,6 +87,15 @@ class NF4Linear(nn.Module):
         self.register_buffer("qweight", packed)
         self.register_buffer("absmax", absmax)
         self.bias = None if base.bias is None else nn.Parameter(base.bias.detach().clone(), requires_grad=False)
+
+    def _apply(self, fn, recurse=True):
+        """Dtype casts (model.half(), .to(torch.bfloat16), .float()) leave the quant state alone - bitsandbytes keeps its
+        absmax out of them in the same way; device moves still apply."""
+        absmax = self.absmax
+        super()._apply(fn, recurse)
+        if self.absmax.dtype != torch.float32:
+            self.absmax = absmax.to(self.absmax.device)
+        return self
 
     @property
     def weight(self) -> torch.Tensor:

@@ -51,10 +51,13 @@ def to_nf4(model: torch.nn.Module) -> torch.nn.Module:
     nf4 storage on the current GPU (transformers places a quantised model there too)."""
     from . import nf4
 
+    # the keep-list is decided where the model was loaded (transformers 4.x deep-copies the model to find tied weights:
+    # on the GPU that would double a 7B model's footprint for a moment)
+    keep = nf4.modules_kept_in_full_precision(model)
     where = next(model.parameters()).device
     if where.type != "cuda":
         model = model.to(torch.device("cuda", torch.cuda.current_device()))
-    nf4.quantize_linears(model)
+    nf4.quantize_linears(model, keep)
     return model
 
 

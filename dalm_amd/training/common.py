@@ -180,6 +180,32 @@ class ShardedBatches:
             yield cur
 
 
+_ABS_POS_MODULES = ("wpe", "embed_positions", "position_embeddings", "positions_embed", "position_embedding", "pos_emb")
+
+
+def has_absolute_positions(model) -> Optional[str]:
+    """Why a generator cannot have its left padding trimmed, or None when it can.  Trimming leading all-padding columns
+    shifts every token of a left-padded row; that is only loss-preserving when positions enter through rotary / ALiBi /
+    relative terms.  Detected structurally (a denylist of model_type strings missed gpt_bigcode, ctrl, xglm,
+    biogpt, ...): a learned or sinusoidal position TABLE among the modules, or a config that says "absolute", refuses;
+    so does a config that names no relative scheme at all."""
+    cfg = getattr(model, "config", None)
+    if getattr(cfg, "position_embedding_type", None) == "absolute":
+        return "config.position_embedding_type == 'absolute'"
+    for name, _ in model.named_modules():
+        leaf = name.rsplit(".", 1)[-1]
+        if leaf in _ABS_POS_MODULES:
+            return f"module {name!r} is an absolute position table"
+    relative = any(getattr(cfg, k, None) not in (None, False) for k in
+                   ("rope_theta", "rope_parameters", "rope_scaling", "rotary_pct", "rotary_dim", "rotary_emb_base", "alibi",
+                    "use_alibi", "relative_attention_num_buckets")) or \
+        getattr(cfg, "position_embedding_type", None) in ("relative_key", "relative_key_query", "rotary", "alibi") or \
+        any(type(m).__name__.lower().endswith("rotaryembedding") for m in model.modules())
+    if not relative:
+        return f"model_type={getattr(cfg, 'model_type', None)!r} names no rotary / ALiBi / relative position scheme"
+    return None
+
+
 def effective_grad_accum(gradient_accumulation_steps: int) -> int:
     """--gradient_accumulation_steps N: the trainers accumulate N micro-batches (each scaled 1/N) per optimizer / scheduler
     step, so the number of optimizer steps, the LR schedule and the step_N / resume arithmetic are the reference's
@@ -200,16 +226,66 @@ def steps_and_epochs(num_batches: int, grad_accum: int, num_train_epochs: int, m
     return per_epoch, max_train_steps, num_train_epochs
 
 
-def parse_resume(path: str, per_epoch: int, num_batches: int, grad_accum: int):
-    """`step_N` / `epoch_N` folder name -> (starting_epoch, resume_step, completed_steps)."""
+def parse_resume(path: str, per_epoch: int, num_batches: int, grad_accum: int, extra: Optional[Dict[str, Any]] = None):
+    """`step_N` / `epoch_N` folder name -> (starting_epoch, batches_to_skip, completed_steps).
+
+    An epoch takes per_epoch = ceil(num_batches / grad_accum) optimizer steps (the last one may be the end-of-epoch flush
+    over fewer micro-batches), so step_K lies in epoch K // per_epoch, (K % per_epoch) * grad_accum micro-batches into it.
+    With grad_accum == 1 this is the reference's arithmetic (train_rage2e.py:400-411); with grad_accum > 1 the reference
+    divides K * grad_accum by the number of batches, which drifts by one batch per epoch whenever num_batches % grad_accum
+    != 0 and then loses the completed epochs from `completed_steps` - not reproduced.  When the checkpoint's
+    trainer_state carries the position it was written at (`extra`: epoch, batch_in_epoch, completed_steps - written by
+    this trainer for the same batch geometry) that position is used as is."""
     tag = os.path.splitext(os.path.basename(path.rstrip("/")))[0]
     if "epoch" in tag:
         e = int(tag.replace("epoch_", "")) + 1
         return e, None, e * per_epoch
-    s = int(tag.replace("step_", "")) * grad_accum
-    e = s // num_batches
-    s -= e * num_batches
-    return e, s, s // grad_accum + e * per_epoch
+    k = int(tag.replace("step_", ""))
+    if extra and extra.get("completed_steps") == k and extra.get("num_batches") == num_batches \
+            and extra.get("grad_accum") == grad_accum and "epoch" in extra and "batch_in_epoch" in extra:
+        return int(extra["epoch"]), int(extra["batch_in_epoch"]), k
+    e = k // max(per_epoch, 1)
+    return e, (k % max(per_epoch, 1)) * grad_accum, k
+
+
+class Progress:
+    """What both trainers do after an optimizer step - the normal one and the end-of-epoch flush of pending micro-batches
+    go through the same block: count it, `on_step`, the every-100-batches log line, `checkpointing_steps`, and the
+    `max_train_steps` stop (reference train_rage2e.py:476-494, train_retriever_only.py:381-397)."""
+
+    def __init__(self, *, comm, is_main: bool, tracker: "Tracker", meter: "Throughput", on_step, checkpointing_steps,
+                 output_dir: Optional[str], max_train_steps: int, save_state: Callable[[str, Dict[str, Any]], None],
+                 num_batches: int, grad_accum: int, completed: int = 0, log=None):
+        self.comm, self.is_main, self.tracker, self.meter, self.on_step = comm, is_main, tracker, meter, on_step
+        self.checkpointing_steps, self.output_dir, self.max_train_steps = checkpointing_steps, output_dir, max_train_steps
+        self.save_state, self.num_batches, self.grad_accum = save_state, num_batches, grad_accum
+        self.completed = completed
+        self.log = log or logger
+
+    def position(self, epoch: int, batches_done: int) -> Dict[str, Any]:
+        return {"completed_steps": self.completed, "epoch": epoch, "batch_in_epoch": batches_done,
+                "num_batches": self.num_batches, "grad_accum": self.grad_accum}
+
+    def after_optimizer_step(self, epoch: int, step: int, skipped: int, loss, total_loss: torch.Tensor) -> bool:
+        """step: index of the micro-batch that completed the optimizer step among the batches this run has consumed in this
+        epoch (the reference's `step`, which restarts at 0 after a resume); skipped: batches skipped by the resume.
+        Returns True when training has to stop (max_train_steps reached)."""
+        batch_index = step
+        self.completed += 1
+        if self.on_step is not None:
+            self.on_step(self.completed, loss)
+        if (batch_index + 1) % 100 == 0:
+            tl = self.comm.all_reduce_sum_(total_loss.clone())
+            rate, recent = self.meter.rate(), self.meter.window_rate()
+            if self.is_main:
+                self.log.info("Step: %d, Loss: %.6f, pairs/s: %.1f (last 100 batches: %.1f)", batch_index + 1,
+                              float(tl) / (batch_index + 1), rate, recent)
+            self.tracker.log({"train/loss": float(tl) / (batch_index + 1), "train/pairs_per_sec": rate,
+                              "train/pairs_per_sec_recent": recent}, self.completed)
+        if isinstance(self.checkpointing_steps, int) and self.completed % self.checkpointing_steps == 0 and self.output_dir:
+            self.save_state(os.path.join(self.output_dir, f"step_{self.completed}"),
+                            self.position(epoch, skipped + batch_index + 1))
+        return self.completed >= self.max_train_steps
 
 
 class Tracker:
@@ -247,17 +323,26 @@ class Tracker:
 
 
 class Throughput:
-    """pairs/sec over rows actually consumed (the reference has no throughput metric)."""
+    """pairs/sec over rows actually consumed (the reference has no throughput metric).  `rate()` is since construction (it
+    includes model warm-up and hipGraph capture); `window_rate()` is since its previous call - both are host clocks around
+    asynchronously launched steps: the loader lets the host run at most two batches ahead of the GPU, so over 100 batches
+    they follow the device rate."""
 
     def __init__(self):
-        self.t0 = time.perf_counter()
-        self.rows = 0
+        self.t0 = self._wt = time.perf_counter()
+        self.rows = self._wrows = 0
 
     def add(self, rows: int) -> None:
         self.rows += rows
 
     def rate(self) -> float:
         return self.rows / max(time.perf_counter() - self.t0, 1e-9)
+
+    def window_rate(self) -> float:
+        now = time.perf_counter()
+        r = (self.rows - self._wrows) / max(now - self._wt, 1e-9)
+        self._wt, self._wrows = now, self.rows
+        return r
 
 
 # ---------------------------------------------------------------------------
@@ -351,22 +436,44 @@ class AsyncSaver:
             raise RuntimeError("asynchronous checkpoint write failed") from e
 
 
+def _shard_name(rank: int, world: int) -> str:
+    return f"optimizer-{rank:05d}-of-{world:05d}.pt"
+
+
 def save_training_state(path: str, model, optimizer, scheduler, extra: Dict[str, Any], save_models: Callable[[str], None],
                         *, rank: int = 0, world: int = 1, saver: Optional[AsyncSaver] = None,
-                        shard_wait_s: float = 600.0) -> None:
+                        shard_wait_s: float = 600.0, barrier: Optional[Callable[[], None]] = None) -> None:
     """<path>/{retriever,generator,...} via `save_models` (rank 0), <path>/trainer_state.pt (scheduler, extra, and the
     optimizer state when world == 1) and, with world > 1, <path>/optimizer-RRRRR-of-WWWWW.pt per rank.  With `saver` the
     device->host copies are enqueued and the files are written by a background thread (the adapters / models are
-    written synchronously: they go through HF / safetensors writers that read the live tensors)."""
+    written synchronously: they go through HF / safetensors writers that read the live tensors).
+
+    Re-used directories (the same output_dir and world size as an earlier run): the commit file and this rank's shard of
+    the EARLIER checkpoint are unlinked first and, with world > 1, `barrier()` (all ranks) runs before anything new is
+    written - from then on a file that exists was written by this save.  Every shard also carries `stamp` (the
+    completed-step count), which `load_training_state` checks against the commit file."""
     os.makedirs(path, exist_ok=True)
+    if saver is not None:
+        saver.wait()              # an earlier asynchronous write into this very directory must not race the unlinks
+    stale = [_shard_name(rank, world)] + (["trainer_state.pt"] if rank == 0 else [])
+    for name in stale:
+        with contextlib.suppress(FileNotFoundError):
+            os.unlink(os.path.join(path, name))
+    if world > 1:
+        if barrier is None:
+            raise ValueError("save_training_state with world > 1 needs `barrier` (stale files of a re-used directory "
+                             "must be gone on every rank before rank 0 starts waiting for the new shards)")
+        barrier()
     if rank == 0:
         save_models(path)
     sched_sd = scheduler.state_dict() if scheduler else None
+    stamp = extra.get("completed_steps")
 
     def snapshot(stream):
         osd = optimizer.state_dict()
         if world > 1:
             osd = shard_optimizer_state(osd, rank, world)
+            osd["stamp"] = stamp
         return _to_host({"optimizer": osd, "scheduler": sched_sd, "extra": dict(extra)}, stream)
 
     def atomic_save(obj, name):
@@ -379,17 +486,17 @@ def save_training_state(path: str, model, optimizer, scheduler, extra: Dict[str,
         # first; rank 0 then waits until all W shard files exist before it writes trainer_state.pt - a directory holding
         # that file is complete, one without it is ignored by parse_resume / load_training_state (crash or early resume)
         if world > 1:
-            atomic_save(host["optimizer"], f"optimizer-{rank:05d}-of-{world:05d}.pt")
+            atomic_save(host["optimizer"], _shard_name(rank, world))
             if rank == 0:
-                files = [os.path.join(path, f"optimizer-{r:05d}-of-{world:05d}.pt") for r in range(world)]
+                files = [os.path.join(path, _shard_name(r, world)) for r in range(world)]
                 deadline = time.time() + shard_wait_s
                 while not all(os.path.exists(x) for x in files):
                     if time.time() > deadline:
                         raise RuntimeError(f"checkpoint {path}: optimizer shards of other ranks did not appear within "
                                            f"{shard_wait_s:.0f} s; trainer_state.pt NOT written (checkpoint stays uncommitted)")
                     time.sleep(0.05)
-                atomic_save({"optimizer": None, "sharded": world, "scheduler": host["scheduler"], "extra": host["extra"]},
-                            "trainer_state.pt")
+                atomic_save({"optimizer": None, "sharded": world, "stamp": stamp, "scheduler": host["scheduler"],
+                             "extra": host["extra"]}, "trainer_state.pt")
         else:
             atomic_save({"optimizer": host["optimizer"], "scheduler": host["scheduler"], "extra": host["extra"]},
                         "trainer_state.pt")
@@ -420,7 +527,12 @@ def load_training_state(path: str, optimizer, scheduler) -> Dict[str, Any]:
         missing = [x for x in files if not os.path.exists(x)]
         if missing:
             raise FileNotFoundError(f"optimizer shards missing: {missing[:2]}")
-        st["optimizer"] = merge_optimizer_shards([torch.load(x, map_location="cpu") for x in files])
+        shards_ = [torch.load(x, map_location="cpu") for x in files]
+        bad = [r for r, sh in enumerate(shards_) if "stamp" in sh and "stamp" in st and sh["stamp"] != st["stamp"]]
+        if bad:
+            raise RuntimeError(f"checkpoint {path}: optimizer shards of ranks {bad} were written at another step than "
+                               f"trainer_state.pt (stamp {st['stamp']}): a mix of two saves, not loadable")
+        st["optimizer"] = merge_optimizer_shards(shards_)
     lr_devices = [g["lr"].device if torch.is_tensor(g["lr"]) else None for g in optimizer.param_groups]
     optimizer.load_state_dict(st["optimizer"])
     for g, dev in zip(optimizer.param_groups, lr_devices):  # a tensor lr (capturable Adam) must stay on its device

@@ -167,16 +167,15 @@ def train_e2e(
             # worker - forking a process that already holds a HIP context and its threads crashed the worker now and
             # then ("One of the subprocesses has abruptly died during map operation")
             batched=True, remove_columns=dataset.column_names, desc="Running tokenizer on dataset")
-        processed = {k: mapped[k] for k in columns}
+        processed = shards.columns_from_dataset(mapped, columns)
         if token_cache_dir and is_main:
             shards.save_token_shards(processed, token_cache_dir, fp)
     trim = None
     if trim_padding:
-        gcfg = rag_model.generator_model.config
-        if getattr(gcfg, "model_type", "") in ("gpt2", "gpt_neo", "opt", "bloom_abs") or (
-                getattr(gcfg, "position_embedding_type", None) == "absolute"):
-            raise ValueError("--trim_padding shifts every token of a left-padded row: it needs a rotary / relative-position "
-                             f"generator (got model_type={getattr(gcfg, 'model_type', None)!r} with absolute positions)")
+        why = common.has_absolute_positions(rag_model.generator_model)
+        if why is not None:
+            raise ValueError("--trim_padding shifts every token of a left-padded row: it needs a rotary / ALiBi / "
+                             f"relative-position generator ({why})")
         trim = dict(groups=[("retriever_query_input_ids", "retriever_query_attention_mask"),
                             ("retriever_passage_input_ids", "retriever_passage_attention_mask"),
                             ("generator_input_input_ids", "generator_input_attention_mask")],
@@ -225,9 +224,9 @@ def train_e2e(
         logger.info("Resumed from checkpoint: %s", resume_from_checkpoint)
         load_submodel(rag_model.generator_model, os.path.join(resume_from_checkpoint, "generator"))
         load_submodel(rag_model.retriever_model, os.path.join(resume_from_checkpoint, "retriever"))
-        common.load_training_state(resume_from_checkpoint, optimizer, scheduler)
+        saved = common.load_training_state(resume_from_checkpoint, optimizer, scheduler)
         starting_epoch, resume_step, completed = common.parse_resume(resume_from_checkpoint, per_epoch, len(batches),
-                                                                     gradient_accumulation_steps)
+                                                                     gradient_accumulation_steps, saved)
 
     if is_main:
         logger.info("***** Running E2E training *****  examples=%d epochs=%d per-device batch=%d global batch=%d steps=%d",
@@ -244,40 +243,39 @@ def train_e2e(
         step_fn = GraphedStep(step_fn, warmup=0, eager_steps=2, max_graphs=24 if fuse_lm_head else 8)
     meter = common.Throughput()
     saver = common.AsyncSaver() if async_checkpoint else None
+
+    def save_state(path: str, position) -> None:
+        common.save_training_state(path, rag_model, optimizer, scheduler, position, save_models, rank=comm.rank,
+                                   world=comm.world_size, saver=saver, barrier=lambda: barrier(comm))
+
+    progress = common.Progress(comm=comm, is_main=is_main, tracker=tracker, meter=meter, on_step=on_step,
+                               checkpointing_steps=checkpointing_steps, output_dir=output_dir,
+                               max_train_steps=max_train_steps, save_state=save_state, num_batches=len(batches),
+                               grad_accum=gradient_accumulation_steps, completed=completed, log=logger)
     for epoch in range(starting_epoch, num_train_epochs):
         rag_model.train()
         total_loss = torch.zeros((), device=device)
         skip = resume_step if (resume_from_checkpoint and epoch == starting_epoch and resume_step) else 0
+        step, loss, stop = -1, None, False
         for step, batch in enumerate(batches.epoch(epoch, device, skip)):
             loss = step_fn(batch)  # rank share of the global-batch loss
             total_loss += loss
             meter.add(batch["query_passage_input_len"].shape[0] * comm.world_size)
             if not getattr(step_fn, "synced", True):
                 continue                  # gradient accumulation: a micro-batch that did not take the optimizer step
-            completed += 1
-            if on_step is not None:
-                on_step(completed, loss)
-            if (step + 1) % 100 == 0:
-                tl = comm.all_reduce_sum_(total_loss.clone())
-                if is_main:
-                    logger.info("Step: %d, Loss: %.6f, pairs/s: %.1f", step + 1, float(tl) / (step + 1), meter.rate())
-                tracker.log({"train/loss": float(tl) / (step + 1), "train/pairs_per_sec": meter.rate()}, completed)
-            if isinstance(checkpointing_steps, int) and completed % checkpointing_steps == 0 and output_dir:
-                common.save_training_state(os.path.join(output_dir, f"step_{completed}"), rag_model, optimizer,
-                                           scheduler, {"completed_steps": completed}, save_models,
-                                           rank=comm.rank, world=comm.world_size, saver=saver)
-            if completed >= max_train_steps:
+            stop = progress.after_optimizer_step(epoch, step, skip, loss, total_loss)
+            if stop:
                 break
-        if gradient_accumulation_steps > 1 and step_fn.flush():     # pending micro-batches at the end of the epoch
-            completed += 1
+        if not stop and gradient_accumulation_steps > 1 and step_fn.flush():
+            # micro-batches still pending at the end of the epoch: that optimizer step is counted, reported, checkpointed
+            # and checked against max_train_steps like any other
+            progress.after_optimizer_step(epoch, step, skip, loss, total_loss)
         tl = comm.all_reduce_sum_(total_loss.clone())
-        tracker.log({"train/epoch_loss": float(tl) / max(len(batches), 1)}, completed)
+        tracker.log({"train/epoch_loss": float(tl) / max(len(batches), 1)}, progress.completed)
         if output_dir is not None:
             barrier(comm)
             if isinstance(checkpointing_steps, str):
-                common.save_training_state(os.path.join(output_dir, f"epoch_{epoch}"), rag_model, optimizer,
-                                           scheduler, {"completed_steps": completed}, save_models,
-                                           rank=comm.rank, world=comm.world_size, saver=saver)
+                save_state(os.path.join(output_dir, f"epoch_{epoch}"), progress.position(epoch + 1, 0))
             if is_main:
                 save_models(output_dir)  # <output_dir>/retriever, <output_dir>/generator (reference :508-524)
                 r_tok.save_pretrained(os.path.join(output_dir, "retriever"))

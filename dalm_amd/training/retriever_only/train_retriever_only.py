@@ -136,7 +136,7 @@ def train_retriever(
                                           passage_column_name=passage_column_name, query_max_len=query_max_len,
                                           passage_max_len=passage_max_len),
             batched=True, remove_columns=dataset.column_names, desc="Running tokenizer on dataset")
-        processed = {k: mapped[k] for k in columns}
+        processed = shards.columns_from_dataset(mapped, columns)
         if token_cache_dir and is_main:
             shards.save_token_shards(processed, token_cache_dir, fp)
     if use_peft and is_main:
@@ -174,9 +174,9 @@ def train_retriever(
     starting_epoch, resume_step, completed = 0, None, 0
     if resume_from_checkpoint:
         load_submodel(model.model, resume_from_checkpoint)
-        common.load_training_state(resume_from_checkpoint, optimizer, scheduler)
+        saved = common.load_training_state(resume_from_checkpoint, optimizer, scheduler)
         starting_epoch, resume_step, completed = common.parse_resume(resume_from_checkpoint, per_epoch, len(batches),
-                                                                     gradient_accumulation_steps)
+                                                                     gradient_accumulation_steps, saved)
     step_fn = RetrieverStep(model, optimizer, scheduler, logit_scale, comm=comm,
                             autocast_dtype=torch.bfloat16 if mixed_precision == "bf16" else None,
                             grad_accum=gradient_accumulation_steps)
@@ -184,40 +184,39 @@ def train_retriever(
         step_fn = GraphedStep(step_fn, warmup=0, eager_steps=2)
     meter = common.Throughput()
     saver = common.AsyncSaver() if async_checkpoint else None
+
+    def save_state(path: str, position) -> None:
+        common.save_training_state(path, model, optimizer, scheduler, position, save_models, rank=comm.rank,
+                                   world=comm.world_size, saver=saver, barrier=lambda: barrier(comm))
+
+    progress = common.Progress(comm=comm, is_main=is_main, tracker=tracker, meter=meter, on_step=on_step,
+                               checkpointing_steps=checkpointing_steps, output_dir=output_dir,
+                               max_train_steps=max_train_steps, save_state=save_state, num_batches=len(batches),
+                               grad_accum=gradient_accumulation_steps, completed=completed, log=logger)
     for epoch in range(starting_epoch, num_train_epochs):
         model.train()
         total_loss = torch.zeros((), device=device)
         skip = resume_step if (resume_from_checkpoint and epoch == starting_epoch and resume_step) else 0
+        step, loss, stop = -1, None, False
         for step, batch in enumerate(batches.epoch(epoch, device, skip)):
-            loss = step_fn(batch)
+            loss = step_fn(batch)  # rank share of the global-batch loss
             total_loss += loss
             meter.add(batch["query_input_ids"].shape[0] * comm.world_size)
             if not getattr(step_fn, "synced", True):
                 continue                  # gradient accumulation: a micro-batch that did not take the optimizer step
-            completed += 1
-            if on_step is not None:
-                on_step(completed, loss)
-            if (step + 1) % 100 == 0:
-                tl = comm.all_reduce_sum_(total_loss.clone())
-                if is_main:
-                    logger.info("Step: %d, Loss: %.6f, pairs/s: %.1f", step + 1, float(tl) / (step + 1), meter.rate())
-                tracker.log({"train/loss": float(tl) / (step + 1), "train/pairs_per_sec": meter.rate()}, completed)
-            if isinstance(checkpointing_steps, int) and completed % checkpointing_steps == 0 and output_dir:
-                common.save_training_state(os.path.join(output_dir, f"step_{completed}"), model, optimizer, scheduler,
-                                           {"completed_steps": completed}, save_models,
-                                           rank=comm.rank, world=comm.world_size, saver=saver)
-            if completed >= max_train_steps:
+            stop = progress.after_optimizer_step(epoch, step, skip, loss, total_loss)
+            if stop:
                 break
-        if gradient_accumulation_steps > 1 and step_fn.flush():     # pending micro-batches at the end of the epoch
-            completed += 1
+        if not stop and gradient_accumulation_steps > 1 and step_fn.flush():
+            # micro-batches still pending at the end of the epoch: that optimizer step is counted, reported, checkpointed
+            # and checked against max_train_steps like any other
+            progress.after_optimizer_step(epoch, step, skip, loss, total_loss)
         tl = comm.all_reduce_sum_(total_loss.clone())
-        tracker.log({"train/epoch_loss": float(tl) / max(len(batches), 1)}, completed)
+        tracker.log({"train/epoch_loss": float(tl) / max(len(batches), 1)}, progress.completed)
         if output_dir is not None:
             barrier(comm)
             if isinstance(checkpointing_steps, str):
-                common.save_training_state(os.path.join(output_dir, f"epoch_{epoch}"), model, optimizer, scheduler,
-                                           {"completed_steps": completed}, save_models,
-                                           rank=comm.rank, world=comm.world_size, saver=saver)
+                save_state(os.path.join(output_dir, f"epoch_{epoch}"), progress.position(epoch + 1, 0))
             if is_main:
                 save_models(os.path.join(output_dir, "retriever"))
                 tokenizer.save_pretrained(os.path.join(output_dir, "retriever"))

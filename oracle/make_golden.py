@@ -549,7 +549,94 @@ def main_realwidth_golden(only=None) -> None:
     print("realwidth_golden.json ok")
 
 
+def trainer_rows(n: int = 18, seed: int = 77):
+    """n synthetic (Question, Abstract, Answer) rows over the words of tests/golden/wordlevel_tokenizer."""
+    import random
+
+    words = sorted({w for col in ROWS.values() for t in col for w in t.split()})
+    r = random.Random(seed)
+
+    def text(lo, hi):
+        return " ".join(r.choice(words) for _ in range(r.randint(lo, hi)))
+
+    return {"Question": [text(4, 12) for _ in range(n)], "Abstract": [text(20, 110) for _ in range(n)],
+            "Answer": [text(1, 8) for _ in range(n)]}
+
+
+def main_trainer_golden() -> None:
+    """Round 4: the reference's own ENTRY POINT - `dalm.training.rag_e2e.train_rage2e.train_e2e`,
+    unmodified, csv in, accelerate + DataLoader + Adam + linear schedule inside - at the REAL width of configs[2]
+    (bge-large 1024 / Llama-2-7b 4096, V = 32000, Tq 50 / Tp 128 / Tg 256, batch 18), depth 1 (oracle/realwidth.py), fp32,
+    every parameter training (no peft in the image).  The csv holds exactly one batch (18 rows), so the reference's
+    shuffling DataLoader and ours present the same SET of rows to every step and the loss is order-independent: one
+    optimizer step per epoch, 3 epochs.  The per-step loss is read where the reference hands it to
+    `accelerator.backward`.  Committed: the rows and 3 scalars (+ the weight checksums)."""
+    import csv
+    import json
+    import tempfile
+
+    import accelerate
+    from transformers import PreTrainedTokenizerFast
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    import realwidth as RW
+
+    import_reference()
+    # resolve every lazy transformers / accelerate import the trainer needs while `peft` is still absent
+    import datasets  # noqa: F401
+    from accelerate import Accelerator  # noqa: F401
+    from transformers import (AutoModel, AutoModelForCausalLM, AutoTokenizer, BitsAndBytesConfig,  # noqa: F401
+                              SchedulerType, default_data_collator, get_scheduler)
+
+    stub = types.ModuleType("peft")
+    for name in ("LoraConfig", "PeftModel", "TaskType", "get_peft_model"):
+        setattr(stub, name, type(name, (), {}))
+    sys.modules["peft"] = stub
+    sys.path.insert(0, str(REF))
+    try:
+        import dalm.training.rag_e2e.train_rage2e as ref_e2e
+    finally:
+        sys.modules.pop("peft", None)
+        sys.path.remove(str(REF))
+    tok = PreTrainedTokenizerFast.from_pretrained(str(OUT / "wordlevel_tokenizer"))
+    rows = trainer_rows()
+    retriever, generator = RW.build_case("cfg3")
+    rec = {"case": "cfg3", "depth": 1, "seed": RW.SEED, "checksum_retriever": RW.checksum(retriever),
+           "checksum_generator": RW.checksum(generator), "rows": rows,
+           "args": {"per_device_train_batch_size": 18, "query_max_len": 50, "passage_max_len": 128, "generator_max_len": 256,
+                    "learning_rate": 1e-4, "num_warmup_steps": 0, "num_train_epochs": 3, "logit_scale": 100, "seed": 42}}
+    losses = []
+    orig_backward = accelerate.Accelerator.backward
+
+    def recording_backward(self, loss, **kw):
+        losses.append(float(loss.detach()))
+        return orig_backward(self, loss, **kw)
+
+    accelerate.Accelerator.backward = recording_backward
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            rdir, gdir, path = f"{td}/retriever", f"{td}/generator", f"{td}/rows.csv"
+            retriever.save_pretrained(rdir); tok.save_pretrained(rdir)
+            generator.save_pretrained(gdir); tok.save_pretrained(gdir)
+            del retriever, generator
+            with open(path, "w", newline="") as f:
+                w = csv.writer(f)
+                w.writerow(["Question", "Abstract", "Answer"])
+                for i in range(len(rows["Question"])):
+                    w.writerow([rows["Question"][i], rows["Abstract"][i], rows["Answer"][i]])
+            ref_e2e.train_e2e(path, rdir, gdir, with_tracking=False, output_dir=None, use_peft=None, use_bnb=None,
+                              sanity_test=False, **rec["args"])
+    finally:
+        accelerate.Accelerator.backward = orig_backward
+    rec["losses"] = losses
+    (OUT / "trainer_golden.json").write_text(json.dumps(rec, indent=1))
+    print("trainer_golden.json", losses)
+
+
 if __name__ == "__main__":
+    if "--trainer-only" in sys.argv:
+        main_trainer_golden()
+        sys.exit(0)
     if "--retriever-step-only" in sys.argv:
         main_retriever_step_golden()
         sys.exit(0)
@@ -563,3 +650,4 @@ if __name__ == "__main__":
     main_step_golden()
     main_retriever_step_golden()
     main_realwidth_golden()
+    main_trainer_golden()

@@ -164,8 +164,17 @@ def test_grad_accum_keeps_the_references_step_arithmetic():
     # 100 batches at N = 4: 25 optimizer steps per epoch (reference: math.ceil(len(dataloader) / N), train_rage2e.py:341-347)
     assert common.steps_and_epochs(100, 4, 1, None) == (25, 25, 1)
     assert common.steps_and_epochs(101, 4, 2, None) == (26, 52, 2)
-    # step_30 with 26 steps per epoch of 101 batches: epoch 1, 19 micro-batches into it (reference :367-380)
-    assert common.parse_resume("out/step_30", 26, 101, 4) == (1, 19, 30)
+    # step_30 with 26 optimizer steps per epoch of 101 batches (25 of 4 micro-batches + the flush over the last one):
+    # epoch 1, 4 steps = 16 micro-batches into it (the reference's K*N // len(dataloader) says 19 and drifts by
+    # one batch per epoch whenever 101 % 4 != 0)
+    assert common.parse_resume("out/step_30", 26, 101, 4) == (1, 16, 30)
+    # nb = 10, N = 4: 3 steps per epoch (4 + 4 + flush of 2); step_4 = 1 step = 4 micro-batches into epoch 1
+    assert common.steps_and_epochs(10, 4, 2, None) == (3, 6, 2)
+    assert common.parse_resume("out/step_4", 3, 10, 4) == (1, 4, 4)
+    # the position recorded in trainer_state wins when it was written for the same geometry
+    pos = {"completed_steps": 4, "epoch": 1, "batch_in_epoch": 4, "num_batches": 10, "grad_accum": 4}
+    assert common.parse_resume("out/step_4", 3, 10, 4, pos) == (1, 4, 4)
+    assert common.parse_resume("out/step_4", 3, 12, 4, pos) == (1, 4, 4)      # other geometry: arithmetic, not the record
 
 
 def test_tensor_lr_scheduler_resume_restores_lr():
@@ -645,3 +654,21 @@ def test_live_row_index_and_row_chunks_properties():
         plan = _row_chunks(rows, cap, unit)
         assert sum(plan) == rows and all(z > 0 for z in plan)
         assert all(z <= max(unit, cap // unit * unit) for z in plan) and all(z % unit == 0 for z in plan[:-1])
+
+
+def test_trim_padding_guard_detects_absolute_positions_structurally():
+    """the --trim_padding guard looks for a position TABLE / a named relative scheme instead of a denylist of
+    model_type strings (gpt_bigcode, ctrl, xglm, biogpt, ... passed the old check)."""
+    from transformers import (BertConfig, BertModel, FalconConfig, FalconForCausalLM, GPT2Config, GPT2LMHeadModel,
+                              GPTBigCodeConfig, GPTBigCodeForCausalLM, LlamaConfig, LlamaForCausalLM)
+
+    from dalm_amd.training.common import has_absolute_positions
+
+    tiny = dict(num_hidden_layers=1, vocab_size=50)
+    assert has_absolute_positions(LlamaForCausalLM(LlamaConfig(hidden_size=32, num_attention_heads=2, num_key_value_heads=2,
+                                                                intermediate_size=64, **tiny))) is None
+    assert has_absolute_positions(FalconForCausalLM(FalconConfig(hidden_size=32, num_attention_heads=2, **tiny))) is None
+    assert has_absolute_positions(FalconForCausalLM(FalconConfig(hidden_size=32, num_attention_heads=2, alibi=True, **tiny))) is None
+    assert "wpe" in has_absolute_positions(GPT2LMHeadModel(GPT2Config(n_embd=32, n_head=2, n_layer=1, vocab_size=50)))
+    assert "wpe" in has_absolute_positions(GPTBigCodeForCausalLM(GPTBigCodeConfig(n_embd=32, n_head=2, n_layer=1, vocab_size=50)))
+    assert has_absolute_positions(BertModel(BertConfig(hidden_size=32, num_attention_heads=2, intermediate_size=64, **tiny)))

@@ -263,9 +263,19 @@ def _ckpt_worker(rank, world, port, out_dir):
         sum((p * p).sum() for p in ps).backward()
         opt.step(); opt.zero_grad()
     saver = common.AsyncSaver()
-    common.save_training_state(os.path.join(out_dir, "step_3"), None, opt, None, {"completed_steps": 3},
+    d = os.path.join(out_dir, "step_3")
+    if rank == 0:
+        # the directory is RE-USED - an earlier run (same output_dir, same world size) left a complete-looking
+        # checkpoint behind.  Its files must be gone before rank 0 starts waiting for the new shards.
+        os.makedirs(d, exist_ok=True)
+        for name in ("optimizer-00000-of-00002.pt", "optimizer-00001-of-00002.pt"):
+            torch.save({"state": {}, "param_groups": None, "num_state": 0, "stamp": 999}, os.path.join(d, name))
+        torch.save({"optimizer": None, "sharded": 2, "stamp": 999, "scheduler": None, "extra": {"completed_steps": 999}},
+                   os.path.join(d, "trainer_state.pt"))
+    dist.barrier()
+    common.save_training_state(d, None, opt, None, {"completed_steps": 3},
                                lambda path: open(os.path.join(path, "models_written_by_rank0"), "w").close(),
-                               rank=rank, world=world, saver=saver)
+                               rank=rank, world=world, saver=saver, barrier=dist.barrier)
     with torch.no_grad():                                  # training moves on while the writer works: the snapshot must not see it
         for p in ps:
             p.add_(100.0)
@@ -324,5 +334,28 @@ def test_rank0_does_not_commit_a_checkpoint_whose_shards_are_missing(tmp_path):
     d = tmp_path / "step_1"
     with pytest.raises(RuntimeError, match="did not appear"):
         common.save_training_state(str(d), None, opt, None, {"completed_steps": 1}, lambda path: None, rank=0, world=2,
-                                   shard_wait_s=0.3)
+                                   shard_wait_s=0.3, barrier=lambda: None)
     assert (d / "optimizer-00000-of-00002.pt").exists() and not (d / "trainer_state.pt").exists()
+    with pytest.raises(ValueError, match="barrier"):
+        common.save_training_state(str(d), None, opt, None, {"completed_steps": 1}, lambda path: None, rank=0, world=2)
+
+
+def test_mixed_saves_are_refused_by_the_stamp(tmp_path):
+    """A shard written at another step than the commit file (two saves mixed in one directory) does not load."""
+    from dalm_amd.training import common
+
+    ps = [torch.nn.Parameter(torch.randn(4)), torch.nn.Parameter(torch.randn(3))]
+    opt = torch.optim.Adam(ps, lr=1e-3)
+    sum((p * p).sum() for p in ps).backward()
+    opt.step()
+    d = tmp_path / "step_5"
+    d.mkdir()
+    sd = opt.state_dict()
+    for r, stamp in ((0, 5), (1, 4)):
+        sh = common.shard_optimizer_state(sd, r, 2)
+        sh["stamp"] = stamp
+        torch.save(sh, d / f"optimizer-{r:05d}-of-00002.pt")
+    torch.save({"optimizer": None, "sharded": 2, "stamp": 5, "scheduler": None, "extra": {"completed_steps": 5}},
+               d / "trainer_state.pt")
+    with pytest.raises(RuntimeError, match="another step"):
+        common.load_training_state(str(d), opt, None)

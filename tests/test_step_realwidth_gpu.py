@@ -10,9 +10,12 @@ Two independent checks per configuration, both on depth-1 towers built from a CP
 Tolerances asserted here (north_star: 1e-3 relative in fp32, stated tolerance in bf16); measured on MI355X in round 3
 (profiles/r03_realwidth_parity.json): fp32 <= 1e-6 everywhere, bf16 loss <= 4e-6 / gradient norm <= 6e-5 at real width:
   fp32            loss / contrastive / generator / grad-norm  <= 1e-4
-  bf16 autocast   loss / contrastive / generator              <= 1e-3   (vs the reference under CPU bf16 autocast)
-                  grad-norm (global and per tower)            <= 5e-3   (bf16 has 8 mantissa bits; CPU and GPU autocast
+  bf16 autocast   loss / contrastive / generator              <= 1e-4   (vs the reference under CPU bf16 autocast)
+                  grad-norm (global and per tower)            <= 5e-4   (bf16 has 8 mantissa bits; CPU and GPU autocast
                                                                          round at different operators)
+Round 4: the bf16 bounds were 1e-3 / 5e-3, 15-250x what was measured - a regression of two orders of
+magnitude would have passed; they are now ~25x / ~8x the measured deviations.  A host whose CPU RNG does not reproduce the
+seeded weights FAILS these tests (they carry row a12) unless DALM_ALLOW_RNG_SKIP=1 is set.
 """
 import copy
 import json
@@ -26,7 +29,7 @@ pytestmark = pytest.mark.gpu
 G = Path(__file__).parent / "golden"
 OUT = Path(__file__).resolve().parent.parent / "gpurun_out"
 
-TOL = {"fp32": {"loss": 1e-4, "grad": 1e-4}, "bf16_autocast": {"loss": 1e-3, "grad": 5e-3}}
+TOL = {"fp32": {"loss": 1e-4, "grad": 1e-4}, "bf16_autocast": {"loss": 1e-4, "grad": 5e-4}}
 
 
 def _rel(a, b):
@@ -76,7 +79,10 @@ def _seeded_case(case, gold):
     retriever, generator = _build(case)
     cs = RW.checksum(retriever)
     if _rel(cs, gold["checksum_retriever"]) > 1e-9:
-        pytest.skip(f"this host's torch CPU RNG does not reproduce the golden's seeded weights ({cs} vs {gold['checksum_retriever']})")
+        msg = f"this host's torch CPU RNG does not reproduce the golden's seeded weights ({cs} vs {gold['checksum_retriever']})"
+        if os.environ.get("DALM_ALLOW_RNG_SKIP") == "1":
+            pytest.skip(msg)
+        pytest.fail(msg + "; the real-width parity tests cannot run here (set DALM_ALLOW_RNG_SKIP=1 to skip them knowingly)")
     if generator is not None:
         assert _rel(RW.checksum(generator), gold["checksum_generator"]) <= 1e-9
     return retriever, generator
@@ -224,9 +230,9 @@ def test_lora_step_matches_the_oracle_on_this_host_at_real_width(case):
 # (fp32 master weights, forward under autocast, fp32 loss code on the up-cast outputs - accelerate's bf16 mode)
 # ---------------------------------------------------------------------------------------------------------------
 def test_bf16_autocast_trajectory_matches_the_reference_under_bf16_autocast():
-    """Stated bf16 tolerance: per-step loss <= 2e-3 relative and per-step gradient norm <= 5e-3 relative against the
+    """Stated bf16 tolerance: per-step loss <= 2e-4 relative and per-step gradient norm <= 5e-4 relative against the
     reference's own bf16-autocast trajectory (step_golden.json["bf16_autocast"]) over 5 Adam steps (measured: 2e-5 /
-    8e-5); the bound against the reference's fp32 trajectory lives in test_step_parity_gpu.py."""
+    8e-5; round 3 asserted 2e-3 / 5e-3); the bound against the reference's fp32 trajectory lives in test_step_parity_gpu.py."""
     from transformers import get_scheduler
 
     from dalm_amd.models import AutoModelForRagE2E
@@ -253,8 +259,8 @@ def test_bf16_autocast_trajectory_matches_the_reference_under_bf16_autocast():
     rel_fp32 = [_rel(a, b) for a, b in zip(losses, gold["losses"])]
     _record("tiny/e2e/bf16_autocast_trajectory", {"losses": losses, "grad_norms": gnorms, "rel_loss": rel_l,
                                                   "rel_grad_norm": rel_g, "rel_loss_vs_fp32_reference": rel_fp32})
-    assert max(rel_l) <= 2e-3, (rel_l, losses, ref["losses"])
-    assert max(rel_g) <= 5e-3, (rel_g, gnorms, ref["grad_norms"])
+    assert max(rel_l) <= 2e-4, (rel_l, losses, ref["losses"])
+    assert max(rel_g) <= 5e-4, (rel_g, gnorms, ref["grad_norms"])
 
 
 @pytest.mark.parametrize("graph", [False, True])

@@ -1,0 +1,107 @@
+"""The TRAINER ENTRY POINT at real width: `dalm_amd.training.rag_e2e.train_rage2e.train_e2e` - csv in,
+tokenise, ShardedBatches, the whole step as a hipGraph, Adam + linear schedule, epoch checkpoints, resume - against the
+numbers the REFERENCE'S OWN `train_e2e` (dalm/training/rag_e2e/train_rage2e.py:229-527, unmodified) produced on the same
+csv and the same seeded depth-1 towers at the true widths of configs[2] (bge-large 1024 / Llama-2-7b 4096, V = 32000,
+Tq 50 / Tp 128 / Tg 256, batch 18) in the build container: tests/golden/trainer_golden.json, written by
+oracle/make_golden.py::main_trainer_golden.  fp32, every parameter trains (the image has no peft), every dropout
+probability of these configs is 0.  The csv holds exactly one batch, so both trainers' shuffles present the same set of
+rows to every step; one optimizer step per epoch.
+
+Tolerance: per-step loss <= 1e-4 relative in fp32 (north_star: 1e-3); the resumed run must continue the straight run's
+trajectory to <= 1e-5 (same code, same kernels, the state came through the checkpoint)."""
+import csv
+import json
+import os
+from pathlib import Path
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = Path(__file__).parent / "golden"
+OUT = Path(__file__).resolve().parent.parent / "gpurun_out"
+
+
+def _rel(a, b):
+    return abs(a - b) / max(abs(b), 1e-30)
+
+
+def _model(gold):
+    from transformers import PreTrainedTokenizerFast
+
+    import realwidth as RW
+
+    from dalm_amd.models import AutoModelForRagE2E
+
+    retriever, generator = RW.build_case(gold["case"])
+    for mod, key in ((retriever, "checksum_retriever"), (generator, "checksum_generator")):
+        if _rel(RW.checksum(mod), gold[key]) > 1e-9:
+            msg = f"this host's torch CPU RNG does not reproduce the golden's seeded weights ({key})"
+            if os.environ.get("DALM_ALLOW_RNG_SKIP") == "1":
+                pytest.skip(msg)
+            pytest.fail(msg + " (set DALM_ALLOW_RNG_SKIP=1 to skip knowingly)")
+    tok = str(G / "wordlevel_tokenizer")
+    return AutoModelForRagE2E.from_modules(retriever, generator, PreTrainedTokenizerFast.from_pretrained(tok),
+                                           PreTrainedTokenizerFast.from_pretrained(tok), normalize=True, get_peft=None)
+
+
+def test_train_e2e_at_real_width_follows_the_reference_trainer_and_resumes(tmp_path):
+    from dalm_amd.training.rag_e2e.train_rage2e import train_e2e
+
+    gold = json.loads((G / "trainer_golden.json").read_text())
+    rows, a = gold["rows"], gold["args"]
+    path = tmp_path / "rows.csv"
+    with open(path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Question", "Abstract", "Answer"])
+        for i in range(len(rows["Question"])):
+            w.writerow([rows["Question"][i], rows["Abstract"][i], rows["Answer"][i]])
+    out = tmp_path / "out"
+    kw = dict(per_device_train_batch_size=a["per_device_train_batch_size"], query_max_len=a["query_max_len"],
+              passage_max_len=a["passage_max_len"], generator_max_len=a["generator_max_len"],
+              learning_rate=a["learning_rate"], num_warmup_steps=a["num_warmup_steps"], logit_scale=a["logit_scale"],
+              seed=a["seed"], num_train_epochs=a["num_train_epochs"], with_tracking=False, mixed_precision="no")
+    # 1. straight through: 3 epochs of one step each, nothing written
+    straight = []
+    train_e2e(str(path), "", "", rag_model=_model(gold), on_step=lambda s, l: straight.append(float(l)), **kw)
+    rel = [_rel(x, y) for x, y in zip(straight, gold["losses"])]
+
+    # 2. the same run with epoch checkpoints, KILLED when step 2 reports (epoch_0 is on disk by then: ~6 GB of fp32
+    #    weights + Adam state for the 510 M parameters of the depth-1 towers)
+    class Killed(RuntimeError):
+        pass
+
+    first = []
+
+    def die_at_two(s, l):
+        first.append(float(l))
+        if s == 2:
+            raise Killed
+
+    with pytest.raises(Killed):
+        train_e2e(str(path), "", "", rag_model=_model(gold), output_dir=str(out), checkpointing_steps="epoch",
+                  on_step=die_at_two, **kw)
+    for sub in ("epoch_0/retriever", "epoch_0/generator", "epoch_0/trainer_state.pt", "retriever", "generator"):
+        assert (out / sub).exists(), sub
+    # 3. freshly built (re-seeded) model objects resume from epoch_0: steps 2 and 3 of the REFERENCE's trajectory
+    resumed = []
+    train_e2e(str(path), "", "", rag_model=_model(gold), resume_from_checkpoint=str(out / "epoch_0"),
+              on_step=lambda s, l: resumed.append((s, float(l))), **kw)
+    import shutil
+
+    shutil.rmtree(out, ignore_errors=True)
+    rel_resume = [_rel(l, gold["losses"][s - 1]) for s, l in resumed]
+    rel_resume_vs_straight = [_rel(l, straight[s - 1]) for s, l in resumed]
+    try:
+        OUT.mkdir(exist_ok=True)
+        (OUT / "trainer_realwidth_parity.json").write_text(json.dumps(
+            {"reference_trainer_losses": gold["losses"], "train_e2e_losses": straight, "rel": rel,
+             "resumed_from_epoch_0": resumed, "rel_resumed_vs_reference": rel_resume,
+             "rel_resumed_vs_straight": rel_resume_vs_straight}, indent=1))
+    except OSError:
+        pass
+    assert len(straight) == a["num_train_epochs"] and max(rel) <= 1e-4, (rel, straight, gold["losses"])
+    assert _rel(first[0], gold["losses"][0]) <= 1e-4
+    assert [s for s, _ in resumed] == [2, 3]
+    assert max(rel_resume) <= 1e-4, (resumed, gold["losses"])
+    assert max(rel_resume_vs_straight) <= 1e-5, (resumed, straight)

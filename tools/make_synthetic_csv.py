@@ -20,23 +20,27 @@ def word_list(n: int = 4000, seed: int = 7):
     return sorted(words)
 
 
+def write_csv(path: str, rows: int, seed: int = 1234) -> None:
+    words = word_list()
+    r = random.Random(seed)
+
+    def text(lo, hi):
+        return " ".join(r.choice(words) for _ in range(r.randint(lo, hi)))
+
+    with open(path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Question", "Abstract", "Answer"])
+        for _ in range(rows):
+            w.writerow([text(4, 12), text(20, 110), text(1, 8)])
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("path")
     ap.add_argument("--rows", type=int, default=2000)
     ap.add_argument("--seed", type=int, default=1234)
     a = ap.parse_args()
-    words = word_list()
-    r = random.Random(a.seed)
-
-    def text(lo, hi):
-        return " ".join(r.choice(words) for _ in range(r.randint(lo, hi)))
-
-    with open(a.path, "w", newline="") as f:
-        w = csv.writer(f)
-        w.writerow(["Question", "Abstract", "Answer"])
-        for _ in range(a.rows):
-            w.writerow([text(4, 12), text(20, 110), text(1, 8)])
+    write_csv(a.path, a.rows, a.seed)
     print(f"wrote {a.rows} rows to {a.path}")
 
 
