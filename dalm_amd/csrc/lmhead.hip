@@ -209,6 +209,10 @@ struct Lm8Params {
   int R, V, K, MT, NT, xcd_order;
   int gh;                    // row tiles per band of the tile order (see lm_tile_of)
   unsigned bytesH, bytesW;
+  unsigned pitchH, pitchW;   // bytes between rows of H / W (K * 2 for the lm_head; 3 D * 2 for the bf16x3 similarity operands)
+  int tpd;                   // SPLIT3: K tiles (64 deep) per segment = D / 64
+  unsigned tpd_inv;          // SPLIT3: ceil(2^24 / tpd): u / tpd == (u * tpd_inv) >> 24 for u < 6 tpd, tpd <= 1024 (checked exhaustively up to 1686)
+  unsigned seg_bytes;        // SPLIT3: D * 2
   float* pm;                 // [4*NT, R]
   float* pl;                 // [4*NT, R]
   float* z;                  // [R]
@@ -358,7 +362,11 @@ __device__ __forceinline__ void lm_tile_epilogue(const Lm8Params& p, f32x16 (&ac
 // N3 / N0 / N1 / N2: load pieces issued in k-step 3 (right after the barrier) / 0 / 1 / 2; measured best: 8, 8, 0, 0.
 // ABL (measurement only, results are garbage unless 0): 1 = no loads in the loop, 2 = no fragment reads, 32 = no barrier,
 // 64 = no epilogue.
-template <int N3, int N0, int N1, int N2, int ABL = 0>
+// SPLIT3 (the bf16x3 similarity, see rowstats_bf16x3 below): the operands are [rows][3 D] bf16 images holding the (hi, mid,
+// lo) bf16 thirds of an f32 matrix side by side; the contraction walks SIX segments of D - the six significant products of
+// (hi + mid + lo) x (hi + mid + lo), smallest first - and K tile u reads third segA[u / tpd] of H against third segB[u / tpd]
+// of W: the same main loop, only the K offset of a tile is looked up instead of being u * 128.
+template <int N3, int N0, int N1, int N2, int ABL = 0, bool SPLIT3 = false>
 __global__ __launch_bounds__(256, 1) void lm_head_lse4w_kernel(const Lm8Params p) {
   static_assert(N3 + N0 + N1 + N2 == 16, "16 load pieces per K tile and wave");
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * L8_BUF];
@@ -372,17 +380,16 @@ __global__ __launch_bounds__(256, 1) void lm_head_lse4w_kernel(const Lm8Params p
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, static_cast<int>(p.bytesW), 0x00020000);
 
   // load piece q (0..7: rows 32 q .. 32 q + 31 of the A tile, 8..15: of the B tile): thread -> row 32 q + tid / 8, chunk tid % 8
-  const unsigned rowbytes = static_cast<unsigned>(p.K) * 2u;
   const int srow = tid >> 3;
   const unsigned schunk = static_cast<unsigned>(((tid & 7) ^ ((srow >> 1) & 7)) * 16);
   unsigned voff[16];
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
-    voff[q] = static_cast<unsigned>(r0 + q * 32 + srow) * rowbytes + schunk;
-    voff[8 + q] = static_cast<unsigned>(c0 + q * 32 + srow) * rowbytes + schunk;
+    voff[q] = static_cast<unsigned>(r0 + q * 32 + srow) * p.pitchH + schunk;
+    voff[8 + q] = static_cast<unsigned>(c0 + q * 32 + srow) * p.pitchW + schunk;
   }
   const int wave_lds = wave * 1024;
-#define L4_DMA(BUF, Q, KSOFF) if (!(ABL & 1)) lds_dma16((Q) < 8 ? rsH : rsW, lds + (BUF) * L8_BUF + (Q) * 4096 + wave_lds, voff[Q], KSOFF);
+#define L4_DMA(BUF, Q, KSA, KSB) if (!(ABL & 1)) lds_dma16((Q) < 8 ? rsH : rsW, lds + (BUF) * L8_BUF + (Q) * 4096 + wave_lds, voff[Q], (Q) < 8 ? (KSA) : (KSB));
 
   const int f = (l31 >> 1) & 7;
   int koff[4];
@@ -400,7 +407,20 @@ __global__ __launch_bounds__(256, 1) void lm_head_lse4w_kernel(const Lm8Params p
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nkt = p.K / 64;
-  auto ks = [&](int u) { return min(u, nkt - 1) * 128; };
+  // byte offset of K tile u inside a row of H (SIDE 0) / W (SIDE 1); tiles past the end re-read the last one (no branch)
+  //   pairs in contraction order: (m,m) (h,l) (l,h) (h,m) (m,h) (h,h) with h = third 0, m = third 1, l = third 2
+  //   third of H per pair, 2 bits each: 1,0,2,0,1,0 -> 0x121;  of W: 1,2,0,1,0,0 -> 0x049
+  auto ks = [&](int u, int side) -> int {
+    u = min(u, nkt - 1);
+    if constexpr (!SPLIT3) {
+      return u * 128;
+    } else {
+      const int sg = static_cast<int>((static_cast<unsigned>(u) * p.tpd_inv) >> 24);
+      const int w = u - sg * p.tpd;
+      const unsigned third = ((side ? 0x049u : 0x121u) >> (2 * sg)) & 3u;
+      return static_cast<int>(third * p.seg_bytes) + w * 128;
+    }
+  };
   bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
 
 #define L4_READ(BUF, KK, FA, FB)                                                                                      \
@@ -418,28 +438,28 @@ __global__ __launch_bounds__(256, 1) void lm_head_lse4w_kernel(const Lm8Params p
     if (i < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                     \
     if ((ND) <= 8 ? (i >= 8 && i - 8 < (ND)) : (i >= 16 - (ND))) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   \
   }
-#define L4_PIECES(BUF, FIRST, COUNT, KSOFF)                                                                           \
-  _Pragma("unroll") for (int q = 0; q < 16; ++q) if (q >= (FIRST) && q < (FIRST) + (COUNT)) { L4_DMA(BUF, q, KSOFF) }
+#define L4_PIECES(BUF, FIRST, COUNT, KSA, KSB)                                                                        \
+  _Pragma("unroll") for (int q = 0; q < 16; ++q) if (q >= (FIRST) && q < (FIRST) + (COUNT)) { L4_DMA(BUF, q, KSA, KSB) }
 
   // one K tile in buffer BUF (OTH = the other buffer); fragments of its k-step 0 are already in fa0 / fb0
 #define L4_TILE(BUF, OTH, t)                                                                                          \
   {                                                                                                                   \
-    const int ks1 = ks((t) + 1), ks2 = ks((t) + 2);                                                                   \
-    L4_READ(BUF, 1, fa1, fb1) L4_PIECES(OTH, N3, N0, ks1) L4_MFMA(fa0, fb0) L4_SCHED(N0)                               \
+    const int ks1a = ks((t) + 1, 0), ks1b = ks((t) + 1, 1), ks2a = ks((t) + 2, 0), ks2b = ks((t) + 2, 1);             \
+    L4_READ(BUF, 1, fa1, fb1) L4_PIECES(OTH, N3, N0, ks1a, ks1b) L4_MFMA(fa0, fb0) L4_SCHED(N0)                        \
     __builtin_amdgcn_sched_barrier(0);                                                                                \
-    L4_READ(BUF, 2, fa0, fb0) L4_PIECES(OTH, N3 + N0, N1, ks1) L4_MFMA(fa1, fb1) L4_SCHED(N1)                          \
+    L4_READ(BUF, 2, fa0, fb0) L4_PIECES(OTH, N3 + N0, N1, ks1a, ks1b) L4_MFMA(fa1, fb1) L4_SCHED(N1)                   \
     __builtin_amdgcn_sched_barrier(0);                                                                                \
-    L4_READ(BUF, 3, fa1, fb1) L4_PIECES(OTH, N3 + N0 + N1, N2, ks1) L4_MFMA(fa0, fb0) L4_SCHED(N2)                     \
+    L4_READ(BUF, 3, fa1, fb1) L4_PIECES(OTH, N3 + N0 + N1, N2, ks1a, ks1b) L4_MFMA(fa0, fb0) L4_SCHED(N2)              \
     __builtin_amdgcn_sched_barrier(0);                                                                                \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                       \
     if (!(ABL & 32)) __builtin_amdgcn_s_barrier();                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                                \
-    L4_READ(OTH, 0, fa0, fb0) L4_PIECES(BUF, 0, N3, ks2) L4_MFMA(fa1, fb1) L4_SCHED(N3)                                \
+    L4_READ(OTH, 0, fa0, fb0) L4_PIECES(BUF, 0, N3, ks2a, ks2b) L4_MFMA(fa1, fb1) L4_SCHED(N3)                         \
     __builtin_amdgcn_sched_barrier(0);                                                                                \
   }
 
   // ---- prologue: tile 0 complete, then the first pieces of tile 1 ----
-  _Pragma("unroll") for (int q = 0; q < 16; ++q) lds_dma16(q < 8 ? rsH : rsW, lds + q * 4096 + wave_lds, voff[q], ks(0));
+  _Pragma("unroll") for (int q = 0; q < 16; ++q) lds_dma16(q < 8 ? rsH : rsW, lds + q * 4096 + wave_lds, voff[q], ks(0, q < 8 ? 0 : 1));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (ABL & 2) {
@@ -452,7 +472,7 @@ __global__ __launch_bounds__(256, 1) void lm_head_lse4w_kernel(const Lm8Params p
     }
   } else
   L4_READ(0, 0, fa0, fb0)
-  L4_PIECES(1, 0, N3, ks(1))
+  L4_PIECES(1, 0, N3, ks(1, 0), ks(1, 1))
   __builtin_amdgcn_sched_barrier(0);
 
   int t = 0;
@@ -479,7 +499,8 @@ __global__ __launch_bounds__(256, 1) void lm_head_lse4w_kernel(const Lm8Params p
 __global__ __launch_bounds__(256) void lm_head_lse_merge_kernel(const float* __restrict__ pm, const float* __restrict__ pl,
                                                                 const float* __restrict__ z,
                                                                 const int64_t* __restrict__ labels, int R, int V, int P,
-                                                                float* __restrict__ row_lse, float* __restrict__ row_nll) {
+                                                                float* __restrict__ row_lse, float* __restrict__ row_nll,
+                                                                float* __restrict__ z_out = nullptr) {
   __shared__ float ms[16][17], ls[16][17];
   const int rl = threadIdx.x & 15, sub = threadIdx.x >> 4;
   const int row = blockIdx.x * 16 + rl;
@@ -515,8 +536,47 @@ __global__ __launch_bounds__(256) void lm_head_lse_merge_kernel(const float* __r
     const float lse = M + __logf(L);
     row_lse[row] = lse;
     const int64_t y = labels[row];
-    row_nll[row] = (y < 0) ? 0.f : (y < V ? lse - z[row] : __builtin_nanf(""));
+    if (row_nll) row_nll[row] = (y < 0) ? 0.f : (y < V ? lse - z[row] : __builtin_nanf(""));
+    if (z_out) z_out[row] = z[row];      // the similarity path wants the label's logit itself (the diagonal score)
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// bf16x3: the f32-accurate similarity on the bf16 matrix cores.
+//   reference: S = matmul(Q, P^T) * scale, get_cosine_sim, dalm/training/utils/train_utils.py:76-77 (rows of log-sum-exp:
+//   :80-88); evaluation scores dalm/eval/utils.py:44-68.
+// x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): every difference is exact in f32 and the
+// three thirds carry 24 significand bits.  Of the nine products of two such sums the six down to 2^-16 relative are kept
+// (hi lo, lo hi and mid mid are the 2^-16 ones; mid lo, lo mid, lo lo <= 2^-24 are dropped); a product of two bf16 values is
+// exact in f32, the matrix core accumulates in f32.  Laid out along K - smallest products first - the whole thing is ONE
+// bf16 contraction of depth 6 D that runs through the lm_head kernel above, row log-sum-exp epilogue included:
+// 6 x the flops of the f32 kernel on a pipe with 16 x its rate.  `scale` is folded into A before the split.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void split3_bf16_kernel(const float* __restrict__ X, int rows, int D, float scale,
+                                                          unsigned short* __restrict__ out, int64_t* __restrict__ labels,
+                                                          int64_t diag_offset) {
+  const int per_row = D >> 3;                                   // threads per row: 8 elements each
+  const int64_t gid = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const int64_t row = gid / per_row;
+  const int c = static_cast<int>(gid % per_row) * 8;
+  if (row >= rows) return;
+  if (labels && c == 0) labels[row] = diag_offset + row;
+  const float4 a = *reinterpret_cast<const float4*>(X + row * D + c);
+  const float4 b = *reinterpret_cast<const float4*>(X + row * D + c + 4);
+  const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  float h[8], m[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float v = __fmul_rn(x[e], scale);
+    h[e] = bf16_to_f32(f32_to_bf16(v));
+    const float r1 = v - h[e];                                  // exact
+    m[e] = bf16_to_f32(f32_to_bf16(r1));
+    l[e] = (r1 - m[e]);                                         // exact; rounded to bf16 by the pack below
+  }
+  unsigned short* o = out + row * (3 * static_cast<int64_t>(D)) + c;
+  *reinterpret_cast<uint4*>(o) = make_uint4(pack_bf16x2(h[0], h[1]), pack_bf16x2(h[2], h[3]), pack_bf16x2(h[4], h[5]), pack_bf16x2(h[6], h[7]));
+  *reinterpret_cast<uint4*>(o + D) = make_uint4(pack_bf16x2(m[0], m[1]), pack_bf16x2(m[2], m[3]), pack_bf16x2(m[4], m[5]), pack_bf16x2(m[6], m[7]));
+  *reinterpret_cast<uint4*>(o + 2 * D) = make_uint4(pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3]), pack_bf16x2(l[4], l[5]), pack_bf16x2(l[6], l[7]));
 }
 
 }  // namespace
@@ -557,6 +617,8 @@ extern "C" int dalm_lm_head_lse_fwd(const void* hidden, const void* weight, cons
     if (q.gh < 1 || q.gh > q.MT) q.gh = q.MT;
     q.bytesH = static_cast<unsigned>(static_cast<uint64_t>(R) * K * 2);
     q.bytesW = static_cast<unsigned>(static_cast<uint64_t>(V) * K * 2);
+    q.pitchH = q.pitchW = static_cast<unsigned>(K * 2);
+    q.tpd = 0; q.tpd_inv = 0; q.seg_bytes = 0;
     float* f8 = static_cast<float*>(ws);
     const int64_t P4 = 4ll * q.NT;
     q.pm = f8; q.pl = f8 + P4 * R; q.z = f8 + 2 * P4 * R;
@@ -604,5 +666,84 @@ extern "C" int dalm_lm_head_lse_fwd(const void* hidden, const void* weight, cons
   else hipLaunchKernelGGL((lm_head_lse_kernel<2, 64>), grid, dim3(256), 0, s, p);
   hipLaunchKernelGGL(lm_head_lse_merge_kernel, dim3(static_cast<unsigned>((R + 15) / 16)), dim3(256), 0, s, p.pm, p.pl,
                      p.z, labels, p.R, p.V, static_cast<int>(2 * NT), row_lse, row_nll);
+  return check_launch(__func__);
+}
+
+
+// ---- bf16x3 similarity row statistics (see split3_bf16_kernel) ------------------------------------------------------------
+namespace {
+inline size_t up256(size_t x) { return (x + 255) / 256 * 256; }
+struct X3Layout { size_t a3, b3, labels, pm, pl, z, total; int64_t P4; };
+inline X3Layout x3_layout(int64_t m, int64_t n, int64_t D) {
+  X3Layout L{};
+  const int64_t NT = (n + 255) / 256;
+  L.P4 = 4 * NT;
+  size_t o = 256;                                            // slack for aligning the caller's pointer up to 256 bytes
+  L.a3 = o; o += up256(static_cast<size_t>(m) * 3 * D * 2);
+  L.b3 = o; o += up256(static_cast<size_t>(n) * 3 * D * 2);
+  L.labels = o; o += up256(static_cast<size_t>(m) * 8);
+  L.pm = o; o += up256(static_cast<size_t>(L.P4) * m * 4);
+  L.pl = o; o += up256(static_cast<size_t>(L.P4) * m * 4);
+  L.z = o; o += up256(static_cast<size_t>(m) * 4);
+  L.total = o;
+  return L;
+}
+}  // namespace
+
+extern "C" int dalm_sim_rowstats_bf16x3_supported(int64_t m, int64_t n, int64_t D) {
+  if (m <= 0 || n <= 0 || D < 64 || D % 64 != 0) return 0;
+  if (D / 64 > 1024) return 0;                                                       // the reciprocal of the tile lookup
+  if (static_cast<uint64_t>(m + 256) * 3 * D * 2 >= 0xffffff00ull) return 0;           // 32-bit buffer offsets
+  if (static_cast<uint64_t>(n + 256) * 3 * D * 2 >= 0xffffff00ull) return 0;
+  return 1;
+}
+
+extern "C" size_t dalm_sim_rowstats_bf16x3_workspace_bytes(int64_t m, int64_t n, int64_t D) {
+  if (!dalm_sim_rowstats_bf16x3_supported(m, n, D)) return 0;
+  return x3_layout(m, n, D).total;
+}
+
+extern "C" int dalm_sim_rowstats_bf16x3(const float* A, const float* Bm, int64_t m, int64_t n, int64_t D, float scale,
+                                        int64_t diag_offset, float* row_lse, float* diag, void* ws, size_t ws_bytes,
+                                        dalm_stream_t stream) {
+  DALM_REQUIRE(A && Bm && row_lse && diag && ws, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(dalm_sim_rowstats_bf16x3_supported(m, n, D), DALM_E_SHAPE,
+               "bf16x3 similarity needs D % 64 == 0 and operand images below 4 GB (dalm_sim_rowstats_bf16x3_supported)");
+  DALM_REQUIRE(diag_offset >= 0 && diag_offset + m <= n, DALM_E_SHAPE, "diag_offset + m must be <= n");
+  DALM_REQUIRE(reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(Bm) % 16 == 0, DALM_E_ALIGN,
+               "A / B must be 16-byte aligned");
+  const X3Layout L = x3_layout(m, n, D);
+  DALM_REQUIRE(ws_bytes >= L.total, DALM_E_WORKSPACE, "workspace too small");
+  hipStream_t s = as_stream(stream);
+  unsigned char* base = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(ws) + 255) / 256 * 256) - 256;
+  // (offsets in L start at 256: base + L.x is 256-byte aligned and inside the caller's buffer)
+  auto* a3 = reinterpret_cast<unsigned short*>(base + L.a3);
+  auto* b3 = reinterpret_cast<unsigned short*>(base + L.b3);
+  auto* labels = reinterpret_cast<int64_t*>(base + L.labels);
+  const int per_row = static_cast<int>(D / 8);
+  hipLaunchKernelGGL(split3_bf16_kernel, dim3(static_cast<unsigned>((m * per_row + 255) / 256)), dim3(256), 0, s, A,
+                     static_cast<int>(m), static_cast<int>(D), scale, a3, labels, diag_offset);
+  hipLaunchKernelGGL(split3_bf16_kernel, dim3(static_cast<unsigned>((n * per_row + 255) / 256)), dim3(256), 0, s, Bm,
+                     static_cast<int>(n), static_cast<int>(D), 1.0f, b3, static_cast<int64_t*>(nullptr), static_cast<int64_t>(0));
+  Lm8Params q;
+  q.H = a3; q.W = b3; q.labels = labels;
+  q.R = static_cast<int>(m); q.V = static_cast<int>(n); q.K = static_cast<int>(6 * D);
+  q.MT = static_cast<int>((m + 255) / 256); q.NT = static_cast<int>((n + 255) / 256);
+  q.xcd_order = 1;
+  const int bands = (q.MT + 7) / 8;
+  q.gh = (q.MT + bands - 1) / bands;
+  if (q.gh < 1 || q.gh > q.MT) q.gh = q.MT;
+  q.pitchH = q.pitchW = static_cast<unsigned>(3 * D * 2);
+  q.bytesH = static_cast<unsigned>(static_cast<uint64_t>(m) * 3 * D * 2);
+  q.bytesW = static_cast<unsigned>(static_cast<uint64_t>(n) * 3 * D * 2);
+  q.tpd = static_cast<int>(D / 64);
+  q.tpd_inv = static_cast<unsigned>(((1u << 24) + q.tpd - 1) / q.tpd);
+  q.seg_bytes = static_cast<unsigned>(D * 2);
+  q.pm = reinterpret_cast<float*>(base + L.pm); q.pl = reinterpret_cast<float*>(base + L.pl);
+  q.z = reinterpret_cast<float*>(base + L.z);
+  DALM_REQUIRE(static_cast<int64_t>(q.MT) * q.NT <= 0x7fffffffll, DALM_E_SHAPE, "too many tiles for one launch");
+  hipLaunchKernelGGL((lm_head_lse4w_kernel<8, 8, 0, 0, 0, true>), dim3(static_cast<unsigned>(q.MT) * q.NT), dim3(256), 0, s, q);
+  hipLaunchKernelGGL(lm_head_lse_merge_kernel, dim3(static_cast<unsigned>((m + 15) / 16)), dim3(256), 0, s, q.pm, q.pl, q.z,
+                     labels, q.R, q.V, static_cast<int>(L.P4), row_lse, static_cast<float*>(nullptr), diag);
   return check_launch(__func__);
 }

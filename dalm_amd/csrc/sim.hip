@@ -1058,8 +1058,21 @@ extern "C" int dalm_sim_matmul(const float* A, const float* Bm, int64_t m, int64
   return dalm_gemm_f32(0, 1, m, n, D, scale, A, D, Bm, D, S, ldS, stream);
 }
 
-extern "C" size_t dalm_sim_rowstats_workspace_bytes(int64_t m, int64_t n, int64_t D) {
-  if (m <= 0 || n <= 0) return 0;
+// Problems large enough for the bf16x3 form (csrc/lmhead.hip: 256 x 256 tiles, a few waves of them over the 256 CUs) go to
+// the bf16 matrix cores; DALM_SIM_BF16X3=0 keeps everything on the f32 MFMA kernels, DALM_SIM_BF16X3_MIN moves the threshold.
+static bool use_bf16x3(int64_t m, int64_t n, int64_t D, const float* A, const float* Bm) {
+  static const int min_rows = [] {
+    const char* off = getenv("DALM_SIM_BF16X3");
+    if (off && off[0] == '0') return -1;
+    const char* e = getenv("DALM_SIM_BF16X3_MIN");
+    return e ? atoi(e) : 4096;
+  }();
+  if (min_rows < 0 || m < min_rows || n < min_rows) return false;
+  if (A && (reinterpret_cast<uintptr_t>(A) % 16 || reinterpret_cast<uintptr_t>(Bm) % 16)) return false;
+  return dalm_sim_rowstats_bf16x3_supported(m, n, D) != 0;
+}
+
+static size_t rowstats_ws_f32(int64_t m, int64_t n, int64_t D) {
   if (const StreamPlan f = stream_plan(m, n, D); f.ok)
     return (static_cast<size_t>(f.kpad) * (f.ldm + f.ldn) + 2 * static_cast<size_t>(f.nsplit) * m) * sizeof(float);
   const int sk = sim_splitk(m, n, D);
@@ -1067,13 +1080,32 @@ extern "C" size_t dalm_sim_rowstats_workspace_bytes(int64_t m, int64_t n, int64_
   return static_cast<size_t>(rowstats_parts(m, n)) * static_cast<size_t>(m) * 2 * sizeof(float);
 }
 
+extern "C" size_t dalm_sim_rowstats_workspace_bytes(int64_t m, int64_t n, int64_t D) {
+  if (m <= 0 || n <= 0) return 0;
+  const size_t f32 = rowstats_ws_f32(m, n, D);
+  if (!use_bf16x3(m, n, D, nullptr, nullptr)) return f32;
+  const size_t x3 = dalm_sim_rowstats_bf16x3_workspace_bytes(m, n, D);   // an unaligned operand still takes the f32 kernel
+  return x3 > f32 ? x3 : f32;
+}
+
 extern "C" int dalm_sim_rowstats(const float* A, const float* Bm, int64_t m, int64_t n, int64_t D,
                                  float scale, int64_t diag_offset, float* row_lse, float* diag, void* ws,
                                  size_t ws_bytes, dalm_stream_t stream) {
   DALM_REQUIRE(A && Bm && row_lse && diag && ws, DALM_E_NULL, "null pointer argument");
   if (int e = check_gemm_dims(m, n, D, __func__)) return e;
-  DALM_REQUIRE(diag_offset >= 0 && diag_offset + m <= n, DALM_E_SHAPE, "diag_offset + m must be <= n");
   DALM_REQUIRE(ws_bytes >= dalm_sim_rowstats_workspace_bytes(m, n, D), DALM_E_WORKSPACE, "workspace too small");
+  if (use_bf16x3(m, n, D, A, Bm))
+    return dalm_sim_rowstats_bf16x3(A, Bm, m, n, D, scale, diag_offset, row_lse, diag, ws, ws_bytes, stream);
+  return dalm_sim_rowstats_f32(A, Bm, m, n, D, scale, diag_offset, row_lse, diag, ws, ws_bytes, stream);
+}
+
+extern "C" int dalm_sim_rowstats_f32(const float* A, const float* Bm, int64_t m, int64_t n, int64_t D,
+                                     float scale, int64_t diag_offset, float* row_lse, float* diag, void* ws,
+                                     size_t ws_bytes, dalm_stream_t stream) {
+  DALM_REQUIRE(A && Bm && row_lse && diag && ws, DALM_E_NULL, "null pointer argument");
+  if (int e = check_gemm_dims(m, n, D, __func__)) return e;
+  DALM_REQUIRE(diag_offset >= 0 && diag_offset + m <= n, DALM_E_SHAPE, "diag_offset + m must be <= n");
+  DALM_REQUIRE(ws_bytes >= rowstats_ws_f32(m, n, D), DALM_E_WORKSPACE, "workspace too small");
   DALM_REQUIRE(reinterpret_cast<uintptr_t>(ws) % 4 == 0, DALM_E_ALIGN, "workspace must be 4-byte aligned");
   hipStream_t s = as_stream(stream);
   if (const StreamPlan f = stream_plan(m, n, D); f.ok) {

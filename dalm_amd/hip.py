@@ -28,6 +28,10 @@ SIGNATURES = {
     "dalm_gemm_f32": (_int, [_int, _int, _i64, _i64, _i64, _f32, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "dalm_sim_rowstats_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "dalm_sim_rowstats": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "dalm_sim_rowstats_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "dalm_sim_rowstats_bf16x3_supported": (_int, [_i64, _i64, _i64]),
+    "dalm_sim_rowstats_bf16x3_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "dalm_sim_rowstats_bf16x3": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _i64, _vp, _vp, _vp, _sz, _vp]),
     "dalm_sim_grad_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "dalm_sim_grad": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dalm_nt_xent_fwd": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),

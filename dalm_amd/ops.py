@@ -92,6 +92,39 @@ class HipOps:
                  hip.ptr(row_lse), hip.ptr(diag), hip.ptr(ws), ws_bytes, hip.stream())
         return row_lse, diag
 
+    def sim_rowstats_f32(self, A: torch.Tensor, Bm: torch.Tensor, scale: float, diag_offset: int):
+        """`sim_rowstats` pinned to the exact-f32 MFMA kernels (what every shape took before round 4) - for A/B checks."""
+        dev = hip.require_gpu(A, Bm)
+        A, Bm = hip.as_f32c(A), hip.as_f32c(Bm)
+        m, D = A.shape
+        n = Bm.shape[0]
+        lib = hip.load()
+        ws_bytes = lib.dalm_sim_rowstats_workspace_bytes(m, n, D)
+        ws = torch.empty((max(ws_bytes, 4) // 4,), device=dev, dtype=torch.float32)
+        row_lse = torch.empty((m,), device=dev, dtype=torch.float32)
+        diag = torch.empty((m,), device=dev, dtype=torch.float32)
+        hip.call("dalm_sim_rowstats_f32", hip.ptr(A), hip.ptr(Bm), m, n, D, float(scale), int(diag_offset),
+                 hip.ptr(row_lse), hip.ptr(diag), hip.ptr(ws), ws_bytes, hip.stream())
+        return row_lse, diag
+
+    def sim_rowstats_bf16x3(self, A: torch.Tensor, Bm: torch.Tensor, scale: float, diag_offset: int):
+        """The same statistics on the bf16 matrix cores at f32 accuracy (three bf16 thirds per operand, six products along
+        K; see include/dalm_hip.h).  `sim_rowstats` routes here by itself for m, n >= 4096."""
+        dev = hip.require_gpu(A, Bm)
+        A, Bm = hip.as_f32c(A), hip.as_f32c(Bm)
+        m, D = A.shape
+        n = Bm.shape[0]
+        lib = hip.load()
+        if not lib.dalm_sim_rowstats_bf16x3_supported(m, n, D):
+            raise ValueError(f"bf16x3 similarity does not support m={m}, n={n}, D={D} (D % 64 == 0, images below 4 GB)")
+        ws_bytes = lib.dalm_sim_rowstats_bf16x3_workspace_bytes(m, n, D)
+        ws = torch.empty((ws_bytes,), device=dev, dtype=torch.uint8)
+        row_lse = torch.empty((m,), device=dev, dtype=torch.float32)
+        diag = torch.empty((m,), device=dev, dtype=torch.float32)
+        hip.call("dalm_sim_rowstats_bf16x3", hip.ptr(A), hip.ptr(Bm), m, n, D, float(scale), int(diag_offset),
+                 hip.ptr(row_lse), hip.ptr(diag), hip.ptr(ws), ws_bytes, hip.stream())
+        return row_lse, diag
+
     def sim_grad(self, A, Bm, scale: float, diag_offset: int, row_coef, row_lse, col_coef, col_lse):
         """dA = scale * dS . Bm with the closed-form dS of include/dalm_hip.h."""
         dev = hip.require_gpu(A, Bm, row_coef, row_lse, col_coef, col_lse)

@@ -110,6 +110,26 @@ int dalm_sim_rowstats(const float* A, const float* Bm, int64_t m, int64_t n,
                       float* row_lse, float* diag, void* ws, size_t ws_bytes,
                       dalm_stream_t stream);
 
+/* The same row statistics on the bf16 matrix cores at f32 accuracy ("bf16x3", round 4): scale*A and B are split into
+ * three bf16 thirds each (x = hi + mid + lo, 24 significand bits), the six products down to 2^-16 relative are laid out
+ * along K (depth 6 D, smallest first) and contracted by the 256 x 256 x 64 bf16 MFMA kernel of dalm_lm_head_lse_fwd with
+ * its row log-sum-exp epilogue: 6 x the flops of the f32 kernel on a pipe with 16 x its rate, no score matrix.
+ * S agrees with the f32 result to a few 1e-7 relative of |scale| (products of bf16 values are exact in f32, accumulation
+ * is f32).  Needs D % 64 == 0, D <= 65536, operand images below 4 GB, 16-byte aligned A / B.
+ * dalm_sim_rowstats routes to it for m, n >= 4096 (DALM_SIM_BF16X3=0 keeps the f32 MFMA kernel).
+ * Reference: get_cosine_sim / get_nt_xent_loss, dalm/training/utils/train_utils.py:76-88; dalm/eval/utils.py:44-68. */
+/* dalm_sim_rowstats pinned to the exact-f32 MFMA kernels whatever the size (same arguments, same workspace query). */
+int dalm_sim_rowstats_f32(const float* A, const float* Bm, int64_t m, int64_t n,
+                          int64_t D, float scale, int64_t diag_offset,
+                          float* row_lse, float* diag, void* ws, size_t ws_bytes,
+                          dalm_stream_t stream);
+int dalm_sim_rowstats_bf16x3_supported(int64_t m, int64_t n, int64_t D);
+size_t dalm_sim_rowstats_bf16x3_workspace_bytes(int64_t m, int64_t n, int64_t D);
+int dalm_sim_rowstats_bf16x3(const float* A, const float* Bm, int64_t m, int64_t n,
+                             int64_t D, float scale, int64_t diag_offset,
+                             float* row_lse, float* diag, void* ws, size_t ws_bytes,
+                             dalm_stream_t stream);
+
 /* Closed-form backward of the above:
  *   dS[i,j] = row_coef[i] exp(S_ij - row_lse[i]) + col_coef[j] exp(S_ij - col_lse[j])
  *             - [j == diag_offset+i] (row_coef[i] + col_coef[j])

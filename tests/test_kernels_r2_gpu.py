@@ -617,3 +617,67 @@ def test_marg_ce_finalize_with_a_context_extent(dev):
     assert torch.equal(a, b_)
     ref1 = O.closed_gen_loss_topk(label_lp[:, :1], mask[:, :1], cut[:, :1], doc_lp[:, :1])
     assert abs(float(a) - float(ref1["generator"])) <= 2e-6 * abs(float(ref1["generator"]))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 4: the similarity row statistics on the bf16 matrix cores at f32 accuracy (three bf16 thirds per operand)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n,D,off", [(256, 256, 64, 0), (300, 517, 128, 100), (37, 1000, 384, 500), (1024, 1536, 1024, 256),
+                                       (4096, 4096, 1024, 0), (513, 4352, 1024, 1111)])
+def test_bf16x3_rowstats_vs_fp64(dev, m, n, D, off):
+    """dalm_sim_rowstats_bf16x3 against fp64 on the `_problem` generator (positives at S ~ 55, negatives ~ N(0, 3)): S
+    itself (through diag) within 2e-6 relative of |S| - VERDICT r3 item 4's bound, 1.1e-4 absolute at 55; the f32 MFMA
+    kernel is allowed 2e-4 there - and the row log-sum-exp to the same absolute bound; ragged row / column tails, all six
+    K segments at D = 64 (one K tile per segment) ... 1024 (16 per segment), sharded diagonal offsets; deterministic."""
+    from dalm_amd.ops import default_ops
+
+    ops = default_ops()
+    A, Bm, scale, S, *_ = _problem(m, n, D, off)
+    row_lse, diag = ops.sim_rowstats_bf16x3(A.to(dev), Bm.to(dev), scale, off)
+    idx = torch.arange(m)
+    ref_d, ref_l = S[idx, off + idx], torch.logsumexp(S, 1)
+    err_d = (diag.cpu().double() - ref_d).abs().max().item()
+    err_l = (row_lse.cpu().double() - ref_l).abs().max().item()
+    assert err_d <= 2e-6 * ref_d.abs().max().item() + 2e-5, (err_d, ref_d.abs().max().item())
+    assert err_l <= 2e-6 * ref_l.abs().max().item() + 2e-5, (err_l, ref_l.abs().max().item())
+    r2, d2 = ops.sim_rowstats_bf16x3(A.to(dev), Bm.to(dev), scale, off)
+    assert torch.equal(r2, row_lse) and torch.equal(d2, diag)
+    # no worse than the exact-f32 MFMA kernel on the same inputs (where that kernel takes the shape)
+    f_l, f_d = ops.sim_rowstats_f32(A.to(dev), Bm.to(dev), scale, off)
+    err_f = (f_d.cpu().double() - ref_d).abs().max().item()
+    assert err_d <= max(2.0 * err_f, 3e-5), (err_d, err_f)
+
+
+def test_bf16x3_scores_off_the_diagonal_vs_fp64(dev):
+    """Every element of S, not only the diagonal: with diag_offset = c the 'label' of row i is column c + i, so sweeping c
+    reads a full wrapped diagonal per call - 40 random offsets of a 300 x 340 problem cover ~12 000 distinct scores,
+    including scores near zero (relative error there is bounded by the ABSOLUTE error, |scale| * 2e-6)."""
+    from dalm_amd.ops import default_ops
+
+    ops = default_ops()
+    m, n, D = 300, 340, 256
+    A, Bm, scale, S, *_ = _problem(m, n, D, 0)
+    idx = torch.arange(m)
+    worst = 0.0
+    for c in range(0, 41):
+        _, diag = ops.sim_rowstats_bf16x3(A.to(dev), Bm.to(dev), scale, c)
+        worst = max(worst, (diag.cpu().double() - S[idx, c + idx]).abs().max().item())
+    assert worst <= scale * 2e-6, worst
+
+
+def test_large_rowstats_route_to_bf16x3_and_keep_the_loss(dev):
+    """dalm_sim_rowstats sends m, n >= 4096 to the bf16x3 form: same statistics as the explicit entry point (bit for bit),
+    and the contrastive loss built from them agrees with fp64 to 1e-6 relative."""
+    from dalm_amd.ops import default_ops
+
+    ops = default_ops()
+    m = n = 4096
+    A, Bm, scale, S, *_ = _problem(m, n, 1024, 0, seed=5)
+    r1, d1 = ops.sim_rowstats(A.to(dev), Bm.to(dev), scale, 0)
+    r2, d2 = ops.sim_rowstats_bf16x3(A.to(dev), Bm.to(dev), scale, 0)
+    assert torch.equal(r1, r2) and torch.equal(d1, d2)
+    c1, _ = ops.sim_rowstats(Bm.to(dev), A.to(dev), scale, 0)
+    idx = torch.arange(m)
+    ref = 0.5 * ((torch.logsumexp(S, 1) - S[idx, idx]).mean() + (torch.logsumexp(S, 0) - S[idx, idx]).mean())
+    got = 0.5 * ((r1.double().cpu() - d1.double().cpu()).mean() + (c1.double().cpu() - d1.double().cpu()).mean())
+    assert abs(float(got) - float(ref)) <= 1e-6 * abs(float(ref)) + 1e-7, (float(got), float(ref))
