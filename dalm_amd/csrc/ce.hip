@@ -540,7 +540,7 @@ __global__ __launch_bounds__(BS) void marg_ce_bwd_kernel(
     const T* __restrict__ logits, int64_t stride_b, int64_t stride_t,
     const int64_t* __restrict__ ids, const int64_t* __restrict__ mask, int Tg, int V,
     const float* __restrict__ stats, const float* __restrict__ row_lse,
-    const float* __restrict__ gscale, T* dlogits) {
+    const float* __restrict__ gscale, T* dlogits, const float* __restrict__ row_w) {
   constexpr int VEC = Elt<T>::VEC;
   const int64_t row = blockIdx.x;
   const int b = static_cast<int>(row / Tg), t = static_cast<int>(row % Tg);
@@ -560,7 +560,8 @@ __global__ __launch_bounds__(BS) void marg_ce_bwd_kernel(
   RowWin<T> w(xrow, V);
   T* grow = dlogits + off;
   T* gbase = grow - w.lead;
-  const float coef = g * static_cast<float>(mi) / M;
+  // row_w (k retrieved contexts, dalm_marg_ce_finalize_topk): the row's own weight -dL/d(label log-prob) replaces m/M
+  const float coef = row_w ? g * row_w[row] : g * static_cast<float>(mi) / M;
   const float nlse = -row_lse[row] * kLog2e;
   for (int slot = tid; slot < w.nslots; slot += BS) {
     float v[VEC];
@@ -649,6 +650,10 @@ __global__ __launch_bounds__(256) void ce_finalize_topk_kernel(const float* __re
         if (weights) weights[base + t] = (t < cu) ? invk / M : 0.f;
       }
     }
+    // the answer rows below overwrite entries the loop above has just zeroed - from OTHER threads (t = cut + j belongs to
+    // thread (cut + j) % 256 above and to thread j % 256 below): without this barrier a wave still in the first loop could
+    // zero a weight another wave had already written
+    if (weights) __syncthreads();
     for (int j = threadIdx.x; j < nans; j += 256) {
       float mx = -INFINITY;
       for (int c = 0; c < k; ++c) {
@@ -656,6 +661,7 @@ __global__ __launch_bounds__(256) void ce_finalize_topk_kernel(const float* __re
         const float v = (t >= 0 && t < Tg) ? doc_lp[b * k + c] - row_nll[(static_cast<int64_t>(b) * k + c) * Tg + t] : -INFINITY;
         mx = fmaxf(mx, v);
       }
+      if (mx == -INFINITY) continue;   // answer row j lies outside every sequence (inconsistent cut / Nb): no term, no weight
       float se = 0.f;
       for (int c = 0; c < k; ++c) {
         const int t = static_cast<int>(cut[b * k + c]) + j;
@@ -671,7 +677,6 @@ __global__ __launch_bounds__(256) void ce_finalize_topk_kernel(const float* __re
           }
         }
     }
-    __syncthreads();      // the weights of sample b are complete before the next sample's rows overwrite nothing of it
   }
   s = block_sum<256>(s, red);
   if (threadIdx.x == 0) out[0] = s / M;
@@ -855,24 +860,43 @@ extern "C" int dalm_marg_ce_fwd(const void* logits, int dtype, int64_t B, int64_
   return check_launch(__func__);
 }
 
-extern "C" int dalm_marg_ce_bwd(const void* logits, int dtype, int64_t B, int64_t Tg, int64_t V,
-                                int64_t stride_b, int64_t stride_t, const int64_t* ids,
-                                const int64_t* mask, const float* stats, const float* row_lse,
-                                const float* gscale, void* dlogits, dalm_stream_t stream) {
-  if (int e = check_common(logits, dtype, B, Tg, V, stride_b, stride_t, ids, mask, stats, __func__)) return e;
-  DALM_REQUIRE(row_lse && dlogits, DALM_E_NULL, "row_lse/dlogits are required");
+namespace {
+int marg_ce_bwd_impl(const void* logits, int dtype, int64_t B, int64_t Tg, int64_t V, int64_t stride_b, int64_t stride_t,
+                     const int64_t* ids, const int64_t* mask, const float* stats, const float* row_lse, const float* gscale,
+                     const float* row_w, void* dlogits, dalm_stream_t stream, const char* fn) {
+  if (int e = check_common(logits, dtype, B, Tg, V, stride_b, stride_t, ids, mask, stats, fn)) return e;
+  if (!(row_lse && dlogits)) return fail(DALM_E_NULL, fn, "row_lse/dlogits are required");
   hipStream_t s = as_stream(stream);
   const dim3 grid(static_cast<unsigned>(B * Tg));
   const int Tgi = static_cast<int>(Tg), Vi = static_cast<int>(V);
   if (dtype == DALM_F32)
     hipLaunchKernelGGL((marg_ce_bwd_kernel<float, 256>), grid, dim3(256), 0, s,
                        static_cast<const float*>(logits), stride_b, stride_t, ids, mask, Tgi, Vi, stats,
-                       row_lse, gscale, static_cast<float*>(dlogits));
+                       row_lse, gscale, static_cast<float*>(dlogits), row_w);
   else
     hipLaunchKernelGGL((marg_ce_bwd_kernel<bf16_t, 256>), grid, dim3(256), 0, s,
                        static_cast<const bf16_t*>(logits), stride_b, stride_t, ids, mask, Tgi, Vi, stats,
-                       row_lse, gscale, static_cast<bf16_t*>(dlogits));
-  return check_launch(__func__);
+                       row_lse, gscale, static_cast<bf16_t*>(dlogits), row_w);
+  return check_launch(fn);
+}
+}  // namespace
+
+extern "C" int dalm_marg_ce_bwd(const void* logits, int dtype, int64_t B, int64_t Tg, int64_t V,
+                                int64_t stride_b, int64_t stride_t, const int64_t* ids,
+                                const int64_t* mask, const float* stats, const float* row_lse,
+                                const float* gscale, void* dlogits, dalm_stream_t stream) {
+  return marg_ce_bwd_impl(logits, dtype, B, Tg, V, stride_b, stride_t, ids, mask, stats, row_lse, gscale, nullptr, dlogits,
+                          stream, __func__);
+}
+
+extern "C" int dalm_marg_ce_bwd_weighted(const void* logits, int dtype, int64_t B, int64_t Tg, int64_t V,
+                                         int64_t stride_b, int64_t stride_t, const int64_t* ids,
+                                         const int64_t* mask, const float* stats, const float* row_lse,
+                                         const float* gscale, const float* row_weight, void* dlogits,
+                                         dalm_stream_t stream) {
+  DALM_REQUIRE(row_weight, DALM_E_NULL, "row_weight is required (dalm_marg_ce_bwd is the scalar m / M form)");
+  return marg_ce_bwd_impl(logits, dtype, B, Tg, V, stride_b, stride_t, ids, mask, stats, row_lse, gscale, row_weight, dlogits,
+                          stream, __func__);
 }
 
 extern "C" int dalm_scale_inplace(void* x, int dtype, int64_t n, const float* gscale, dalm_stream_t stream) {
@@ -950,5 +974,121 @@ extern "C" int dalm_marginalize_rows_dev(const float* lp, int64_t T, int64_t V, 
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(marginalize_rows_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
                      as_stream(stream), lp, T, V, doc_lp, static_cast<int64_t>(0), qlen_dev, out);
+  return check_launch(__func__);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k retrieved contexts per sample, end to end (round 4; the reference is k = 1: train_utils.py:123-124, and only muses about
+// more at train_rage2e.py:461-462).  Scores of the k contexts of query b and their log-softmax over the k (RAG-token:
+// p(c | q_b) = softmax_c(scale q_b . P[b,c])), and the closed-form backward from the per-row weights that
+// dalm_marg_ce_finalize_topk returns (w = -dL/d(label log-prob), 1/M included):
+//     dL/d doc_lp[b,c] = -sum_{j < N_b} w[b, c, cut_bc + j]           (the posterior mass of context c over the answer rows)
+//     dL/d s[b,c]      = g_bc - p_bc sum_c' g_bc'                      (through the log-softmax over the k contexts)
+//     dq_b = scale sum_c ds_bc P[b,c]        dP[b,c] = scale ds_bc q_b
+// One workgroup per sample; k <= 64.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace dalm {
+namespace {
+
+constexpr int kMaxCtx = 64;
+
+__global__ __launch_bounds__(256) void doc_scores_topk_fwd_kernel(const float* __restrict__ q, const float* __restrict__ P,
+                                                                  int k, int D, float scale, float* __restrict__ s_out,
+                                                                  float* __restrict__ doc_lp) {
+  __shared__ float red[4];
+  __shared__ float sc[kMaxCtx];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* qb = q + static_cast<int64_t>(b) * D;
+  for (int c = 0; c < k; ++c) {
+    const float* pc = P + (static_cast<int64_t>(b) * k + c) * D;
+    float a = 0.f;
+    for (int d = tid; d < D; d += 256) a = fmaf(qb[d], pc[d], a);
+    a = block_sum<256>(a, red);
+    if (tid == 0) sc[c] = __fmul_rn(scale, a);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float mx = -INFINITY;
+    for (int c = 0; c < k; ++c) mx = fmaxf(mx, sc[c]);
+    float se = 0.f;
+    for (int c = 0; c < k; ++c) se += __expf(sc[c] - mx);
+    const float lse = mx + __logf(se);
+    for (int c = 0; c < k; ++c) {
+      s_out[b * k + c] = sc[c];
+      doc_lp[b * k + c] = sc[c] - lse;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void doc_scores_topk_bwd_kernel(const float* __restrict__ q, const float* __restrict__ P,
+                                                                  int k, int D, int Tg, float scale,
+                                                                  const float* __restrict__ doc_lp,
+                                                                  const float* __restrict__ weights,
+                                                                  const int64_t* __restrict__ cut,
+                                                                  const float* __restrict__ Nb,
+                                                                  const float* __restrict__ gscale, float* __restrict__ dq,
+                                                                  float* __restrict__ dP, float* __restrict__ ds_out) {
+  __shared__ float gs[kMaxCtx], ds[kMaxCtx];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nans = static_cast<int>(Nb[b]);
+  const float g0 = gscale ? gscale[0] : 1.f;
+  for (int c = wave; c < k; c += 4) {                        // one wave per context: fixed order inside the wave
+    const int64_t base = (static_cast<int64_t>(b) * k + c) * Tg;
+    const int cu = static_cast<int>(cut[b * k + c]);
+    float a = 0.f;
+    for (int j = lane; j < nans; j += 64) {
+      const int t = cu + j;
+      if (t >= 0 && t < Tg) a += weights[base + t];
+    }
+    a = wave_sum(a);
+    if (lane == 0) gs[c] = -g0 * a;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float G = 0.f;
+    for (int c = 0; c < k; ++c) G += gs[c];
+    for (int c = 0; c < k; ++c) {
+      ds[c] = gs[c] - __expf(doc_lp[b * k + c]) * G;
+      if (ds_out) ds_out[b * k + c] = ds[c];
+    }
+  }
+  __syncthreads();
+  const float* qb = q + static_cast<int64_t>(b) * D;
+  for (int d = tid; d < D; d += 256) {
+    float a = 0.f;
+    const float qv = qb[d];
+    for (int c = 0; c < k; ++c) {
+      const int64_t at = (static_cast<int64_t>(b) * k + c) * D + d;
+      a = fmaf(ds[c], P[at], a);
+      if (dP) dP[at] = scale * ds[c] * qv;
+    }
+    if (dq) dq[static_cast<int64_t>(b) * D + d] = scale * a;
+  }
+}
+
+}  // namespace
+}  // namespace dalm
+
+extern "C" int dalm_doc_scores_topk_fwd(const float* q, const float* P, int64_t B, int64_t k, int64_t D, float scale,
+                                        float* scores, float* doc_lp, dalm_stream_t stream) {
+  DALM_REQUIRE(q && P && scores && doc_lp, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(B > 0 && k > 0 && k <= kMaxCtx && D > 0 && B <= 0x7fffffffll && D <= 0x7fffffffll, DALM_E_SHAPE,
+               "need B > 0, 0 < k <= 64, D > 0");
+  hipLaunchKernelGGL(doc_scores_topk_fwd_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 0, as_stream(stream), q, P,
+                     static_cast<int>(k), static_cast<int>(D), scale, scores, doc_lp);
+  return check_launch(__func__);
+}
+
+extern "C" int dalm_doc_scores_topk_bwd(const float* q, const float* P, int64_t B, int64_t k, int64_t D, int64_t Tg,
+                                        float scale, const float* doc_lp, const float* weights, const int64_t* cut,
+                                        const float* Nb, const float* gscale, float* dq, float* dP, float* dscores,
+                                        dalm_stream_t stream) {
+  DALM_REQUIRE(q && P && doc_lp && weights && cut && Nb, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(dq || dP || dscores, DALM_E_NULL, "at least one output is required");
+  DALM_REQUIRE(B > 0 && k > 0 && k <= kMaxCtx && D > 0 && Tg > 0 && B <= 0x7fffffffll && D <= 0x7fffffffll &&
+               B * k * Tg < (1ll << 31), DALM_E_SHAPE, "need B > 0, 0 < k <= 64, D > 0, Tg > 0");
+  hipLaunchKernelGGL(doc_scores_topk_bwd_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 0, as_stream(stream), q, P,
+                     static_cast<int>(k), static_cast<int>(D), static_cast<int>(Tg), scale, doc_lp, weights, cut, Nb, gscale,
+                     dq, dP, dscores);
   return check_launch(__func__);
 }

@@ -279,6 +279,70 @@ def rag_e2e_loss(query_embs, passage_embs, generator_logits, input_ids, attentio
 
 
 # ---------------------------------------------------------------------------
+# k retrieved contexts per sample (RAG-token marginalisation), end to end.  The reference marginalises over ONE context -
+# the gold in-batch passage (train_utils.py:123-124) - and leaves more as a TODO (train_rage2e.py:461-462); this is the
+# extension SURVEY section 8a leaves room for: forward + closed-form backward for the logits, the query and the k contexts.
+# ---------------------------------------------------------------------------
+class _RagTopK(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, P, logits, ids, mask, qlen, scale, ops, aux):
+        B, k, Tg, V = logits.shape
+        if P.shape[:2] != (B, k) or ids.shape != (B, k, Tg) or mask.shape != (B, k, Tg) or qlen.shape != (B, k):
+            raise ValueError(f"shapes: P {tuple(P.shape)}, logits {tuple(logits.shape)}, ids {tuple(ids.shape)}, "
+                             f"mask {tuple(mask.shape)}, qlen {tuple(qlen.shape)}")
+        qd, Pd = q.detach().float().contiguous(), P.detach().float().contiguous()
+        scores, doc_lp = ops.doc_scores_topk_fwd(qd, Pd, scale)
+        flat = logits.detach().reshape(B * k, Tg, V)
+        ids_f, mask_f = ids.reshape(B * k, Tg), mask.reshape(B * k, Tg)
+        stats, Nb_seq, _ = ops.ce_prep(mask_f, qlen.reshape(-1))
+        stats = stats.clone()
+        stats[0] = stats[0] / k                     # M = live rows per context set (every context repeats the answer)
+        Nb = Nb_seq.reshape(B, k)[:, 0].contiguous()  # the answer has the same number of live rows under every context
+        # first answer row of sequence (b,c): the python slice start of lp[qlen-1:] over the Tg-1 shifted rows
+        cut = qlen.to(torch.int64) - 1
+        cut = torch.where(cut < 0, torch.clamp(cut + (Tg - 1), min=0), cut)
+        row_lse, row_nll, _ = ops.ce_fwd(flat, ids_f, mask_f, stats, False)
+        out, w = ops.ce_finalize_topk(row_nll.reshape(B, k, Tg), cut, Nb, doc_lp, stats, want_weights=True)
+        ctx.ops, ctx.scale, ctx.dims = ops, scale, (B, k, Tg, V)
+        ctx.in_dtypes = (q.dtype, P.dtype)
+        ctx.save_for_backward(qd, Pd, flat, ids_f, mask_f, stats, row_lse, w, doc_lp, cut, Nb)
+        if aux is not None:
+            aux["doc_scores"], aux["doc_logprobs"], aux["num_target_tokens"] = scores, doc_lp, stats[0]
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        ops = ctx.ops
+        qd, Pd, flat, ids_f, mask_f, stats, row_lse, w, doc_lp, cut, Nb = ctx.saved_tensors
+        B, k, Tg, V = ctx.dims
+        g = g.float().reshape(1)
+        dlogits = None
+        if ctx.needs_input_grad[2]:
+            dlogits = ops.ce_bwd_weighted(flat, ids_f, mask_f, stats, row_lse, g, w.reshape(-1)).reshape(B, k, Tg, V)
+        dq = dP = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dq, dP, _ = ops.doc_scores_topk_bwd(qd, Pd, ctx.scale, doc_lp, w, cut, Nb, g)
+            dq, dP = dq.to(ctx.in_dtypes[0]), dP.to(ctx.in_dtypes[1])
+        return (dq, dP, dlogits) + (None,) * 6
+
+
+def rag_e2e_loss_topk(query_embs, context_embs, generator_logits, input_ids, attention_mask, query_token_length,
+                      logit_scale, *, ops=None, aux: Optional[dict] = None):
+    """Generator loss marginalised over k retrieved contexts per query (RAG-token):
+
+        L = -( sum_b [ 1/k sum_c sum_{t < cut_bc} m lp_bct + sum_j log sum_c p(c|q_b) p(y_bj | context c) ] ) / M
+        p(c|q_b) = softmax_c(logit_scale * q_b . P[b,c]),   M = (live rows of all B k sequences) / k
+
+    query_embs [B,D], context_embs [B,k,D], generator_logits [B,k,Tg,V] (sequence (b,c) = the prompt built with context c),
+    input_ids / attention_mask [B,k,Tg], query_token_length [B,k] (un-truncated prompt length of every sequence; the answer
+    must have the same number of live rows under every context).  Differentiable in the logits, the query and the
+    contexts (closed forms, no log-probabilities in HBM).  The reference's loss is the k = 1 special case with the
+    in-batch softmax of the gold passage as p(c|q) (`rag_e2e_loss`); this entry point is what its TODO asks for."""
+    return _RagTopK.apply(query_embs, context_embs, generator_logits, input_ids, attention_mask, query_token_length,
+                          float(logit_scale), ops or default_ops(), aux)
+
+
+# ---------------------------------------------------------------------------
 # SURVEY section 8(f) rank 1: lm_head + marginalised CE without ever holding the [B,Tg,V] logits.
 # Samples are processed in chunks: logits_c = h_c W^T (hipBLASLt) -> the fused CE kernel turns the chunk into
 # its own gradient in place -> dh_c = dlogits_c W (and dW += dlogits_c^T h_c when the head is trainable).

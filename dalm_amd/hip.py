@@ -42,6 +42,9 @@ SIGNATURES = {
     "dalm_scale_inplace": (_int, [_vp, _int, _i64, _vp, _vp]),
     "dalm_marg_ce_finalize": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
     "dalm_marg_ce_finalize_topk": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dalm_marg_ce_bwd_weighted": (_int, [_vp, _int, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dalm_doc_scores_topk_fwd": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _vp, _vp, _vp]),
+    "dalm_doc_scores_topk_bwd": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dalm_doc_logprob_fwd": (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "dalm_doc_logprob_bwd": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _int, _vp]),
     "dalm_gather_nll": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),

@@ -342,6 +342,50 @@ class HipOps:
                  hip.ptr(mask), hip.ptr(stats), hip.ptr(row_lse), hip.ptr(gscale), hip.ptr(dlogits), hip.stream())
         return dlogits
 
+    def ce_bwd_weighted(self, logits, ids, mask, stats, row_lse, gscale, row_weight):
+        """dlogits = gscale * row_weight[row] * (softmax - onehot) on live rows (k retrieved contexts: the per-row weights of
+        `ce_finalize_topk`); logits [S,Tg,V] with S = B*k sequences."""
+        dev = hip.require_gpu(logits, ids, mask, stats, row_lse, gscale, row_weight)
+        logits, sb, st = self._logits_view(logits)
+        ids, mask = hip.as_i64(ids), hip.as_i64(mask)
+        B, Tg, V = logits.shape
+        row_weight = hip.as_f32c(row_weight)
+        if row_weight.numel() != B * Tg:
+            raise ValueError(f"row_weight must hold B*Tg = {B * Tg} values, got {row_weight.numel()}")
+        dlogits = torch.empty_strided(logits.shape, logits.stride(), device=dev, dtype=logits.dtype)
+        hip.call("dalm_marg_ce_bwd_weighted", hip.ptr(logits), hip.dtype_code(logits), B, Tg, V, sb, st, hip.ptr(ids),
+                 hip.ptr(mask), hip.ptr(stats), hip.ptr(row_lse), hip.ptr(gscale), hip.ptr(row_weight), hip.ptr(dlogits),
+                 hip.stream())
+        return dlogits
+
+    def doc_scores_topk_fwd(self, q: torch.Tensor, P: torch.Tensor, scale: float):
+        """scores [B,k] = scale * q[b] . P[b,c] and doc_lp = log_softmax over the k contexts."""
+        dev = hip.require_gpu(q, P)
+        q, P = hip.as_f32c(q), hip.as_f32c(P)
+        B, k, D = P.shape
+        if q.shape != (B, D):
+            raise ValueError(f"q must be [B,D] = {(B, D)}, got {tuple(q.shape)}")
+        scores = torch.empty((B, k), device=dev, dtype=torch.float32)
+        doc_lp = torch.empty((B, k), device=dev, dtype=torch.float32)
+        hip.call("dalm_doc_scores_topk_fwd", hip.ptr(q), hip.ptr(P), B, k, D, float(scale), hip.ptr(scores), hip.ptr(doc_lp),
+                 hip.stream())
+        return scores, doc_lp
+
+    def doc_scores_topk_bwd(self, q, P, scale: float, doc_lp, weights, cut, Nb, gscale):
+        """(dq [B,D], dP [B,k,D], dscores [B,k]) of the k-context loss from the weights of `ce_finalize_topk`."""
+        dev = hip.require_gpu(q, P, doc_lp, weights, cut, Nb, gscale)
+        q, P = hip.as_f32c(q), hip.as_f32c(P)
+        B, k, D = P.shape
+        Tg = weights.shape[-1]
+        doc_lp, weights, Nb = hip.as_f32c(doc_lp), hip.as_f32c(weights), hip.as_f32c(Nb)
+        cut = hip.as_i64(cut).contiguous()
+        dq = torch.empty((B, D), device=dev, dtype=torch.float32)
+        dP = torch.empty((B, k, D), device=dev, dtype=torch.float32)
+        ds = torch.empty((B, k), device=dev, dtype=torch.float32)
+        hip.call("dalm_doc_scores_topk_bwd", hip.ptr(q), hip.ptr(P), B, k, D, Tg, float(scale), hip.ptr(doc_lp),
+                 hip.ptr(weights), hip.ptr(cut), hip.ptr(Nb), hip.ptr(gscale), hip.ptr(dq), hip.ptr(dP), hip.ptr(ds), hip.stream())
+        return dq, dP, ds
+
     def scale_inplace(self, x: torch.Tensor, gscale: torch.Tensor) -> torch.Tensor:
         hip.require_gpu(x, gscale)
         if not x.is_contiguous():

@@ -223,6 +223,14 @@ int dalm_marg_ce_bwd(const void* logits, int dtype, int64_t B, int64_t Tg,
                      const int64_t* ids, const int64_t* mask, const float* stats,
                      const float* row_lse, const float* gscale, void* dlogits,
                      dalm_stream_t stream);
+/* the same with a weight PER ROW in place of the scalar m/M: dlogits[row] = gscale[0] * row_weight[row] * (softmax - onehot)
+ * on rows with mask != 0, zeros elsewhere.  row_weight [B*Tg] = the `weights` of dalm_marg_ce_finalize_topk (k retrieved
+ * contexts per sample: B here is B*k sequences).  dalm_marg_ce_bwd is this entry point with row_weight = m/M. */
+int dalm_marg_ce_bwd_weighted(const void* logits, int dtype, int64_t B, int64_t Tg,
+                              int64_t V, int64_t stride_b, int64_t stride_t,
+                              const int64_t* ids, const int64_t* mask, const float* stats,
+                              const float* row_lse, const float* gscale,
+                              const float* row_weight, void* dlogits, dalm_stream_t stream);
 /* x *= gscale[0] in place (n elements); no-op kernel exit when gscale[0] == 1. */
 int dalm_scale_inplace(void* x, int dtype, int64_t n, const float* gscale,
                        dalm_stream_t stream);
@@ -249,6 +257,19 @@ int dalm_marg_ce_finalize_topk(const float* row_nll, int64_t B, int64_t k, int64
                                const int64_t* cut, const float* Nb, const float* doc_lp,
                                const float* stats, float* out, float* weights,
                                dalm_stream_t stream);
+
+/* Scores of the k retrieved contexts of every query and their log-softmax over the k (RAG-token, p(c | q_b)):
+ *   scores[b,c] = scale * q[b] . P[b,c],   doc_lp[b,c] = scores[b,c] - logsumexp_c' scores[b,c']      q [B,D], P [B,k,D]
+ * and the closed-form backward of the k-context loss from the weights of dalm_marg_ce_finalize_topk:
+ *   g[b,c] = -gscale[0] * sum_{j < Nb[b]} weights[b,c,cut[b,c]+j],  ds[b,c] = g[b,c] - exp(doc_lp[b,c]) sum_c' g[b,c'],
+ *   dq[b] = scale sum_c ds[b,c] P[b,c],   dP[b,c] = scale ds[b,c] q[b]            (dq / dP / dscores may be NULL; k <= 64)
+ * The reference marginalises over ONE context (train_utils.py:123-124; TODO at train_rage2e.py:461-462). */
+int dalm_doc_scores_topk_fwd(const float* q, const float* P, int64_t B, int64_t k, int64_t D,
+                             float scale, float* scores, float* doc_lp, dalm_stream_t stream);
+int dalm_doc_scores_topk_bwd(const float* q, const float* P, int64_t B, int64_t k, int64_t D,
+                             int64_t Tg, float scale, const float* doc_lp, const float* weights,
+                             const int64_t* cut, const float* Nb, const float* gscale,
+                             float* dq, float* dP, float* dscores, dalm_stream_t stream);
 
 /* doc_lp[b] = S[b,b] - logsumexp_j S[b,j] on a materialised S
  * (train_utils.py:124), plus its backward

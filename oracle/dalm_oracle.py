@@ -261,6 +261,22 @@ def closed_gen_loss_topk(label_lp: torch.Tensor, mask: torch.Tensor, cut: torch.
     return {"generator": -tot / M, "M": M, "Nb": torch.tensor(nans, dtype=dt)}
 
 
+def ref_rag_topk_loss(q: torch.Tensor, P: torch.Tensor, logits: torch.Tensor, ids: torch.Tensor, mask: torch.Tensor,
+                      qlen: torch.Tensor, scale: float) -> torch.Tensor:
+    """The k-context generator loss stated through torch ops an autograd can differentiate (fp64 in the tests): document
+    posteriors = softmax over the k contexts of scale * q.P, token log-probs = log_softmax of the logits gathered at the
+    shifted labels (train_utils.py:121-131 per sequence), combined by `closed_gen_loss_topk` (probability form).
+    q [B,D], P [B,k,D], logits [B,k,Tg,V], ids / mask [B,k,Tg], qlen [B,k].  TEST INFRASTRUCTURE."""
+    B, k, Tg, V = logits.shape
+    doc_lp = torch.log_softmax(scale * torch.einsum("bd,bkd->bk", q, P), dim=1)
+    lp = torch.log_softmax(logits[:, :, :-1, :], dim=-1)
+    label_lp = torch.gather(lp, 3, ids[:, :, 1:].unsqueeze(-1)).squeeze(-1)
+    m = mask[:, :, 1:]
+    cut = qlen.to(torch.int64) - 1
+    cut = torch.where(cut < 0, torch.clamp(cut + (Tg - 1), min=0), cut)
+    return closed_gen_loss_topk(label_lp, m, cut, doc_lp)["generator"]
+
+
 # ---------------------------------------------------------------------------
 # OracleOps: the dalm_amd.ops.HipOps interface on CPU tensors (float64 inside).
 # Injected by tests/test_sharded_gloo.py to exercise the world_size>1 host logic

@@ -113,6 +113,15 @@ def bench_sim(m, n, D):
     if graphed:
         gm, _ = time_graph(lambda: ops.sim_rowstats(A, Bm, 100.0, 0), reps=10, replays=7)
         out["rowstats"].update({"graph_s": gm, "graph_frac": 2.0 * m * n * D / gm / MFMA_F32_PEAK})
+    if m >= 1024 and n >= 1024:
+        # round 4: the same statistics on the bf16 matrix cores (three bf16 thirds per operand, 6 D deep); "TFLOPs" stays the
+        # f32-EQUIVALENT rate 2 m n D / t (the kernel executes 6 x that on the bf16 pipe); sim_rowstats itself routes
+        # m, n >= 4096 there, so the exact-f32 kernel is timed through its pinned entry point
+        med, _ = time_fn(lambda: ops.sim_rowstats_bf16x3(A, Bm, 100.0, 0), iters=10, warmup=3)
+        out["rowstats_bf16x3"] = {"s": med, "TFLOPs": 2.0 * m * n * D / med / 1e12, "frac_of_f32_peak": 2.0 * m * n * D / med / MFMA_F32_PEAK,
+                                  "bf16_TFLOPs": 12.0 * m * n * D / med / 1e12, "frac_of_bf16_peak": 12.0 * m * n * D / med / 2.5e15}
+        med, _ = time_fn(lambda: ops.sim_rowstats_f32(A, Bm, 100.0, 0), iters=10, warmup=3)
+        out["rowstats_f32"] = {"s": med, "TFLOPs": 2.0 * m * n * D / med / 1e12, "frac": 2.0 * m * n * D / med / MFMA_F32_PEAK}
     if m * n <= 20000 * 20000:
         rl, _ = ops.sim_rowstats(A, Bm, 100.0, 0)
         cl = torch.zeros(n, device=dev) + 5.0
