@@ -459,7 +459,7 @@ def main():
         # WORLD_SIZE / MASTER_ADDR=127.0.0.1), rank 0 prints the JSON line; fewer than N visible GPUs -> exit 2
         raise SystemExit(spawn_ranks([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], args.gpus))
     if args.graph_collectives:
-        os.environ["DALM_NATIVE_COMM"] = "1"
+        os.environ["DALM_NATIVE_COMM"] = "1"       # (the default since round 4; a capture needs it, so insist)
     args.hw_queues = dalm_amd.configure_hw_queues(args.gpus)   # before the HIP runtime starts
 
     from dalm_amd import hip
@@ -562,12 +562,9 @@ def main():
         torch.cuda.synchronize()
         ops.enabled = False
         probe_note = "HIP events around the launch in 5 eager steps run right after the timed hipGraph-replay region"
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if torch.distributed.is_available() and torch.distributed.is_initialized():
-        import torch.distributed as dist
+    from dalm_amd.sharded import max_over_ranks
 
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = max_over_ranks(comm, elapsed)        # the slowest rank's clock
 
     ranks_seen, backend = 1, "none (one process)"
     if torch.distributed.is_available() and torch.distributed.is_initialized():
@@ -735,14 +732,14 @@ def main_retriever_only(args):
     torch.cuda.synchronize()
     barrier(comm)
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if torch.distributed.is_available() and torch.distributed.is_initialized():
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    from dalm_amd.sharded import max_over_ranks
+
+    elapsed = max_over_ranks(comm, elapsed)
     if comm.rank == 0:
-        value = args.gpus * B * args.steps / float(t.item())
+        value = args.gpus * B * args.steps / elapsed
         print(json.dumps({
             "metric": "training pairs/sec (global batch) retriever-only " + ("bge-small" if small else "bge-large"), "value": value, "unit": "pairs/s",
-            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * float(t.item()) / args.steps,
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload} retriever-only: {'bge-small-en' if small else 'bge-large-en'} architecture (random init), "
                                    f"LoRA r=8 q/k/v, per-GPU batch {B}, Tq50/Tp128, logit_scale 100, Adam, {args.dtype}",

@@ -8,26 +8,33 @@ logging.getLogger(__name__).addHandler(logging.NullHandler())
 
 
 def configure_hw_queues(world_size=None) -> str:
-    """Opt-in hardware-queue setting for processes that keep an RCCL communicator alive.
+    """Opt-in hardware-queue setting for the one configuration it was measured in.
 
-    HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The step runs the retriever towers and
-    the generator on two streams; measured on MI355X with ONE rank and a live RCCL process group, RCCL's own streams
-    shifted the mapping so that the two compute streams shared a queue (214 ms/step at 4 queues, 180 ms at 3; without
-    a process group 181 ms at 3 or 4).  That is the only configuration the evidence covers, so nothing is changed
-    at import any more: entry points (bench.py, the trainers) call this before the HIP runtime starts, it applies 3
-    only when a process group will exist (world_size > 1 or DALM_FORCE_DIST=1), an explicit GPU_MAX_HW_QUEUES always
-    wins, and DALM_HW_QUEUES=<n> forces a value (0 = leave the runtime default).  Returns what was decided."""
+    HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The step runs the retriever towers and the
+    generator on two streams; measured on MI355X with ONE rank and a live RCCL communicator (DALM_FORCE_DIST=1: the W > 1 code
+    path on a 1-GPU box), RCCL's own streams shifted the mapping so that the two compute streams shared a queue (214 ms/step
+    at 4 queues, 180 ms at 3; without a communicator 181 ms at 3 or 4).  That single-rank measurement is all the evidence
+    there is (no multi-GPU box in rounds 1-4), so 3 is applied ONLY there: world_size == 1 with DALM_FORCE_DIST=1.  With
+    world_size > 1 the runtime default stays (round 3 applied 3 at every rank count - a guess that changes the
+    process-wide queue mapping).  An explicit GPU_MAX_HW_QUEUES always wins, DALM_HW_QUEUES=<n> forces a value at
+    any rank count (0 = leave the runtime default).  Entry points (bench.py, the trainers) call this before the HIP
+    runtime starts; whatever is applied is logged and returned."""
+    log = logging.getLogger(__name__)
     if "GPU_MAX_HW_QUEUES" in os.environ:
         return "user:" + os.environ["GPU_MAX_HW_QUEUES"]
     forced = os.environ.get("DALM_HW_QUEUES")
     if forced is not None:
         if forced not in ("", "0"):
             os.environ["GPU_MAX_HW_QUEUES"] = forced
+            log.info("GPU_MAX_HW_QUEUES=%s (DALM_HW_QUEUES)", forced)
             return "DALM_HW_QUEUES:" + forced
         return "runtime-default"
     if world_size is None:
         world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    if world_size > 1 or os.environ.get("DALM_FORCE_DIST", "0") == "1":
+    if world_size == 1 and os.environ.get("DALM_FORCE_DIST", "0") == "1":
         os.environ["GPU_MAX_HW_QUEUES"] = "3"
-        return "rccl-alive:3"
+        log.info("GPU_MAX_HW_QUEUES=3: one rank with a live RCCL communicator (the configuration this was measured in)")
+        return "rccl-alive-one-rank:3"
+    if world_size > 1:
+        return f"runtime-default (world_size {world_size}: the 3-queue setting was only ever measured with one rank)"
     return "runtime-default"

@@ -49,9 +49,7 @@ def rank_env(rank: int, world: int, port: int, base: Optional[Dict[str, str]] = 
                 "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
     # the host driver supports only dmabuf IPC: without this RCCL's cross-process buffer sharing fails
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    # rendezvous file of the opt-in native communicator (dalm_amd.comm): unique per launch, so that the id file a
-    # crashed earlier job left behind on the same port can never be picked up
-    env.setdefault("DALM_COMM_ID_FILE", f"/tmp/dalm_comm_{port}_{os.getpid()}_{int(_LAUNCH_T0 * 1000)}.id")
+    # (the native communicator's rendezvous runs over a TCPStore on MASTER_PORT since round 4: no id file under /tmp)
     return env
 
 

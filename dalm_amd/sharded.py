@@ -36,13 +36,17 @@ def init_distributed(backend: Optional[str] = None):
     import torch.distributed as dist
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if torch.cuda.is_available() and os.environ.get("DALM_NATIVE_COMM", "0") == "1":
-        # opt-in: the library's own RCCL binding (dalm_comm_*), no torch.distributed process group at all
-        from .comm import NativeRcclComm
-
+    # W > 1 on GPUs: the library's OWN RCCL binding (dalm_comm_* behind the C ABI, collectives on the caller's stream) is the
+    # default since round 4 - it ties torch.distributed on one rank (188.1 vs 188.9 ms per step, profiles/r03_comm_modes.txt)
+    # and is what north_star asks for.  DALM_NATIVE_COMM=0 selects torch.distributed(nccl); =1 insists on the native
+    # binding (errors propagate); unset: native, verified by a self-test collective, and torch.distributed if that raises.
+    native = os.environ.get("DALM_NATIVE_COMM")
+    if torch.cuda.is_available() and backend in (None, "nccl") and native != "0":
         dev = torch.device("cuda", local_rank)
         torch.cuda.set_device(dev)
-        return NativeRcclComm(), dev
+        comm = native_comm_or_none(int(os.environ.get("RANK", "0")), world, insist=(native == "1"))
+        if comm is not None:
+            return comm, dev
     if torch.cuda.is_available():
         dev = torch.device("cuda", local_rank)
         torch.cuda.set_device(dev)
@@ -60,6 +64,46 @@ def init_distributed(backend: Optional[str] = None):
         else:
             dist.init_process_group(backend=backend)
     return TorchDistComm(), dev
+
+
+def native_comm_or_none(rank: int, world: int, insist: bool = False, make=None):
+    """The library's own RCCL communicator, brought up and self-tested - or None when ANY rank failed to (the ranks agree
+    through the rendezvous store, so either all of them continue natively or all fall back to torch.distributed).
+    insist: raise instead of returning None.  `make(rendezvous)` builds the communicator (tests inject a fake)."""
+    import warnings
+
+    from .comm import NativeRcclComm, Rendezvous
+
+    if os.environ.get("DALM_COMM_ID_FILE"):          # explicit file rendezvous: no agreement channel, errors propagate
+        comm = NativeRcclComm()
+        comm.self_test()
+        return comm
+    rdv, comm, err = None, None, None
+    try:
+        rdv = Rendezvous(rank, world)
+        comm = (make or (lambda r: NativeRcclComm(rendezvous=r)))(rdv)
+        comm.self_test()
+    except Exception as e:
+        err = e
+    if rdv is None:                                    # no channel to agree over: every rank fails the same way here
+        if insist:
+            raise err
+        warnings.warn(f"dalm_amd: native RCCL communicator unavailable ({err!r}); using torch.distributed(nccl)")
+        return None
+    all_ok = rdv.agree(err is None)
+    if all_ok:
+        return comm
+    if comm is not None:
+        try:
+            comm.close()
+        except Exception:
+            pass
+    rdv.release()                                      # rank 0 gives MASTER_PORT back for init_process_group
+    if insist:
+        raise err if err is not None else RuntimeError("another rank could not bring up the native RCCL communicator")
+    warnings.warn("dalm_amd: native RCCL communicator unavailable on at least one rank"
+                  + (f" (here: {err!r})" if err is not None else "") + "; all ranks use torch.distributed(nccl)")
+    return None
 
 
 def allreduce_grads(params: Iterable[torch.nn.Parameter], comm) -> None:
@@ -204,6 +248,23 @@ class GradBucket:
             if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * off:
                 p.grad = self.flat[off:off + n].view_as(p)
             off += n
+
+
+def max_over_ranks(comm, value: float) -> float:
+    """MAX of a host scalar over the ranks (bench.py: the slowest rank's elapsed time) on whichever communicator runs."""
+    if isinstance(comm, LocalComm):
+        return float(value)
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        t = torch.tensor([value], dtype=torch.float64,
+                         device=torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    # native communicator: all-gather the values (sum / gather are the collectives the C ABI exposes); float32 keeps a few
+    # seconds to ~1e-7 relative
+    t = torch.tensor([[value]], dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
+    return float(comm.all_gather_rows(t).max().item())
 
 
 def barrier(comm) -> None:

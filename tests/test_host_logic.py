@@ -506,8 +506,9 @@ def test_length_bucketing_and_padding_trim():
 
 
 def test_hw_queue_setting_is_opt_in(monkeypatch):
-    """importing the package must not touch GPU_MAX_HW_QUEUES; the entry points apply 3 only when an
-    RCCL process group will exist, an explicit setting wins, DALM_HW_QUEUES forces / disables."""
+    """importing the package must not touch GPU_MAX_HW_QUEUES; the entry points apply 3 only in
+    the configuration it was measured in (ONE rank with a live RCCL communicator, DALM_FORCE_DIST=1) - not at world sizes it
+    was never measured at; an explicit setting wins, DALM_HW_QUEUES forces / disables at any rank count."""
     import importlib
     import os
 
@@ -518,18 +519,21 @@ def test_hw_queue_setting_is_opt_in(monkeypatch):
     importlib.reload(dalm_amd)
     assert "GPU_MAX_HW_QUEUES" not in os.environ
     assert dalm_amd.configure_hw_queues(1) == "runtime-default" and "GPU_MAX_HW_QUEUES" not in os.environ
-    assert dalm_amd.configure_hw_queues(8) == "rccl-alive:3" and os.environ["GPU_MAX_HW_QUEUES"] == "3"
+    assert dalm_amd.configure_hw_queues(8).startswith("runtime-default") and "GPU_MAX_HW_QUEUES" not in os.environ
+    monkeypatch.setenv("DALM_FORCE_DIST", "1")
+    assert dalm_amd.configure_hw_queues(1) == "rccl-alive-one-rank:3" and os.environ["GPU_MAX_HW_QUEUES"] == "3"
+    monkeypatch.delenv("DALM_FORCE_DIST")
     monkeypatch.setenv("GPU_MAX_HW_QUEUES", "4")
     assert dalm_amd.configure_hw_queues(8) == "user:4" and os.environ["GPU_MAX_HW_QUEUES"] == "4"
     monkeypatch.delenv("GPU_MAX_HW_QUEUES")
     monkeypatch.setenv("DALM_HW_QUEUES", "0")
     assert dalm_amd.configure_hw_queues(8) == "runtime-default" and "GPU_MAX_HW_QUEUES" not in os.environ
     monkeypatch.setenv("DALM_HW_QUEUES", "2")
-    assert dalm_amd.configure_hw_queues(1) == "DALM_HW_QUEUES:2"
+    assert dalm_amd.configure_hw_queues(8) == "DALM_HW_QUEUES:2"
     monkeypatch.delenv("GPU_MAX_HW_QUEUES")
     monkeypatch.delenv("DALM_HW_QUEUES")
     monkeypatch.setenv("WORLD_SIZE", "4")
-    assert dalm_amd.configure_hw_queues() == "rccl-alive:3"
+    assert dalm_amd.configure_hw_queues().startswith("runtime-default") and "GPU_MAX_HW_QUEUES" not in os.environ
 
 
 def test_live_row_index_lists_the_shifted_label_rows():

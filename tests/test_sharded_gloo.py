@@ -359,3 +359,65 @@ def test_mixed_saves_are_refused_by_the_stamp(tmp_path):
                d / "trainer_state.pt")
     with pytest.raises(RuntimeError, match="another step"):
         common.load_training_state(str(d), opt, None)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 4: the native communicator is the W > 1 default - its rendezvous (unique id over a TCPStore, no id file) and the
+# ALL-OR-NONE fallback agreement, on CPU with two processes and a fake communicator (no RCCL here)
+# ---------------------------------------------------------------------------------------------------------------------
+class _FakeComm:
+    def __init__(self, rdv, fail_on=None):
+        self.uid = rdv.exchange(lambda: bytes([rdv.rank + 7]) * 128)       # only rank 0's lambda runs
+        self.rank, self.fail_on, self.closed = rdv.rank, fail_on, False
+
+    def self_test(self):
+        if self.fail_on == self.rank:
+            raise RuntimeError("self-test failed on this rank")
+
+    def close(self):
+        self.closed = True
+
+
+def _rdv_worker(rank, world, port, out_dir, fail_on):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    os.environ.pop("DALM_COMM_ID_FILE", None)
+    os.environ.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+    import warnings
+
+    import torch.distributed as dist
+
+    from dalm_amd.sharded import native_comm_or_none
+
+    made = []
+
+    def make(rdv):
+        c = _FakeComm(rdv, fail_on)
+        made.append(c)
+        return c
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        comm = native_comm_or_none(rank, world, make=make)
+    res = {"native": comm is not None, "uid0": made[0].uid[0], "closed": made[0].closed}
+    if comm is None:        # the fallback every rank takes together: MASTER_PORT must be free again for the process group
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        res["fallback_sum"] = float(t)
+        dist.destroy_process_group()
+    torch.save(res, os.path.join(out_dir, f"r{rank}.pt"))
+
+
+@pytest.mark.parametrize("fail_on", [None, 1, 0])
+def test_native_comm_rendezvous_and_all_or_none_fallback(tmp_path, fail_on):
+    """Both ranks get rank 0's unique id through the store; when ONE rank's communicator fails its self-test, BOTH ranks
+    drop the native communicator (the healthy one is closed) and meet again in torch.distributed on the same port."""
+    mp.spawn(_rdv_worker, args=(2, _free_port(), str(tmp_path), fail_on), nprocs=2, join=True)
+    res = [torch.load(tmp_path / f"r{r}.pt") for r in range(2)]
+    assert all(r["uid0"] == 7 for r in res)                      # rank 0's payload (bytes of value 0 + 7) on both ranks
+    if fail_on is None:
+        assert all(r["native"] and not r["closed"] for r in res)
+    else:
+        assert not any(r["native"] for r in res) and all(r["closed"] for r in res)
+        assert all(r["fallback_sum"] == 3.0 for r in res)

@@ -116,13 +116,16 @@ def test_train_e2e_end_to_end_on_csv(tmp_path):
     assert [s for s, _ in more] == [7, 8, 9]  # epochs 0-1 are skipped, one more epoch of 3 steps runs
 
 
-def test_multi_gpu_code_path_on_one_rank_matches_reference(monkeypatch):
+@pytest.mark.parametrize("which", ["native-default", "torch-distributed"])
+def test_multi_gpu_code_path_on_one_rank_matches_reference(monkeypatch, which):
     """The W > 1 step (RCCL all-gathers on a side stream, stats exchange, flat gradient all-reduce, graphed
-    towers) run through a real one-rank RCCL process group: collectives are identities, so the trajectory
-    must still be the reference's."""
+    towers) run through a real one-rank RCCL communicator: collectives are identities, so the trajectory
+    must still be the reference's.  Round 4: `init_distributed` hands out the library's own RCCL binding by default
+    (rendezvous over a TCPStore, self-test collective); DALM_NATIVE_COMM=0 selects torch.distributed(nccl)."""
     import torch.distributed as dist
     from transformers import get_scheduler
 
+    from dalm_amd.comm import NativeRcclComm
     from dalm_amd.fused import TorchDistComm
     from dalm_amd.models import AutoModelForRagE2E
     from dalm_amd.sharded import init_distributed
@@ -130,13 +133,21 @@ def test_multi_gpu_code_path_on_one_rank_matches_reference(monkeypatch):
 
     monkeypatch.setenv("DALM_FORCE_DIST", "1")
     monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
-    monkeypatch.setenv("MASTER_PORT", "29641")
+    monkeypatch.setenv("MASTER_PORT", "29641" if which == "torch-distributed" else "29643")
     monkeypatch.setenv("RANK", "0")
     monkeypatch.setenv("WORLD_SIZE", "1")
     monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.delenv("DALM_COMM_ID_FILE", raising=False)
+    if which == "torch-distributed":
+        monkeypatch.setenv("DALM_NATIVE_COMM", "0")
+    else:
+        monkeypatch.delenv("DALM_NATIVE_COMM", raising=False)
     comm, dev = init_distributed()
     try:
-        assert isinstance(comm, TorchDistComm) and comm.world_size == 1 and dist.get_backend() == "nccl"
+        if which == "torch-distributed":
+            assert isinstance(comm, TorchDistComm) and comm.world_size == 1 and dist.get_backend() == "nccl"
+        else:
+            assert isinstance(comm, NativeRcclComm) and comm.world_size == 1 and not dist.is_initialized()
         gold = json.loads((G / "step_golden.json").read_text())
         rag = AutoModelForRagE2E(str(G / "tiny_retriever"), str(G / "tiny_generator")).to(dev)
         g_tok = rag.generator_tokenizer
@@ -154,6 +165,8 @@ def test_multi_gpu_code_path_on_one_rank_matches_reference(monkeypatch):
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()
+        if isinstance(comm, NativeRcclComm):
+            comm.close()
 
 
 def test_falcon_architecture_generator_runs_through_the_step():
