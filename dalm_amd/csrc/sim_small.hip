@@ -127,6 +127,73 @@ __global__ __launch_bounds__(256) void small_partial_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The same partial tiles with the operand loads SOFTWARE-PIPELINED (round 4): the loop above is load -> wait -> 16 MFMAs
+// per round of 32 k, i.e. every round pays a full L2 / fabric round trip (the ISA shows s_waitcnt vmcnt(0..2) in front of
+// every group of four MFMAs and wave-uniform branches around the later groups).  Here a wave's K range is a compile-time
+// number of whole rounds (ROUNDS x 32, no tail: the planner only sends exact covers), DEPTH rounds are in flight, and the
+// group of four MFMAs that has just consumed a pair of float4 registers is followed by the loads that refill them for
+// round r + DEPTH.  Same summation order as small_partial_kernel (k ascending per wave, waves 0..3 through LDS): same bits.
+// ---------------------------------------------------------------------------------------------------
+template <int ROUNDS, int DEPTH>
+__global__ __launch_bounds__(256) void small_partial_pipe_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                                 int m, int n, int K, int k_chunk, int tiles_n,
+                                                                 float* __restrict__ slab, int ldn,
+                                                                 float* __restrict__ slabT, int ldm) {
+  __shared__ float red[4 * 32 * RED_STRIDE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+  const int ti = blockIdx.x / tiles_n, tj = blockIdx.x % tiles_n, z = blockIdx.y;
+  const int i0 = ti * 32, j0 = tj * 32;
+  const int k_lo = z * k_chunk + wave * (ROUNDS * 32) + 4 * lhi;
+  // rows past m / n are clamped to the last row: their tile rows are never stored
+  const float* ap = A + static_cast<int64_t>(min(i0 + l31, m - 1)) * K + k_lo;
+  const float* bp = B + static_cast<int64_t>(min(j0 + l31, n - 1)) * K + k_lo;
+  constexpr int NB = DEPTH < ROUNDS ? DEPTH : ROUNDS;
+  float4 av[NB][4], bv[NB][4];
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int r = 0; r < NB; ++r)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      av[r][u] = *reinterpret_cast<const float4*>(ap + 32 * r + 8 * u);
+      bv[r][u] = *reinterpret_cast<const float4*>(bp + 32 * r + 8 * u);
+    }
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    constexpr int dummy = 0; (void)dummy;
+    const int b = r % NB;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[b][u].x, bv[b][u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[b][u].y, bv[b][u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[b][u].z, bv[b][u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[b][u].w, bv[b][u].w, acc, 0, 0, 0);
+      if (r + NB < ROUNDS) {
+        av[b][u] = *reinterpret_cast<const float4*>(ap + 32 * (r + NB) + 8 * u);
+        bv[b][u] = *reinterpret_cast<const float4*>(bp + 32 * (r + NB) + 8 * u);
+      }
+    }
+  }
+  stash_acc(red, acc, wave, l31, lhi);
+  __syncthreads();
+  float* sl = slab + static_cast<int64_t>(z) * m * ldn;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = tid + 256 * q, row = e >> 5, col = e & 31;
+    if (i0 + row < m && j0 + col < n) sl[static_cast<int64_t>(i0 + row) * ldn + j0 + col] = red_sum(red, row, col);
+  }
+  if (slabT) {
+    float* st = slabT + static_cast<int64_t>(z) * n * ldm;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + 256 * q, col = e >> 5, row = e & 31;
+      if (i0 + row < m && j0 + col < n) st[static_cast<int64_t>(j0 + col) * ldm + i0 + row] = red_sum(red, row, col);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // row statistics of S (blockIdx.y == 0: slab, also writes S and diag) and of S^T (blockIdx.y == 1: slabT).
 // One wave per row; slabs summed in fixed order z = 0..SK-1, then scaled with a separate rounding so that the
 // S read by the backward and the S the statistics saw are the same bits.
@@ -465,6 +532,7 @@ __global__ __launch_bounds__(1024) void rag_loss_finalize_kernel(const float* __
 
 inline int64_t round_up(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
 
+constexpr int kDefaultPipeDepth = 0;     // decided by measurement (profiles/r04_small_pipe.txt)
 struct SmallPlan { int sk, k_chunk; int64_t ldn, ldm; };
 inline SmallPlan small_plan(int64_t m, int64_t n, int64_t D) {
   const int64_t tiles = ((m + 31) / 32) * ((n + 31) / 32);
@@ -516,7 +584,18 @@ extern "C" int dalm_sim_small_fwd(const float* A, const float* Bm, int64_t m, in
   float* slabT = want_cols ? slab + static_cast<size_t>(pl.sk) * m * pl.ldn : nullptr;
   const int tiles_m = static_cast<int>((m + 31) / 32), tiles_n = static_cast<int>((n + 31) / 32);
   const dim3 pgrid(static_cast<unsigned>(tiles_m * tiles_n), static_cast<unsigned>(pl.sk));
-  if (vec16(A, D) && vec16(Bm, D) && D % 8 == 0)
+  // pipelined form: the split covers K exactly and a wave's share is 4 or 8 whole rounds of 32 (D = 1024 with 1 or 2
+  // slices: 512^2 ... 1024^2 on one GPU, the 150 x 1200 per-rank blocks); DALM_SMALL_PIPE = 0 (off) | 2 | 3 | 4 = rounds in flight
+  static const int pipe_depth = getenv("DALM_SMALL_PIPE") ? atoi(getenv("DALM_SMALL_PIPE")) : kDefaultPipeDepth;
+  const int rounds = (pl.k_chunk % 128 == 0 && static_cast<int64_t>(pl.k_chunk) * pl.sk == D) ? pl.k_chunk / 128 : 0;
+  const bool fast = vec16(A, D) && vec16(Bm, D) && D % 8 == 0;
+#define DALM_PIPE(R, DP) hipLaunchKernelGGL((small_partial_pipe_kernel<R, DP>), pgrid, dim3(256), 0, s, A, Bm, static_cast<int>(m), \
+    static_cast<int>(n), static_cast<int>(D), pl.k_chunk, tiles_n, slab, static_cast<int>(pl.ldn), slabT, static_cast<int>(pl.ldm))
+  if (fast && pipe_depth >= 2 && (rounds == 4 || rounds == 8)) {
+    if (rounds == 4) { if (pipe_depth == 2) DALM_PIPE(4, 2); else if (pipe_depth == 3) DALM_PIPE(4, 3); else DALM_PIPE(4, 4); }
+    else { if (pipe_depth == 2) DALM_PIPE(8, 2); else if (pipe_depth == 3) DALM_PIPE(8, 3); else DALM_PIPE(8, 4); }
+  } else if (fast)
+#undef DALM_PIPE
     hipLaunchKernelGGL(small_partial_kernel<true>, pgrid, dim3(256), 0, s, A, Bm, static_cast<int>(m),
                        static_cast<int>(n), static_cast<int>(D), pl.k_chunk, tiles_n, 1, 1, slab,
                        static_cast<int>(pl.ldn), slabT, static_cast<int>(pl.ldm));

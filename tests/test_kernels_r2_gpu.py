@@ -667,17 +667,28 @@ def test_bf16x3_scores_off_the_diagonal_vs_fp64(dev):
 
 def test_large_rowstats_route_to_bf16x3_and_keep_the_loss(dev):
     """dalm_sim_rowstats sends m, n >= 4096 to the bf16x3 form: same statistics as the explicit entry point (bit for bit),
-    and the contrastive loss built from them agrees with fp64 to 1e-6 relative."""
+    and the contrastive loss built from them agrees with fp64.  Embeddings WITHOUT stand-out positives (an untrained
+    retriever: loss ~ log n, every score matters) and the `_problem` ones (loss ~ 0: the terms lse - diag cancel to ~1e-7,
+    so that case is held to the ABSOLUTE error of a score, 2e-6 |S|)."""
     from dalm_amd.ops import default_ops
 
     ops = default_ops()
     m = n = 4096
-    A, Bm, scale, S, *_ = _problem(m, n, 1024, 0, seed=5)
-    r1, d1 = ops.sim_rowstats(A.to(dev), Bm.to(dev), scale, 0)
-    r2, d2 = ops.sim_rowstats_bf16x3(A.to(dev), Bm.to(dev), scale, 0)
-    assert torch.equal(r1, r2) and torch.equal(d1, d2)
-    c1, _ = ops.sim_rowstats(Bm.to(dev), A.to(dev), scale, 0)
     idx = torch.arange(m)
-    ref = 0.5 * ((torch.logsumexp(S, 1) - S[idx, idx]).mean() + (torch.logsumexp(S, 0) - S[idx, idx]).mean())
-    got = 0.5 * ((r1.double().cpu() - d1.double().cpu()).mean() + (c1.double().cpu() - d1.double().cpu()).mean())
-    assert abs(float(got) - float(ref)) <= 1e-6 * abs(float(ref)) + 1e-7, (float(got), float(ref))
+    for kind in ("untrained", "trained"):
+        if kind == "trained":
+            A, Bm, scale, S, *_ = _problem(m, n, 1024, 0, seed=5)
+        else:
+            g = torch.Generator().manual_seed(6)
+            A = torch.nn.functional.normalize(torch.randn(m, 1024, generator=g), dim=1)
+            Bm = torch.nn.functional.normalize(torch.randn(n, 1024, generator=g), dim=1)
+            scale = 100.0
+            S = scale * (A.double() @ Bm.double().t())
+        r1, d1 = ops.sim_rowstats(A.to(dev), Bm.to(dev), scale, 0)
+        r2, d2 = ops.sim_rowstats_bf16x3(A.to(dev), Bm.to(dev), scale, 0)
+        assert torch.equal(r1, r2) and torch.equal(d1, d2)
+        c1, _ = ops.sim_rowstats(Bm.to(dev), A.to(dev), scale, 0)
+        ref = 0.5 * ((torch.logsumexp(S, 1) - S[idx, idx]).mean() + (torch.logsumexp(S, 0) - S[idx, idx]).mean())
+        got = 0.5 * ((r1.double().cpu() - d1.double().cpu()).mean() + (c1.double().cpu() - d1.double().cpu()).mean())
+        tol = 1e-6 * abs(float(ref)) + 2e-6 * float(S.abs().max()) * (1.0 if kind == "trained" else 0.0)
+        assert abs(float(got) - float(ref)) <= tol + 1e-7, (kind, float(got), float(ref))
