@@ -1,0 +1,86 @@
+"""Kernel-time breakdown of the TIMED steps only, from a rocprofv3 `*_kernel_trace.csv` of bench.py.
+
+rocprofv3's own `*_kernel_stats.csv` aggregates the whole process: model initialisation (normal_ / uniform_ kernels, hundreds
+of launches), warm-up steps and the post-run probes dilute every percentage.  Here the window is cut out of the
+trace itself: step boundaries are the fused-Adam launches (`multi_tensor_apply`) that end every step - the window runs from
+the end of the last warm-up step's optimizer kernels to the end of the last timed step's, located through the launches of the
+marginalised-CE kernel (one per step).
+
+    python tools/summarize_step_window.py <kernel_trace.csv> --warmup 2 --steps 5 [--top 45]
+"""
+import argparse
+import csv
+import sys
+
+sys.path.insert(0, __file__.rsplit("/", 1)[0])
+from summarize_rocprof import short  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("trace")
+    ap.add_argument("--warmup", type=int, required=True)
+    ap.add_argument("--steps", type=int, required=True)
+    ap.add_argument("--top", type=int, default=45)
+    a = ap.parse_args()
+    rows = []
+    with open(a.trace) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    rows.sort()
+    ce = [s for s, e, n in rows if "marg_ce_row" in n or "marg_ce_stream" in n]
+    adam = [(s, e) for s, e, n in rows if "multi_tensor_apply" in n]
+    need = a.warmup + a.steps
+    if len(ce) < need:
+        sys.exit(f"only {len(ce)} CE launches in the trace, expected >= {need}")
+    ce = ce[:need]          # later launches belong to post-run probes
+
+    def step_end(i):        # end of the last optimizer kernel between CE launch i and CE launch i + 1 (or the next 2 s)
+        lo, hi = ce[i], (ce[i + 1] if i + 1 < len(ce) else ce[i] + 2_000_000_000)
+        ends = [e for s, e in adam if lo < s < hi]
+        return max(ends) if ends else hi
+
+    t0 = step_end(a.warmup - 1) if a.warmup > 0 else rows[0][0]
+    t1 = step_end(need - 1)
+    agg, total, launches = {}, 0.0, 0
+    for s, e, n in rows:
+        if s < t0 or e > t1:
+            continue
+        k = short(n)
+        v = agg.setdefault(k, [0, 0.0])
+        v[0] += 1
+        v[1] += e - s
+        total += e - s
+        launches += 1
+    span = t1 - t0
+    print(f"# source: {a.trace}")
+    print(f"# window: the {a.steps} timed steps only (after {a.warmup} warm-up steps; initialisation and post-run probes excluded)")
+    print(f"# wall span {span/1e6:.2f} ms = {span/1e6/a.steps:.2f} ms per step; kernel time {total/1e6:.2f} ms "
+          f"({100*total/span:.1f} % of the span: >100 % means kernels overlap on several streams) over {launches} launches "
+          f"= {launches // a.steps} per step")
+    print(f"{'kernel':92s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>6s}")
+    for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:a.top]:
+        print(f"{k:92s} {c:7d} {t/1e6:10.3f} {t/c/1e3:10.2f} {100*t/total:6.2f}")
+    groups = {"hipBLASLt / rocBLAS GEMM": 0.0, "aten elementwise / reduce / copy": 0.0, "attention (SDPA)": 0.0,
+              "dalm_* (this library)": 0.0, "optimizer": 0.0, "other": 0.0}
+    for k, (c, t) in agg.items():
+        if k.startswith("hipBLASLt") or "Cijk" in k or "gemm" in k.lower() and "dalm" not in k and "mfma" not in k:
+            groups["hipBLASLt / rocBLAS GEMM"] += t
+        elif "multi_tensor_apply" in k:
+            groups["optimizer"] += t
+        elif any(x in k for x in ("attention", "attn", "fmha", "flash_fwd", "flash_bwd", "sdpa")):
+            groups["attention (SDPA)"] += t
+        elif any(x in k for x in ("marg_ce", "pool_", "small_", "rag_loss", "ce_prep", "ce_finalize", "rms_norm", "nf4", "l2norm",
+                                  "sim_", "scale_inplace", "contrastive")):
+            groups["dalm_* (this library)"] += t
+        elif k.startswith("aten::") or "at::native" in k or "elementwise" in k:
+            groups["aten elementwise / reduce / copy"] += t
+        else:
+            groups["other"] += t
+    print("# --- by family ---")
+    for g, t in sorted(groups.items(), key=lambda kv: -kv[1]):
+        print(f"# {g:40s} {t/1e6:10.3f} ms {100*t/total:6.2f} %")
+
+
+if __name__ == "__main__":
+    main()
