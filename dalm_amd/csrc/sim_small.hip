@@ -38,6 +38,7 @@ __device__ __forceinline__ float4 ld4_guard(const float* p, int nvalid, bool vec
 __device__ __forceinline__ int mfma_row(int r, int lhi) { return (r & 3) + 8 * (r >> 2) + 4 * lhi; }
 
 constexpr int RED_STRIDE = 33;
+constexpr int SK_MAX = 16;       // most K slices a tile is split into
 
 // sums the 4 waves' 32x32 accumulators through LDS (fixed order w = 0..3); afterwards thread t owns tile
 // elements e = t + 256 q.  red: [4][32][33] floats.
@@ -53,16 +54,190 @@ __device__ __forceinline__ float red_sum(const float* red, int row, int col) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// ONE-LAUNCH forward (round 4): the statistics pass moves INTO the partial-tile kernel - the last
+// workgroup to arrive finishes what the others left, in a fixed order, so the result does not depend on who was last:
+//   level 1  (sk > 1)  every K slice of a tile publishes its 32 x 32 partial (tile-major private slab, 4 KB); the LAST of
+//                      the sk slices sums them in slice order z = 0 .. sk-1, scales, writes S / diag and reduces the
+//                      finished tile to one (max, sum exp) pair per row (and per column) of the tile;
+//   level 2            those pairs are published per tile; the LAST tile of a row strip merges the strip's tiles_n pairs
+//                      per row in tile order -> row_lse; likewise the last tile of a column strip -> col_lse.
+// Hand-off form (guide section 6, Guideline 16; MI355X: 8 XCDs with private L2s, per-CU L1 never refreshed by other CUs):
+// payload with WRITE-THROUGH agent-scope stores (sc1: 4-byte slab words, 8-byte (max, sum) granules - the natural widths
+// of this epilogue), every storing wave drains (`s_waitcnt vmcnt(0)`), __syncthreads(), ONE lane draws an agent-scope
+// ticket; the last arriver reads the payload with agent-scope (sc1, L1-bypassing) loads - no fences, no polling, no
+// spinning.  Every payload line has exactly one writer and one reader and is not read before it is complete, so no stale
+// copy can exist in the reader's L2 within the launch; kernel boundaries take care of the previous call's lines.
+// Tickets: zero on entry, reset to zero by the last arriver (the caller zeroes them ONCE, at allocation).
+// ---------------------------------------------------------------------------------------------------
+struct FusedFwd {
+  float* S; int64_t ldS;
+  float* row_lse; float* diag; float* col_lse;     // col_lse may be null (rows only)
+  float alpha; int64_t diag_offset;
+  float* tslab;                 // [sk][tiles][1024] partial tiles (unused when sk == 1)
+  unsigned long long* rowpart;  // [tiles_n][m_pad] (max, sum exp) granules, m_pad = tiles_m * 32
+  unsigned long long* colpart;  // [tiles_m][n_pad]
+  unsigned* tickets;            // [tiles] tile tickets | [tiles_m] row-strip tickets | [tiles_n] column-strip tickets
+  int sk, tiles_m, tiles_n;
+};
+
+typedef __attribute__((address_space(1))) unsigned gu32_t;
+typedef __attribute__((address_space(1))) unsigned long long gu64_t;
+__device__ __forceinline__ void st_agent(float* p, float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_agent(const float* p) {
+  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_pair(unsigned long long* p, float mx, float l) {
+  const unsigned long long g = (static_cast<unsigned long long>(__float_as_uint(l)) << 32) | __float_as_uint(mx);
+  __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ld_pair(const unsigned long long* p, float& mx, float& l) {
+  const unsigned long long g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  mx = __uint_as_float(static_cast<unsigned>(g));
+  l = __uint_as_float(static_cast<unsigned>(g >> 32));
+}
+// publish: every wave has drained its stores, then ONE lane draws the ticket; returns it to every thread through `slot`
+__device__ __forceinline__ unsigned draw_ticket(unsigned* counter, unsigned* slot) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) *slot = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  return *slot;
+}
+
+// red: the four waves' 32 x 32 accumulators (stash_acc layout), already synchronised.  LDS beyond the first wave's tile is
+// reused as scratch once the sums are in registers.
+__device__ __forceinline__ void fused_fwd_epilogue(const FusedFwd& p, float* red, int ti, int tj, int z, int m, int n) {
+  const int tid = threadIdx.x;
+  const int i0 = ti * 32, j0 = tj * 32;
+  const int tile = ti * p.tiles_n + tj, tiles = p.tiles_m * p.tiles_n;
+  float v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = tid + 256 * q;
+    v[q] = red_sum(red, e >> 5, e & 31);
+  }
+  __syncthreads();                                   // red is free from here on
+  unsigned* slot = reinterpret_cast<unsigned*>(red + 3 * 32 * RED_STRIDE);   // ticket broadcast words (3 used)
+  if (p.sk > 1) {
+    float* mine = p.tslab + (static_cast<int64_t>(z) * tiles + tile) * 1024;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) st_agent(mine + tid + 256 * q, v[q]);
+    if (draw_ticket(p.tickets + tile, slot) != static_cast<unsigned>(p.sk - 1)) return;
+    if (tid == 0) __hip_atomic_store(p.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // every slice's partial, all loads of a thread in flight together, summed in slice order (not arrival order)
+    float w[4][SK_MAX];
+#pragma unroll
+    for (int zz = 0; zz < SK_MAX; ++zz) {
+      const float* src = p.tslab + (static_cast<int64_t>(min(zz, p.sk - 1)) * tiles + tile) * 1024;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[q][zz] = ld_agent(src + tid + 256 * q);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float a = w[q][0];
+#pragma unroll
+      for (int zz = 1; zz < SK_MAX; ++zz) a += (zz < p.sk) ? w[q][zz] : 0.f;
+      v[q] = a;
+    }
+  }
+  // ---- the finished tile: S, diag, and its (max, sum exp) per row / per column ----
+  float* Ts = red;                                   // [32][33], -inf outside the matrix
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = tid + 256 * q, row = e >> 5, col = e & 31;
+    const float sv = __fmul_rn(p.alpha, v[q]);
+    const bool in = (i0 + row < m) && (j0 + col < n);
+    if (in) {
+      p.S[static_cast<int64_t>(i0 + row) * p.ldS + j0 + col] = sv;
+      if (static_cast<int64_t>(j0 + col) == p.diag_offset + i0 + row) p.diag[i0 + row] = sv;
+    }
+    Ts[row * RED_STRIDE + col] = in ? sv : -INFINITY;
+  }
+  __syncthreads();
+  const int m_pad = p.tiles_m * 32, n_pad = p.tiles_n * 32;
+  if (tid < 64) {                                    // lanes 0-31: the tile's rows; lanes 32-63: its columns
+    const bool colside = tid >= 32;
+    const int r = tid & 31;
+    if (!colside || p.col_lse) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < 32; ++c) mx = fmaxf(mx, colside ? Ts[c * RED_STRIDE + r] : Ts[r * RED_STRIDE + c]);
+      float l = 0.f;
+      if (mx > -INFINITY) {
+#pragma unroll
+        for (int c = 0; c < 32; ++c) l += fast_exp((colside ? Ts[c * RED_STRIDE + r] : Ts[r * RED_STRIDE + c]) - mx);
+      }
+      if (colside) st_pair(p.colpart + static_cast<int64_t>(ti) * n_pad + j0 + r, mx, l);
+      else st_pair(p.rowpart + static_cast<int64_t>(tj) * m_pad + i0 + r, mx, l);
+    }
+  }
+  unsigned* t_row = p.tickets + tiles + ti;
+  unsigned* t_col = p.tickets + tiles + p.tiles_m + tj;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    slot[1] = __hip_atomic_fetch_add(t_row, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    slot[2] = p.col_lse ? __hip_atomic_fetch_add(t_col, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+  }
+  __syncthreads();
+  const bool last_row = slot[1] == static_cast<unsigned>(p.tiles_n - 1);
+  const bool last_col = p.col_lse && slot[2] == static_cast<unsigned>(p.tiles_m - 1);
+  if (!last_row && !last_col) return;
+  __syncthreads();                                   // slot[] has been read by everyone before the scratch below reuses LDS
+  float* pm = red;                                   // [8][32] group maxima, [8][32] group sums
+  float* pl = red + 256;
+  const int r = tid & 31, g = tid >> 5;
+  for (int side = 0; side < 2; ++side) {
+    if (!(side ? last_col : last_row)) continue;     // workgroup-uniform
+    if (tid == 0) __hip_atomic_store(side ? t_col : t_row, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int parts = side ? p.tiles_m : p.tiles_n;
+    const unsigned long long* base = side ? p.colpart + j0 + r : p.rowpart + i0 + r;
+    const int64_t stride = side ? n_pad : m_pad;
+    float mx = -INFINITY, l = 0.f;
+    for (int t0 = g; t0 < parts; t0 += 8 * 4) {      // group g folds tiles g, g + 8, ... in ascending order, 4 loads in flight
+      float a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ld_pair(base + static_cast<int64_t>(min(t0 + 8 * u, parts - 1)) * stride, a[u], b[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (t0 + 8 * u < parts && a[u] > -INFINITY) {
+          const float mn = fmaxf(mx, a[u]);
+          l = l * fast_exp(mx - mn) + b[u] * fast_exp(a[u] - mn);   // exp(-inf) = 0 on the first fold
+          mx = mn;
+        }
+      }
+    }
+    pm[g * 32 + r] = mx;
+    pl[g * 32 + r] = l;
+    __syncthreads();
+    if (tid < 32) {
+      float M = pm[tid];
+#pragma unroll
+      for (int gg = 1; gg < 8; ++gg) M = fmaxf(M, pm[gg * 32 + tid]);
+      float L = 0.f;
+#pragma unroll
+      for (int gg = 0; gg < 8; ++gg) L += (pm[gg * 32 + tid] == -INFINITY) ? 0.f : pl[gg * 32 + tid] * fast_exp(pm[gg * 32 + tid] - M);
+      const int idx = (side ? j0 : i0) + tid;
+      if (idx < (side ? n : m)) (side ? p.col_lse : p.row_lse)[idx] = M + __logf(L);
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // partial tiles.  grid (tiles_m * tiles_n, SK); 256 threads; wave w of slice z contracts
 //   k in [z*k_chunk + w*k_chunk/4, ... + k_chunk/4)   (k_chunk is a multiple of 32)
 // lane (r = l&31, h = l>>5) loads A[i0+r][k+4h .. k+4h+3] and B[j0+r][k+4h .. +3] for k = lo, lo+8, ...;
 // MFMA step t of such a pair multiplies A[.][k+4h+t] with B[.][k+4h+t] over h = 0,1: every k exactly once.
 // ---------------------------------------------------------------------------------------------------
-template <bool FAST>
+template <bool FAST, bool FUSED = false>
 __global__ __launch_bounds__(256) void small_partial_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                             int m, int n, int K, int k_chunk, int tiles_n,
                                                             int a_vec, int b_vec, float* __restrict__ slab,
-                                                            int ldn, float* __restrict__ slabT, int ldm) {
+                                                            int ldn, float* __restrict__ slabT, int ldm,
+                                                            const FusedFwd fz) {
   __shared__ float red[4 * 32 * RED_STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int ti = blockIdx.x / tiles_n, tj = blockIdx.x % tiles_n, z = blockIdx.y;
@@ -110,6 +285,10 @@ __global__ __launch_bounds__(256) void small_partial_kernel(const float* __restr
   }
   stash_acc(red, acc, wave, l31, lhi);
   __syncthreads();
+  if constexpr (FUSED) {            // one-launch forward: the statistics are finished by the last arrivers (see above)
+    fused_fwd_epilogue(fz, red, ti, tj, z, m, n);
+    return;
+  }
   float* sl = slab + static_cast<int64_t>(z) * m * ldn;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -134,11 +313,11 @@ __global__ __launch_bounds__(256) void small_partial_kernel(const float* __restr
 // group of four MFMAs that has just consumed a pair of float4 registers is followed by the loads that refill them for
 // round r + DEPTH.  Same summation order as small_partial_kernel (k ascending per wave, waves 0..3 through LDS): same bits.
 // ---------------------------------------------------------------------------------------------------
-template <int ROUNDS, int DEPTH>
+template <int ROUNDS, int DEPTH, bool FUSED = false>
 __global__ __launch_bounds__(256) void small_partial_pipe_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                                  int m, int n, int K, int k_chunk, int tiles_n,
                                                                  float* __restrict__ slab, int ldn,
-                                                                 float* __restrict__ slabT, int ldm) {
+                                                                 float* __restrict__ slabT, int ldm, const FusedFwd fz) {
   __shared__ float red[4 * 32 * RED_STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int ti = blockIdx.x / tiles_n, tj = blockIdx.x % tiles_n, z = blockIdx.y;
@@ -177,6 +356,10 @@ __global__ __launch_bounds__(256) void small_partial_pipe_kernel(const float* __
   }
   stash_acc(red, acc, wave, l31, lhi);
   __syncthreads();
+  if constexpr (FUSED) {            // one-launch forward: the statistics are finished by the last arrivers (see above)
+    fused_fwd_epilogue(fz, red, ti, tj, z, m, n);
+    return;
+  }
   float* sl = slab + static_cast<int64_t>(z) * m * ldn;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -198,7 +381,6 @@ __global__ __launch_bounds__(256) void small_partial_pipe_kernel(const float* __
 // One wave per row; slabs summed in fixed order z = 0..SK-1, then scaled with a separate rounding so that the
 // S read by the backward and the S the statistics saw are the same bits.
 // ---------------------------------------------------------------------------------------------------
-constexpr int SK_MAX = 16;
 
 // S value at one position: the SK slab entries are fetched as ONE batch (unconditional, slab index clamped) and
 // summed in fixed order z = 0..SK-1 - a `for z < SK` loop of loads compiles to a serial latency chain
@@ -589,8 +771,9 @@ extern "C" int dalm_sim_small_fwd(const float* A, const float* Bm, int64_t m, in
   static const int pipe_depth = getenv("DALM_SMALL_PIPE") ? atoi(getenv("DALM_SMALL_PIPE")) : kDefaultPipeDepth;
   const int rounds = (pl.k_chunk % 128 == 0 && static_cast<int64_t>(pl.k_chunk) * pl.sk == D) ? pl.k_chunk / 128 : 0;
   const bool fast = vec16(A, D) && vec16(Bm, D) && D % 8 == 0;
+  const FusedFwd none{};
 #define DALM_PIPE(R, DP) hipLaunchKernelGGL((small_partial_pipe_kernel<R, DP>), pgrid, dim3(256), 0, s, A, Bm, static_cast<int>(m), \
-    static_cast<int>(n), static_cast<int>(D), pl.k_chunk, tiles_n, slab, static_cast<int>(pl.ldn), slabT, static_cast<int>(pl.ldm))
+    static_cast<int>(n), static_cast<int>(D), pl.k_chunk, tiles_n, slab, static_cast<int>(pl.ldn), slabT, static_cast<int>(pl.ldm), none)
   if (fast && pipe_depth >= 2 && (rounds == 4 || rounds == 8)) {
     if (rounds == 4) { if (pipe_depth == 2) DALM_PIPE(4, 2); else if (pipe_depth == 3) DALM_PIPE(4, 3); else DALM_PIPE(4, 4); }
     else { if (pipe_depth == 2) DALM_PIPE(8, 2); else if (pipe_depth == 3) DALM_PIPE(8, 3); else DALM_PIPE(8, 4); }
@@ -598,11 +781,11 @@ extern "C" int dalm_sim_small_fwd(const float* A, const float* Bm, int64_t m, in
 #undef DALM_PIPE
     hipLaunchKernelGGL(small_partial_kernel<true>, pgrid, dim3(256), 0, s, A, Bm, static_cast<int>(m),
                        static_cast<int>(n), static_cast<int>(D), pl.k_chunk, tiles_n, 1, 1, slab,
-                       static_cast<int>(pl.ldn), slabT, static_cast<int>(pl.ldm));
+                       static_cast<int>(pl.ldn), slabT, static_cast<int>(pl.ldm), none);
   else
     hipLaunchKernelGGL(small_partial_kernel<false>, pgrid, dim3(256), 0, s, A, Bm, static_cast<int>(m),
                        static_cast<int>(n), static_cast<int>(D), pl.k_chunk, tiles_n, static_cast<int>(vec16(A, D)),
-                       static_cast<int>(vec16(Bm, D)), slab, static_cast<int>(pl.ldn), slabT, static_cast<int>(pl.ldm));
+                       static_cast<int>(vec16(Bm, D)), slab, static_cast<int>(pl.ldn), slabT, static_cast<int>(pl.ldm), none);
   const int64_t rmax = want_cols ? (m > n ? m : n) : m;
   const int64_t cmax = want_cols ? (m > n ? m : n) : n;                  // longest row the statistics pass reduces
   if (cmax > 256)
@@ -613,6 +796,74 @@ extern "C" int dalm_sim_small_fwd(const float* A, const float* Bm, int64_t m, in
     hipLaunchKernelGGL(small_stats_kernel, dim3(static_cast<unsigned>((rmax + 3) / 4), want_cols ? 2u : 1u), dim3(256), 0,
                        s, slab, static_cast<int>(pl.ldn), slabT, static_cast<int>(pl.ldm), pl.sk, static_cast<int>(m),
                        static_cast<int>(n), scale, diag_offset, S, ldS, row_lse, diag, col_lse);
+  return check_launch(__func__);
+}
+
+// ---- one-launch forward --------------------------------------------------------------------------------------
+namespace {
+struct Fused1Layout { size_t tslab, rowpart, colpart, total; int tiles_m, tiles_n; };
+inline Fused1Layout fused1_layout(int64_t m, int64_t n, int64_t D, int want_cols) {
+  const SmallPlan pl = small_plan(m, n, D);
+  Fused1Layout L{};
+  L.tiles_m = static_cast<int>((m + 31) / 32); L.tiles_n = static_cast<int>((n + 31) / 32);
+  const size_t tiles = static_cast<size_t>(L.tiles_m) * L.tiles_n;
+  size_t o = 256;                                           // slack for aligning the caller's pointer up to 256 bytes
+  L.tslab = o; o += (pl.sk > 1 ? static_cast<size_t>(pl.sk) * tiles * 4096 : 0);
+  L.rowpart = o; o += static_cast<size_t>(L.tiles_n) * L.tiles_m * 32 * 8;
+  L.colpart = o; o += want_cols ? static_cast<size_t>(L.tiles_m) * L.tiles_n * 32 * 8 : 0;
+  L.total = o;
+  return L;
+}
+}  // namespace
+
+extern "C" size_t dalm_sim_small_fwd1_workspace_bytes(int64_t m, int64_t n, int64_t D, int want_cols) {
+  if (!dalm_sim_small_supported(m, n, D)) return 0;
+  return fused1_layout(m, n, D, want_cols).total;
+}
+
+extern "C" size_t dalm_sim_small_fwd1_ticket_words(int64_t m, int64_t n) {
+  if (m <= 0 || n <= 0) return 0;
+  const size_t tm = static_cast<size_t>((m + 31) / 32), tn = static_cast<size_t>((n + 31) / 32);
+  return tm * tn + tm + tn;
+}
+
+extern "C" int dalm_sim_small_fwd1(const float* A, const float* Bm, int64_t m, int64_t n, int64_t D, float scale,
+                                   int64_t diag_offset, float* S, int64_t ldS, float* row_lse, float* diag,
+                                   float* col_lse, void* ws, size_t ws_bytes, unsigned* tickets, dalm_stream_t stream) {
+  DALM_REQUIRE(A && Bm && S && row_lse && diag && ws && tickets, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(dalm_sim_small_supported(m, n, D), DALM_E_SHAPE, "shape outside the small-batch path (see dalm_sim_small_supported)");
+  DALM_REQUIRE(ldS >= n, DALM_E_SHAPE, "ldS must be >= n");
+  DALM_REQUIRE(diag_offset >= 0 && diag_offset + m <= n, DALM_E_SHAPE, "diag_offset + m must be <= n");
+  const int want_cols = col_lse != nullptr;
+  const Fused1Layout L = fused1_layout(m, n, D, want_cols);
+  DALM_REQUIRE(ws_bytes >= L.total, DALM_E_WORKSPACE, "workspace too small");
+  DALM_REQUIRE(reinterpret_cast<uintptr_t>(tickets) % 4 == 0, DALM_E_ALIGN, "tickets must be 4-byte aligned");
+  hipStream_t s = as_stream(stream);
+  const SmallPlan pl = small_plan(m, n, D);
+  unsigned char* base = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(ws) + 255) / 256 * 256) - 256;
+  FusedFwd fz{};
+  fz.S = S; fz.ldS = ldS; fz.row_lse = row_lse; fz.diag = diag; fz.col_lse = col_lse;
+  fz.alpha = scale; fz.diag_offset = diag_offset;
+  fz.tslab = reinterpret_cast<float*>(base + L.tslab);
+  fz.rowpart = reinterpret_cast<unsigned long long*>(base + L.rowpart);
+  fz.colpart = want_cols ? reinterpret_cast<unsigned long long*>(base + L.colpart) : nullptr;
+  fz.tickets = tickets; fz.sk = pl.sk; fz.tiles_m = L.tiles_m; fz.tiles_n = L.tiles_n;
+  const dim3 pgrid(static_cast<unsigned>(L.tiles_m * L.tiles_n), static_cast<unsigned>(pl.sk));
+  const int rounds = (pl.k_chunk % 128 == 0 && static_cast<int64_t>(pl.k_chunk) * pl.sk == D) ? pl.k_chunk / 128 : 0;
+  const bool fast = vec16(A, D) && vec16(Bm, D) && D % 8 == 0;
+  float* nof = nullptr;
+#define DALM_PIPE1(R) hipLaunchKernelGGL((small_partial_pipe_kernel<R, 4, true>), pgrid, dim3(256), 0, s, A, Bm, static_cast<int>(m), \
+    static_cast<int>(n), static_cast<int>(D), pl.k_chunk, L.tiles_n, nof, 0, nof, 0, fz)
+  if (fast && rounds == 4) DALM_PIPE1(4);
+  else if (fast && rounds == 8) DALM_PIPE1(8);
+#undef DALM_PIPE1
+  else if (fast)
+    hipLaunchKernelGGL((small_partial_kernel<true, true>), pgrid, dim3(256), 0, s, A, Bm, static_cast<int>(m),
+                       static_cast<int>(n), static_cast<int>(D), pl.k_chunk, L.tiles_n, 1, 1, nof, 0, nof, 0, fz);
+  else
+    hipLaunchKernelGGL((small_partial_kernel<false, true>), pgrid, dim3(256), 0, s, A, Bm, static_cast<int>(m),
+                       static_cast<int>(n), static_cast<int>(D), pl.k_chunk, L.tiles_n, static_cast<int>(vec16(A, D)),
+                       static_cast<int>(vec16(Bm, D)), nof, 0, nof, 0, fz);
   return check_launch(__func__);
 }
 

@@ -12,6 +12,8 @@ backend injected by the tests.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional, Tuple
 
 import torch
@@ -146,18 +148,44 @@ class HipOps:
     def sim_small_supported(self, m: int, n: int, D: int) -> bool:
         return bool(hip.load().dalm_sim_small_supported(int(m), int(n), int(D)))
 
-    def sim_small_fwd(self, A: torch.Tensor, Bm: torch.Tensor, scale: float, diag_offset: int, want_cols: bool):
+    # one launch (dalm_sim_small_fwd1) or two (dalm_sim_small_fwd): DALM_SMALL_FWD1 = 1 / 0; decided by measurement
+    # (profiles/r04_small_one_launch.txt)
+    small_one_launch = os.environ.get("DALM_SMALL_FWD1", "0") == "1"
+    _tickets: dict = {}
+
+    def _small_tickets(self, dev: torch.device, words: int) -> torch.Tensor:
+        """Arrival tickets of the one-launch forward: zeroed ONCE here, left zero by every call.  One buffer per device,
+        allocated on first use (an eager warm-up step, i.e. outside any hipGraph pool) and kept for the life of the process:
+        calls that share it must be stream-ordered - every caller in this package issues the contrastive forward of a step
+        from one stream, and a captured step replays in that order."""
+        key = dev.index
+        buf = HipOps._tickets.get(key)
+        if buf is None or buf.numel() < words:
+            buf = torch.zeros((max(words, 4096),), device=dev, dtype=torch.int32)
+            HipOps._tickets[key] = buf
+        return buf
+
+    def sim_small_fwd(self, A: torch.Tensor, Bm: torch.Tensor, scale: float, diag_offset: int, want_cols: bool,
+                      one_launch: Optional[bool] = None):
         """S = scale*A.B^T (saved), row_lse, diag and (want_cols) col_lse = logsumexp over rows."""
         dev = hip.require_gpu(A, Bm)
         A, Bm = hip.as_f32c(A), hip.as_f32c(Bm)
         m, D = A.shape
         n = Bm.shape[0]
-        ws_bytes = hip.load().dalm_sim_small_workspace_bytes(m, n, D, int(want_cols))
-        ws = torch.empty((max(ws_bytes, 4) // 4,), device=dev, dtype=torch.float32)
+        lib = hip.load()
         S = torch.empty((m, n), device=dev, dtype=torch.float32)
         row_lse = torch.empty((m,), device=dev, dtype=torch.float32)
         diag = torch.empty((m,), device=dev, dtype=torch.float32)
         col_lse = torch.empty((n,), device=dev, dtype=torch.float32) if want_cols else None
+        if self.small_one_launch if one_launch is None else one_launch:
+            ws_bytes = lib.dalm_sim_small_fwd1_workspace_bytes(m, n, D, int(want_cols))
+            ws = torch.empty((ws_bytes,), device=dev, dtype=torch.uint8)
+            tickets = self._small_tickets(dev, lib.dalm_sim_small_fwd1_ticket_words(m, n))
+            hip.call("dalm_sim_small_fwd1", hip.ptr(A), hip.ptr(Bm), m, n, D, float(scale), int(diag_offset), hip.ptr(S), n,
+                     hip.ptr(row_lse), hip.ptr(diag), hip.ptr(col_lse), hip.ptr(ws), ws_bytes, hip.ptr(tickets), hip.stream())
+            return S, row_lse, diag, col_lse
+        ws_bytes = lib.dalm_sim_small_workspace_bytes(m, n, D, int(want_cols))
+        ws = torch.empty((max(ws_bytes, 4) // 4,), device=dev, dtype=torch.float32)
         hip.call("dalm_sim_small_fwd", hip.ptr(A), hip.ptr(Bm), m, n, D, float(scale), int(diag_offset), hip.ptr(S), n,
                  hip.ptr(row_lse), hip.ptr(diag), hip.ptr(col_lse), hip.ptr(ws), ws_bytes, hip.stream())
         return S, row_lse, diag, col_lse

@@ -157,6 +157,18 @@ int dalm_sim_grad(const float* A, const float* Bm, int64_t m, int64_t n,
  * and two dalm_sim_grad calls (4 computations of S, ~10 launches). */
 int dalm_sim_small_supported(int64_t m, int64_t n, int64_t D);
 size_t dalm_sim_small_workspace_bytes(int64_t m, int64_t n, int64_t D, int want_cols);
+/* dalm_sim_small_fwd1: the same forward in ONE launch (round 4).  The statistics pass is finished inside the partial-tile
+ * kernel by the last workgroups to arrive (arrival tickets; merge orders fixed by tile / slice index, so the result does
+ * not depend on who arrives last: deterministic, same S bits as the two-launch form, row / column log-sum-exp equal to
+ * it within f32 rounding of a different - fixed - merge tree).  `tickets`: dalm_sim_small_fwd1_ticket_words(m, n)
+ * 32-bit words that MUST BE ZERO on entry; the kernel leaves them zero (zero them once, when allocating; calls sharing
+ * a ticket buffer must be stream-ordered).  Workspace: dalm_sim_small_fwd1_workspace_bytes. */
+size_t dalm_sim_small_fwd1_workspace_bytes(int64_t m, int64_t n, int64_t D, int want_cols);
+size_t dalm_sim_small_fwd1_ticket_words(int64_t m, int64_t n);
+int dalm_sim_small_fwd1(const float* A, const float* Bm, int64_t m, int64_t n,
+                        int64_t D, float scale, int64_t diag_offset, float* S,
+                        int64_t ldS, float* row_lse, float* diag, float* col_lse,
+                        void* ws, size_t ws_bytes, unsigned* tickets, dalm_stream_t stream);
 int dalm_sim_small_fwd(const float* A, const float* Bm, int64_t m, int64_t n,
                        int64_t D, float scale, int64_t diag_offset, float* S,
                        int64_t ldS, float* row_lse, float* diag, float* col_lse,

@@ -46,6 +46,53 @@ SMALL = [(18, 18, 1024, 0), (150, 150, 1024, 0), (19, 19, 384, 0), (1, 1, 64, 0)
          (150, 1200, 1024, 450), (257, 300, 100, 20), (33, 65, 1030, 7), (600, 600, 768, 0), (1024, 1024, 32, 0)]
 
 
+@pytest.mark.parametrize("m,n,D,off", SMALL + [(150, 1200, 1024, 0), (512, 512, 1024, 0), (70, 2100, 256, 1000), (1000, 1000, 64, 0)])
+def test_small_forward_in_one_launch_equals_the_two_launch_form(dev, m, n, D, off):
+    """dalm_sim_small_fwd1 (round 4): the statistics are finished inside the partial-tile kernel by the last-arriving
+    workgroups.  S and diag: the SAME bits as the two-launch form (same slice order); row / column log-sum-exp: a different
+    but fixed merge tree - equal to fp64 to the same bound and to the two-launch values to 2e-6; 30 repetitions bit-identical
+    (the result must not depend on which workgroup arrives last); rows-only form; tickets left at zero."""
+    from dalm_amd.ops import HipOps, default_ops
+
+    ops = default_ops()
+    A, Bm, scale, S, *_ = _problem(m, n, D, off)
+    Ad, Bd = A.to(dev), Bm.to(dev)
+    S2, r2, d2, c2 = ops.sim_small_fwd(Ad, Bd, scale, off, True, one_launch=False)
+    S1, r1, d1, c1 = ops.sim_small_fwd(Ad, Bd, scale, off, True, one_launch=True)
+    assert torch.equal(S1, S2) and torch.equal(d1, d2)
+    torch.testing.assert_close(r1, r2, rtol=2e-6, atol=2e-6)
+    torch.testing.assert_close(c1, c2, rtol=2e-6, atol=2e-6)
+    torch.testing.assert_close(r1.cpu().double(), torch.logsumexp(S, 1), rtol=1e-6, atol=3e-5)
+    torch.testing.assert_close(c1.cpu().double(), torch.logsumexp(S, 0), rtol=1e-6, atol=3e-5)
+    for _ in range(30):
+        Sx, rx, dx, cx = ops.sim_small_fwd(Ad, Bd, scale, off, True, one_launch=True)
+        assert torch.equal(Sx, S1) and torch.equal(rx, r1) and torch.equal(cx, c1) and torch.equal(dx, d1)
+    Sr, rr, dr, none = ops.sim_small_fwd(Ad, Bd, scale, off, False, one_launch=True)
+    assert none is None and torch.equal(Sr, S1) and torch.equal(rr, r1) and torch.equal(dr, d1)
+    assert int(HipOps._tickets[dev.index].abs().sum()) == 0
+
+
+def test_small_forward_in_one_launch_under_uneven_load(dev):
+    """The hand-off must not depend on timing: the same problem while other kernels keep the chip busy on a second stream
+    (arrival orders change from run to run) - 40 repetitions, every word of every output identical."""
+    from dalm_amd.ops import default_ops
+
+    ops = default_ops()
+    A, Bm, scale, S, *_ = _problem(150, 1200, 1024, 450)
+    Ad, Bd = A.to(dev), Bm.to(dev)
+    ref = ops.sim_small_fwd(Ad, Bd, scale, 450, False, one_launch=True)
+    noise = torch.randn(4096, 4096, device=dev)
+    side = torch.cuda.Stream()
+    for i in range(40):
+        with torch.cuda.stream(side):
+            for _ in range(1 + i % 3):
+                noise = torch.tanh(noise @ noise[:, : 4096] * 1e-3)
+        got = ops.sim_small_fwd(Ad, Bd, scale, 450, False, one_launch=True)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2])
+    torch.cuda.synchronize()
+    torch.testing.assert_close(ref[1].cpu().double(), torch.logsumexp(S, 1), rtol=1e-6, atol=3e-5)
+
+
 @pytest.mark.parametrize("m,n,D,off", SMALL)
 def test_small_path_vs_fp64(dev, m, n, D, off):
     from dalm_amd.ops import default_ops

@@ -142,8 +142,11 @@ def bench_small(m, n, D, want_cols=True):
     A = torch.nn.functional.normalize(torch.randn(m, D, device=dev), dim=1)
     Bm = torch.nn.functional.normalize(torch.randn(n, D, device=dev), dim=1)
     out = {}
-    med, best = time_graph(lambda: ops.sim_small_fwd(A, Bm, 100.0, 0, want_cols))
+    med, best = time_graph(lambda: ops.sim_small_fwd(A, Bm, 100.0, 0, want_cols, one_launch=False))
     out["fwd(partial+stats)"] = {"us": med * 1e6, "best_us": best * 1e6, "TFLOPs": 2.0 * m * n * D / med / 1e12}
+    ops.sim_small_fwd(A, Bm, 100.0, 0, want_cols, one_launch=True)        # tickets allocated outside the capture
+    med, best = time_graph(lambda: ops.sim_small_fwd(A, Bm, 100.0, 0, want_cols, one_launch=True))
+    out["fwd(one launch)"] = {"us": med * 1e6, "best_us": best * 1e6, "TFLOPs": 2.0 * m * n * D / med / 1e12}
     S, rl, _, cl = ops.sim_small_fwd(A, Bm, 100.0, 0, True)
     rc = torch.full((m,), 1.0 / m, device=dev)
     cc = torch.full((n,), 1.0 / n, device=dev)
