@@ -821,6 +821,17 @@ extern "C" size_t dalm_sim_small_fwd1_workspace_bytes(int64_t m, int64_t n, int6
   return fused1_layout(m, n, D, want_cols).total;
 }
 
+// Whether the one-launch forward is the faster form for a shape (profiles/r04_small_one_launch.txt): a tile grid of >= 128
+// tiles with at most 2 K slices per tile - the hand-offs then replace a statistics kernel that had real work to do
+// (512^2: 19.7 -> 18.6 us, 150 x 1200: 16.4 -> 15.7 us); with few tiles and 16 slices the last slice's serial sum loses
+// (18^2: 6.3 -> 8.7 us).  Callers that follow this advice keep BOTH forms available: dalm_sim_small_fwd needs no tickets.
+extern "C" int dalm_sim_small_fwd1_preferred(int64_t m, int64_t n, int64_t D) {
+  if (!dalm_sim_small_supported(m, n, D)) return 0;
+  const SmallPlan pl = small_plan(m, n, D);
+  const int64_t tiles = ((m + 31) / 32) * ((n + 31) / 32);
+  return (tiles >= 128 && pl.sk <= 2) ? 1 : 0;
+}
+
 extern "C" size_t dalm_sim_small_fwd1_ticket_words(int64_t m, int64_t n) {
   if (m <= 0 || n <= 0) return 0;
   const size_t tm = static_cast<size_t>((m + 31) / 32), tn = static_cast<size_t>((n + 31) / 32);

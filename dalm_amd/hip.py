@@ -56,6 +56,7 @@ SIGNATURES = {
     "dalm_sim_small_supported": (_int, [_i64, _i64, _i64]),
     "dalm_sim_small_workspace_bytes": (_sz, [_i64, _i64, _i64, _int]),
     "dalm_sim_small_fwd": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dalm_sim_small_fwd1_preferred": (_int, [_i64, _i64, _i64]),
     "dalm_sim_small_fwd1_workspace_bytes": (_sz, [_i64, _i64, _i64, _int]),
     "dalm_sim_small_fwd1_ticket_words": (_sz, [_i64, _i64]),
     "dalm_sim_small_fwd1": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),

@@ -148,9 +148,9 @@ class HipOps:
     def sim_small_supported(self, m: int, n: int, D: int) -> bool:
         return bool(hip.load().dalm_sim_small_supported(int(m), int(n), int(D)))
 
-    # one launch (dalm_sim_small_fwd1) or two (dalm_sim_small_fwd): DALM_SMALL_FWD1 = 1 / 0; decided by measurement
-    # (profiles/r04_small_one_launch.txt)
-    small_one_launch = os.environ.get("DALM_SMALL_FWD1", "0") == "1"
+    # one launch (dalm_sim_small_fwd1) or two (dalm_sim_small_fwd): by shape, as measured (dalm_sim_small_fwd1_preferred,
+    # profiles/r04_small_one_launch.txt); DALM_SMALL_FWD1 = 1 / 0 forces either
+    small_one_launch = {"1": True, "0": False}.get(os.environ.get("DALM_SMALL_FWD1", ""), None)
     _tickets: dict = {}
 
     def _small_tickets(self, dev: torch.device, words: int) -> torch.Tensor:
@@ -177,7 +177,11 @@ class HipOps:
         row_lse = torch.empty((m,), device=dev, dtype=torch.float32)
         diag = torch.empty((m,), device=dev, dtype=torch.float32)
         col_lse = torch.empty((n,), device=dev, dtype=torch.float32) if want_cols else None
-        if self.small_one_launch if one_launch is None else one_launch:
+        if one_launch is None:
+            one_launch = self.small_one_launch
+        if one_launch is None:
+            one_launch = bool(lib.dalm_sim_small_fwd1_preferred(m, n, D))
+        if one_launch:
             ws_bytes = lib.dalm_sim_small_fwd1_workspace_bytes(m, n, D, int(want_cols))
             ws = torch.empty((ws_bytes,), device=dev, dtype=torch.uint8)
             tickets = self._small_tickets(dev, lib.dalm_sim_small_fwd1_ticket_words(m, n))

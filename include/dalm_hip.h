@@ -163,6 +163,7 @@ size_t dalm_sim_small_workspace_bytes(int64_t m, int64_t n, int64_t D, int want_
  * it within f32 rounding of a different - fixed - merge tree).  `tickets`: dalm_sim_small_fwd1_ticket_words(m, n)
  * 32-bit words that MUST BE ZERO on entry; the kernel leaves them zero (zero them once, when allocating; calls sharing
  * a ticket buffer must be stream-ordered).  Workspace: dalm_sim_small_fwd1_workspace_bytes. */
+int dalm_sim_small_fwd1_preferred(int64_t m, int64_t n, int64_t D);   /* 1: measured faster than the two-launch form */
 size_t dalm_sim_small_fwd1_workspace_bytes(int64_t m, int64_t n, int64_t D, int want_cols);
 size_t dalm_sim_small_fwd1_ticket_words(int64_t m, int64_t n);
 int dalm_sim_small_fwd1(const float* A, const float* Bm, int64_t m, int64_t n,

@@ -488,7 +488,7 @@ def main_realwidth_golden(only=None) -> None:
         if only and case not in only:
             continue
         retriever, generator = RW.build_case(case)
-        rec = {"seed": RW.SEED, "depth": 1, "checksum_retriever": RW.checksum(retriever),
+        rec = {"seed": RW.SEED, "depth": RW.CASES[case].get("depth", 1), "checksum_retriever": RW.checksum(retriever),
                "checksum_generator": RW.checksum(generator) if generator is not None else None}
         batch = RW.synthetic_batch(case)
         with tempfile.TemporaryDirectory() as td:

@@ -21,6 +21,9 @@ CASES = {
     "cfg3": {"generator": "llama", "B": 18, "V": 32000, "Tq": 50, "Tp": 128, "Tg": 256},
     "cfg5": {"generator": "falcon", "B": 18, "V": 65024, "Tq": 50, "Tp": 128, "Tg": 256},
     "cfg2": {"generator": None, "B": 150, "V": None, "Tq": 50, "Tp": 128, "Tg": None},
+    # round 4 ("real-width parity is depth 1 ... nothing compares a depth > 1 step, where tower-side bf16 drift
+    # would actually show"): cfg3 with TWO layers in both towers
+    "cfg3_d2": {"generator": "llama", "B": 18, "V": 32000, "Tq": 50, "Tp": 128, "Tg": 256, "depth": 2},
 }
 SEED = 0
 
@@ -45,10 +48,12 @@ def build_generator(kind: str, depth: int = 1):
     raise ValueError(kind)
 
 
-def build_case(name: str, depth: int = 1):
+def build_case(name: str, depth: int = None):
     """(retriever, generator-or-None) in fp32 on the CPU, from SEED: identical on every machine whose torch CPU RNG
-    agrees (checked through `checksum`)."""
+    agrees (checked through `checksum`).  depth: layers per tower (default: the case's own, 1 unless it says otherwise)."""
     c = CASES[name]
+    if depth is None:
+        depth = c.get("depth", 1)
     torch.manual_seed(SEED)
     retriever = build_retriever(depth)
     generator = build_generator(c["generator"], depth) if c["generator"] else None

@@ -89,8 +89,10 @@ def _seeded_case(case, gold):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16_autocast"])
-@pytest.mark.parametrize("case", ["cfg3", "cfg5"])
+@pytest.mark.parametrize("case", ["cfg3", "cfg5", "cfg3_d2"])
 def test_full_finetune_step_matches_the_reference_at_real_width(case, precision):
+    """cfg3_d2 (round 4): two layers per tower - the bf16-autocast comparison then crosses two attention + MLP blocks per
+    tower, where CPU and GPU autocast round at different operators (the depth-1 cases cannot show tower-side drift)."""
     import realwidth as RW
 
     from dalm_amd.models import AutoModelForRagE2E
@@ -117,6 +119,11 @@ def test_full_finetune_step_matches_the_reference_at_real_width(case, precision)
     rel = {k: _rel(got[k], ref[k]) for k in ref}
     _record(f"{case}/full_ft/{precision}", {"got": got, "reference": ref, "rel": rel})
     tol = TOL[precision]
+    if case.endswith("_d2") and precision == "bf16_autocast":
+        # two blocks per tower: the CPU and the GPU autocast round at different operators in EVERY block, and the reference's
+        # own bf16 result already sits 2.8e-3 (generator gradient norm) from its fp32 one at this depth - stated bound 2e-4 on the
+        # losses, 2e-3 on the gradient norms (the measured deviations are kept in profiles/r04_realwidth_parity.json)
+        tol = {"loss": 2e-4, "grad": 2e-3}
     for k, r in rel.items():
         assert r <= (tol["grad"] if k.startswith("grad_norm") else tol["loss"]), (k, rel, got, ref)
 
