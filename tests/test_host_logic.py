@@ -676,3 +676,29 @@ def test_trim_padding_guard_detects_absolute_positions_structurally():
     assert "wpe" in has_absolute_positions(GPT2LMHeadModel(GPT2Config(n_embd=32, n_head=2, n_layer=1, vocab_size=50)))
     assert "wpe" in has_absolute_positions(GPTBigCodeForCausalLM(GPTBigCodeConfig(n_embd=32, n_head=2, n_layer=1, vocab_size=50)))
     assert has_absolute_positions(BertModel(BertConfig(hidden_size=32, num_attention_heads=2, intermediate_size=64, **tiny)))
+
+
+def test_columns_from_dataset_reads_arrow_buffers_exactly():
+    """shards.columns_from_dataset (round 4): the tokenised columns straight from the Arrow buffers == what `mapped[k]`
+    materialises as python lists (several Arrow chunks, list and scalar columns), and ragged rows are refused."""
+    import datasets as hf_datasets
+    import numpy as np
+
+    from dalm_amd.training.shards import columns_from_dataset
+
+    rng = np.random.default_rng(0)
+    ds = hf_datasets.Dataset.from_dict({"x": list(range(2500))})
+    mapped = ds.map(lambda ex: {"ids": [[int(v) for v in rng.integers(0, 30000, 7)] for _ in ex["x"]],
+                                "mask": [[1, 1, 1, 0, 0, 0, 0] for _ in ex["x"]], "qlen": [int(v) % 11 for v in ex["x"]]},
+                    batched=True, batch_size=400, remove_columns=["x"])
+    got = columns_from_dataset(mapped, ["ids", "mask", "qlen"])
+    for k in ("ids", "mask", "qlen"):
+        want = np.asarray(mapped[k], dtype=np.int32)
+        assert got[k].dtype == np.int32 and got[k].shape == want.shape and (got[k] == want).all(), k
+    # a selection (index mapping) takes the slow path and still agrees
+    sub = mapped.select([5, 3, 2400])
+    got = columns_from_dataset(sub, ["ids", "qlen"])
+    assert (got["ids"] == np.asarray(sub["ids"], dtype=np.int32)).all() and got["qlen"].tolist() == [5, 3, 2400 % 11]
+    ragged = hf_datasets.Dataset.from_dict({"ids": [[1, 2, 3], [4, 5]]})
+    with pytest.raises(ValueError, match="ragged"):
+        columns_from_dataset(ragged, ["ids"])
