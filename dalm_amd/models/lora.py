@@ -19,8 +19,6 @@ from typing import Dict, Iterable, List
 import torch
 from torch import nn
 
-# DALM_LORA_ADDMM=0: the round-3 form (separate B GEMM, then scale + add) for A/B runs
-FUSE_ADDMM = os.environ.get("DALM_LORA_ADDMM", "1") != "0"
 ADAPTER_WEIGHTS = "adapter_model.bin"
 ADAPTER_CONFIG = "adapter_config.json"
 
@@ -63,18 +61,7 @@ class LoRALinear(nn.Module):
         z = self.lora_dropout["default"](x)
         if not torch.is_autocast_enabled() and z.dtype != a.weight.dtype:
             z = z.to(a.weight.dtype)  # outside autocast the fp32 adapters need fp32 activations
-        za = a(z)
-        if not FUSE_ADDMM:
-            return torch.add(out, b(za).to(out.dtype), alpha=self.scaling)  # one kernel for scale + add
-        # out + scaling * (za . B^T) as ONE GEMM with the base output as its accumulator input (round 4): the [tokens, out]
-        # delta tensor, the kernel that scaled and added it, and - in the backward - the elementwise multiply that produced
-        # the delta's gradient all disappear (the GEMM's alpha carries the scaling both ways).  Same math; the sum is
-        # rounded once instead of after every operand (peft: base(x) + lora_B(lora_A(dropout(x))) * scaling).
-        bw = b.weight
-        if not torch.is_autocast_enabled():
-            za, bw = za.to(out.dtype), bw.to(out.dtype)
-        y = torch.addmm(out.reshape(-1, out.shape[-1]), za.reshape(-1, za.shape[-1]), bw.t(), alpha=self.scaling)
-        return y.view(out.shape)
+        return torch.add(out, b(a(z)).to(out.dtype), alpha=self.scaling)  # one kernel for scale + add
 
     @torch.no_grad()
     def merge(self) -> nn.Linear:
