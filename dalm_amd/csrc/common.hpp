@@ -5,6 +5,11 @@
 #include <string>
 #include "../../include/dalm_hip.h"
 
+// internal cross-file entry points (csrc/lmhead.hip -> csrc/sim.hip): bf16x3 group maxima for the exact top-k's first pass
+extern "C" size_t dalm_x3_group_max_workspace_bytes(int64_t m, int64_t n, int64_t D);
+extern "C" int dalm_x3_group_max(const float* A, const float* Bm, int64_t m, int64_t n, int64_t D, float scale, float* gmax,
+                                 int64_t ng, void* ws, size_t ws_bytes, dalm_stream_t stream);
+
 namespace dalm {
 
 // ---- error plumbing (host) -------------------------------------------------

@@ -213,6 +213,8 @@ struct Lm8Params {
   int tpd;                   // SPLIT3: K tiles (64 deep) per segment = D / 64
   unsigned tpd_inv;          // SPLIT3: ceil(2^24 / tpd): u / tpd == (u * tpd_inv) >> 24 for u < 6 tpd, tpd <= 1024 (checked exhaustively up to 1686)
   unsigned seg_bytes;        // SPLIT3: D * 2
+  float* gmax;               // MODE_GMAX: [R][ng] one maximum per (row, 32 consecutive columns)
+  int ng;
   float* pm;                 // [4*NT, R]
   float* pl;                 // [4*NT, R]
   float* z;                  // [R]
@@ -261,6 +263,19 @@ __device__ __forceinline__ void row16_max4(float& a, float& b, float& c, float& 
 __device__ __forceinline__ void row16_sum4(float& a, float& b, float& c, float& d) {
   asm volatile("s_nop 1\n\t" DALM_DPP4("v_add_f32_dpp", "quad_perm:[1,0,3,2]") DALM_DPP4("v_add_f32_dpp", "quad_perm:[2,3,0,1]")
                DALM_DPP4("v_add_f32_dpp", "row_half_mirror") DALM_DPP4("v_add_f32_dpp", "row_mirror") "s_nop 0"
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+// max over the 32 lanes of each half-wave for four registers at once: the 16-lane butterflies of row16_max4, then lane 15
+// of rows 0 / 2 (which holds its row's maximum) is broadcast into rows 1 / 3 (`row_bcast:15`, a GFX9 DPP control; row_mask
+// 0xa enables rows 1 and 3 only): the lanes of rows 1 and 3 end up with the half-wave maximum, rows 0 and 2 keep theirs.
+__device__ __forceinline__ void half32_max4(float& a, float& b, float& c, float& d) {
+  asm volatile("s_nop 1\n\t" DALM_DPP4("v_max_f32_dpp", "quad_perm:[1,0,3,2]") DALM_DPP4("v_max_f32_dpp", "quad_perm:[2,3,0,1]")
+               DALM_DPP4("v_max_f32_dpp", "row_half_mirror") DALM_DPP4("v_max_f32_dpp", "row_mirror")
+               "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "v_max_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "v_max_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "v_max_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "s_nop 0"
                : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 #undef DALM_DPP4
@@ -359,6 +374,36 @@ __device__ __forceinline__ void lm_tile_epilogue(const Lm8Params& p, f32x16 (&ac
   }
 }
 
+// MODE_GMAX epilogue (exact top-k, first pass): one maximum per (row, 32 consecutive columns) = per accumulator tile,
+// written to gmax[row][column / 32] - the layout topk_threshold_kernel / topk_refine_kernel (sim.hip) read.  Zero-filled
+// columns >= V count as -inf.  VALU only: 5 DPP steps per accumulator register.
+__device__ __forceinline__ void lm_tile_epilogue_gmax(const Lm8Params& p, f32x16 (&acc)[4][4], int r0, int c0, int wr, int wc,
+                                                      int tid) {
+  const int lane = tid & 63, l31 = lane & 31, lhi = lane >> 5, l15 = lane & 15;
+  const int colw = wc * 128 + l31;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float pen = (c0 + colw + 32 * j < p.V) ? 0.f : -INFINITY;
+    const int g = (c0 + wc * 128 + 32 * j) >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float keep = -INFINITY;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float x0 = acc[i][j][4 * q + 0] + pen, x1 = acc[i][j][4 * q + 1] + pen;
+        float x2 = acc[i][j][4 * q + 2] + pen, x3 = acc[i][j][4 * q + 3] + pen;
+        half32_max4(x0, x1, x2, x3);
+        keep = (l15 == 4 * q + 0) ? x0 : keep;
+        keep = (l15 == 4 * q + 1) ? x1 : keep;
+        keep = (l15 == 4 * q + 2) ? x2 : keep;
+        keep = (l15 == 4 * q + 3) ? x3 : keep;
+      }
+      const int row = r0 + wr * 128 + i * 32 + (l15 & 3) + 8 * (l15 >> 2) + 4 * lhi;
+      if ((l31 >> 4) == 1 && row < p.R && g < p.ng) p.gmax[static_cast<int64_t>(row) * p.ng + g] = keep;
+    }
+  }
+}
+
 // N3 / N0 / N1 / N2: load pieces issued in k-step 3 (right after the barrier) / 0 / 1 / 2; measured best: 8, 8, 0, 0.
 // ABL (measurement only, results are garbage unless 0): 1 = no loads in the loop, 2 = no fragment reads, 32 = no barrier,
 // 64 = no epilogue.
@@ -366,7 +411,7 @@ __device__ __forceinline__ void lm_tile_epilogue(const Lm8Params& p, f32x16 (&ac
 // lo) bf16 thirds of an f32 matrix side by side; the contraction walks SIX segments of D - the six significant products of
 // (hi + mid + lo) x (hi + mid + lo), smallest first - and K tile u reads third segA[u / tpd] of H against third segB[u / tpd]
 // of W: the same main loop, only the K offset of a tile is looked up instead of being u * 128.
-template <int N3, int N0, int N1, int N2, int ABL = 0, bool SPLIT3 = false>
+template <int N3, int N0, int N1, int N2, int ABL = 0, bool SPLIT3 = false, bool GMAX = false>
 __global__ __launch_bounds__(256, 1) void lm_head_lse4w_kernel(const Lm8Params p) {
   static_assert(N3 + N0 + N1 + N2 == 16, "16 load pieces per K tile and wave");
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * L8_BUF];
@@ -490,7 +535,8 @@ __global__ __launch_bounds__(256, 1) void lm_head_lse4w_kernel(const Lm8Params p
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // tail re-reads still target the LDS about to be reused
   __builtin_amdgcn_s_barrier();
 
-  lm_tile_epilogue<ABL>(p, acc, lds, r0, c0, nt, wr, wc, tid);
+  if constexpr (GMAX) lm_tile_epilogue_gmax(p, acc, r0, c0, wr, wc, tid);
+  else lm_tile_epilogue<ABL>(p, acc, lds, r0, c0, nt, wr, wc, tid);
 }
 
 // One workgroup = 16 rows: thread t folds the partials p = t/16, t/16 + 16, .. of row t % 16 (16 consecutive rows per
@@ -618,7 +664,7 @@ extern "C" int dalm_lm_head_lse_fwd(const void* hidden, const void* weight, cons
     q.bytesH = static_cast<unsigned>(static_cast<uint64_t>(R) * K * 2);
     q.bytesW = static_cast<unsigned>(static_cast<uint64_t>(V) * K * 2);
     q.pitchH = q.pitchW = static_cast<unsigned>(K * 2);
-    q.tpd = 0; q.tpd_inv = 0; q.seg_bytes = 0;
+    q.tpd = 0; q.tpd_inv = 0; q.seg_bytes = 0; q.gmax = nullptr; q.ng = 0;
     float* f8 = static_cast<float*>(ws);
     const int64_t P4 = 4ll * q.NT;
     q.pm = f8; q.pl = f8 + P4 * R; q.z = f8 + 2 * P4 * R;
@@ -739,11 +785,54 @@ extern "C" int dalm_sim_rowstats_bf16x3(const float* A, const float* Bm, int64_t
   q.tpd = static_cast<int>(D / 64);
   q.tpd_inv = static_cast<unsigned>(((1u << 24) + q.tpd - 1) / q.tpd);
   q.seg_bytes = static_cast<unsigned>(D * 2);
+  q.gmax = nullptr; q.ng = 0;
   q.pm = reinterpret_cast<float*>(base + L.pm); q.pl = reinterpret_cast<float*>(base + L.pl);
   q.z = reinterpret_cast<float*>(base + L.z);
   DALM_REQUIRE(static_cast<int64_t>(q.MT) * q.NT <= 0x7fffffffll, DALM_E_SHAPE, "too many tiles for one launch");
   hipLaunchKernelGGL((lm_head_lse4w_kernel<8, 8, 0, 0, 0, true>), dim3(static_cast<unsigned>(q.MT) * q.NT), dim3(256), 0, s, q);
   hipLaunchKernelGGL(lm_head_lse_merge_kernel, dim3(static_cast<unsigned>((m + 15) / 16)), dim3(256), 0, s, q.pm, q.pl, q.z,
                      labels, q.R, q.V, static_cast<int>(L.P4), row_lse, static_cast<float*>(nullptr), diag);
+  return check_launch(__func__);
+}
+
+
+// ---- bf16x3 group maxima for the exact top-k (first pass of dalm_sim_topk): gmax[m][ng], ng groups of 32 columns ----
+extern "C" size_t dalm_x3_group_max_workspace_bytes(int64_t m, int64_t n, int64_t D) {
+  if (!dalm_sim_rowstats_bf16x3_supported(m, n, D)) return 0;
+  return 256 + up256(static_cast<size_t>(m) * 3 * D * 2) + up256(static_cast<size_t>(n) * 3 * D * 2);
+}
+
+extern "C" int dalm_x3_group_max(const float* A, const float* Bm, int64_t m, int64_t n, int64_t D, float scale, float* gmax,
+                                 int64_t ng, void* ws, size_t ws_bytes, dalm_stream_t stream) {
+  DALM_REQUIRE(A && Bm && gmax && ws, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(dalm_sim_rowstats_bf16x3_supported(m, n, D), DALM_E_SHAPE, "shape outside the bf16x3 form");
+  DALM_REQUIRE(ws_bytes >= dalm_x3_group_max_workspace_bytes(m, n, D), DALM_E_WORKSPACE, "workspace too small");
+  DALM_REQUIRE(ng > 0 && ng <= 0x7fffffffll, DALM_E_SHAPE, "need ng > 0");
+  hipStream_t s = as_stream(stream);
+  unsigned char* base = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(ws) + 255) / 256 * 256);
+  auto* a3 = reinterpret_cast<unsigned short*>(base);
+  auto* b3 = reinterpret_cast<unsigned short*>(base + up256(static_cast<size_t>(m) * 3 * D * 2));
+  const int per_row = static_cast<int>(D / 8);
+  hipLaunchKernelGGL(split3_bf16_kernel, dim3(static_cast<unsigned>((m * per_row + 255) / 256)), dim3(256), 0, s, A,
+                     static_cast<int>(m), static_cast<int>(D), scale, a3, static_cast<int64_t*>(nullptr), static_cast<int64_t>(0));
+  hipLaunchKernelGGL(split3_bf16_kernel, dim3(static_cast<unsigned>((n * per_row + 255) / 256)), dim3(256), 0, s, Bm,
+                     static_cast<int>(n), static_cast<int>(D), 1.0f, b3, static_cast<int64_t*>(nullptr), static_cast<int64_t>(0));
+  Lm8Params q{};
+  q.H = a3; q.W = b3; q.labels = nullptr;
+  q.R = static_cast<int>(m); q.V = static_cast<int>(n); q.K = static_cast<int>(6 * D);
+  q.MT = static_cast<int>((m + 255) / 256); q.NT = static_cast<int>((n + 255) / 256);
+  q.xcd_order = 1;
+  const int bands = (q.MT + 7) / 8;
+  q.gh = (q.MT + bands - 1) / bands;
+  if (q.gh < 1 || q.gh > q.MT) q.gh = q.MT;
+  q.pitchH = q.pitchW = static_cast<unsigned>(3 * D * 2);
+  q.bytesH = static_cast<unsigned>(static_cast<uint64_t>(m) * 3 * D * 2);
+  q.bytesW = static_cast<unsigned>(static_cast<uint64_t>(n) * 3 * D * 2);
+  q.tpd = static_cast<int>(D / 64);
+  q.tpd_inv = static_cast<unsigned>(((1u << 24) + q.tpd - 1) / q.tpd);
+  q.seg_bytes = static_cast<unsigned>(D * 2);
+  q.gmax = gmax; q.ng = static_cast<int>(ng);
+  DALM_REQUIRE(static_cast<int64_t>(q.MT) * q.NT <= 0x7fffffffll, DALM_E_SHAPE, "too many tiles for one launch");
+  hipLaunchKernelGGL((lm_head_lse4w_kernel<8, 8, 0, 0, 0, true, true>), dim3(static_cast<unsigned>(q.MT) * q.NT), dim3(256), 0, s, q);
   return check_launch(__func__);
 }

@@ -1318,7 +1318,15 @@ extern "C" int dalm_contrastive_finalize(const float* row_lse, const float* col_
 
 // ---- exact top-k (eval retrieval): scores = scale * Q . C^T, k largest per query, no score matrix -------------
 namespace {
-struct TopkLayout { StreamPlan f; int cap; size_t at, bt, gmax, thr, total; };
+// First pass (one maximum per row and 32 corpus columns) on the bf16 matrix cores at f32 accuracy (csrc/lmhead.hip, round 4)
+// once the score matrix has >= 1024 tiles of 256 x 256: 1.6x the f32 MFMA kernel's rate there.  DALM_TOPK_BF16X3 = 0 / 1
+// forces the f32 / bf16x3 pass (read per call: tests switch it).
+inline bool topk_use_x3(int64_t m, int64_t n, int64_t D) {
+  if (!dalm_sim_rowstats_bf16x3_supported(m, n, D)) return false;
+  if (const char* e = getenv("DALM_TOPK_BF16X3")) return e[0] == '1';
+  return ((m + 255) / 256) * ((n + 255) / 256) >= 1024;
+}
+struct TopkLayout { StreamPlan f; int cap; size_t at, bt, gmax, thr, x3, x3_bytes, total; };
 inline TopkLayout topk_layout(int64_t m, int64_t n, int64_t D, int64_t k) {
   TopkLayout L{};
   L.f = stream_plan(m, n, D, true);
@@ -1329,6 +1337,9 @@ inline TopkLayout topk_layout(int64_t m, int64_t n, int64_t D, int64_t k) {
   L.bt = take(static_cast<size_t>(L.f.kpad) * L.f.ldn * 4);
   L.gmax = take(static_cast<size_t>(m) * (L.f.ldn / 32) * 4);
   L.thr = take(static_cast<size_t>(m) * 4);
+  // room for the bf16x3 operand images whenever that pass COULD be taken (the choice may be forced per call)
+  L.x3_bytes = dalm_sim_rowstats_bf16x3_supported(m, n, D) ? dalm_x3_group_max_workspace_bytes(m, n, D) : 0;
+  L.x3 = take(L.x3_bytes);
   L.total = o;
   return L;
 }
@@ -1376,10 +1387,16 @@ extern "C" int dalm_sim_topk(const float* Q, const float* C, int64_t m, int64_t 
   float* thr = reinterpret_cast<float*>(base + L.thr);
   const dim3 grid(static_cast<unsigned>(f.row_blocks * f.nsplit));
   if (hipError_t e = hipMemsetAsync(overflow, 0, 4, s); e != hipSuccess) return static_cast<int>(e);
-  if (f.rt == 2) hipLaunchKernelGGL((sim_rowstats_stream_kernel<2, MODE_GMAX>), grid, dim3(256), 0, s, q);
+  float abs_slack = 2.4e-7f * sqrtf(static_cast<float>(f.kpad)) * fabsf(scale);
+  if (topk_use_x3(m, n, D) && reinterpret_cast<uintptr_t>(Q) % 16 == 0 && reinterpret_cast<uintptr_t>(C) % 16 == 0) {
+    // the group maxima come from the bf16x3 kernel (every score within 2e-6 |scale| of the exact one): the threshold gives
+    // way by twice that on top of the f32 slack, the refine pass below still recomputes the candidates in f32
+    if (int e = dalm_x3_group_max(Q, C, m, n, D, scale, q.gmax, q.ng, base + L.x3, L.x3_bytes, stream)) return e;
+    abs_slack += 5e-6f * fabsf(scale);
+  } else if (f.rt == 2) hipLaunchKernelGGL((sim_rowstats_stream_kernel<2, MODE_GMAX>), grid, dim3(256), 0, s, q);
   else hipLaunchKernelGGL((sim_rowstats_stream_kernel<1, MODE_GMAX>), grid, dim3(256), 0, s, q);
   hipLaunchKernelGGL(topk_threshold_kernel, dim3(static_cast<unsigned>(m)), dim3(256), 0, s, q.gmax, q.ng,
-                     static_cast<int>(k), 2.4e-7f * sqrtf(static_cast<float>(f.kpad)) * fabsf(scale), thr);
+                     static_cast<int>(k), abs_slack, thr);
   const size_t lds = (static_cast<size_t>(f.kpad) + 3 * static_cast<size_t>(L.cap)) * 4;
   hipLaunchKernelGGL(topk_refine_kernel, dim3(static_cast<unsigned>(m)), dim3(256), lds, s, At, static_cast<int>(f.ldm),
                      Bt, static_cast<int>(f.ldn), static_cast<int>(f.kpad), static_cast<int>(n), scale, q.gmax, q.ng, thr,

@@ -359,6 +359,39 @@ def test_fused_topk_vs_fp64(dev, nq, nc, D, k):
     torch.testing.assert_close(torch.gather(ref, 1, i2.cpu()), rs, rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("nq,nc,D,k,scale", [(300, 70000, 384, 10, 1.0), (129, 3001, 1024, 1, 1.0), (5, 40, 64, 7, 1.0),
+                                              (260, 20000, 256, 20, 100.0), (64, 6000, 256, 8, 1.0)])
+def test_fused_topk_with_the_bf16x3_first_pass(dev, monkeypatch, nq, nc, D, k, scale):
+    """Round 4: the first pass of dalm_sim_topk (one maximum per row and 32 corpus columns) on the bf16 matrix cores
+    (DALM_TOPK_BF16X3=1 forces it at these small sizes; it is automatic from 1024 tiles of 256 x 256).  The candidates are
+    still recomputed in f32, so the result is the exact top-k: picks identical to fp64 brute force, values to f32 - for
+    unit-norm embeddings, for scale 100, and for UN-normalised embeddings whose scores sit near zero (the threshold's slack
+    has to cover the first pass's absolute error there)."""
+    from dalm_amd.ops import default_ops
+
+    monkeypatch.setenv("DALM_TOPK_BF16X3", "1")
+    g = torch.Generator().manual_seed(nq + nc)
+    if nc == 6000:       # scores near zero, large norms
+        corpus = torch.randn(nc, D, generator=g)
+        queries = torch.randn(nq, D, generator=g) * 0.05
+    else:
+        corpus = torch.nn.functional.normalize(torch.randn(nc, D, generator=g), dim=1)
+        queries = torch.nn.functional.normalize(corpus[:nq] + 0.05 * torch.randn(nq, D, generator=g), dim=1)
+    ref = scale * (queries.double() @ corpus.double().t())
+    rs, ri = torch.topk(ref, k, dim=1)
+    val, idx, ovf = default_ops().sim_topk(queries.to(dev), corpus.to(dev), k, scale)
+    assert int(ovf) == 0
+    picked = torch.gather(ref, 1, idx.cpu())
+    tol = 2e-6 * max(1.0, float(ref.abs().max()))
+    torch.testing.assert_close(picked, rs, rtol=0, atol=tol)
+    torch.testing.assert_close(val.cpu().double(), rs, rtol=1e-5, atol=tol)
+    assert (idx.cpu()[:, 0] == ri[:, 0]).float().mean() > 0.99
+    monkeypatch.setenv("DALM_TOPK_BF16X3", "0")          # and the f32 first pass picks the same passages
+    v0, i0, o0 = default_ops().sim_topk(queries.to(dev), corpus.to(dev), k, scale)
+    assert int(o0) == 0 and torch.equal(i0, idx)
+    torch.testing.assert_close(v0, val, rtol=0, atol=0)   # values come from the same f32 refine pass either way
+
+
 def test_fused_topk_ties_overflow_falls_back(dev):
     from dalm_amd.ops import default_ops
     from dalm_amd.retrieval import exact_topk

@@ -122,8 +122,8 @@ def test_full_finetune_step_matches_the_reference_at_real_width(case, precision)
     if case.endswith("_d2") and precision == "bf16_autocast":
         # two blocks per tower: the CPU and the GPU autocast round at different operators in EVERY block, and the reference's
         # own bf16 result already sits 2.8e-3 (generator gradient norm) from its fp32 one at this depth - stated bound 2e-4 on the
-        # losses, 2e-3 on the gradient norms (the measured deviations are kept in profiles/r04_realwidth_parity.json)
-        tol = {"loss": 2e-4, "grad": 2e-3}
+        # losses (measured 4.5e-5 ... 6.4e-5), 5e-4 on the gradient norms (measured <= 3.7e-5); profiles/r04_realwidth_parity.json
+        tol = {"loss": 2e-4, "grad": 5e-4}
     for k, r in rel.items():
         assert r <= (tol["grad"] if k.startswith("grad_norm") else tol["loss"]), (k, rel, got, ref)
 
