@@ -15,7 +15,7 @@ def load(pat):
     for f in glob.glob(pat, recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].replace("(anonymous namespace)::", "")
-            if not any(t in k for t in ("gemm_f32_mfma", "sim_flash", "sim_rowstats_stream")): continue
+            if not any(t in k for t in ("gemm_f32_mfma", "sim_flash", "sim_rowstats_stream", "lm_head_lse4w", "split3_bf16")): continue
             k = re.sub(r"\(.*", "", k).replace("void ", "").replace("dalm::", "")
             grid = int(r["Grid_Size"]) // int(r["Workgroup_Size"])
             agg[(k, grid)][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -32,5 +32,5 @@ for name, pat in (("mfma", "gpurun_out/pmc_sim/mfma/**/*counter_collection.csv")
         print(line)
 PY
 t=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
-python tools/summarize_trace.py "$t" "gemm_f32|flash|rowstats|splitk" 40 > $OUT/per_shape.txt; cat $OUT/per_shape.txt
+python tools/summarize_trace.py "$t" "gemm_f32|flash|rowstats|splitk|lm_head|split3" 40 > $OUT/per_shape.txt; cat $OUT/per_shape.txt
 find $OUT -name "*kernel_trace.csv" -delete

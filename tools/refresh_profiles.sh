@@ -1,8 +1,8 @@
 #!/bin/bash
 # One GPU session that regenerates everything under profiles/ for a round (run on the GPU box, repo root):
-#   bash tools/refresh_profiles.sh r03
+#   bash tools/refresh_profiles.sh r04
 # Output lands in gpurun_out/profiles_<tag>/ ; copy the summaries into profiles/ afterwards.
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 P=gpurun_out/profiles_$TAG
 rm -rf $P; mkdir -p $P
