@@ -60,19 +60,35 @@ class Rendezvous:
             try:
                 data = bytes(make_payload())
             except Exception as e:
-                self.store.set(key, b"FAILED:" + repr(e).encode()[:200])
+                self.publish_failure(e)
                 raise
             self.store.set(key, b"OK:" + data)
+            self.published = True
             return data
         got = bytes(self.store.get(key))             # blocks until rank 0 has published (or the timeout raises)
         if not got.startswith(b"OK:"):
             raise RuntimeError(f"rank 0 could not create the RCCL unique id: {got[7:].decode(errors='replace')}")
         return got[3:]
 
+    published = False
+
+    def publish_failure(self, err: BaseException) -> None:
+        """Rank 0 could not produce the payload (or failed before it got there): tell the ranks blocked in `exchange` now
+        instead of letting them run into the timeout.  No-op once something has been published."""
+        if self.rank == 0 and not self.published:
+            self.store.set(self.prefix + "/uid", b"FAILED:" + repr(err).encode()[:200])
+            self.published = True
+
     def agree(self, ok: bool) -> bool:
-        """True iff EVERY rank reports ok.  Every rank calls this exactly once."""
+        """True iff EVERY rank reports ok.  Every rank calls this exactly once.  A rank whose verdict does not arrive within
+        the store's timeout counts as failed (the caller then falls back - as will that rank, if it is still alive)."""
         self.store.set(f"{self.prefix}/status/{self.rank}", b"1" if ok else b"0")
-        all_ok = all(bytes(self.store.get(f"{self.prefix}/status/{r}")) == b"1" for r in range(self.world_size))
+        all_ok = True
+        for r in range(self.world_size):
+            try:
+                all_ok &= bytes(self.store.get(f"{self.prefix}/status/{r}")) == b"1"
+            except Exception:
+                all_ok = False
         self.store.add(self.prefix + "/read", 1)
         return all_ok
 

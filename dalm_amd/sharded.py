@@ -85,6 +85,11 @@ def native_comm_or_none(rank: int, world: int, insist: bool = False, make=None):
         comm.self_test()
     except Exception as e:
         err = e
+        if rdv is not None:
+            try:
+                rdv.publish_failure(e)                 # rank 0 failing before it published the id: unblock the others now
+            except Exception:
+                pass
     if rdv is None:                                    # no channel to agree over: every rank fails the same way here
         if insist:
             raise err

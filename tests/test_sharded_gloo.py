@@ -367,6 +367,8 @@ def test_mixed_saves_are_refused_by_the_stamp(tmp_path):
 # ---------------------------------------------------------------------------------------------------------------------
 class _FakeComm:
     def __init__(self, rdv, fail_on=None):
+        if fail_on == "rank0-early" and rdv.rank == 0:
+            raise RuntimeError("rank 0 died before it could publish the unique id")
         self.uid = rdv.exchange(lambda: bytes([rdv.rank + 7]) * 128)       # only rank 0's lambda runs
         self.rank, self.fail_on, self.closed = rdv.rank, fail_on, False
 
@@ -399,7 +401,7 @@ def _rdv_worker(rank, world, port, out_dir, fail_on):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         comm = native_comm_or_none(rank, world, make=make)
-    res = {"native": comm is not None, "uid0": made[0].uid[0], "closed": made[0].closed}
+    res = {"native": comm is not None, "uid0": made[0].uid[0] if made else None, "closed": made[0].closed if made else True}
     if comm is None:        # the fallback every rank takes together: MASTER_PORT must be free again for the process group
         dist.init_process_group("gloo", rank=rank, world_size=world)
         t = torch.tensor([float(rank + 1)])
@@ -409,12 +411,15 @@ def _rdv_worker(rank, world, port, out_dir, fail_on):
     torch.save(res, os.path.join(out_dir, f"r{rank}.pt"))
 
 
-@pytest.mark.parametrize("fail_on", [None, 1, 0])
+@pytest.mark.parametrize("fail_on", [None, 1, 0, "rank0-early"])
 def test_native_comm_rendezvous_and_all_or_none_fallback(tmp_path, fail_on):
     """Both ranks get rank 0's unique id through the store; when ONE rank's communicator fails its self-test, BOTH ranks
     drop the native communicator (the healthy one is closed) and meet again in torch.distributed on the same port."""
     mp.spawn(_rdv_worker, args=(2, _free_port(), str(tmp_path), fail_on), nprocs=2, join=True)
     res = [torch.load(tmp_path / f"r{r}.pt") for r in range(2)]
+    if fail_on == "rank0-early":       # rank 1 is told at once that no id will come (no 120 s timeout), both fall back
+        assert not any(r["native"] for r in res) and all(r["fallback_sum"] == 3.0 for r in res)
+        return
     assert all(r["uid0"] == 7 for r in res)                      # rank 0's payload (bytes of value 0 + 7) on both ranks
     if fail_on is None:
         assert all(r["native"] and not r["closed"] for r in res)
