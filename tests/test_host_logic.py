@@ -702,3 +702,46 @@ def test_columns_from_dataset_reads_arrow_buffers_exactly():
     ragged = hf_datasets.Dataset.from_dict({"ids": [[1, 2, 3], [4, 5]]})
     with pytest.raises(ValueError, match="ragged"):
         columns_from_dataset(ragged, ["ids"])
+
+
+def test_progress_counts_reports_and_checkpoints_the_flush_step_like_any_other():
+    import os
+
+    """ADVICE r3: with gradient accumulation the end-of-epoch flush is an optimizer step - it is counted, reported to
+    `on_step`, checkpointed at `checkpointing_steps` and checked against `max_train_steps` through the same block as a
+    normal step; the saved position resumes exactly where the step ended."""
+    from dalm_amd.training import common
+
+    class Comm:
+        rank, world_size = 0, 1
+
+        def all_reduce_sum_(self, t):
+            return t
+
+    nb, N = 10, 4                                   # 3 optimizer steps per epoch: batches 0-3, 4-7, flush over 8-9
+    per_epoch, max_steps, epochs = common.steps_and_epochs(nb, N, 2, None)
+    assert (per_epoch, max_steps, epochs) == (3, 6, 2)
+    saved, seen = {}, []
+    tracker = common.Tracker(False, None, "x", {}, True)
+    prog = common.Progress(comm=Comm(), is_main=True, tracker=tracker, meter=common.Throughput(), on_step=lambda s, l: seen.append(s),
+                           checkpointing_steps=1, output_dir="/out", max_train_steps=max_steps,
+                           save_state=lambda path, pos: saved.__setitem__(os.path.basename(path), pos), num_batches=nb, grad_accum=N)
+    total = torch.zeros(())
+    for epoch in range(epochs):
+        stop, step = False, -1
+        for step in range(nb):
+            if (step + 1) % N:                      # a micro-batch that did not take the optimizer step
+                continue
+            stop = prog.after_optimizer_step(epoch, step, 0, torch.tensor(1.0), total)
+            if stop:
+                break
+        if not stop:                                # step_fn.flush() returned True: 2 pending micro-batches
+            stop = prog.after_optimizer_step(epoch, step, 0, torch.tensor(1.0), total)
+    assert seen == [1, 2, 3, 4, 5, 6] and prog.completed == 6 and stop
+    assert saved["step_3"] == {"completed_steps": 3, "epoch": 0, "batch_in_epoch": 10, "num_batches": 10, "grad_accum": 4}
+    assert saved["step_4"]["epoch"] == 1 and saved["step_4"]["batch_in_epoch"] == 4
+    # resuming from the flush step: nothing of epoch 0 is left, the recorded position says so; without the record the
+    # arithmetic lands on the same place (step 3 = 0 steps into epoch 1)
+    assert common.parse_resume("/out/step_3", per_epoch, nb, N, saved["step_3"]) == (0, 10, 3)
+    assert common.parse_resume("/out/step_3", per_epoch, nb, N) == (1, 0, 3)
+    assert common.parse_resume("/out/step_4", per_epoch, nb, N, saved["step_4"]) == (1, 4, 4) == common.parse_resume("/out/step_4", per_epoch, nb, N)
