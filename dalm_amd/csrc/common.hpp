@@ -89,4 +89,33 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
   return __builtin_bit_cast(unsigned short, static_cast<__bf16>(f));
 }
 
+// ---- in-launch hand-off between workgroups (guide section 6, Guideline 16; MI355X_MICROARCH "inter-workgroup visibility"):
+// payloads leave through WRITE-THROUGH agent-scope stores (global_store ... sc1) and are re-read with agent-scope,
+// L1-bypassing loads (global_load ... sc1); every storing wave drains (s_waitcnt vmcnt(0)), __syncthreads(), ONE lane draws
+// an agent-scope ticket.  No fences, no polling.  Used by the one-launch small forward / backward (sim_small.hip) and the
+// streaming row statistics (sim.hip).
+__device__ __forceinline__ void st_agent(float* p, float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_agent(const float* p) {
+  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_pair(unsigned long long* p, float mx, float l) {
+  const unsigned long long g = (static_cast<unsigned long long>(__float_as_uint(l)) << 32) | __float_as_uint(mx);
+  __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ld_pair(const unsigned long long* p, float& mx, float& l) {
+  const unsigned long long g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  mx = __uint_as_float(static_cast<unsigned>(g));
+  l = __uint_as_float(static_cast<unsigned>(g >> 32));
+}
+// publish: every wave has drained its stores, then ONE lane draws the ticket; returns it to every thread through `slot`
+__device__ __forceinline__ unsigned draw_ticket(unsigned* counter, unsigned* slot) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) *slot = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  return *slot;
+}
+
 }  // namespace dalm

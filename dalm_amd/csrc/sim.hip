@@ -414,8 +414,13 @@ constexpr int FBM = 32, FBN = 128;
 // LDS; grid (ld/32, ceil(K/32), 2): blockIdx.z selects (X0 -> Xt0) or (X1 -> Xt1) so both operands go in one launch.
 __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ X0, int R0, int ld0,
                                                             float* __restrict__ Xt0, const float* __restrict__ X1,
-                                                            int R1, int ld1, float* __restrict__ Xt1, int K, int Kpad) {
+                                                            int R1, int ld1, float* __restrict__ Xt1, int K, int Kpad,
+                                                            unsigned* __restrict__ tickets = nullptr, int ntickets = 0) {
   __shared__ float tile[32][33];
+  // the arrival tickets of the kernel that follows in the same call (streaming row statistics): zeroed here, so the caller
+  // owes no initialisation and a poisoned workspace cannot survive a call
+  if (tickets && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+    for (int i = threadIdx.x; i < ntickets; i += 256) tickets[i] = 0u;
   const bool second = blockIdx.z != 0;
   const float* X = second ? X1 : X0;
   float* Xt = second ? Xt1 : Xt0;
@@ -610,7 +615,10 @@ struct StreamStatsParams {
   int m, n, Kpad, ldm, ldn;
   float alpha;
   int64_t diag_offset;
-  float* part_m; float* part_l;       // [nsplit][m]
+  float* part_m; float* part_l;       // [nsplit][m]  (GEMM-epilogue paths; the streaming kernel publishes granules)
+  unsigned long long* part;           // streaming kernel: [nsplit][m] (max, sum exp) granules, merged IN the launch
+  unsigned* tickets;                  // [row_blocks], zeroed by transpose_pad_kernel at the start of the call
+  float* row_lse;
   float* diag;
   int row_blocks, nsplit, blocks_per_split;
   // top-k modes
@@ -776,9 +784,35 @@ __global__ __launch_bounds__(256, KS > 1 ? 3 : 2) void sim_rowstats_stream_kerne
 #pragma unroll
     for (int w = 0; w < 4; ++w)
       if (red_m[w][tid] != -INFINITY) l += red_l[w][tid] * fast_exp(red_m[w][tid] - mx);
-    const int64_t pi = static_cast<int64_t>(z) * p.m + i0 + tid;
-    p.part_m[pi] = mx;
-    p.part_l[pi] = l;
+    if (p.nsplit == 1) {
+      p.row_lse[i0 + tid] = mx + __logf(l);
+    } else {
+      st_pair(p.part + static_cast<int64_t>(z) * p.m + i0 + tid, mx, l);   // write-through (sc1) granule
+    }
+  }
+  if (p.nsplit == 1) return;
+  // ---- round 4: the merge of the column splits moved INTO the launch (it was rowstats_merge_kernel, a 4 us launch at
+  // 1200^2): the last of a row block's nsplit workgroups folds the nsplit granules of its rows in split order z = 0 ..
+  // nsplit-1 (the order the merge kernel used: same bits whoever arrives last).  Hand-off: common.hpp. ----
+  unsigned* slot = reinterpret_cast<unsigned*>(&red_l[3][0]);
+  if (draw_ticket(p.tickets + rb, slot) != static_cast<unsigned>(p.nsplit - 1)) return;
+  if (tid == 0) __hip_atomic_store(p.tickets + rb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid < 32 * RT && i0 + tid < p.m) {
+    float m = -INFINITY, l = 0.f;
+    for (int q0 = 0; q0 < p.nsplit; q0 += 8) {
+      float pm[8], pl[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) ld_pair(p.part + static_cast<int64_t>(min(q0 + u, p.nsplit - 1)) * p.m + i0 + tid, pm[u], pl[u]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (q0 + u < p.nsplit && pm[u] != -INFINITY) {
+          const float mn = fmaxf(m, pm[u]);
+          l = l * fast_exp(m - mn) + pl[u] * fast_exp(pm[u] - mn);
+          m = mn;
+        }
+      }
+    }
+    p.row_lse[i0 + tid] = m + __logf(l);
   }
 }
 
@@ -1073,8 +1107,8 @@ static bool use_bf16x3(int64_t m, int64_t n, int64_t D, const float* A, const fl
 }
 
 static size_t rowstats_ws_f32(int64_t m, int64_t n, int64_t D) {
-  if (const StreamPlan f = stream_plan(m, n, D); f.ok)
-    return (static_cast<size_t>(f.kpad) * (f.ldm + f.ldn) + 2 * static_cast<size_t>(f.nsplit) * m) * sizeof(float);
+  if (const StreamPlan f = stream_plan(m, n, D); f.ok)   // k-major copies | (max, sum) granules [nsplit][m] (8 B each) | tickets
+    return (static_cast<size_t>(f.kpad) * (f.ldm + f.ldn) + 2 * static_cast<size_t>(f.nsplit) * m + f.row_blocks + 2) * sizeof(float);
   const int sk = sim_splitk(m, n, D);
   if (sk > 1) return static_cast<size_t>(sk) * static_cast<size_t>(m) * static_cast<size_t>(round_up4(n)) * sizeof(float);
   return static_cast<size_t>(rowstats_parts(m, n)) * static_cast<size_t>(m) * 2 * sizeof(float);
@@ -1111,25 +1145,24 @@ extern "C" int dalm_sim_rowstats_f32(const float* A, const float* Bm, int64_t m,
   if (const StreamPlan f = stream_plan(m, n, D); f.ok) {
     float* At = static_cast<float*>(ws);
     float* Bt = At + static_cast<size_t>(f.kpad) * f.ldm;
-    float* pm = Bt + static_cast<size_t>(f.kpad) * f.ldn;
-    float* pl = pm + static_cast<size_t>(f.nsplit) * m;
+    float* pg = Bt + static_cast<size_t>(f.kpad) * f.ldn;
+    if (reinterpret_cast<uintptr_t>(pg) % 8) ++pg;                                   // 8-byte granules
+    unsigned* tickets = reinterpret_cast<unsigned*>(pg + 2 * static_cast<size_t>(f.nsplit) * m);
     const int64_t ldmax = f.ldm > f.ldn ? f.ldm : f.ldn;
     hipLaunchKernelGGL(transpose_pad_kernel, dim3(static_cast<unsigned>(ldmax / 32), static_cast<unsigned>(f.kpad / 32 + (f.kpad % 32 != 0)), 2),
                        dim3(256), 0, s, A, static_cast<int>(m), static_cast<int>(f.ldm), At, Bm, static_cast<int>(n),
-                       static_cast<int>(f.ldn), Bt, static_cast<int>(D), static_cast<int>(f.kpad));
+                       static_cast<int>(f.ldn), Bt, static_cast<int>(D), static_cast<int>(f.kpad), tickets, f.row_blocks);
     StreamStatsParams q{};
     q.At = At; q.Bt = Bt; q.m = static_cast<int>(m); q.n = static_cast<int>(n); q.Kpad = static_cast<int>(f.kpad);
     q.ldm = static_cast<int>(f.ldm); q.ldn = static_cast<int>(f.ldn); q.alpha = scale; q.diag_offset = diag_offset;
-    q.part_m = pm; q.part_l = pl; q.diag = diag;
+    q.part = reinterpret_cast<unsigned long long*>(pg); q.tickets = tickets; q.row_lse = row_lse; q.diag = diag;
     q.row_blocks = f.row_blocks; q.nsplit = f.nsplit; q.blocks_per_split = f.blocks_per_split;
     const dim3 grid(static_cast<unsigned>(f.row_blocks * f.nsplit));
     if (f.rt == 2) hipLaunchKernelGGL((sim_rowstats_stream_kernel<2, MODE_STATS>), grid, dim3(256), 0, s, q);
     else if (f.ks == 4) hipLaunchKernelGGL((sim_rowstats_stream_kernel<1, MODE_STATS, 4>), grid, dim3(256), 0, s, q);
     else if (f.ks == 2) hipLaunchKernelGGL((sim_rowstats_stream_kernel<1, MODE_STATS, 2>), grid, dim3(256), 0, s, q);
     else hipLaunchKernelGGL((sim_rowstats_stream_kernel<1, MODE_STATS>), grid, dim3(256), 0, s, q);
-    hipLaunchKernelGGL(rowstats_merge_kernel, dim3(static_cast<unsigned>((m + 255) / 256)), dim3(256), 0, s, pm, pl,
-                       f.nsplit, static_cast<int>(m), row_lse);
-    return check_launch(__func__);
+    return check_launch(__func__);      // (the merge of the column splits happens inside the kernel since round 4)
   }
   const int64_t P = rowstats_parts(m, n);
   GemmParams p{};

@@ -80,32 +80,6 @@ struct FusedFwd {
   int sk, tiles_m, tiles_n;
 };
 
-typedef __attribute__((address_space(1))) unsigned gu32_t;
-typedef __attribute__((address_space(1))) unsigned long long gu64_t;
-__device__ __forceinline__ void st_agent(float* p, float v) {
-  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float ld_agent(const float* p) {
-  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void st_pair(unsigned long long* p, float mx, float l) {
-  const unsigned long long g = (static_cast<unsigned long long>(__float_as_uint(l)) << 32) | __float_as_uint(mx);
-  __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void ld_pair(const unsigned long long* p, float& mx, float& l) {
-  const unsigned long long g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  mx = __uint_as_float(static_cast<unsigned>(g));
-  l = __uint_as_float(static_cast<unsigned>(g >> 32));
-}
-// publish: every wave has drained its stores, then ONE lane draws the ticket; returns it to every thread through `slot`
-__device__ __forceinline__ unsigned draw_ticket(unsigned* counter, unsigned* slot) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) *slot = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  return *slot;
-}
-
 // red: the four waves' 32 x 32 accumulators (stash_acc layout), already synchronised.  LDS beyond the first wave's tile is
 // reused as scratch once the sums are in registers.
 __device__ __forceinline__ void fused_fwd_epilogue(const FusedFwd& p, float* red, int ti, int tj, int z, int m, int n) {
@@ -551,7 +525,8 @@ __global__ __launch_bounds__(256, 4) void small_grad_kernel(const float* __restr
                                                          const float* __restrict__ rc, const float* __restrict__ rl,
                                                          const float* __restrict__ cc, const float* __restrict__ cl,
                                                          float* __restrict__ dA, float* __restrict__ dB, int dir0, int nsl,
-                                                         float* __restrict__ slabA, float* __restrict__ slabB) {
+                                                         float* __restrict__ slabA, float* __restrict__ slabB,
+                                                         unsigned* __restrict__ tickets) {
   // the wave-sum scratch of the epilogue (4 x 32 x 33 floats) overlays the dS strip, which is dead by then: 34 KB instead of
   // 51 KB of LDS per workgroup = 4 resident workgroups per CU (the VGPR limit) instead of 3
   __shared__ float Ds[GK * RED_STRIDE];
@@ -571,7 +546,7 @@ __global__ __launch_bounds__(256, 4) void small_grad_kernel(const float* __restr
   const float* rowc = dir ? cc : rc; const float* rowl = dir ? cl : rl;
   const float* kc = dir ? rc : cc;   const float* kl = dir ? rl : cl;
   float* out = dir ? dB : dA;
-  if (nsl > 1) out = (dir ? slabB : slabA) + static_cast<int64_t>(slice) * R * D;
+  if (nsl > 1 && !tickets) out = (dir ? slabB : slabA) + static_cast<int64_t>(slice) * R * D;
   const int nchunks = (Kd + GK - 1) / GK, cps = (nchunks + nsl - 1) / nsl;
   const int k_begin = slice * cps * GK, k_end = min(Kd, (slice + 1) * cps * GK);
   const int dcol = min(d0 + l31, D - 1);
@@ -675,6 +650,48 @@ __global__ __launch_bounds__(256, 4) void small_grad_kernel(const float* __restr
   __syncthreads();
   stash_acc(red, acc, wave, l31, lhi);
   __syncthreads();
+  if (nsl > 1 && tickets) {
+    // ---- round 4: the slices of a contraction are summed IN the launch (it was small_slice_sum_kernel, a 5 us launch at
+    // 150 x 1200): every slice publishes its 32 x 32 partial (tile-major private slab, write-through stores), the LAST
+    // slice of an output tile to arrive adds them in slice order 0 .. nsl-1 - the order the separate kernel used, so the
+    // same bits whoever is last.  Hand-off: common.hpp.  One direction per launch on this path (dir == dir0). ----
+    const int tile = blockIdx.x * gridDim.y + blockIdx.y, tiles = gridDim.x * gridDim.y;
+    float* sl = dir ? slabB : slabA;
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + 256 * q;
+      v[q] = __fmul_rn(alpha, red_sum(red, e >> 5, e & 31));
+      st_agent(sl + (static_cast<int64_t>(slice) * tiles + tile) * 1024 + e, v[q]);
+    }
+    __syncthreads();                                  // red is read out: its last words carry the ticket broadcast
+    unsigned* slot = reinterpret_cast<unsigned*>(red + 3 * 32 * RED_STRIDE);
+    if (draw_ticket(tickets + tile, slot) != static_cast<unsigned>(nsl - 1)) return;
+    if (tid == 0) __hip_atomic_store(tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int z0 = 0; z0 < nsl; z0 += 8) {             // 8 slices' loads in flight at a time, added in slice order
+      float w[4][8];
+#pragma unroll
+      for (int zz = 0; zz < 8; ++zz) {
+        const float* src = sl + (static_cast<int64_t>(min(z0 + zz, nsl - 1)) * tiles + tile) * 1024;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q][zz] = ld_agent(src + tid + 256 * q);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int zz = 0; zz < 8; ++zz) {
+          if (z0 + zz == 0) a[q] = w[q][0];           // first term as is (0 + x would turn -0 into +0)
+          else if (z0 + zz < nsl) a[q] += w[q][zz];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + 256 * q, row = e >> 5, col = e & 31;
+      if (r0 + row < R && d0 + col < D) out[static_cast<int64_t>(r0 + row) * D + d0 + col] = a[q];
+    }
+    return;
+  }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int e = tid + 256 * q, row = e >> 5, col = e & 31;
@@ -898,18 +915,59 @@ extern "C" size_t dalm_sim_small_bwd_workspace_bytes(int64_t m, int64_t n, int64
   return static_cast<size_t>(nsl) * static_cast<size_t>(want_dA ? m : n) * static_cast<size_t>(D) * sizeof(float);
 }
 
+// One-launch form of the sliced backward (round 4): the slices of a contraction are summed by the last slice of every output
+// tile to arrive instead of by small_slice_sum_kernel.  `tickets`: dalm_sim_small_bwd1_ticket_words words, ZERO on entry, left
+// zero (the forward's ticket buffer can be shared: calls are stream-ordered).  Workspace: tile-major partial tiles.
+extern "C" size_t dalm_sim_small_bwd1_workspace_bytes(int64_t m, int64_t n, int64_t D, int want_dA, int want_dB) {
+  if (!dalm_sim_small_supported(m, n, D)) return 0;
+  const int nsl = small_bwd_slices(m, n, D, want_dA != 0, want_dB != 0);
+  if (nsl <= 1) return 0;
+  const int64_t R = want_dA ? m : n;
+  return static_cast<size_t>(nsl) * static_cast<size_t>((R + 31) / 32) * static_cast<size_t>((D + 31) / 32) * 4096;
+}
+
+extern "C" size_t dalm_sim_small_bwd1_ticket_words(int64_t m, int64_t n, int64_t D) {
+  if (m <= 0 || n <= 0 || D <= 0) return 0;
+  const int64_t R = m > n ? m : n;
+  return static_cast<size_t>((R + 31) / 32) * static_cast<size_t>((D + 31) / 32);
+}
+
+static int small_bwd_impl(const float* S, int64_t ldS, const float* A, const float* Bm, int64_t m, int64_t n, int64_t D,
+                          float scale, int64_t diag_offset, const float* row_coef, const float* row_lse, const float* col_coef,
+                          const float* col_lse, float* dA, float* dB, void* ws, size_t ws_bytes, unsigned* tickets,
+                          dalm_stream_t stream, const char* fn);
+
+extern "C" int dalm_sim_small_bwd1(const float* S, int64_t ldS, const float* A, const float* Bm, int64_t m, int64_t n,
+                                   int64_t D, float scale, int64_t diag_offset, const float* row_coef,
+                                   const float* row_lse, const float* col_coef, const float* col_lse, float* dA,
+                                   float* dB, void* ws, size_t ws_bytes, unsigned* tickets, dalm_stream_t stream) {
+  DALM_REQUIRE(tickets, DALM_E_NULL, "tickets are required (dalm_sim_small_bwd_ws is the two-launch form)");
+  return small_bwd_impl(S, ldS, A, Bm, m, n, D, scale, diag_offset, row_coef, row_lse, col_coef, col_lse, dA, dB, ws, ws_bytes,
+                        tickets, stream, __func__);
+}
+
 extern "C" int dalm_sim_small_bwd_ws(const float* S, int64_t ldS, const float* A, const float* Bm, int64_t m, int64_t n,
                                      int64_t D, float scale, int64_t diag_offset, const float* row_coef,
                                      const float* row_lse, const float* col_coef, const float* col_lse, float* dA,
                                      float* dB, void* ws, size_t ws_bytes, dalm_stream_t stream) {
-  DALM_REQUIRE(S && A && Bm && row_coef && row_lse && col_coef && col_lse, DALM_E_NULL, "null pointer argument");
-  DALM_REQUIRE(dA || dB, DALM_E_NULL, "at least one of dA / dB is required");
-  DALM_REQUIRE(dalm_sim_small_supported(m, n, D), DALM_E_SHAPE, "shape outside the small-batch path");
-  DALM_REQUIRE(ldS >= n, DALM_E_SHAPE, "ldS must be >= n");
+  return small_bwd_impl(S, ldS, A, Bm, m, n, D, scale, diag_offset, row_coef, row_lse, col_coef, col_lse, dA, dB, ws, ws_bytes,
+                        nullptr, stream, __func__);
+}
+
+static int small_bwd_impl(const float* S, int64_t ldS, const float* A, const float* Bm, int64_t m, int64_t n, int64_t D,
+                          float scale, int64_t diag_offset, const float* row_coef, const float* row_lse, const float* col_coef,
+                          const float* col_lse, float* dA, float* dB, void* ws, size_t ws_bytes, unsigned* tickets,
+                          dalm_stream_t stream, const char* fn) {
+  if (!(S && A && Bm && row_coef && row_lse && col_coef && col_lse)) return fail(DALM_E_NULL, fn, "null pointer argument");
+  if (!(dA || dB)) return fail(DALM_E_NULL, fn, "at least one of dA / dB is required");
+  if (!dalm_sim_small_supported(m, n, D)) return fail(DALM_E_SHAPE, fn, "shape outside the small-batch path");
+  if (ldS < n) return fail(DALM_E_SHAPE, fn, "ldS must be >= n");
   const int dir0 = dA ? 0 : 1, ndir = (dA && dB) ? 2 : 1;
   int nsl = small_bwd_slices(m, n, D, dA != nullptr, dB != nullptr);
-  const size_t need = dalm_sim_small_bwd_workspace_bytes(m, n, D, dA != nullptr, dB != nullptr);
+  const size_t need = tickets ? dalm_sim_small_bwd1_workspace_bytes(m, n, D, dA != nullptr, dB != nullptr)
+                              : dalm_sim_small_bwd_workspace_bytes(m, n, D, dA != nullptr, dB != nullptr);
   if (nsl > 1 && (!ws || ws_bytes < need || reinterpret_cast<uintptr_t>(ws) % 16 != 0)) nsl = 1;   // no workspace: unsliced form
+  if (nsl <= 1) tickets = nullptr;
   const int64_t rmax = (ndir == 2) ? (m > n ? m : n) : (dir0 ? n : m);
   const dim3 grid(static_cast<unsigned>((rmax + 31) / 32), static_cast<unsigned>((D + 31) / 32),
                   static_cast<unsigned>(ndir * nsl));
@@ -920,12 +978,12 @@ extern "C" int dalm_sim_small_bwd_ws(const float* S, int64_t ldS, const float* A
   if (kd_min > 64)
     hipLaunchKernelGGL(small_grad_kernel<true>, grid, dim3(256), 0, s, S, ldS, A, Bm, static_cast<int>(m),
                        static_cast<int>(n), static_cast<int>(D), scale, diag_offset, row_coef, row_lse, col_coef, col_lse,
-                       dA, dB, dir0, nsl, dA ? slab : nullptr, dA ? nullptr : slab);
+                       dA, dB, dir0, nsl, dA ? slab : nullptr, dA ? nullptr : slab, tickets);
   else
     hipLaunchKernelGGL(small_grad_kernel<false>, grid, dim3(256), 0, s, S, ldS, A, Bm, static_cast<int>(m),
                        static_cast<int>(n), static_cast<int>(D), scale, diag_offset, row_coef, row_lse, col_coef, col_lse,
-                       dA, dB, dir0, nsl, dA ? slab : nullptr, dA ? nullptr : slab);
-  if (nsl > 1) {
+                       dA, dB, dir0, nsl, dA ? slab : nullptr, dA ? nullptr : slab, tickets);
+  if (nsl > 1 && !tickets) {
     const int64_t count = (dA ? m : n) * D;
     int64_t blocks = (count / 4 + 255) / 256;
     if (blocks > 1024) blocks = 1024;
@@ -933,7 +991,7 @@ extern "C" int dalm_sim_small_bwd_ws(const float* S, int64_t ldS, const float* A
     hipLaunchKernelGGL(small_slice_sum_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, slab, nsl, count,
                        dA ? dA : dB);
   }
-  return check_launch(__func__);
+  return check_launch(fn);
 }
 
 extern "C" int dalm_sim_small_bwd(const float* S, int64_t ldS, const float* A, const float* Bm, int64_t m, int64_t n,

@@ -62,6 +62,9 @@ SIGNATURES = {
     "dalm_sim_small_fwd1": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "dalm_sim_small_bwd": (_int, [_vp, _i64, _vp, _vp, _i64, _i64, _i64, _f32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dalm_sim_small_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64, _int, _int]),
+    "dalm_sim_small_bwd1_workspace_bytes": (_sz, [_i64, _i64, _i64, _int, _int]),
+    "dalm_sim_small_bwd1_ticket_words": (_sz, [_i64, _i64, _i64]),
+    "dalm_sim_small_bwd1": (_int, [_vp, _i64, _vp, _vp, _i64, _i64, _i64, _f32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "dalm_sim_small_bwd_ws": (_int, [_vp, _i64, _vp, _vp, _i64, _i64, _i64, _f32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dalm_rag_loss_finalize": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "dalm_sim_topk_supported": (_int, [_i64, _i64]),

@@ -194,8 +194,13 @@ class HipOps:
                  hip.ptr(row_lse), hip.ptr(diag), hip.ptr(col_lse), hip.ptr(ws), ws_bytes, hip.stream())
         return S, row_lse, diag, col_lse
 
+    # sliced backward (one direction of a long contraction): slices summed in the launch (dalm_sim_small_bwd1) or by a
+    # second kernel (dalm_sim_small_bwd_ws); DALM_SMALL_BWD1 = 1 / 0, default decided by measurement
+    # (profiles/r04_small_one_launch.txt)
+    small_bwd_one_launch = os.environ.get("DALM_SMALL_BWD1", "1") == "1"
+
     def sim_small_bwd(self, S, A, Bm, scale: float, diag_offset: int, row_coef, row_lse, col_coef, col_lse,
-                      want_dA: bool = True, want_dB: bool = True):
+                      want_dA: bool = True, want_dB: bool = True, one_launch: Optional[bool] = None):
         """(dA, dB) = (scale dS.B, scale dS^T.A) from the saved S; the closed-form dS of include/dalm_hip.h."""
         dev = hip.require_gpu(S, A, Bm, row_coef, row_lse, col_coef, col_lse)
         A, Bm, S = hip.as_f32c(A), hip.as_f32c(Bm), hip.as_f32c(S)
@@ -205,7 +210,18 @@ class HipOps:
         n = Bm.shape[0]
         dA = torch.empty((m, D), device=dev, dtype=torch.float32) if want_dA else None
         dB = torch.empty((n, D), device=dev, dtype=torch.float32) if want_dB else None
-        ws_bytes = hip.load().dalm_sim_small_bwd_workspace_bytes(m, n, D, int(want_dA), int(want_dB))
+        lib = hip.load()
+        if one_launch is None:
+            one_launch = self.small_bwd_one_launch
+        ws_bytes = lib.dalm_sim_small_bwd1_workspace_bytes(m, n, D, int(want_dA), int(want_dB)) if one_launch else 0
+        if one_launch and ws_bytes:        # sliced: the last slice of every output tile adds the slices (one launch)
+            ws = torch.empty((ws_bytes // 4,), device=dev, dtype=torch.float32)
+            tickets = self._small_tickets(dev, lib.dalm_sim_small_bwd1_ticket_words(m, n, D))
+            hip.call("dalm_sim_small_bwd1", hip.ptr(S), S.shape[1], hip.ptr(A), hip.ptr(Bm), m, n, D, float(scale),
+                     int(diag_offset), hip.ptr(row_coef), hip.ptr(row_lse), hip.ptr(col_coef), hip.ptr(col_lse),
+                     hip.ptr(dA), hip.ptr(dB), hip.ptr(ws), ws_bytes, hip.ptr(tickets), hip.stream())
+            return dA, dB
+        ws_bytes = lib.dalm_sim_small_bwd_workspace_bytes(m, n, D, int(want_dA), int(want_dB))
         ws = torch.empty((ws_bytes // 4,), device=dev, dtype=torch.float32) if ws_bytes else None   # contraction slices
         hip.call("dalm_sim_small_bwd_ws", hip.ptr(S), S.shape[1], hip.ptr(A), hip.ptr(Bm), m, n, D, float(scale),
                  int(diag_offset), hip.ptr(row_coef), hip.ptr(row_lse), hip.ptr(col_coef), hip.ptr(col_lse),

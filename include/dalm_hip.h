@@ -191,6 +191,17 @@ int dalm_sim_small_bwd_ws(const float* S, int64_t ldS, const float* A, const flo
                           const float* row_lse, const float* col_coef,
                           const float* col_lse, float* dA, float* dB,
                           void* ws, size_t ws_bytes, dalm_stream_t stream);
+/* dalm_sim_small_bwd1: the sliced backward (one direction of a long contraction: the per-rank blocks of a sharded batch) in
+ * ONE launch - the last slice of every output tile to arrive adds the slices in slice order (same bits as the two-launch
+ * form, whoever arrives last).  `tickets`: dalm_sim_small_bwd1_ticket_words words, ZERO on entry, left zero (may be the
+ * forward's ticket buffer: calls sharing one must be stream-ordered).  Workspace: dalm_sim_small_bwd1_workspace_bytes. */
+size_t dalm_sim_small_bwd1_workspace_bytes(int64_t m, int64_t n, int64_t D, int want_dA, int want_dB);
+size_t dalm_sim_small_bwd1_ticket_words(int64_t m, int64_t n, int64_t D);
+int dalm_sim_small_bwd1(const float* S, int64_t ldS, const float* A, const float* Bm, int64_t m, int64_t n,
+                        int64_t D, float scale, int64_t diag_offset, const float* row_coef,
+                        const float* row_lse, const float* col_coef, const float* col_lse,
+                        float* dA, float* dB, void* ws, size_t ws_bytes, unsigned* tickets,
+                        dalm_stream_t stream);
 
 /* ---- K3 drop-in: get_nt_xent_loss on a materialised square S -----------
  * dalm/training/utils/train_utils.py:80-88 (cross_entropy(S, arange(n)), mean).

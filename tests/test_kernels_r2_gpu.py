@@ -93,6 +93,35 @@ def test_small_forward_in_one_launch_under_uneven_load(dev):
     torch.testing.assert_close(ref[1].cpu().double(), torch.logsumexp(S, 1), rtol=1e-6, atol=3e-5)
 
 
+@pytest.mark.parametrize("m,n,D,off,want_a", [(150, 1200, 1024, 450, True), (150, 1200, 1024, 450, False), (18, 8000, 1024, 100, True),
+                                               (70, 2100, 256, 1000, True), (33, 900, 1030, 7, True), (600, 600, 768, 0, True)])
+def test_small_backward_sliced_in_one_launch_equals_the_two_launch_form(dev, m, n, D, off, want_a):
+    """dalm_sim_small_bwd1 (round 4): the slices of a long contraction are added by the last slice of every output tile to
+    arrive, in slice order - the SAME bits as small_slice_sum_kernel gives the two-launch form, 30 repetitions identical
+    (also with another stream keeping the chip busy), tickets left at zero; unsliced shapes are untouched."""
+    from dalm_amd.ops import HipOps, default_ops
+
+    ops = default_ops()
+    A, Bm, scale, S, rc, rl, cc, cl, dS = _problem(m, n, D, off)
+    Sg, *_ = ops.sim_small_fwd(A.to(dev), Bm.to(dev), scale, off, False)
+    args = (Sg, A.to(dev), Bm.to(dev), scale, off, rc.to(dev), rl.float().to(dev), cc.to(dev), cl.float().to(dev))
+    two = ops.sim_small_bwd(*args, want_a, not want_a, one_launch=False)[0 if want_a else 1]
+    one = ops.sim_small_bwd(*args, want_a, not want_a, one_launch=True)[0 if want_a else 1]
+    assert torch.equal(one, two)
+    ref = scale * (dS @ Bm.double()) if want_a else scale * (dS.t() @ A.double())
+    assert_grad_close(one, ref, 5e-4, "dA" if want_a else "dB")
+    noise = torch.randn(2048, 2048, device=dev)
+    side = torch.cuda.Stream()
+    for i in range(30):
+        if i % 2:
+            with torch.cuda.stream(side):
+                noise = torch.tanh(noise @ noise * 1e-3)
+        again = ops.sim_small_bwd(*args, want_a, not want_a, one_launch=True)[0 if want_a else 1]
+        assert torch.equal(again, one)
+    torch.cuda.synchronize()
+    assert int(HipOps._tickets[dev.index].abs().sum()) == 0
+
+
 @pytest.mark.parametrize("m,n,D,off", SMALL)
 def test_small_path_vs_fp64(dev, m, n, D, off):
     from dalm_amd.ops import default_ops

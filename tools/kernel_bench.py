@@ -150,10 +150,14 @@ def bench_small(m, n, D, want_cols=True):
     S, rl, _, cl = ops.sim_small_fwd(A, Bm, 100.0, 0, True)
     rc = torch.full((m,), 1.0 / m, device=dev)
     cc = torch.full((n,), 1.0 / n, device=dev)
-    med, best = time_graph(lambda: ops.sim_small_bwd(S, A, Bm, 100.0, 0, rc, rl, cc, cl, True, want_cols))
+    med, best = time_graph(lambda: ops.sim_small_bwd(S, A, Bm, 100.0, 0, rc, rl, cc, cl, True, want_cols, one_launch=False))
     nd = 2 if want_cols else 1
     out["bwd(dQ,dP)" if want_cols else "bwd(dQ)"] = {"us": med * 1e6, "best_us": best * 1e6,
                                                       "TFLOPs": nd * 2.0 * m * n * D / med / 1e12}
+    if not want_cols:       # one direction of a long contraction: the slices summed inside the launch (round 4)
+        ops.sim_small_bwd(S, A, Bm, 100.0, 0, rc, rl, cc, cl, True, False, one_launch=True)
+        med, best = time_graph(lambda: ops.sim_small_bwd(S, A, Bm, 100.0, 0, rc, rl, cc, cl, True, False, one_launch=True))
+        out["bwd(dQ, one launch)"] = {"us": med * 1e6, "best_us": best * 1e6, "TFLOPs": 2.0 * m * n * D / med / 1e12}
     return out
 
 
