@@ -1099,7 +1099,7 @@ static bool use_bf16x3(int64_t m, int64_t n, int64_t D, const float* A, const fl
     const char* off = getenv("DALM_SIM_BF16X3");
     if (off && off[0] == '0') return -1;
     const char* e = getenv("DALM_SIM_BF16X3_MIN");
-    return e ? atoi(e) : 4096;
+    return e ? atoi(e) : 3072;   // measured crossover: 2048^2 64 vs 100 TF (f32 wins), 3072^2 142 vs 122 TF (profiles/r04_sim_midsize_merge_inlaunch.txt)
   }();
   if (min_rows < 0 || m < min_rows || n < min_rows) return false;
   if (A && (reinterpret_cast<uintptr_t>(A) % 16 || reinterpret_cast<uintptr_t>(Bm) % 16)) return false;

@@ -111,7 +111,7 @@ class HipOps:
 
     def sim_rowstats_bf16x3(self, A: torch.Tensor, Bm: torch.Tensor, scale: float, diag_offset: int):
         """The same statistics on the bf16 matrix cores at f32 accuracy (three bf16 thirds per operand, six products along
-        K; see include/dalm_hip.h).  `sim_rowstats` routes here by itself for m, n >= 4096."""
+        K; see include/dalm_hip.h).  `sim_rowstats` routes here by itself for m, n >= 3072."""
         dev = hip.require_gpu(A, Bm)
         A, Bm = hip.as_f32c(A), hip.as_f32c(Bm)
         m, D = A.shape

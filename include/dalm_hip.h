@@ -116,7 +116,7 @@ int dalm_sim_rowstats(const float* A, const float* Bm, int64_t m, int64_t n,
  * its row log-sum-exp epilogue: 6 x the flops of the f32 kernel on a pipe with 16 x its rate, no score matrix.
  * S agrees with the f32 result to a few 1e-7 relative of |scale| (products of bf16 values are exact in f32, accumulation
  * is f32).  Needs D % 64 == 0, D <= 65536, operand images below 4 GB, 16-byte aligned A / B.
- * dalm_sim_rowstats routes to it for m, n >= 4096 (DALM_SIM_BF16X3=0 keeps the f32 MFMA kernel).
+ * dalm_sim_rowstats routes to it for m, n >= 3072 (DALM_SIM_BF16X3=0 keeps the f32 MFMA kernel).
  * Reference: get_cosine_sim / get_nt_xent_loss, dalm/training/utils/train_utils.py:76-88; dalm/eval/utils.py:44-68. */
 /* dalm_sim_rowstats pinned to the exact-f32 MFMA kernels whatever the size (same arguments, same workspace query). */
 int dalm_sim_rowstats_f32(const float* A, const float* Bm, int64_t m, int64_t n,
