@@ -161,7 +161,10 @@ class HipOps:
         key = dev.index
         buf = HipOps._tickets.get(key)
         if buf is None or buf.numel() < words:
-            buf = torch.zeros((max(words, 4096),), device=dev, dtype=torch.int32)
+            # 64 Ki words cover every shape of the small path at D <= 8192 (forward: <= ~1.5 k tiles; sliced backward:
+            # (rows / 32) x (D / 32) output tiles): no re-allocation - and so no buffer handed back to the allocator while a
+            # launch on another stream might still hold it - in any configuration this package runs
+            buf = torch.zeros((max(words, 1 << 16),), device=dev, dtype=torch.int32)
             HipOps._tickets[key] = buf
         return buf
 
