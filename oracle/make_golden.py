@@ -633,9 +633,84 @@ def main_trainer_golden() -> None:
     print("trainer_golden.json", losses)
 
 
+def main_retriever_trainer_golden() -> None:
+    """Round 4: the reference's own `train_retriever` (dalm/training/retriever_only/train_retriever_only.py:175-422,
+    unmodified) at the REAL width and batch of configs[1] - bge-large (D = 1024), batch 150, Tq 50 / Tp 128 - on the depth-1
+    seeded BERT of oracle/realwidth.py, fp32, every parameter training (use_peft=False, use_bnb=False).  The csv holds exactly
+    one batch (150 rows): 3 epochs of one step.  `AutoModel.from_pretrained` is patched only to drop the reference's
+    `device_map={"": 0}` (there is no GPU here).  Committed: the rows' seed and 3 per-step losses."""
+    import csv
+    import json
+    import tempfile
+
+    import accelerate
+    import datasets  # noqa: F401
+    from accelerate import Accelerator  # noqa: F401
+    from transformers import (AutoModel, AutoModelForCausalLM, AutoTokenizer, BitsAndBytesConfig,  # noqa: F401
+                              PreTrainedTokenizerFast, SchedulerType, default_data_collator, get_scheduler)
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    import realwidth as RW
+
+    import_reference()
+    stub = types.ModuleType("peft")
+    for name in ("LoraConfig", "PeftModel", "TaskType", "get_peft_model"):
+        setattr(stub, name, type(name, (), {}))
+    sys.modules["peft"] = stub
+    sys.path.insert(0, str(REF))
+    try:
+        import dalm.training.retriever_only.train_retriever_only as ref_ret
+    finally:
+        sys.modules.pop("peft", None)
+        sys.path.remove(str(REF))
+    tok = PreTrainedTokenizerFast.from_pretrained(str(OUT / "wordlevel_tokenizer"))
+    rows = trainer_rows(n=150, seed=78)
+    retriever, _ = RW.build_case("cfg2")
+    rec = {"case": "cfg2", "depth": 1, "seed": RW.SEED, "checksum_retriever": RW.checksum(retriever),
+           "rows_seed": 78, "rows_n": 150, "first_row": {k: v[0] for k, v in rows.items()},
+           "args": {"per_device_train_batch_size": 150, "query_max_len": 50, "passage_max_len": 128, "learning_rate": 1e-4,
+                    "num_warmup_steps": 0, "num_train_epochs": 3, "logit_scale": 100, "seed": 42}}
+    losses = []
+    orig_backward = accelerate.Accelerator.backward
+    orig_fp = AutoModel.from_pretrained
+
+    def recording_backward(self, loss, **kw):
+        losses.append(float(loss.detach()))
+        return orig_backward(self, loss, **kw)
+
+    def cpu_from_pretrained(*a, **kw):
+        kw.pop("device_map", None)
+        kw.pop("quantization_config", None)
+        return orig_fp(*a, **kw)
+
+    accelerate.Accelerator.backward = recording_backward
+    AutoModel.from_pretrained = cpu_from_pretrained
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            rdir, path = f"{td}/retriever", f"{td}/rows.csv"
+            retriever.save_pretrained(rdir); tok.save_pretrained(rdir)
+            del retriever
+            with open(path, "w", newline="") as f:
+                w = csv.writer(f)
+                w.writerow(["Question", "Abstract", "Answer"])
+                for i in range(len(rows["Question"])):
+                    w.writerow([rows["Question"][i], rows["Abstract"][i], rows["Answer"][i]])
+            ref_ret.train_retriever(rdir, path, with_tracking=False, output_dir=None, use_peft=False, use_bnb=False,
+                                    sanity_test=False, **rec["args"])
+    finally:
+        accelerate.Accelerator.backward = orig_backward
+        AutoModel.from_pretrained = orig_fp
+    rec["losses"] = losses
+    (OUT / "retriever_trainer_golden.json").write_text(json.dumps(rec, indent=1))
+    print("retriever_trainer_golden.json", losses)
+
+
 if __name__ == "__main__":
     if "--trainer-only" in sys.argv:
         main_trainer_golden()
+        sys.exit(0)
+    if "--retriever-trainer-only" in sys.argv:
+        main_retriever_trainer_golden()
         sys.exit(0)
     if "--retriever-step-only" in sys.argv:
         main_retriever_step_golden()
@@ -651,3 +726,4 @@ if __name__ == "__main__":
     main_retriever_step_golden()
     main_realwidth_golden()
     main_trainer_golden()
+    main_retriever_trainer_golden()

@@ -105,3 +105,49 @@ def test_train_e2e_at_real_width_follows_the_reference_trainer_and_resumes(tmp_p
     assert [s for s, _ in resumed] == [2, 3]
     assert max(rel_resume) <= 1e-4, (resumed, gold["losses"])
     assert max(rel_resume_vs_straight) <= 1e-5, (resumed, straight)
+
+
+def test_train_retriever_at_real_width_follows_the_reference_trainer(tmp_path):
+    """configs[1] through the entry point: `train_retriever` (csv in, tokenise, ShardedBatches, hipGraph steps, Adam + linear
+    schedule) on the depth-1 bge-large tower at batch 150 against the per-step losses of the REFERENCE'S OWN
+    `train_retriever` (train_retriever_only.py:175-422) on the same 150-row csv: tests/golden/retriever_trainer_golden.json
+    (oracle/make_golden.py::main_retriever_trainer_golden).  fp32, every parameter trains; tolerance 1e-4 (north_star 1e-3)."""
+    from transformers import PreTrainedTokenizerFast
+
+    import realwidth as RW
+    from make_golden import trainer_rows
+
+    from dalm_amd.models import AutoModelForSentenceEmbedding
+    from dalm_amd.training.retriever_only.train_retriever_only import train_retriever
+
+    gold = json.loads((G / "retriever_trainer_golden.json").read_text())
+    rows = trainer_rows(n=gold["rows_n"], seed=gold["rows_seed"])
+    assert {k: v[0] for k, v in rows.items()} == gold["first_row"]          # the generator of the rows has not drifted
+    bert, _ = RW.build_case(gold["case"])
+    if _rel(RW.checksum(bert), gold["checksum_retriever"]) > 1e-9:
+        msg = "this host's torch CPU RNG does not reproduce the golden's seeded weights"
+        if os.environ.get("DALM_ALLOW_RNG_SKIP") == "1":
+            pytest.skip(msg)
+        pytest.fail(msg + " (set DALM_ALLOW_RNG_SKIP=1 to skip knowingly)")
+    tok = PreTrainedTokenizerFast.from_pretrained(str(G / "wordlevel_tokenizer"))
+    model = AutoModelForSentenceEmbedding.from_modules(bert, tok, normalize=True, get_peft=False)
+    path = tmp_path / "rows.csv"
+    with open(path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Question", "Abstract", "Answer"])
+        for i in range(len(rows["Question"])):
+            w.writerow([rows["Question"][i], rows["Abstract"][i], rows["Answer"][i]])
+    a = gold["args"]
+    got = []
+    train_retriever("", str(path), per_device_train_batch_size=a["per_device_train_batch_size"], query_max_len=a["query_max_len"],
+                    passage_max_len=a["passage_max_len"], learning_rate=a["learning_rate"], num_warmup_steps=a["num_warmup_steps"],
+                    num_train_epochs=a["num_train_epochs"], logit_scale=a["logit_scale"], seed=a["seed"], with_tracking=False,
+                    use_peft=False, use_bnb=False, mixed_precision="no", model=model, on_step=lambda s, l: got.append(float(l)))
+    rel = [_rel(x, y) for x, y in zip(got, gold["losses"])]
+    try:
+        OUT.mkdir(exist_ok=True)
+        (OUT / "retriever_trainer_realwidth_parity.json").write_text(json.dumps(
+            {"reference_trainer_losses": gold["losses"], "train_retriever_losses": got, "rel": rel}, indent=1))
+    except OSError:
+        pass
+    assert len(got) == a["num_train_epochs"] and max(rel) <= 1e-4, (rel, got, gold["losses"])
