@@ -629,8 +629,41 @@ def main_trainer_golden() -> None:
     finally:
         accelerate.Accelerator.backward = orig_backward
     rec["losses"] = losses
+    # the same entry point in accelerate's bf16 mode (ACCELERATE_MIXED_PRECISION=bf16: fp32 master weights, forward under
+    # torch.autocast(bfloat16), outputs up-cast to fp32 before the reference's loss code): the precision dalm_amd's trainers
+    # default to (--mixed_precision bf16)
+    retriever, generator = RW.build_case("cfg3")
+    bf16_losses = []
+
+    def recording_backward16(self, loss, **kw):
+        bf16_losses.append(float(loss.detach()))
+        return orig_backward(self, loss, **kw)
+
+    accelerate.Accelerator.backward = recording_backward16
+    os.environ["ACCELERATE_MIXED_PRECISION"] = "bf16"
+    try:
+        from accelerate.state import AcceleratorState, PartialState
+
+        AcceleratorState._reset_state(reset_partial_state=True)
+        with tempfile.TemporaryDirectory() as td:
+            rdir, gdir, path = f"{td}/retriever", f"{td}/generator", f"{td}/rows.csv"
+            retriever.save_pretrained(rdir); tok.save_pretrained(rdir)
+            generator.save_pretrained(gdir); tok.save_pretrained(gdir)
+            del retriever, generator
+            with open(path, "w", newline="") as f:
+                w = csv.writer(f)
+                w.writerow(["Question", "Abstract", "Answer"])
+                for i in range(len(rows["Question"])):
+                    w.writerow([rows["Question"][i], rows["Abstract"][i], rows["Answer"][i]])
+            ref_e2e.train_e2e(path, rdir, gdir, with_tracking=False, output_dir=None, use_peft=None, use_bnb=None,
+                              sanity_test=False, **rec["args"])
+    finally:
+        accelerate.Accelerator.backward = orig_backward
+        os.environ.pop("ACCELERATE_MIXED_PRECISION", None)
+        AcceleratorState._reset_state(reset_partial_state=True)
+    rec["bf16_autocast_losses"] = bf16_losses
     (OUT / "trainer_golden.json").write_text(json.dumps(rec, indent=1))
-    print("trainer_golden.json", losses)
+    print("trainer_golden.json", losses, "bf16", bf16_losses)
 
 
 def main_retriever_trainer_golden() -> None:

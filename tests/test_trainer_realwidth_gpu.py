@@ -151,3 +151,38 @@ def test_train_retriever_at_real_width_follows_the_reference_trainer(tmp_path):
     except OSError:
         pass
     assert len(got) == a["num_train_epochs"] and max(rel) <= 1e-4, (rel, got, gold["losses"])
+
+
+def test_train_e2e_in_bf16_mode_follows_the_reference_trainer_in_accelerates_bf16_mode(tmp_path):
+    """The trainers' DEFAULT precision (--mixed_precision bf16: fp32 master weights, towers under autocast, fp32 loss path on
+    the up-cast outputs) against the reference's `train_e2e` run with ACCELERATE_MIXED_PRECISION=bf16 on the same csv and
+    seeded real-width towers (`bf16_autocast_losses` in trainer_golden.json): 3 optimizer steps through the entry point.
+    Stated bf16 tolerance: 2e-4 on the first loss (forward only), 1e-3 after Adam updates computed from bf16 gradients
+    (the reference's own bf16 trajectory sits 1.6e-5 / 1.3e-4 / 4.2e-4 from its fp32 one)."""
+    from dalm_amd.training.rag_e2e.train_rage2e import train_e2e
+
+    gold = json.loads((G / "trainer_golden.json").read_text())
+    rows, a = gold["rows"], gold["args"]
+    path = tmp_path / "rows.csv"
+    with open(path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Question", "Abstract", "Answer"])
+        for i in range(len(rows["Question"])):
+            w.writerow([rows["Question"][i], rows["Abstract"][i], rows["Answer"][i]])
+    got = []
+    train_e2e(str(path), "", "", rag_model=_model(gold), on_step=lambda s, l: got.append(float(l)),
+              per_device_train_batch_size=a["per_device_train_batch_size"], query_max_len=a["query_max_len"],
+              passage_max_len=a["passage_max_len"], generator_max_len=a["generator_max_len"], learning_rate=a["learning_rate"],
+              num_warmup_steps=a["num_warmup_steps"], logit_scale=a["logit_scale"], seed=a["seed"],
+              num_train_epochs=a["num_train_epochs"], with_tracking=False, mixed_precision="bf16")
+    ref = gold["bf16_autocast_losses"]
+    rel = [_rel(x, y) for x, y in zip(got, ref)]
+    rel32 = [_rel(x, y) for x, y in zip(got, gold["losses"])]
+    try:
+        OUT.mkdir(exist_ok=True)
+        (OUT / "trainer_realwidth_bf16_parity.json").write_text(json.dumps(
+            {"reference_trainer_bf16_losses": ref, "train_e2e_bf16_losses": got, "rel": rel,
+             "rel_vs_reference_fp32_trajectory": rel32}, indent=1))
+    except OSError:
+        pass
+    assert len(got) == len(ref) and rel[0] <= 2e-4 and max(rel) <= 1e-3, (rel, got, ref)
