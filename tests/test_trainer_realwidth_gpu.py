@@ -157,8 +157,9 @@ def test_train_e2e_in_bf16_mode_follows_the_reference_trainer_in_accelerates_bf1
     """The trainers' DEFAULT precision (--mixed_precision bf16: fp32 master weights, towers under autocast, fp32 loss path on
     the up-cast outputs) against the reference's `train_e2e` run with ACCELERATE_MIXED_PRECISION=bf16 on the same csv and
     seeded real-width towers (`bf16_autocast_losses` in trainer_golden.json): 3 optimizer steps through the entry point.
-    Stated bf16 tolerance: 2e-4 on the first loss (forward only), 1e-3 after Adam updates computed from bf16 gradients
-    (the reference's own bf16 trajectory sits 1.6e-5 / 1.3e-4 / 4.2e-4 from its fp32 one)."""
+    Stated bf16 tolerance: 5e-5 on the first loss (forward only; measured 2.3e-6), 3e-4 after Adam updates computed from
+    bf16 gradients (measured 2.3e-5 / 1.7e-5; the reference's own bf16 trajectory sits 1.6e-5 / 1.3e-4 / 4.2e-4 from its fp32
+    one, so a trainer that ran fp32 towers would FAIL this test at step 3)."""
     from dalm_amd.training.rag_e2e.train_rage2e import train_e2e
 
     gold = json.loads((G / "trainer_golden.json").read_text())
@@ -185,4 +186,4 @@ def test_train_e2e_in_bf16_mode_follows_the_reference_trainer_in_accelerates_bf1
              "rel_vs_reference_fp32_trajectory": rel32}, indent=1))
     except OSError:
         pass
-    assert len(got) == len(ref) and rel[0] <= 2e-4 and max(rel) <= 1e-3, (rel, got, ref)
+    assert len(got) == len(ref) and rel[0] <= 5e-5 and max(rel) <= 3e-4, (rel, got, ref)
