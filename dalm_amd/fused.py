@@ -441,13 +441,26 @@ def _lm_head_live_rows(ops, h, w, ids, mask, stats, live_rows, chunk_rows, dw, n
     return dh, row_nll
 
 
-def _use_lm_head_kernel(ops, h, H) -> bool:
-    """DALM_LM_HEAD_KERNEL=1: evaluation through the library's own bf16 MFMA kernel (`dalm_lm_head_lse_fwd`: no logits
-    buffer at all).  Off by default - the hipBLASLt GEMM + forward CE kernel is ~1.5x faster."""
+# bytes of lm_head weight the fused kernel is preferred up to: 1.1 x the 256 MiB Infinity Cache.  Measured
+# (profiles/r04_lm_head_rows_sweep.txt): Llama-2-7b's head (32000 x 4096 bf16 = 262 MB) - the kernel is faster than hipBLASLt's
+# default-heuristic GEMM + the forward CE kernel at 10 of 15 row counts between 1024 and 4608 (0.84 ... 1.05, mean 0.97) and
+# allocates no logits; Falcon-7B's head (65024 x 4544 = 591 MB, re-read from HBM once per band of row tiles) - 2-14 % slower
+# at every row count.
+_LM_HEAD_KERNEL_MAX_WEIGHT_BYTES = int(1.1 * (256 << 20))
+
+
+def _use_lm_head_kernel(ops, h, H, w=None) -> bool:
+    """Evaluation (no gradient wanted) through the library's own bf16 MFMA kernel (`dalm_lm_head_lse_fwd`: lm_head +
+    log-sum-exp + label gather in one kernel, no logits buffer at all).  Default since round 4 where it measured faster:
+    lm_head weights that fit the Infinity Cache (see above); DALM_LM_HEAD_KERNEL=1 / 0 forces it on / off."""
     import os
 
-    return (os.environ.get("DALM_LM_HEAD_KERNEL", "0") == "1" and h.is_cuda and h.dtype == torch.bfloat16 and H % 64 == 0
-            and hasattr(ops, "lm_head_lse"))
+    if not (h.is_cuda and h.dtype == torch.bfloat16 and H % 64 == 0 and hasattr(ops, "lm_head_lse")):
+        return False
+    env = os.environ.get("DALM_LM_HEAD_KERNEL")
+    if env is not None:
+        return env == "1"
+    return w is not None and w.dtype == torch.bfloat16 and w.numel() * 2 <= _LM_HEAD_KERNEL_MAX_WEIGHT_BYTES
 
 
 def _lm_head_nll_kernel(ops, h, w, ids, mask, live_rows):
@@ -485,7 +498,7 @@ class _LMHeadRagE2E(torch.autograd.Function):
         dw = torch.zeros(w.shape, device=w.device, dtype=torch.float32) if need_dw else None
         # evaluation (torch.no_grad(), or nothing upstream wants a gradient): forward-only CE, no d(hidden) GEMM
         need_grad = need_dw or any(ctx.needs_input_grad[:3])
-        if not need_grad and _use_lm_head_kernel(ops, h, H):
+        if not need_grad and _use_lm_head_kernel(ops, h, H, w):
             dh, row_nll = None, _lm_head_nll_kernel(ops, h, w, ids, mask, live_rows)
         elif live_rows is None:
             dh = torch.empty_like(h) if need_grad else None

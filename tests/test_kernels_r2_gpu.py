@@ -648,8 +648,12 @@ def test_lm_head_over_live_rows_equals_all_rows(dtype):
     import os
 
     with torch.no_grad():   # evaluation: forward-only CE kernels, no d(hidden) GEMM, same value
-        for kern in ("0", "1"):   # "1": through the bf16 MFMA kernel (logits never stored); f32 inputs keep the library path
-            os.environ["DALM_LM_HEAD_KERNEL"] = kern
+        # "1": through the bf16 MFMA kernel (logits never stored); f32 inputs keep the library path; None: the default
+        # (round 4: the kernel whenever the lm_head weight fits the Infinity Cache - it does here)
+        for kern in ("0", "1", None):
+            os.environ.pop("DALM_LM_HEAD_KERNEL", None)
+            if kern is not None:
+                os.environ["DALM_LM_HEAD_KERNEL"] = kern
             try:
                 for rows in (None, live.to(dev)):
                     ev = rag_e2e_loss_from_hidden(q, p, h, W, ids.to(dev), mask.to(dev), qlen.to(dev), 100.0, chunk_samples=2,

@@ -82,11 +82,25 @@ def main():
             print(f"   {label:34s} {med * 1e3:7.3f} ms   {flops / med / 1e12:7.1f} TF/s on the GEMM flops   "
                   f"peak extra memory {peak:8.1f} MB   dh rel diff vs materialised {err:.2e}")
         if not arms or any("eval" in a for a in arms):
-            lv = [float(evaluate(None, False)()), float(evaluate(None)()), float(evaluate(live)())]
-            for label, fn in (("eval (no_grad): materialised logits", evaluate(None, False)),
-                              ("eval (no_grad): sample chunks", evaluate(None)), ("eval (no_grad): live rows", evaluate(live))):
-                med, _ = time_fn(fn, iters=10, warmup=3)
-                print(f"   {label:38s} {med * 1e3:7.3f} ms   (loss values {lv[0]:.5f} / {lv[1]:.5f} / {lv[2]:.5f})")
+            import os
+
+            for kern, tag in (("0", "library GEMM + forward CE"), ("1", "dalm_lm_head_lse_fwd kernel (no logits)"), (None, "DEFAULT")):
+                os.environ.pop("DALM_LM_HEAD_KERNEL", None)
+                if kern is not None:
+                    os.environ["DALM_LM_HEAD_KERNEL"] = kern
+                lv = [float(evaluate(None, False)()), float(evaluate(None)()), float(evaluate(live)())]
+                for label, fn in (("eval (no_grad): materialised logits", evaluate(None, False)),
+                                  ("eval (no_grad): sample chunks", evaluate(None)), ("eval (no_grad): live rows", evaluate(live))):
+                    if "materialised" in label and kern != "0":
+                        continue          # the materialised form never takes the kernel
+                    torch.cuda.reset_peak_memory_stats()
+                    base = torch.cuda.memory_allocated()
+                    fn()
+                    peak = (torch.cuda.max_memory_allocated() - base) / 1e6
+                    med, _ = time_fn(fn, iters=10, warmup=3)
+                    print(f"   {label:38s} [{tag:40s}] {med * 1e3:7.3f} ms   peak extra memory {peak:7.1f} MB   "
+                          f"(loss values {lv[0]:.5f} / {lv[1]:.5f} / {lv[2]:.5f})")
+            os.environ.pop("DALM_LM_HEAD_KERNEL", None)
 
 
 if __name__ == "__main__":
