@@ -445,14 +445,15 @@ def _lm_head_live_rows(ops, h, w, ids, mask, stats, live_rows, chunk_rows, dw, n
 # (profiles/r04_lm_head_rows_sweep.txt): Llama-2-7b's head (32000 x 4096 bf16 = 262 MB) - the kernel is faster than hipBLASLt's
 # default-heuristic GEMM + the forward CE kernel at 10 of 15 row counts between 1024 and 4608 (0.84 ... 1.05, mean 0.97) and
 # allocates no logits; Falcon-7B's head (65024 x 4544 = 591 MB, re-read from HBM once per band of row tiles) - 2-14 % slower
-# at every row count.
+# at every row count.  (Both measured against hipBLASLt's DEFAULT heuristics: a data-dependent live-row count has no tuned solution.)
 _LM_HEAD_KERNEL_MAX_WEIGHT_BYTES = int(1.1 * (256 << 20))
 
 
 def _use_lm_head_kernel(ops, h, H, w=None) -> bool:
     """Evaluation (no gradient wanted) through the library's own bf16 MFMA kernel (`dalm_lm_head_lse_fwd`: lm_head +
     log-sum-exp + label gather in one kernel, no logits buffer at all).  Default since round 4 where it measured faster:
-    lm_head weights that fit the Infinity Cache (see above); DALM_LM_HEAD_KERNEL=1 / 0 forces it on / off."""
+    lm_head weights that fit the Infinity Cache (see above) while the library runs on its default heuristics (no tuned
+    solution table); DALM_LM_HEAD_KERNEL=1 / 0 forces it on / off."""
     import os
 
     if not (h.is_cuda and h.dtype == torch.bfloat16 and H % 64 == 0 and hasattr(ops, "lm_head_lse")):
@@ -460,7 +461,19 @@ def _use_lm_head_kernel(ops, h, H, w=None) -> bool:
     env = os.environ.get("DALM_LM_HEAD_KERNEL")
     if env is not None:
         return env == "1"
-    return w is not None and w.dtype == torch.bfloat16 and w.numel() * 2 <= _LM_HEAD_KERNEL_MAX_WEIGHT_BYTES
+    if w is None or w.dtype != torch.bfloat16 or w.numel() * 2 > _LM_HEAD_KERNEL_MAX_WEIGHT_BYTES:
+        return False
+    # With the pre-tuned GEMM solution table replayed (dalm_amd.tuning - the trainers and bench.py switch it on) the library
+    # path wins at the row counts the table holds (cfg3 live rows, chunks [2048, 1536]: 0.79 vs 0.84 ms,
+    # profiles/r04_lm_head_eval_paths.txt): the kernel is the default where the library runs on its default heuristics.
+    try:
+        import torch.cuda.tunable as tunable
+
+        if tunable.is_enabled():
+            return False
+    except Exception:
+        pass
+    return True
 
 
 def _lm_head_nll_kernel(ops, h, w, ids, mask, live_rows):
