@@ -191,11 +191,17 @@ class NativeRcclComm:
         if getattr(self, "_h", None) is not None:
             hip.call("dalm_comm_destroy", self._h)
             self._h = None
-            if self.rank == 0:
+            if self.rank == 0 and os.environ.get("DALM_COMM_ID_FILE"):
                 try:
                     os.remove(_id_path())
                 except OSError:
                     pass
+            if self.rendezvous is not None:        # rank 0 may be hosting the store: give MASTER_PORT back
+                try:
+                    self.rendezvous.release()
+                except Exception:
+                    pass
+                self.rendezvous = None
 
     def __del__(self):
         try:
