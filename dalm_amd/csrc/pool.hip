@@ -14,6 +14,8 @@ namespace dalm {
 namespace {
 
 struct bf16_t { unsigned short v; };
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 
 template <typename T> struct HV;
 template <> struct HV<float> {
@@ -29,9 +31,15 @@ template <> struct HV<float> {
       for (int e = 0; e < 4; ++e) x[e] = (e < nvalid) ? p[e] : 0.f;
     }
   }
+  template <bool NTS = false>
   __device__ static __forceinline__ void store(float* p, int nvalid, bool vec, const float (&x)[4]) {
     if (nvalid >= 4 && vec) {
-      *reinterpret_cast<float4*>(p) = make_float4(x[0], x[1], x[2], x[3]);
+      if (NTS) {
+        v4f v = {x[0], x[1], x[2], x[3]};
+        __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p));
+      } else {
+        *reinterpret_cast<float4*>(p) = make_float4(x[0], x[1], x[2], x[3]);
+      }
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e) if (e < nvalid) p[e] = x[e];
@@ -54,13 +62,19 @@ template <> struct HV<bf16_t> {
       for (int e = 0; e < 8; ++e) x[e] = (e < nvalid) ? bf16_to_f32(p[e].v) : 0.f;
     }
   }
+  template <bool NTS = false>
   __device__ static __forceinline__ void store(bf16_t* p, int nvalid, bool vec, const float (&x)[8]) {
     if (nvalid >= 8 && vec) {
       unsigned int w[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         w[i] = pack_bf16x2(x[2 * i], x[2 * i + 1]);
-      *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+      if (NTS) {
+        v4u v = {w[0], w[1], w[2], w[3]};
+        __builtin_nontemporal_store(v, reinterpret_cast<v4u*>(p));
+      } else {
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+      }
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) if (e < nvalid) p[e].v = f32_to_bf16(x[e]);
@@ -144,13 +158,16 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ em
 // it, grid.x = TZ) across the full embedding width, so the mean, |u| and the normalisation happen in the
 // same launch (the two-launch form above costs ~20 us at batch 18 for ~2 us of data movement).
 //   TPR threads cover one token row (VEC elements each, NCH d-chunks per thread when D > TPR*VEC),
-//   G = 1024/TPR token groups stride through the tokens, 4 token rows in flight per group.
+//   G = NT/TPR token groups stride through the tokens, 4-8 token rows in flight per group.
+//   NT = 1024 threads when the batch is small (one workgroup has to keep a CU's memory pipe full on its own);
+//   NT = 256 for large batches: with >= 2 samples per CU, 1024-thread workgroups run in ceil(B/512) rounds and the
+//   reduction tail of each round leaves the memory pipe idle (B = 1200: 3 rounds for 2.3 rounds of work).
 //   TZ == 1: sums are combined through LDS in fixed group order, then u, |u|, e are written.
 //   TZ  > 1: raw partial sums go to part[b][z][D] (+ counts) and pool_finish_kernel completes the sample;
 //            used when B alone cannot occupy the chip (B * bytes per sample is large but B < ~128).
 // ---------------------------------------------------------------------------------------------------
-template <typename T, int NCH>
-__global__ __launch_bounds__(1024) void pool_fused_kernel(const T* __restrict__ h, const int64_t* __restrict__ mask,
+template <typename T, int NCH, int NT>
+__global__ __launch_bounds__(NT) void pool_fused_kernel(const T* __restrict__ h, const int64_t* __restrict__ mask,
                                                           int Tn, int D, int tpr_log2, int vec_ok, int normalize,
                                                           float* __restrict__ emb, float* __restrict__ norm,
                                                           float* __restrict__ inv_count, float* __restrict__ part,
@@ -162,7 +179,7 @@ __global__ __launch_bounds__(1024) void pool_fused_kernel(const T* __restrict__ 
   __shared__ float cnt_s[16];
   const int b = blockIdx.y, z = blockIdx.x, TZ = gridDim.x;
   const int tid = threadIdx.x;
-  const int TPR = 1 << tpr_log2, G = 1024 >> tpr_log2;
+  const int TPR = 1 << tpr_log2, G = NT >> tpr_log2;
   const int g = tid >> tpr_log2, c = tid & (TPR - 1);
   const int per = (Tn + TZ - 1) / TZ;
   const int t_lo = z * per, t_hi = min(Tn, t_lo + per);
@@ -284,7 +301,7 @@ __global__ __launch_bounds__(1024) void pool_fused_kernel(const T* __restrict__ 
         ss = fmaf(u[q][e], u[q][e], ss);
       }
   }
-  ss = block_sum<1024>(ss, red);
+  ss = block_sum<NT>(ss, red);
   const float nrm = sqrtf(ss);
   if (tid == 0) { norm[b] = nrm; inv_count[b] = 1.f / cden; }
   if (g == 0) {
@@ -335,7 +352,7 @@ __global__ __launch_bounds__(256) void pool_finish_kernel(const float* __restric
 //   du = d_emb                                  (normalize == 0)
 //   du = (d_emb - e (e . d_emb)) / |u|           (|u| >= 1e-12)
 //   du = d_emb / 1e-12                           (|u| <  1e-12: clamp_min branch)
-template <typename T>
+template <typename T, bool NTS>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ d_emb,
                                                        const float* __restrict__ emb,
                                                        const float* __restrict__ norm,
@@ -379,7 +396,73 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
     float o[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) o[e] = f * g[e];
-    HV<T>::store(hb + static_cast<int64_t>(t) * D, nvalid, vec_ok, o);
+    HV<T>::template store<NTS>(hb + static_cast<int64_t>(t) * D, nvalid, vec_ok, o);
+  }
+}
+
+
+// Row-major backward for large batches: grid (TZ, B), 256 threads.  TPR threads cover one token row (NCH d-chunks each), the
+// G = 256/TPR token groups write CONSECUTIVE rows, so a workgroup streams whole contiguous rows (2-4 KB per step at D = 1024)
+// and rebuilds du once per sample slice instead of once per 64*VEC-wide d-chunk.  Needs 16-byte aligned rows (vec_ok).
+template <typename T, int NCH, bool NTS>
+__global__ __launch_bounds__(256) void pool_bwd_rows_kernel(const float* __restrict__ d_emb,
+                                                            const float* __restrict__ emb,
+                                                            const float* __restrict__ norm,
+                                                            const float* __restrict__ inv_count,
+                                                            const int64_t* __restrict__ mask, int Tn, int D,
+                                                            int normalize, int tpr_log2, T* __restrict__ dh) {
+  constexpr int VEC = HV<T>::VEC;
+  __shared__ float red[4];
+  const int b = blockIdx.y, z = blockIdx.x, TZ = gridDim.x, tid = threadIdx.x;
+  const int TPR = 1 << tpr_log2, G = 256 >> tpr_log2;
+  const int g = tid >> tpr_log2, c = tid & (TPR - 1);
+  const float* de = d_emb + static_cast<int64_t>(b) * D;
+  const float* eb = emb + static_cast<int64_t>(b) * D;
+  const float ic = inv_count[b];
+  float dot = 0.f, nrm = 1.f;
+  if (normalize) {
+    for (int i = tid; i < D; i += 256) dot = fmaf(eb[i], de[i], dot);
+    dot = block_sum<256>(dot, red);
+    nrm = norm[b];
+  }
+  float gv[NCH][VEC];
+#pragma unroll
+  for (int q = 0; q < NCH; ++q) {
+    const int d = (q * TPR + c) * VEC;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float v = 0.f;
+      if (d + e < D) {
+        if (!normalize) v = de[d + e];
+        else v = (nrm >= 1e-12f) ? (de[d + e] - eb[d + e] * dot) / nrm : de[d + e] / 1e-12f;
+      }
+      gv[q][e] = v * ic;
+    }
+  }
+  const int per = (Tn + TZ - 1) / TZ;
+  const int t_lo = z * per, t_hi = min(Tn, t_lo + per);
+  T* hb = dh + static_cast<int64_t>(b) * Tn * D;
+  const int64_t* mb = mask + static_cast<int64_t>(b) * Tn;
+  for (int t0 = t_lo + g; t0 < t_hi; t0 += 4 * G) {
+    float f[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) f[u] = static_cast<float>(mb[min(t0 + u * G, t_hi - 1)]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + u * G;
+      if (t < t_hi) {
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+          const int d = (q * TPR + c) * VEC;
+          if (d < D) {
+            float o[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = f[u] * gv[q][e];
+            HV<T>::template store<NTS>(hb + static_cast<int64_t>(t) * D + d, VEC, true, o);
+          }
+        }
+      }
+    }
   }
 }
 
@@ -391,9 +474,9 @@ using namespace dalm;
 namespace dalm {
 namespace {
 // Geometry of the fused forward: TPR threads per token row (power of two), NCH chunks per thread, TZ token slices.
-struct PoolPlan { int tpr_log2, nch, tz; bool fused; };
+struct PoolPlan { int tpr_log2, nch, tz, nt; bool fused; };
 inline PoolPlan pool_plan(int64_t B, int64_t T, int64_t D, int vec) {
-  PoolPlan p{0, 1, 1, false};
+  PoolPlan p{0, 1, 1, 1024, false};
   const int64_t lanes = (D + vec - 1) / vec;
   int lg = 6;                                  // at least one wave per row
   while ((1ll << lg) < lanes && lg < 10) ++lg;
@@ -414,22 +497,33 @@ inline PoolPlan pool_plan(int64_t B, int64_t T, int64_t D, int vec) {
     if (tz < 1) tz = 1;
   }
   p.tz = static_cast<int>(tz);
+  static const int nt_env = [] { const char* e = getenv("DALM_POOL_NT"); return e ? atoi(e) : 0; }();
+  if (tz == 1 && tpr <= 256 && (nt_env == 256 || (nt_env == 0 && B >= 512))) p.nt = 256;
   return p;
 }
 template <typename T>
 void launch_pool_fused(const PoolPlan& pl, const T* h, const int64_t* mask, int B, int Tn, int D, int vok, int normalize,
                        float* emb, float* norm, float* inv_count, float* part, float* part_cnt, hipStream_t s) {
   const int vec = HV<T>::VEC;
-  const size_t lds = static_cast<size_t>(1024 >> pl.tpr_log2) * (1u << pl.tpr_log2) * vec * pl.nch * sizeof(float);
+  const size_t lds = static_cast<size_t>(pl.nt) * vec * pl.nch * sizeof(float);
   const dim3 grid(static_cast<unsigned>(pl.tz), static_cast<unsigned>(B));
-#define DALM_POOL_LAUNCH(N) \
-  hipLaunchKernelGGL((pool_fused_kernel<T, N>), grid, dim3(1024), lds, s, h, mask, Tn, D, pl.tpr_log2, vok, normalize, \
+#define DALM_POOL_LAUNCH(N, NT) \
+  hipLaunchKernelGGL((pool_fused_kernel<T, N, NT>), grid, dim3(NT), lds, s, h, mask, Tn, D, pl.tpr_log2, vok, normalize, \
                      emb, norm, inv_count, part, part_cnt)
-  switch (pl.nch) {
-    case 1: DALM_POOL_LAUNCH(1); break;
-    case 2: DALM_POOL_LAUNCH(2); break;
-    case 3: DALM_POOL_LAUNCH(3); break;
-    default: DALM_POOL_LAUNCH(4); break;
+  if (pl.nt == 256) {
+    switch (pl.nch) {
+      case 1: DALM_POOL_LAUNCH(1, 256); break;
+      case 2: DALM_POOL_LAUNCH(2, 256); break;
+      case 3: DALM_POOL_LAUNCH(3, 256); break;
+      default: DALM_POOL_LAUNCH(4, 256); break;
+    }
+  } else {
+    switch (pl.nch) {
+      case 1: DALM_POOL_LAUNCH(1, 1024); break;
+      case 2: DALM_POOL_LAUNCH(2, 1024); break;
+      case 3: DALM_POOL_LAUNCH(3, 1024); break;
+      default: DALM_POOL_LAUNCH(4, 1024); break;
+    }
   }
 #undef DALM_POOL_LAUNCH
   if (pl.tz > 1)
@@ -504,16 +598,54 @@ extern "C" int dalm_pool_l2norm_bwd(const float* d_emb, const float* emb, const 
   // 1044 WGs 12.4 us, 540 WGs 9.2 us, 396 WGs 7.7 us; at B = 150 two slices beat one (17.3 vs 19.2 us bf16)
   int64_t tz = (384 + B * dc - 1) / (B * dc);
   if (B * dc < 1024 && T >= 64 && tz < 2) tz = 2;
+  // (slicing large batches further does NOT help: every workgroup first rebuilds du, and at [1200,128,1024] bf16 2 / 4 / 8
+  // slices measured 91 / 123 / 192 us against 81 us for one - profiles/r04_pool_probe_bwd_tz.txt; large batches take the
+  // row-major kernel below instead)
+  static const int tz_env = [] { const char* e = getenv("DALM_POOL_BWD_TZ"); return e ? atoi(e) : 0; }();
+  if (tz_env > 0) tz = tz_env;
   const int64_t tz_max = (T + 3) / 4;
   if (tz > tz_max) tz = tz_max;
   if (tz < 1) tz = 1;
   if (tz > 64) tz = 64;
+  // cached stores: the encoder's backward reads dh next.  DALM_POOL_BWD_NT=1 selects non-temporal stores (measured alone:
+  // 17.5 -> 13.8 us at [150,128,1024] bf16, 79 -> 84 us at B = 1200; profiles/r04_pool_probe.txt)
+  static const int nts_env = [] { const char* e = getenv("DALM_POOL_BWD_NT"); return e ? atoi(e) : -1; }();
+  const bool nts = nts_env > 0;
+  static const int rows_env = [] { const char* e = getenv("DALM_POOL_BWD_ROWS"); return e ? atoi(e) : -1; }();
+  PoolPlan pl{6, 1, 1, 256, true};                 // rows kernel: TPR <= 256 threads per row, up to 4 d-chunks per thread
+  const int64_t row_lanes = (D + vec - 1) / vec;
+  while ((1ll << pl.tpr_log2) < row_lanes && pl.tpr_log2 < 8) ++pl.tpr_log2;
+  pl.nch = static_cast<int>((row_lanes + (1ll << pl.tpr_log2) - 1) >> pl.tpr_log2);
+  const bool rows_ok = vok && pl.nch <= 4;
+  const bool rows = rows_ok && (rows_env >= 0 ? rows_env != 0 : true);
+  if (rows) {
+    // token slices: ~768 workgroups, at most 8 slices (measured, profiles/r04_pool_probe_bwd_rows.txt: [18,128,1024] bf16
+    // 16.8 / 10.9 / 7.9 / 6.5 / 7.5 us for 1 / 2 / 4 / 8 / 16 slices; [1200,128,1024] 71.7 / 78.6 / 86.4 / 112 us for 1 / 2 / 4 / 8)
+    int64_t rz = tz_env > 0 ? tz_env : (768 + B - 1) / B;
+    if (tz_env <= 0 && rz > 8) rz = 8;
+    const int64_t groups = 256 >> pl.tpr_log2;
+    const int64_t rz_max = (T + 4 * groups - 1) / (4 * groups);
+    if (rz > rz_max) rz = rz_max;
+    if (rz < 1) rz = 1;
+    const dim3 rgrid(static_cast<unsigned>(rz), static_cast<unsigned>(B));
+#define DALM_POOL_BWD_ROWS(TT, N, S) \
+    hipLaunchKernelGGL((pool_bwd_rows_kernel<TT, N, S>), rgrid, dim3(256), 0, s, d_emb, emb, norm, inv_count, mask, \
+                       static_cast<int>(T), static_cast<int>(D), normalize, pl.tpr_log2, static_cast<TT*>(dh))
+#define DALM_POOL_BWD_ROWS_N(TT, S) \
+    switch (pl.nch) { case 1: DALM_POOL_BWD_ROWS(TT, 1, S); break; case 2: DALM_POOL_BWD_ROWS(TT, 2, S); break; \
+                      case 3: DALM_POOL_BWD_ROWS(TT, 3, S); break; default: DALM_POOL_BWD_ROWS(TT, 4, S); break; }
+    if (dtype == DALM_F32) { if (nts) { DALM_POOL_BWD_ROWS_N(float, true) } else { DALM_POOL_BWD_ROWS_N(float, false) } }
+    else { if (nts) { DALM_POOL_BWD_ROWS_N(bf16_t, true) } else { DALM_POOL_BWD_ROWS_N(bf16_t, false) } }
+#undef DALM_POOL_BWD_ROWS_N
+#undef DALM_POOL_BWD_ROWS
+    return check_launch(__func__);
+  }
   const dim3 grid(static_cast<unsigned>(dc), static_cast<unsigned>(B), static_cast<unsigned>(tz));
-  if (dtype == DALM_F32)
-    hipLaunchKernelGGL(pool_bwd_kernel<float>, grid, dim3(256), 0, s, d_emb, emb, norm, inv_count, mask,
-                       static_cast<int>(T), static_cast<int>(D), normalize, vok, static_cast<float*>(dh));
-  else
-    hipLaunchKernelGGL(pool_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, d_emb, emb, norm, inv_count, mask,
-                       static_cast<int>(T), static_cast<int>(D), normalize, vok, static_cast<bf16_t*>(dh));
+#define DALM_POOL_BWD(TT, N) \
+  hipLaunchKernelGGL((pool_bwd_kernel<TT, N>), grid, dim3(256), 0, s, d_emb, emb, norm, inv_count, mask, \
+                     static_cast<int>(T), static_cast<int>(D), normalize, vok, static_cast<TT*>(dh))
+  if (dtype == DALM_F32) { if (nts) DALM_POOL_BWD(float, true); else DALM_POOL_BWD(float, false); }
+  else { if (nts) DALM_POOL_BWD(bf16_t, true); else DALM_POOL_BWD(bf16_t, false); }
+#undef DALM_POOL_BWD
   return check_launch(__func__);
 }

@@ -213,7 +213,11 @@ def test_flash_workspace_is_not_m_times_n():
 
 
 POOL = [(18, 50, 1024), (18, 128, 1024), (150, 128, 1024), (19, 160, 384), (3, 17, 100), (5, 9, 5000),
-        (4, 4096, 1024), (2, 1, 64), (130, 33, 96)]
+        (4, 4096, 1024), (2, 1, 64), (130, 33, 96),
+        # round 4: batches >= 512 take the 256-thread form of the forward (TPR 128 / 64 / 256 threads per row, two d-chunks)
+        (600, 37, 1024), (512, 9, 384), (515, 5, 2056), (700, 3, 3000),
+        # ... and their backward slices the tokens (B * d-chunks > 1024 workgroups)
+        (1200, 60, 1024), (1100, 7, 96), (530, 21, 1504), (1030, 3, 4104), (2100, 2, 8200)]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
