@@ -91,46 +91,61 @@ __global__ __launch_bounds__(256) void nf4_quantize_kernel(const T* __restrict__
   }
 }
 
-template <typename T>
+// One thread per 8 consecutive weights and step; a workgroup walks STEPS consecutive tiles of 2048 weights with all its loads
+// issued before the first store (22 000 single-step workgroups of one 4-byte load + one 16-byte store each were bound by
+// workgroup dispatch, not by HBM).
+template <typename T, int STEPS, bool NTL>
 __global__ __launch_bounds__(256) void nf4_dequantize_kernel(const unsigned char* __restrict__ packed,
                                                              const float* __restrict__ absmax, int64_t n,
                                                              T* __restrict__ out) {
   __shared__ float level[16];
   if (threadIdx.x < 16) level[threadIdx.x] = kNf4Level[threadIdx.x];
   __syncthreads();
-  const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  const int64_t e0 = t * 8;
-  if (e0 >= n) return;
-  const float a = absmax[e0 >> 6];
-  const int64_t b0 = t * 4, nbytes = (n + 1) >> 1;
-  unsigned int word = 0;
-  if (b0 + 4 <= nbytes) {
-    word = *reinterpret_cast<const unsigned int*>(packed + b0);
-  } else {
-    for (int j = 0; j < 4; ++j)
-      if (b0 + j < nbytes) word |= static_cast<unsigned int>(packed[b0 + j]) << (8 * j);
-  }
-  float v[8];
+  const int64_t nbytes = (n + 1) >> 1;
+  const int64_t t0 = static_cast<int64_t>(blockIdx.x) * (256 * STEPS) + threadIdx.x;
+  unsigned int word[STEPS];
+  float a[STEPS];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const unsigned int byte = (word >> (8 * j)) & 0xffu;
-    v[2 * j] = level[byte >> 4] * a;
-    v[2 * j + 1] = level[byte & 15u] * a;
-  }
-  if (e0 + 8 <= n) {
-    if constexpr (sizeof(T) == 4) {
-      *reinterpret_cast<float4*>(out + e0) = make_float4(v[0], v[1], v[2], v[3]);
-      *reinterpret_cast<float4*>(out + e0 + 4) = make_float4(v[4], v[5], v[6], v[7]);
-    } else {
-      uint4 o;
-      o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-      o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
-      *reinterpret_cast<uint4*>(out + e0) = o;
+  for (int k = 0; k < STEPS; ++k) {
+    const int64_t t = t0 + k * 256, e0 = t * 8, b0 = t * 4;
+    word[k] = 0; a[k] = 0.f;
+    if (e0 < n) {
+      a[k] = absmax[e0 >> 6];
+      if (b0 + 4 <= nbytes) {
+        const unsigned int* src = reinterpret_cast<const unsigned int*>(packed + b0);
+        word[k] = NTL ? __builtin_nontemporal_load(src) : *src;
+      } else {
+        for (int j = 0; j < 4; ++j)
+          if (b0 + j < nbytes) word[k] |= static_cast<unsigned int>(packed[b0 + j]) << (8 * j);
+      }
     }
-  } else {
-    for (int j = 0; j < 8 && e0 + j < n; ++j) {
-      if constexpr (sizeof(T) == 4) out[e0 + j] = v[j];
-      else out[e0 + j] = f32_to_bf16(v[j]);
+  }
+#pragma unroll
+  for (int k = 0; k < STEPS; ++k) {
+    const int64_t e0 = (t0 + k * 256) * 8;
+    if (e0 >= n) continue;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned int byte = (word[k] >> (8 * j)) & 0xffu;
+      v[2 * j] = level[byte >> 4] * a[k];
+      v[2 * j + 1] = level[byte & 15u] * a[k];
+    }
+    if (e0 + 8 <= n) {
+      if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<float4*>(out + e0) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(out + e0 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+        uint4 o;
+        o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+        o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+        *reinterpret_cast<uint4*>(out + e0) = o;
+      }
+    } else {
+      for (int j = 0; j < 8 && e0 + j < n; ++j) {
+        if constexpr (sizeof(T) == 4) out[e0 + j] = v[j];
+        else out[e0 + j] = f32_to_bf16(v[j]);
+      }
     }
   }
 }
@@ -169,13 +184,26 @@ extern "C" int dalm_nf4_dequantize(const uint8_t* packed, const float* absmax, i
   DALM_REQUIRE(dtype == DALM_F32 || dtype == DALM_BF16, DALM_E_DTYPE, "dtype must be DALM_F32 or DALM_BF16");
   DALM_REQUIRE(aligned(out, 16) && aligned(packed, 4) && aligned(absmax, 4), DALM_E_ALIGN,
                "out must be 16-byte aligned, packed / absmax 4-byte aligned");
-  const int64_t threads = (n + 7) / 8, blocks = (threads + 255) / 256;
+  const int64_t threads = (n + 7) / 8;
+  static const int steps_env = [] { const char* e = getenv("DALM_NF4_STEPS"); return e ? atoi(e) : 0; }();
+  // measured (profiles/r04_nf4_steps.txt, 8 different weights in turn inside a hipGraph): bf16 out 11008x4096 28.0 / 23.0 /
+  // 21.3 / 21.7 us and 4096^2 9.3 / 9.2 / 8.6 / 8.6 us for 1 / 2 / 4 / 8 tiles per workgroup; f32 out is best at 1 (46.7 us
+  // vs 48.9 at 4: twice the store bytes per tile already); a non-temporal load of the packed words is no gain (DALM_NF4_NT=1)
+  int steps = steps_env > 0 ? steps_env : ((dtype == DALM_BF16 && threads >= 256 * 4 * 2048) ? 4 : 1);
+  if (steps != 1 && steps != 2 && steps != 8) steps = 4;
+  const int64_t blocks = (threads + 256 * steps - 1) / (256 * steps);
   DALM_REQUIRE(blocks <= 0x7fffffffLL, DALM_E_SHAPE, "n too large for one launch");
-  if (dtype == DALM_F32)
-    hipLaunchKernelGGL(nf4_dequantize_kernel<float>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, as_stream(stream),
-                       packed, absmax, n, static_cast<float*>(out));
-  else
-    hipLaunchKernelGGL(nf4_dequantize_kernel<unsigned short>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
-                       as_stream(stream), packed, absmax, n, static_cast<unsigned short*>(out));
+  static const bool ntl = [] { const char* e = getenv("DALM_NF4_NT"); return e && atoi(e) != 0; }();
+#define DALM_NF4_DEQ(TT, S) \
+  if (ntl) hipLaunchKernelGGL((nf4_dequantize_kernel<TT, S, true>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, \
+                              as_stream(stream), packed, absmax, n, static_cast<TT*>(out)); \
+  else hipLaunchKernelGGL((nf4_dequantize_kernel<TT, S, false>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, \
+                          as_stream(stream), packed, absmax, n, static_cast<TT*>(out))
+#define DALM_NF4_DEQ_S(TT) \
+  switch (steps) { case 1: DALM_NF4_DEQ(TT, 1); break; case 2: DALM_NF4_DEQ(TT, 2); break; case 8: DALM_NF4_DEQ(TT, 8); break; \
+                   default: DALM_NF4_DEQ(TT, 4); break; }
+  if (dtype == DALM_F32) { DALM_NF4_DEQ_S(float) } else { DALM_NF4_DEQ_S(unsigned short) }
+#undef DALM_NF4_DEQ_S
+#undef DALM_NF4_DEQ
   return check_launch(__func__);
 }

@@ -193,6 +193,17 @@ def bench_nf4(rows, cols, dtype):
     p, a = nf4.quantize(w)
     med, _ = time_fn(lambda: nf4.dequantize(p, a, (rows, cols), dtype))
     out["dequantize"] = {"s": med, "GBps": b / med / 1e9, "frac": b / med / HBM_PEAK}
+    # as the step runs it: inside a hipGraph (no host time), a DIFFERENT weight every call (8 layers' worth, so the packed
+    # input of a call was not just read by the previous one)
+    ws = [nf4.quantize((torch.randn(rows, cols, device=dev) * 0.02).to(dtype)) for _ in range(8)]
+
+    def sweep():
+        for pk, am in ws:
+            nf4.dequantize(pk, am, (rows, cols), dtype)
+
+    med, _ = time_graph(sweep, reps=4)
+    med /= len(ws)
+    out["dequantize (graph, 8 weights in turn)"] = {"s": med, "GBps": b / med / 1e9, "frac": b / med / HBM_PEAK}
     return out
 
 
