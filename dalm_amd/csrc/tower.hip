@@ -1,0 +1,297 @@
+// dalm_rope_qk / dalm_swiglu_*: the two elementwise chains of a Llama-family generator layer that the step spends the most
+// launches on, each as ONE streaming kernel per direction (gfx950).
+//
+// The reference runs its generator through transformers (dalm/models/rag_e2e_base_model.py:104-106 ->
+// transformers/models/llama/modeling_llama.py): apply_rotary_pos_emb is  q*cos + rotate_half(q)*sin  for q and k
+// (8 eager launches forward, ~14 backward per layer) and LlamaMLP is  down(silu(gate(x)) * up(x))  (2 forward, 4 backward,
+// plus a saved [tokens, intermediate] activation).  Both are pure HBM streams; measured in the cfg3 step they were ~12 ms +
+// ~5 ms of 175 ms (profiles/r04_bench_step_kernel_stats.txt: roll / addcmul / MulFunctor / silu / silu_backward rows).
+//
+// Rounding contract: torch evaluates every eager elementwise op in f32 and rounds its result to the tensor dtype.  These
+// kernels round at exactly the same points (rb() below: a bf16 round trip for bf16 tensors, the identity for f32; separate
+// mul / add, never a fused multiply-add), so forward AND backward results are the values the eager chain - and autograd's
+// backward of it - produce, not merely close to them.
+//   rope forward :  o1 = rb(rb(x1 c1) - rb(x2 s1))          o2 = rb(rb(x2 c2) + rb(x1 s2))        (halves 1 | 2 of head_dim)
+//   rope backward:  d1 = rb(rb(g1 c1) + rb(g2 s2))          d2 = rb(rb(g2 c2) - rb(g1 s1))
+//   swiglu forward :  s = rb(g / (1 + exp(-g)));  a = rb(s u)
+//   swiglu backward:  ds = rb(da u);  du = rb(da s);  sig = 1 / (1 + exp(-g));  dg = rb(ds sig (1 + g (1 - sig)))
+// Algorithmic bytes: rope 2 * (|q| + |k|) * el (+ cos/sin, shared by all heads); swiglu forward 3 * n * el, backward 5 * n * el.
+#include "common.hpp"
+
+namespace dalm {
+namespace {
+
+struct bf16_t { unsigned short v; };
+
+template <typename T> struct EV;
+template <> struct EV<float> {
+  static constexpr int VEC = 4;
+  __device__ static __forceinline__ float rb(float x) { return x; }
+  __device__ static __forceinline__ void load(const float* p, float (&x)[4]) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+  }
+  __device__ static __forceinline__ void store(float* p, const float (&x)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(x[0], x[1], x[2], x[3]);
+  }
+  __device__ static __forceinline__ float load1(const float* p) { return *p; }
+  __device__ static __forceinline__ void store1(float* p, float x) { *p = x; }
+};
+template <> struct EV<bf16_t> {
+  static constexpr int VEC = 8;
+  __device__ static __forceinline__ float rb(float x) { return bf16_to_f32(f32_to_bf16(x)); }
+  __device__ static __forceinline__ void load(const bf16_t* p, float (&x)[8]) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      x[2 * i] = __uint_as_float(w[i] << 16);
+      x[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  __device__ static __forceinline__ void store(bf16_t* p, const float (&x)[8]) {   // x already on the bf16 grid
+    uint4 o;
+    o.x = pack_bf16x2(x[0], x[1]); o.y = pack_bf16x2(x[2], x[3]);
+    o.z = pack_bf16x2(x[4], x[5]); o.w = pack_bf16x2(x[6], x[7]);
+    *reinterpret_cast<uint4*>(p) = o;
+  }
+  __device__ static __forceinline__ float load1(const bf16_t* p) { return bf16_to_f32(p->v); }
+  __device__ static __forceinline__ void store1(bf16_t* p, float x) { p->v = f32_to_bf16(x); }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// rotary embedding of q and k in one launch.  Tensors are [B, H, T, hd] VIEWS with arbitrary (b, h, t) strides and a
+// contiguous last dimension (transformers hands over transposed views of the [B, T, H*hd] projections); cos / sin are
+// [B, T, hd] with (b, t) strides.  A row = one (b, t, head); rows are walked head-fastest, the memory order of those views.
+// ---------------------------------------------------------------------------------------------------
+struct RopeTensor { const void* x; void* o; int64_t xs[3]; int64_t os[3]; };   // strides of (b, h, t) in elements
+struct RopeParams {
+  RopeTensor q, k;
+  const void* cos; const void* sin; int64_t cs[2];   // strides of (b, t)
+  int B, T, Hq, Hk, hd, backward;
+};
+
+template <typename T, bool VECTOR>
+__global__ __launch_bounds__(256) void rope_qk_kernel(const RopeParams p) {
+#pragma clang fp contract(off)   // the eager chain is separate mul and add kernels: a fused multiply-add would round once less (f32)
+  constexpr int VEC = VECTOR ? EV<T>::VEC : 1;
+  const int h = p.hd >> 1;
+  const int tpr = h / VEC;                       // threads per row
+  const int64_t gid = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const int64_t row = gid / tpr;
+  const int c = static_cast<int>(gid - row * tpr) * VEC;
+  const int H = p.Hq + p.Hk;
+  const int64_t rows = static_cast<int64_t>(p.B) * p.T * H;
+  if (row >= rows) return;
+  const int hh = static_cast<int>(row % H);
+  const int64_t bt = row / H;
+  const int t = static_cast<int>(bt % p.T), b = static_cast<int>(bt / p.T);
+  const bool is_k = hh >= p.Hq;
+  const RopeTensor& R = is_k ? p.k : p.q;
+  const int head = is_k ? hh - p.Hq : hh;
+  const T* x = static_cast<const T*>(R.x) + b * R.xs[0] + head * R.xs[1] + t * R.xs[2] + c;
+  T* o = static_cast<T*>(R.o) + b * R.os[0] + head * R.os[1] + t * R.os[2] + c;
+  const T* cs = static_cast<const T*>(p.cos) + b * p.cs[0] + t * p.cs[1] + c;
+  const T* sn = static_cast<const T*>(p.sin) + b * p.cs[0] + t * p.cs[1] + c;
+  float x1[VEC], x2[VEC], c1[VEC], c2[VEC], s1[VEC], s2[VEC], o1[VEC], o2[VEC];
+  if constexpr (VECTOR) {
+    EV<T>::load(x, x1); EV<T>::load(x + h, x2);
+    EV<T>::load(cs, c1); EV<T>::load(cs + h, c2);
+    EV<T>::load(sn, s1); EV<T>::load(sn + h, s2);
+  } else {
+    x1[0] = EV<T>::load1(x); x2[0] = EV<T>::load1(x + h);
+    c1[0] = EV<T>::load1(cs); c2[0] = EV<T>::load1(cs + h);
+    s1[0] = EV<T>::load1(sn); s2[0] = EV<T>::load1(sn + h);
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    // plain operators on purpose: the contract(off) pragma above governs THIS function's operations (the __f*_rn helpers are
+    // inlined from a header compiled with contraction allowed and would fuse)
+    const float a1 = EV<T>::rb(x1[e] * c1[e]), a2 = EV<T>::rb(x2[e] * c2[e]);
+    if (!p.backward) {
+      const float b1 = EV<T>::rb(x2[e] * s1[e]), b2 = EV<T>::rb(x1[e] * s2[e]);
+      o1[e] = EV<T>::rb(a1 - b1);
+      o2[e] = EV<T>::rb(a2 + b2);
+    } else {
+      const float b1 = EV<T>::rb(x2[e] * s2[e]), b2 = EV<T>::rb(x1[e] * s1[e]);
+      o1[e] = EV<T>::rb(a1 + b1);
+      o2[e] = EV<T>::rb(a2 - b2);
+    }
+  }
+  if constexpr (VECTOR) {
+    EV<T>::store(o, o1); EV<T>::store(o + h, o2);
+  } else {
+    EV<T>::store1(o, o1[0]); EV<T>::store1(o + h, o2[0]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// SwiGLU over n contiguous elements.  A workgroup walks STEPS tiles of 256*VEC elements with every load issued before the
+// first store (single-tile workgroups are bound by workgroup dispatch at this size: profiles/r04_nf4_steps.txt).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + expf(-x)); }
+
+template <typename T, int STEPS>
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const T* __restrict__ g, const T* __restrict__ u, T* __restrict__ a,
+                                                         int64_t n) {
+  constexpr int VEC = EV<T>::VEC;
+  const int64_t base = (static_cast<int64_t>(blockIdx.x) * STEPS * 256 + threadIdx.x) * VEC;
+  float gv[STEPS][VEC], uv[STEPS][VEC];
+#pragma unroll
+  for (int k = 0; k < STEPS; ++k) {
+    const int64_t e0 = base + static_cast<int64_t>(k) * 256 * VEC;
+    if (e0 + VEC <= n) { EV<T>::load(g + e0, gv[k]); EV<T>::load(u + e0, uv[k]); }
+    else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        gv[k][e] = e0 + e < n ? EV<T>::load1(g + e0 + e) : 0.f;
+        uv[k][e] = e0 + e < n ? EV<T>::load1(u + e0 + e) : 0.f;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < STEPS; ++k) {
+    const int64_t e0 = base + static_cast<int64_t>(k) * 256 * VEC;
+    if (e0 >= n) continue;
+    float o[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o[e] = EV<T>::rb(__fmul_rn(EV<T>::rb(silu_f32(gv[k][e])), uv[k][e]));
+    if (e0 + VEC <= n) EV<T>::store(a + e0, o);
+    else
+      for (int e = 0; e < VEC && e0 + e < n; ++e) EV<T>::store1(a + e0 + e, o[e]);
+  }
+}
+
+template <typename T, int STEPS>
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const T* __restrict__ da, const T* __restrict__ g,
+                                                         const T* __restrict__ u, T* __restrict__ dg, T* __restrict__ du,
+                                                         int64_t n) {
+  constexpr int VEC = EV<T>::VEC;
+  const int64_t base = (static_cast<int64_t>(blockIdx.x) * STEPS * 256 + threadIdx.x) * VEC;
+  float av[STEPS][VEC], gv[STEPS][VEC], uv[STEPS][VEC];
+#pragma unroll
+  for (int k = 0; k < STEPS; ++k) {
+    const int64_t e0 = base + static_cast<int64_t>(k) * 256 * VEC;
+    if (e0 + VEC <= n) { EV<T>::load(da + e0, av[k]); EV<T>::load(g + e0, gv[k]); EV<T>::load(u + e0, uv[k]); }
+    else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const bool ok = e0 + e < n;
+        av[k][e] = ok ? EV<T>::load1(da + e0 + e) : 0.f;
+        gv[k][e] = ok ? EV<T>::load1(g + e0 + e) : 0.f;
+        uv[k][e] = ok ? EV<T>::load1(u + e0 + e) : 0.f;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < STEPS; ++k) {
+    const int64_t e0 = base + static_cast<int64_t>(k) * 256 * VEC;
+    if (e0 >= n) continue;
+    float og[VEC], ou[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float x = gv[k][e];
+      const float s = EV<T>::rb(silu_f32(x));                       // the activation the eager chain saved
+      const float ds = EV<T>::rb(__fmul_rn(av[k][e], uv[k][e]));
+      ou[e] = EV<T>::rb(__fmul_rn(av[k][e], s));
+      const float sig = 1.0f / (1.0f + expf(-x));
+      og[e] = EV<T>::rb(ds * sig * (1.0f + x * (1.0f - sig)));      // torch's silu_backward expression, contraction as compiled
+    }
+    if (e0 + VEC <= n) { EV<T>::store(dg + e0, og); EV<T>::store(du + e0, ou); }
+    else
+      for (int e = 0; e < VEC && e0 + e < n; ++e) { EV<T>::store1(dg + e0 + e, og[e]); EV<T>::store1(du + e0 + e, ou[e]); }
+  }
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+}  // namespace dalm
+
+using namespace dalm;
+
+extern "C" int dalm_rope_qk(const void* q, const void* k, void* q_out, void* k_out, const void* cos, const void* sin, int dtype,
+                            int64_t B, int64_t T, int64_t Hq, int64_t Hk, int64_t hd, const int64_t* q_strides,
+                            const int64_t* k_strides, const int64_t* qo_strides, const int64_t* ko_strides,
+                            const int64_t* cs_strides, int backward, dalm_stream_t stream) {
+  DALM_REQUIRE(q && k && q_out && k_out && cos && sin && q_strides && k_strides && qo_strides && ko_strides && cs_strides,
+               DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(dtype == DALM_F32 || dtype == DALM_BF16, DALM_E_DTYPE, "dtype must be DALM_F32 or DALM_BF16");
+  DALM_REQUIRE(B > 0 && T > 0 && Hq > 0 && Hk >= 0 && hd >= 2 && hd % 2 == 0 && hd <= 4096 && Hq + Hk <= 65535,
+               DALM_E_SHAPE, "need B, T, Hq > 0, Hk >= 0, even 2 <= head_dim <= 4096");
+  const int64_t rows = B * T * (Hq + Hk);
+  DALM_REQUIRE(rows * (hd / 2) < (1ll << 40), DALM_E_SHAPE, "tensor too large for one launch");
+  RopeParams p;
+  p.q.x = q; p.q.o = q_out; p.k.x = k; p.k.o = k_out;
+  const int vec = dtype == DALM_F32 ? 4 : 8;
+  bool vector = (hd / 2) % vec == 0 && al16(q) && al16(k) && al16(q_out) && al16(k_out) && al16(cos) && al16(sin);
+  for (int i = 0; i < 3; ++i) {
+    p.q.xs[i] = q_strides[i]; p.k.xs[i] = k_strides[i]; p.q.os[i] = qo_strides[i]; p.k.os[i] = ko_strides[i];
+    vector = vector && q_strides[i] % vec == 0 && k_strides[i] % vec == 0 && qo_strides[i] % vec == 0 && ko_strides[i] % vec == 0;
+  }
+  p.cos = cos; p.sin = sin; p.cs[0] = cs_strides[0]; p.cs[1] = cs_strides[1];
+  vector = vector && cs_strides[0] % vec == 0 && cs_strides[1] % vec == 0;
+  p.B = static_cast<int>(B); p.T = static_cast<int>(T); p.Hq = static_cast<int>(Hq); p.Hk = static_cast<int>(Hk);
+  p.hd = static_cast<int>(hd); p.backward = backward != 0;
+  const int64_t threads = rows * ((hd / 2) / (vector ? vec : 1));
+  const int64_t blocks = (threads + 255) / 256;
+  DALM_REQUIRE(blocks <= 0x7fffffffLL, DALM_E_SHAPE, "tensor too large for one launch");
+  const dim3 grid(static_cast<unsigned>(blocks));
+  hipStream_t s = as_stream(stream);
+  if (dtype == DALM_F32) {
+    if (vector) hipLaunchKernelGGL((rope_qk_kernel<float, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((rope_qk_kernel<float, false>), grid, dim3(256), 0, s, p);
+  } else {
+    if (vector) hipLaunchKernelGGL((rope_qk_kernel<bf16_t, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((rope_qk_kernel<bf16_t, false>), grid, dim3(256), 0, s, p);
+  }
+  return check_launch(__func__);
+}
+
+namespace {
+constexpr int kSwigluSteps = 4;
+inline int64_t swiglu_blocks(int64_t n, int vec) {
+  const int64_t per = static_cast<int64_t>(kSwigluSteps) * 256 * vec;
+  return (n + per - 1) / per;
+}
+}  // namespace
+
+extern "C" int dalm_swiglu_fwd(const void* gate, const void* up, void* act, int dtype, int64_t n, dalm_stream_t stream) {
+  DALM_REQUIRE(n >= 0, DALM_E_SHAPE, "n must be >= 0");
+  if (n == 0) return 0;
+  DALM_REQUIRE(gate && up && act, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(dtype == DALM_F32 || dtype == DALM_BF16, DALM_E_DTYPE, "dtype must be DALM_F32 or DALM_BF16");
+  DALM_REQUIRE(al16(gate) && al16(up) && al16(act), DALM_E_ALIGN, "gate / up / act must be 16-byte aligned");
+  const int64_t blocks = swiglu_blocks(n, dtype == DALM_F32 ? 4 : 8);
+  DALM_REQUIRE(blocks <= 0x7fffffffLL, DALM_E_SHAPE, "n too large for one launch");
+  const dim3 grid(static_cast<unsigned>(blocks));
+  if (dtype == DALM_F32)
+    hipLaunchKernelGGL((swiglu_fwd_kernel<float, kSwigluSteps>), grid, dim3(256), 0, as_stream(stream),
+                       static_cast<const float*>(gate), static_cast<const float*>(up), static_cast<float*>(act), n);
+  else
+    hipLaunchKernelGGL((swiglu_fwd_kernel<bf16_t, kSwigluSteps>), grid, dim3(256), 0, as_stream(stream),
+                       static_cast<const bf16_t*>(gate), static_cast<const bf16_t*>(up), static_cast<bf16_t*>(act), n);
+  return check_launch(__func__);
+}
+
+extern "C" int dalm_swiglu_bwd(const void* d_act, const void* gate, const void* up, void* d_gate, void* d_up, int dtype,
+                               int64_t n, dalm_stream_t stream) {
+  DALM_REQUIRE(n >= 0, DALM_E_SHAPE, "n must be >= 0");
+  if (n == 0) return 0;
+  DALM_REQUIRE(d_act && gate && up && d_gate && d_up, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(dtype == DALM_F32 || dtype == DALM_BF16, DALM_E_DTYPE, "dtype must be DALM_F32 or DALM_BF16");
+  DALM_REQUIRE(al16(d_act) && al16(gate) && al16(up) && al16(d_gate) && al16(d_up), DALM_E_ALIGN,
+               "all tensors must be 16-byte aligned");
+  const int64_t blocks = swiglu_blocks(n, dtype == DALM_F32 ? 4 : 8);
+  DALM_REQUIRE(blocks <= 0x7fffffffLL, DALM_E_SHAPE, "n too large for one launch");
+  const dim3 grid(static_cast<unsigned>(blocks));
+  if (dtype == DALM_F32)
+    hipLaunchKernelGGL((swiglu_bwd_kernel<float, kSwigluSteps>), grid, dim3(256), 0, as_stream(stream),
+                       static_cast<const float*>(d_act), static_cast<const float*>(gate), static_cast<const float*>(up),
+                       static_cast<float*>(d_gate), static_cast<float*>(d_up), n);
+  else
+    hipLaunchKernelGGL((swiglu_bwd_kernel<bf16_t, kSwigluSteps>), grid, dim3(256), 0, as_stream(stream),
+                       static_cast<const bf16_t*>(d_act), static_cast<const bf16_t*>(gate), static_cast<const bf16_t*>(up),
+                       static_cast<bf16_t*>(d_gate), static_cast<bf16_t*>(d_up), n);
+  return check_launch(__func__);
+}

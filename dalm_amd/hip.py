@@ -87,6 +87,9 @@ SIGNATURES = {
     "dalm_nf4_absmax_count": (_sz, [_i64]),
     "dalm_nf4_quantize": (_int, [_vp, _int, _i64, _vp, _vp, _vp]),
     "dalm_nf4_dequantize": (_int, [_vp, _vp, _i64, _int, _vp, _vp]),
+    "dalm_rope_qk": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _int, _vp]),
+    "dalm_swiglu_fwd": (_int, [_vp, _vp, _vp, _int, _i64, _vp]),
+    "dalm_swiglu_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]),
 }
 
 

@@ -1,4 +1,5 @@
-"""Plumbing-level speed-ups of the HF towers that keep the math: no new kernels, only PyTorch-ROCm natives.
+"""Speed-ups of the HF towers that keep the math: PyTorch-ROCm natives, and (round 4) two HIP kernels for the elementwise
+chains of a Llama-family layer the step spent the most launches on (rotary embedding, SwiGLU: `tower_ops.py`).
 
 `use_native_rms_norm(model)`: transformers' *RMSNorm modules (Llama, Mistral, ...) spell the norm as
 ~7 eager elementwise kernels forward and ~10 backward (upcast, pow, mean, rsqrt, mul, downcast, mul).
@@ -56,10 +57,23 @@ def _rope_roll(q, k, cos, sin, position_ids=None, unsqueeze_dim=1):
     return q_embed, k_embed
 
 
+def _rope_hip(q, k, cos, sin, position_ids=None, unsqueeze_dim=1):
+    """transformers' apply_rotary_pos_emb as one HIP launch for q and k together (`dalm_rope_qk`, one more in the backward),
+    rounding where the eager chain rounds: same values and gradients as transformers' own code (round 4; the roll + addcmul
+    form above was 6 launches forward / 8 backward per layer and rounded once less than transformers does).
+    DALM_ROPE_KERNEL=0 keeps the roll form; CPU tensors and layouts the kernel does not take use it as well."""
+    from . import tower_ops
+
+    if unsqueeze_dim == 1 and tower_ops.rope_supported(q, k, cos, sin):
+        return tower_ops.rope_qk(q, k, cos, sin)
+    return _rope_roll(q, k, cos, sin, position_ids, unsqueeze_dim)
+
+
 def use_roll_rope(model: torch.nn.Module) -> bool:
     """Swap the module-level apply_rotary_pos_emb of the model's own modeling file (Llama family only)."""
     if os.environ.get("DALM_FAST_ROPE", "1") == "0":
         return False
+    fn = _rope_roll if os.environ.get("DALM_ROPE_KERNEL", "1") == "0" else _rope_hip
     import importlib
 
     mod_name = type(getattr(model, "base_model", model)).__module__
@@ -68,10 +82,43 @@ def use_roll_rope(model: torch.nn.Module) -> bool:
     mod = importlib.import_module(mod_name)
     if not hasattr(mod, "apply_rotary_pos_emb"):
         return False
-    if getattr(mod.apply_rotary_pos_emb, "__name__", "") != "_rope_roll":
+    if getattr(mod.apply_rotary_pos_emb, "__name__", "") not in ("_rope_roll", "_rope_hip"):
         mod._dalm_orig_apply_rotary_pos_emb = mod.apply_rotary_pos_emb
-        mod.apply_rotary_pos_emb = _rope_roll
+    mod.apply_rotary_pos_emb = fn
     return True
+
+
+# ---------------------------------------------------------------------------
+# SwiGLU MLP: silu(gate) * up as one launch per direction, no saved activation
+# ---------------------------------------------------------------------------
+def _swiglu_mlp_forward(self, x):
+    from . import tower_ops
+
+    gate, up = self.gate_proj(x), self.up_proj(x)
+    if tower_ops.swiglu_supported(gate, up):
+        return self.down_proj(tower_ops.swiglu(gate, up))
+    return self.down_proj(self.act_fn(gate) * up)
+
+
+def use_swiglu_kernel(model: torch.nn.Module) -> int:
+    """Patch the `*MLP` modules that are exactly transformers' LlamaMLP formula - down(act(gate(x)) * up(x)) with
+    act = SiLU - to evaluate silu(gate) * up through `dalm_swiglu_{fwd,bwd}`: 2 eager launches forward and 4 backward
+    become 1 + 1, and the [tokens, intermediate] activation is recomputed instead of saved (101 MB per layer at cfg3).
+    Same rounding points as the eager chain.  DALM_SWIGLU_KERNEL=0 disables; returns how many modules were patched."""
+    if os.environ.get("DALM_SWIGLU_KERNEL", "1") == "0":
+        return 0
+    n = 0
+    for mod in model.modules():
+        if type(mod).__name__ not in ("LlamaMLP", "MistralMLP", "Qwen2MLP"):
+            continue
+        act = getattr(mod, "act_fn", None)
+        if not all(hasattr(mod, a) for a in ("gate_proj", "up_proj", "down_proj")):
+            continue
+        if not (isinstance(act, torch.nn.SiLU) or type(act).__name__ in ("SiLUActivation", "SiLU")):
+            continue
+        mod.forward = types.MethodType(_swiglu_mlp_forward, mod)
+        n += 1
+    return n
 
 
 # ---------------------------------------------------------------------------

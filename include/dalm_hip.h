@@ -406,6 +406,28 @@ int dalm_nf4_quantize(const void* w, int dtype, int64_t n, uint8_t* packed, floa
 int dalm_nf4_dequantize(const uint8_t* packed, const float* absmax, int64_t n, int dtype, void* out,
                         dalm_stream_t stream);
 
+/* ---- generator-tower elementwise chains (Llama family) ---------------------------------------------------------
+ * The reference runs the generator through transformers (dalm/models/rag_e2e_base_model.py:104-106 calls
+ * `self.generator_model(...)`); inside, every decoder layer evaluates
+ *   apply_rotary_pos_emb:  q*cos + rotate_half(q)*sin  for q and k   (modeling_llama.py, 8 eager launches + ~14 backward)
+ *   LlamaMLP:              down(silu(gate(x)) * up(x))               (2 eager launches + 4 backward, one saved activation)
+ * as chains of elementwise torch ops.  These entry points evaluate each chain in ONE streaming launch per direction and
+ * round at exactly the points the eager chain (and autograd's backward of it) rounds, so results are the same values.
+ *
+ * dalm_rope_qk: q / k / outputs are [B, H, T, hd] views with element strides {b, h, t} and a contiguous last dimension;
+ *   cos / sin are [B, T, hd] with element strides {b, t}.  backward != 0: q / k are the gradients of the outputs and the
+ *   outputs receive the gradients of the inputs.  Vector path when hd/2 is a multiple of 16 bytes' worth of elements and all
+ *   pointers / strides are 16-byte aligned; any even hd otherwise.
+ * dalm_swiglu_fwd:  act = silu(gate) * up over n contiguous elements.
+ * dalm_swiglu_bwd:  d_gate, d_up from d_act, gate, up (the activation is recomputed, nothing is saved by the forward). */
+int dalm_rope_qk(const void* q, const void* k, void* q_out, void* k_out, const void* cos, const void* sin, int dtype,
+                 int64_t B, int64_t T, int64_t Hq, int64_t Hk, int64_t hd, const int64_t* q_strides,
+                 const int64_t* k_strides, const int64_t* qo_strides, const int64_t* ko_strides,
+                 const int64_t* cs_strides, int backward, dalm_stream_t stream);
+int dalm_swiglu_fwd(const void* gate, const void* up, void* act, int dtype, int64_t n, dalm_stream_t stream);
+int dalm_swiglu_bwd(const void* d_act, const void* gate, const void* up, void* d_gate, void* d_up, int dtype, int64_t n,
+                    dalm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

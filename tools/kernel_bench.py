@@ -207,6 +207,40 @@ def bench_nf4(rows, cols, dtype):
     return out
 
 
+def bench_tower(B, T, H, hd, inter, dtype):
+    """The two elementwise chains of a Llama-family generator layer: dalm_rope_qk / dalm_swiglu_* against the eager chains
+    they replace (transformers' apply_rotary_pos_emb as the step ran it before - roll + addcmul - and silu(gate) * up)."""
+    from dalm_amd.models import fastpath, tower_ops
+
+    dev = torch.device("cuda:0")
+    el = torch.empty((), dtype=dtype).element_size()
+    q = torch.randn(B, T, H * hd, device=dev, dtype=dtype).view(B, T, H, hd).transpose(1, 2)
+    k = torch.randn(B, T, H * hd, device=dev, dtype=dtype).view(B, T, H, hd).transpose(1, 2)
+    cos, sin = torch.rand(B, T, hd, device=dev, dtype=dtype), torch.rand(B, T, hd, device=dev, dtype=dtype)
+    out = {}
+    b = 4 * q.numel() * el + 2 * cos.numel() * el
+    med, _ = time_graph(lambda: tower_ops._rope_launch(q, k, cos, sin, False))
+    out["rope fwd (1 launch)"] = {"s": med, "GBps": b / med / 1e9, "frac": b / med / HBM_PEAK}
+    med, _ = time_graph(lambda: tower_ops._rope_launch(q, k, cos, sin, True))
+    out["rope bwd (1 launch)"] = {"s": med, "GBps": b / med / 1e9, "frac": b / med / HBM_PEAK}
+    med, _ = time_graph(lambda: fastpath._rope_roll(q, k, cos, sin))
+    out["rope fwd eager (roll+addcmul)"] = {"s": med, "GBps": b / med / 1e9, "frac": b / med / HBM_PEAK}
+    n = B * T * inter
+    gate, up, da = (torch.randn(B * T, inter, device=dev, dtype=dtype) for _ in range(3))
+    act, dg, du = torch.empty_like(gate), torch.empty_like(gate), torch.empty_like(gate)
+    from dalm_amd import hip
+
+    code = hip.dtype_code(gate)
+    med, _ = time_graph(lambda: hip.call("dalm_swiglu_fwd", hip.ptr(gate), hip.ptr(up), hip.ptr(act), code, n, hip.stream()))
+    out["swiglu fwd (1 launch)"] = {"s": med, "GBps": 3 * n * el / med / 1e9, "frac": 3 * n * el / med / HBM_PEAK}
+    med, _ = time_graph(lambda: hip.call("dalm_swiglu_bwd", hip.ptr(da), hip.ptr(gate), hip.ptr(up), hip.ptr(dg), hip.ptr(du),
+                                         code, n, hip.stream()))
+    out["swiglu bwd (1 launch)"] = {"s": med, "GBps": 5 * n * el / med / 1e9, "frac": 5 * n * el / med / HBM_PEAK}
+    med, _ = time_graph(lambda: torch.nn.functional.silu(gate) * up)
+    out["swiglu fwd eager (2 launches)"] = {"s": med, "GBps": 3 * n * el / med / 1e9, "frac": 3 * n * el / med / HBM_PEAK}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
@@ -254,6 +288,8 @@ def main():
         res["nf4 11008x4096 -> bf16"] = bench_nf4(11008, 4096, torch.bfloat16)
         res["nf4 4096x4096 -> bf16"] = bench_nf4(4096, 4096, torch.bfloat16)
         res["nf4 11008x4096 -> f32"] = bench_nf4(11008, 4096, torch.float32)
+    if args.only in ("", "tower"):
+        res["tower cfg3 layer: rope [18,32,256,128] + swiglu [4608,11008] bf16"] = bench_tower(18, 256, 32, 128, 11008, torch.bfloat16)
     for k, v in res.items():
         print(k)
         for kk, vv in v.items():
