@@ -27,6 +27,19 @@ def _free_port() -> int:
     return port
 
 
+def _spawn(fn, world, *rest):
+    """mp.spawn(fn, (world, <free port>, *rest)); one retry on a fresh port: the port found by _free_port() is released
+    before the ranks bind it, and on a busy host something else can take it in between (seen once in ~30 suite runs)."""
+    for attempt in (0, 1):
+        try:
+            mp.spawn(fn, args=(world, _free_port()) + tuple(rest), nprocs=world, join=True)
+            return
+        except Exception as e:                      # ProcessRaisedException / ProcessExitedException
+            text = str(e).lower()
+            if attempt == 1 or not any(w in text for w in ("address already in use", "socket", "connection", "tcpstore")):
+                raise
+
+
 def _worker(rank, world, port, mode, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
@@ -80,8 +93,7 @@ def test_ranks_equal_one_process_at_global_batch(tmp_path, mode, world):
     import dalm_oracle as O
     from helpers import synth_batch
 
-    port = _free_port()
-    mp.spawn(_worker, args=(world, port, mode, str(tmp_path)), nprocs=world, join=True)
+    _spawn(_worker, world, mode, str(tmp_path))
     res = [torch.load(tmp_path / f"r{r}.pt") for r in range(world)]
 
     # single process at the global batch, reference op sequence in fp64
@@ -153,8 +165,7 @@ def _bucket_worker(rank, world, port, out_dir):
 def test_overlapped_grad_buckets_fixed_launch_order(tmp_path):
     """Hook-driven bucketed all-reduce: SUM over ranks in every view, unused parameters flushed, and the same
     launch order (descending bucket index) on every rank and every step whatever order the hooks fire in."""
-    port = _free_port()
-    mp.spawn(_bucket_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    _spawn(_bucket_worker, 2, str(tmp_path))
     l0, l1 = torch.load(tmp_path / "log0.pt"), torch.load(tmp_path / "log1.pt")
     assert l0 == l1 == [[2, 1, 0], [2, 1, 0]]
 
@@ -188,8 +199,7 @@ def test_gradient_accumulation_with_two_ranks_reduces_once_per_optimizer_step(tm
     """`--gradient_accumulation_steps 2` at W = 2 (reference: accelerate's accumulate(), train_rage2e.py:431): micro-batch
     gradients (each scaled 1/N) add up locally, the cross-rank SUM runs once, on the step that takes the update - an
     all-reduce per micro-batch would count the earlier micro-batches W times."""
-    port = _free_port()
-    mp.spawn(_accum_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    _spawn(_accum_worker, 2, str(tmp_path))
     r0, r1 = torch.load(tmp_path / "acc0.pt"), torch.load(tmp_path / "acc1.pt")
     assert [s for s, _ in r0["seen"]] == [False, True, False, True]
     # d(sum(model(x)))/dW[o, i] = sum_b x[b, i] = 2 * value; optimizer step 1 sees micro 0 + 1 of both ranks, each / 2
@@ -293,7 +303,7 @@ def test_sharded_async_checkpoint_roundtrip(tmp_path):
     loading merges the shards; values are those at submit time, not whatever training did afterwards."""
     from dalm_amd.training import common
 
-    mp.spawn(_ckpt_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    _spawn(_ckpt_worker, 2, str(tmp_path))
     d = tmp_path / "step_3"
     assert sorted(p.name for p in d.iterdir()) == ["models_written_by_rank0", "optimizer-00000-of-00002.pt",
                                                    "optimizer-00001-of-00002.pt", "trainer_state.pt"]
@@ -415,7 +425,7 @@ def _rdv_worker(rank, world, port, out_dir, fail_on):
 def test_native_comm_rendezvous_and_all_or_none_fallback(tmp_path, fail_on):
     """Both ranks get rank 0's unique id through the store; when ONE rank's communicator fails its self-test, BOTH ranks
     drop the native communicator (the healthy one is closed) and meet again in torch.distributed on the same port."""
-    mp.spawn(_rdv_worker, args=(2, _free_port(), str(tmp_path), fail_on), nprocs=2, join=True)
+    _spawn(_rdv_worker, 2, str(tmp_path), fail_on)
     res = [torch.load(tmp_path / f"r{r}.pt") for r in range(2)]
     if fail_on == "rank0-early":       # rank 1 is told at once that no id will come (no 120 s timeout), both fall back
         assert not any(r["native"] for r in res) and all(r["fallback_sum"] == 3.0 for r in res)
