@@ -19,6 +19,8 @@ from typing import Dict, Iterable, List
 import torch
 from torch import nn
 
+# DALM_LORA_KERNEL=0: keep the eager branch (dropout, two skinny GEMMs, an add) on the GPU too
+_FUSED = os.environ.get("DALM_LORA_KERNEL", "1") != "0"
 ADAPTER_WEIGHTS = "adapter_model.bin"
 ADAPTER_CONFIG = "adapter_config.json"
 
@@ -36,6 +38,10 @@ class LoRALinear(nn.Module):
         nn.init.kaiming_uniform_(self.lora_A["default"].weight, a=math.sqrt(5))
         nn.init.zeros_(self.lora_B["default"].weight)
         self.merged = False
+        LoRALinear._count += 1
+        self._uid = LoRALinear._count
+
+    _count = 0
 
     @property
     def weight(self):  # some HF code peeks at .weight
@@ -54,10 +60,21 @@ class LoRALinear(nn.Module):
         return self.base_layer.out_features
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        out = self.base_layer(x)
         if self.merged:
-            return out
+            return self.base_layer(x)
         a, b = self.lora_A["default"], self.lora_B["default"]
+        if x.is_cuda and _FUSED:
+            from . import lora_ops
+
+            if lora_ops.supported(x, self.base_layer, a.weight, b.weight) and not self.base_layer.weight.requires_grad:
+                drop = self.lora_dropout["default"]
+                p = float(getattr(drop, "p", 0.0)) if self.training else 0.0
+                # salt: this module's id in the upper bits, a host call counter below it (graph replays re-use the captured
+                # salt; there the device-side seed word, advanced once per step, changes the masks)
+                self._calls = getattr(self, "_calls", 0) + 1
+                salt = (self._uid << 12) ^ (self._calls & 0xFFF)
+                return lora_ops.lora_linear(x, self.base_layer, a.weight, b.weight, self.scaling, p, salt)
+        out = self.base_layer(x)
         z = self.lora_dropout["default"](x)
         if not torch.is_autocast_enabled() and z.dtype != a.weight.dtype:
             z = z.to(a.weight.dtype)  # outside autocast the fp32 adapters need fp32 activations

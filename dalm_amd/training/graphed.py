@@ -221,8 +221,8 @@ class _GeneratorCall(torch.nn.Module):
 
     def _run(self, input_ids, attention_mask):
         if self.hidden_only:
-            return self.generator.base_model(input_ids=input_ids, attention_mask=attention_mask)[0]
-        return self.generator(input_ids=input_ids, attention_mask=attention_mask).logits
+            return self.generator.base_model(input_ids=input_ids, attention_mask=attention_mask, use_cache=False)[0]
+        return self.generator(input_ids=input_ids, attention_mask=attention_mask, use_cache=False).logits   # no KV cache copies
 
     def forward(self, input_ids, attention_mask):
         if self.autocast_dtype is None:

@@ -19,6 +19,17 @@ from ..fused import GatherHandle, LocalComm, contrastive_loss, rag_e2e_loss, rag
 from ..sharded import GradBucket, allreduce_grads
 
 
+
+def _advance_dropout(batch) -> None:
+    """New LoRA dropout masks for this step: one device op on the current stream (captured with the step when it runs as a
+    hipGraph, so every replay advances too).  See dalm_amd/models/lora_ops.py."""
+    t = next((v for v in batch.values() if torch.is_tensor(v)), None)
+    if t is not None and t.is_cuda:
+        from ..models import lora_ops
+
+        lora_ops.advance_dropout_seed(t.device)
+
+
 class _StepBase:
     def __init__(self, model, optimizer, lr_scheduler, logit_scale, comm=None, autocast_dtype=None, ops=None,
                  grad_overlap: bool = True, track_grad_norm: bool = False, grad_accum: int = 1):
@@ -181,13 +192,14 @@ class RagE2EStep(_StepBase):
             return m("generation", batch["generator_input_input_ids"], batch["generator_input_attention_mask"])
         gm = m.generator_model
         return gm.base_model(input_ids=batch["generator_input_input_ids"],
-                             attention_mask=batch["generator_input_attention_mask"])[0]
+                             attention_mask=batch["generator_input_attention_mask"], use_cache=False)[0]
 
     def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         m = self.model
         self.calls += 1
         self.graph_after = getattr(self, "graph_after", 2)
         self._maybe_build_towers(batch)
+        _advance_dropout(batch)
         with self._autocast():
             if self.tower_stream is not None:
                 cur = torch.cuda.current_stream()
@@ -238,6 +250,7 @@ class RetrieverStep(_StepBase):
 
     def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         m = self.model
+        _advance_dropout(batch)
         with self._autocast():
             if self.tower_stream is not None:
                 cur = torch.cuda.current_stream()

@@ -428,6 +428,32 @@ int dalm_swiglu_fwd(const void* gate, const void* up, void* act, int dtype, int6
 int dalm_swiglu_bwd(const void* d_act, const void* gate, const void* up, void* d_gate, void* d_up, int dtype, int64_t n,
                     dalm_stream_t stream);
 
+/* ---- the low-rank branch of a LoRA-wrapped Linear ----------------------------------------------------------------
+ * The reference wraps q_proj / v_proj (key / query / value for BERT retrievers) in peft LoRA adapters, r = 8, alpha = 16,
+ * dropout 0.05 (dalm/models/rag_e2e_base_model.py:145-160, retriever_only_base_model.py:92-107); peft evaluates
+ *   out = W x + s * B(A(dropout(x)))                                  (peft/tuners/lora/layer.py, Linear.forward)
+ * as eager ops and autograd differentiates it op by op.  With r <= 16 every tensor of the branch is [rows, r] or streams a
+ * [rows, K] activation once; the three entry points below are the branch and its backward as HBM-bound kernels:
+ *   dalm_lora_rowdot :  out[row, j]  = scale * sum_k m x[row, k] W(j, k)       z = dropout(x) A^T / (1-p);  dz = s g B
+ *   dalm_lora_rankupd:  y[row, c]   += scale * m * sum_j z[row, j] W(j, c)     out += s z B^T;  dx += m (dz A) / (1-p)
+ *   dalm_lora_colacc :  out(j, c)    = scale * sum_row m x[row, c] z[row, j]   dB = s g^T z;  dA = dz^T (m x) / (1-p)
+ * x / y: [R, K|C] row-major, `dtype` DALM_F32 or DALM_BF16, 16-byte aligned, column count a multiple of 8.  W, z, out: f32.
+ *   rowdot : w_kmajor != 0 reads W as [rank][K] (lora_A.weight), 0 as [K][rank] (lora_B.weight).
+ *   rankupd: w_cmajor != 0 reads W as [C][rank] (lora_B.weight), 0 as [rank][C] (lora_A.weight).
+ *   colacc : out_jmajor != 0 writes [rank][C] (the layout of lora_A.weight), 0 writes [C][rank] (lora_B.weight).
+ * rank: 8 or 16.  m: dropout keep mask with drop probability p (p = 0: no mask), never stored - a counter-based hash of
+ * (the 64-bit word at `seed`, a DEVICE pointer read when the kernel runs, NULL = 0; `salt`; the flat element index
+ * row * columns + column), so the three kernels regenerate the same mask for the same (seed, salt, shape).  1 / (1 - p) is the
+ * caller's business (fold it into `scale`).  All sums run in fixed orders: results are bit-reproducible. */
+int dalm_lora_rowdot(const void* x, int dtype, const float* W, int w_kmajor, int64_t R, int64_t K, int rank, float scale,
+                     float p, const void* seed, uint32_t salt, float* out, dalm_stream_t stream);
+int dalm_lora_rankupd(void* y, int dtype, const float* z, const float* W, int w_cmajor, int64_t R, int64_t C, int rank,
+                      float scale, float p, const void* seed, uint32_t salt, dalm_stream_t stream);
+size_t dalm_lora_colacc_workspace_bytes(int64_t R, int64_t C, int rank);
+int dalm_lora_colacc(const void* x, int dtype, const float* z, int64_t R, int64_t C, int rank, float scale, float p,
+                     const void* seed, uint32_t salt, float* out, int out_jmajor, void* ws, size_t ws_bytes,
+                     dalm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

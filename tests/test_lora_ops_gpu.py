@@ -1,0 +1,169 @@
+"""`dalm_lora_{rowdot,rankupd,colacc}` (dalm_amd/csrc/lora.hip) and the fused LoRA Linear built on them, against the eager
+branch peft evaluates for the reference (dalm/models/rag_e2e_base_model.py:145-160: r = 8, alpha = 16, dropout 0.05):
+    out = W x + s * B(A(dropout(x)))
+* p = 0: outputs and all gradients against a float64 evaluation of that formula (f32: 2e-6 relative; bf16 tensors: the
+  branch is accumulated in f32 and rounded once, so it is at least as close to float64 as the eager bf16 chain is).
+* p > 0: the mask is never stored, three kernels regenerate it - adjoint identities <L x, u> = <x, L^T u> prove that forward,
+  dx and dA saw the SAME mask; keep rate and rescaling are checked statistically; the seed word changes the mask."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+SHAPES = [(4608, 4096, 4096, 8), (150 * 50, 1024, 1024, 8), (37, 64, 40, 8), (5, 4104, 8200, 8), (300, 96, 72, 16), (1, 8, 8, 16)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("R,K,N,rank", SHAPES)
+def test_kernels_vs_float64(dev, R, K, N, rank, dtype):
+    from dalm_amd.models import lora_ops as L
+
+    g = torch.Generator().manual_seed(R + K + N)
+    x = torch.randn(R, K, generator=g).to(dtype)
+    y = torch.randn(R, N, generator=g).to(dtype)
+    A = torch.randn(rank, K, generator=g) / K ** 0.5
+    Bm = torch.randn(N, rank, generator=g) / rank ** 0.5
+    xd, yd, Ad, Bd = (t.to(dev) for t in (x, y, A, Bm))
+    x64, y64, A64, B64 = (t.double() for t in (x, y, A, Bm))
+    tol = 2e-6
+    # rowdot, both weight layouts (bf16 rows with K % 32 == 0 run on the matrix cores with W split into bf16 high + low parts)
+    tol_rd = tol if dtype == torch.float32 else 2e-5
+    z = L._rowdot(xd, Ad, True, rank, 1.5, 0.0, None, 0)
+    assert _rel(z, 1.5 * x64 @ A64.t()) < tol_rd
+    dz = L._rowdot(yd, Bd, False, rank, 2.0, 0.0, None, 0)
+    assert _rel(dz, 2.0 * y64 @ B64) < tol_rd
+    # colacc, both output layouts
+    db = L._colacc(yd, z, rank, 2.0, 0.0, None, 0, False)
+    assert _rel(db, 2.0 * y64.t() @ z.double().cpu()) < tol
+    da = L._colacc(xd, dz, rank, 1.0, 0.0, None, 0, True)
+    assert _rel(da, dz.double().cpu().t() @ x64) < tol
+    # rankupd, both weight layouts (result rounded once to the tensor dtype)
+    rt = 1e-6 if dtype == torch.float32 else 4e-3
+    out = L._rankupd_(yd.clone(), z, Bd, True, rank, 2.0, 0.0, None, 0)
+    assert _rel(out, y64 + 2.0 * z.double().cpu() @ B64.t()) < rt
+    dx = L._rankupd_(xd.clone(), dz, Ad, False, rank, 0.5, 0.0, None, 0)
+    assert _rel(dx, x64 + 0.5 * dz.double().cpu() @ A64) < rt
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("R,K,rank", [(4608, 4096, 8), (333, 1024, 8), (64, 8200, 8), (200, 96, 16)])
+def test_dropout_mask_is_the_same_in_all_three_kernels(dev, R, K, rank, dtype):
+    """bf16 rows take the matrix-core rowdot (K % 32 == 0) and the VALU rankupd / colacc: three different code paths that have
+    to agree on every mask bit."""
+    from dalm_amd.models import lora_ops as L
+
+    # small-integer data and p = 0.5 (rescale 2): every product and sum is an exact integer in bf16 / f32 / the MFMA
+    # accumulator, so the adjoint identities hold EXACTLY if - and, for all practical purposes, only if - the three kernels
+    # kept the same elements
+    g = torch.Generator().manual_seed(R + K)
+    x = torch.randint(-2, 3, (R, K), generator=g).to(dtype).to(dev)
+    A = torch.randint(-1, 2, (rank, K), generator=g).float().to(dev)
+    u = torch.randint(-1, 2, (R, rank), generator=g).float().to(dev)
+    seed = L.dropout_seed(dev)
+    salt = 1234
+    z = L._rowdot(x, A, True, rank, 2.0, 0.5, seed, salt)                                        # L x
+    dx = L._rankupd_(torch.zeros(R, K, device=dev), u, A, False, rank, 2.0, 0.5, seed, salt)     # L^T u
+    da = L._colacc(x, u, rank, 2.0, 0.5, seed, salt, True)                                       # d <L x, u> / dA
+    lhs = float((z.double() * u.double()).sum())
+    assert lhs == float((x.double() * dx.double()).sum())
+    assert lhs == float((A.double() * da.double()).sum())
+    assert float(z.abs().sum()) > 0
+    p = 0.05
+    # keep rate: with A = ones and x = ones, z (1 - p) counts the survivors of each row
+    ones = torch.ones(R, K, device=dev, dtype=dtype)
+    cnt = L._rowdot(ones, torch.ones(rank, K, device=dev), True, rank, 1.0, p, seed, salt)[:, 0]
+    rate = float(cnt.sum()) / (R * K)
+    assert abs(rate - (1 - p)) < 4 * (p * (1 - p) / (R * K)) ** 0.5 + 1e-4, rate
+    # another salt, and an advanced seed word, give other masks; the same (seed, salt) gives the same one
+    again = L._rowdot(ones, torch.ones(rank, K, device=dev), True, rank, 1.0, p, seed, salt)[:, 0]
+    assert torch.equal(again, cnt)
+    other = L._rowdot(ones, torch.ones(rank, K, device=dev), True, rank, 1.0, p, seed, salt + 1)[:, 0]
+    assert not torch.equal(other, cnt) or K < 64
+    L.advance_dropout_seed(dev)
+    moved = L._rowdot(ones, torch.ones(rank, K, device=dev), True, rank, 1.0, p, seed, salt)[:, 0]
+    assert not torch.equal(moved, cnt) or K < 64
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16-autocast", "bf16-weights-autocast"])
+def test_fused_lora_linear_matches_the_eager_branch(dev, mode):
+    """LoRALinear through lora_ops (the GPU default) against the same module with DALM_LORA_KERNEL=0 semantics (its eager
+    branch), dropout off: outputs, dx, dA, dB."""
+    from dalm_amd.models import lora as lora_mod
+
+    torch.manual_seed(0)
+    K, N, R = 1024, 768, 300
+    base = torch.nn.Linear(K, N, bias=True)
+    mods = []
+    for fused in (False, True):
+        b = torch.nn.Linear(K, N, bias=True)
+        b.load_state_dict(base.state_dict())
+        if mode == "bf16-weights-autocast":
+            b = b.to(torch.bfloat16)
+        b.requires_grad_(False)
+        m = lora_mod.LoRALinear(b.to(dev), r=8, lora_alpha=16, lora_dropout=0.05).eval()     # eval: dropout off
+        mods.append(m)
+    mods[1].load_state_dict(mods[0].state_dict())
+    with torch.no_grad():
+        for m in mods:
+            m.lora_B["default"].weight.copy_(torch.randn(N, 8, generator=torch.Generator().manual_seed(1)) * 0.1)
+    x = torch.randn(4, R // 4, K, generator=torch.Generator().manual_seed(2)).to(dev)
+    up = torch.randn(4, R // 4, N, generator=torch.Generator().manual_seed(3)).to(dev)
+    res = []
+    for m, fused in zip(mods, (False, True)):
+        lora_mod._FUSED = fused
+        try:
+            xi = x.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode != "fp32"):
+                out = m(xi)
+            (out.float() * up).sum().backward()
+            res.append((out.detach().float(), xi.grad.float(), m.lora_A["default"].weight.grad.float(),
+                        m.lora_B["default"].weight.grad.float()))
+        finally:
+            lora_mod._FUSED = True
+    tol = 3e-6 if mode == "fp32" else 1.5e-2
+    for name, a, b in zip(("out", "dx", "dA", "dB"), res[1], res[0]):
+        assert _rel(a, b) < tol, f"{name}: {_rel(a, b):.2e}"
+    assert res[1][0].dtype == res[0][0].dtype
+
+
+def test_training_mode_draws_new_masks_per_step_and_backward_sees_the_forward_mask(dev):
+    from dalm_amd.models import lora as lora_mod
+    from dalm_amd.models import lora_ops as L
+
+    torch.manual_seed(0)
+    base = torch.nn.Linear(256, 256, bias=False).to(dev).requires_grad_(False)
+    with torch.no_grad():
+        base.weight.zero_()                                   # only the low-rank branch is left
+    m = lora_mod.LoRALinear(base, r=8, lora_alpha=16, lora_dropout=0.5).train()
+    with torch.no_grad():
+        m.lora_B["default"].weight.normal_()
+    x = torch.ones(64, 256, device=dev, requires_grad=True)
+    outs = []
+    for _ in range(2):
+        L.advance_dropout_seed(dev)
+        out = m(x)
+        outs.append(out.detach().clone())
+        x.grad = None
+        out.sum().backward()
+        # d out.sum() / dx[r, k] = mask[r, k] / (1 - p) * sum_c (s B A)[c, k]: zero exactly where the forward dropped x[r, k]
+        col = (m.scaling * m.lora_B["default"].weight @ m.lora_A["default"].weight).sum(0)          # [K]
+        mask = (x.grad / (col / 0.5)).round()
+        assert set(mask.unique().tolist()) <= {0.0, 1.0}
+        z_ref = (mask * x.detach() / 0.5) @ m.lora_A["default"].weight.t()
+        ref = m.scaling * z_ref @ m.lora_B["default"].weight.t()
+        torch.testing.assert_close(out.detach(), ref, rtol=1e-4, atol=1e-4)
+        assert 0.4 < float(mask.mean()) < 0.6
+    assert not torch.equal(outs[0], outs[1])

@@ -22,11 +22,18 @@ def main():
     ap.add_argument("--warmup", type=int, required=True)
     ap.add_argument("--steps", type=int, required=True)
     ap.add_argument("--top", type=int, default=45)
+    ap.add_argument("--by-stream", action="store_true",
+                    help="also: kernel time per HIP stream / queue inside the window, its busiest kernels, and the small launches "
+                         "(< 8 us) by name and grid - which stream is the long pole of the step, and what fills it")
+    ap.add_argument("--sequence", type=int, default=0, help="with --by-stream: print this many consecutive launches of the busiest stream, forward and backward")
     a = ap.parse_args()
-    rows = []
+    rows, lanes = [], {}
     with open(a.trace) as f:
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+            lane = r.get("Stream_Id") or r.get("Queue_Id") or "?"
+            grid = "x".join(str(r.get(k, "?")) for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"))
+            lanes[(rows[-1][0], rows[-1][1])] = (lane, grid)
     rows.sort()
     ce = [s for s, e, n in rows if "marg_ce_row" in n or "marg_ce_stream" in n]
     adam = [(s, e) for s, e, n in rows if "multi_tensor_apply" in n]
@@ -81,6 +88,44 @@ def main():
     print("# --- by family ---")
     for g, t in sorted(groups.items(), key=lambda kv: -kv[1]):
         print(f"# {g:40s} {t/1e6:10.3f} ms {100*t/total:6.2f} %")
+    if not a.by_stream:
+        return
+    per = {}
+    for s, e, n in rows:
+        if s < t0 or e > t1:
+            continue
+        lane, grid = lanes[(s, e)]
+        d = per.setdefault(lane, {"t": 0.0, "n": 0, "k": {}, "small": {}})
+        d["t"] += e - s
+        d["n"] += 1
+        v = d["k"].setdefault(short(n), [0, 0.0])
+        v[0] += 1
+        v[1] += e - s
+        if e - s < 8000:
+            w = d["small"].setdefault((short(n), grid), [0, 0.0])
+            w[0] += 1
+            w[1] += e - s
+    if a.sequence:
+        # the launches of the busiest stream around the middle of the first timed step's forward and backward: what runs
+        # between two GEMMs of a layer, in order
+        busiest = max(per.items(), key=lambda kv: kv[1]["t"])[0]
+        seq = [(s, e, n) for s, e, n in rows if t0 <= s and e <= t1 and lanes[(s, e)][0] == busiest]
+        per_step = len(seq) // a.steps
+        for label, frac in (("forward", 0.15), ("backward", 0.65)):
+            i0 = int(per_step * frac)
+            print(f"\n# --- {a.sequence} consecutive launches of stream {busiest}, {label} (launch {i0} of {per_step} in step 1) ---")
+            for s, e, n in seq[i0:i0 + a.sequence]:
+                print(f"   {(e - s) / 1e3:9.2f} us  grid {lanes[(s, e)][1]:16s} {short(n)[:110]}")
+    print("\n# --- by stream (per step) ---")
+    for lane, d in sorted(per.items(), key=lambda kv: -kv[1]["t"]):
+        print(f"## stream {lane}: {d['t']/1e6/a.steps:.2f} ms of kernels per step, {d['n'] // a.steps} launches per step")
+        for k, (c, t) in sorted(d["k"].items(), key=lambda kv: -kv[1][1])[:28]:
+            print(f"   {k:88s} {c / a.steps:8.1f} {t/1e6/a.steps:9.3f} ms {t/c/1e3:9.2f} us")
+        sm = sorted(d["small"].items(), key=lambda kv: -kv[1][1])
+        tot = sum(v[1] for _, v in sm)
+        print(f"   -- launches under 8 us: {sum(v[0] for _, v in sm) // a.steps} per step, {tot/1e6/a.steps:.2f} ms per step")
+        for (k, grid), (c, t) in sm[:14]:
+            print(f"      {k:70s} grid {grid:14s} {c / a.steps:8.1f} {t/1e6/a.steps:9.3f} ms")
 
 
 if __name__ == "__main__":
