@@ -14,7 +14,8 @@ import torch
 from ..fused import pool_l2norm
 from ..utils import eos_mask
 from . import lora
-from .fastpath import use_capturable_falcon_heads, use_native_rms_norm, use_roll_rope, use_swiglu_kernel
+from .fastpath import (use_capturable_falcon_heads, use_fused_residual_norm, use_native_rms_norm, use_roll_rope,
+                       use_swiglu_kernel)
 
 
 class Mode(Enum):
@@ -113,6 +114,7 @@ class AutoModelForRagE2E(torch.nn.Module):
         use_native_rms_norm(self.generator_model)
         use_roll_rope(self.generator_model)
         use_swiglu_kernel(self.generator_model)
+        use_fused_residual_norm(self.generator_model)
         use_capturable_falcon_heads(self.generator_model)
         if autoregressive:
             use_native_rms_norm(self.retriever_model)

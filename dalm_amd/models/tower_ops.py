@@ -96,3 +96,75 @@ def swiglu_supported(gate, up) -> bool:
 def swiglu(gate, up):
     """silu(gate) * up."""
     return _SwiGLU.apply(gate, up)
+
+
+# ---------------------------------------------------------------------------
+# RMSNorm, optionally fused with the residual add in front of it (dalm_rms_norm_{fwd,bwd})
+# ---------------------------------------------------------------------------
+def rms_norm_supported(x: torch.Tensor, w: torch.Tensor) -> bool:
+    D = x.shape[-1]
+    vec = 4 if x.dtype == torch.float32 else 8
+    return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and w.dim() == 1 and w.shape[0] == D
+            and D % vec == 0 and D <= 64 * vec * 16)
+
+
+def _norm_fwd(x2, delta2, w, eps):
+    R, D = x2.shape
+    y = torch.empty_like(x2)
+    h = torch.empty_like(x2) if delta2 is not None else None
+    rstd = torch.empty(R, device=x2.device, dtype=torch.float32)
+    hip.call("dalm_rms_norm_fwd", hip.ptr(x2), hip.ptr(delta2), hip.ptr(w), hip.dtype_code(x2), R, D, float(eps), hip.ptr(h),
+             hip.ptr(y), hip.ptr(rstd), hip.stream())
+    return h, y, rstd
+
+
+def _norm_bwd(dy2, h2, w, rstd, dres2):
+    R, D = h2.shape
+    dx = torch.empty_like(h2)
+    hip.call("dalm_rms_norm_bwd", hip.ptr(dy2), hip.ptr(h2), hip.ptr(w), hip.ptr(rstd), hip.ptr(dres2), hip.dtype_code(h2), R, D,
+             hip.ptr(dx), hip.stream())
+    return dx
+
+
+def _weight_grad(dy2, h2, rstd):
+    return (dy2.float() * (h2.float() * rstd.unsqueeze(1))).sum(0)
+
+
+def _as_rows(t, D, dtype):
+    t = t.reshape(-1, D)
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+class _AddRmsNorm(torch.autograd.Function):
+    """(h, y) = (x + delta, rmsnorm(x + delta) * w);  with delta None: h IS x (returned as is) and only the backward is fused:
+    the gradient that reaches h through the residual path is added inside the norm's backward kernel."""
+
+    @staticmethod
+    def forward(ctx, x, delta, w, eps):
+        D = x.shape[-1]
+        w_c = w if w.dtype == x.dtype else w.to(x.dtype)
+        x2 = _as_rows(x, D, x.dtype)
+        d2 = _as_rows(delta, D, x.dtype) if delta is not None else None
+        h2, y2, rstd = _norm_fwd(x2, d2, w_c, eps)
+        ctx.save_for_backward(h2 if h2 is not None else x2, w_c, rstd)
+        ctx.shape, ctx.has_delta, ctx.w_dtype = x.shape, delta is not None, w.dtype
+        h = h2.view(x.shape) if h2 is not None else x
+        return h, y2.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dh, dy):
+        h2, w_c, rstd = ctx.saved_tensors
+        D = h2.shape[1]
+        dy2 = _as_rows(dy, D, h2.dtype)
+        dres2 = _as_rows(dh, D, h2.dtype) if dh is not None else None
+        d = _norm_bwd(dy2, h2, w_c, rstd, dres2).view(ctx.shape)
+        dw = _weight_grad(dy2, h2, rstd).to(ctx.w_dtype) if ctx.needs_input_grad[2] else None
+        return d, (d if ctx.has_delta else None), dw, None
+
+
+def add_rms_norm(x, delta, w, eps):
+    """x + delta and its RMSNorm in one launch (one more in the backward, which also folds in the residual-path gradient).
+    delta = None: (x itself, rmsnorm(x) * w)."""
+    return _AddRmsNorm.apply(x, delta, w, eps)

@@ -427,6 +427,16 @@ int dalm_rope_qk(const void* q, const void* k, void* q_out, void* k_out, const v
 int dalm_swiglu_fwd(const void* gate, const void* up, void* act, int dtype, int64_t n, dalm_stream_t stream);
 int dalm_swiglu_bwd(const void* d_act, const void* gate, const void* up, void* d_gate, void* d_up, int dtype, int64_t n,
                     dalm_stream_t stream);
+/* RMSNorm of a decoder layer (modeling_llama.py LlamaRMSNorm: w * (x * rsqrt(mean(x^2) + eps)).to(dtype)), optionally with the
+ * residual add in front of it, one wave per row, [R, D] row-major, D a multiple of 16 bytes, at most 8192 (bf16) / 4096 (f32):
+ *   fwd: delta != NULL: h_out = x + delta (rounded to dtype) and the norm is taken of h_out; delta == NULL (then h_out == NULL
+ *        too): of x.  y [R, D], rstd [R] (f32, kept for the backward).
+ *   bwd: dx = rstd * (g - xh * mean(g * xh)), g = dy * w, xh = h * rstd, plus dres (the gradient reaching h through the
+ *        residual path) when dres != NULL.  The weight gradient is not produced (LoRA freezes the norm weights). */
+int dalm_rms_norm_fwd(const void* x, const void* delta, const void* w, int dtype, int64_t R, int64_t D, float eps, void* h_out,
+                      void* y, float* rstd, dalm_stream_t stream);
+int dalm_rms_norm_bwd(const void* dy, const void* h, const void* w, const float* rstd, const void* dres, int dtype, int64_t R,
+                      int64_t D, void* dx, dalm_stream_t stream);
 
 /* ---- the low-rank branch of a LoRA-wrapped Linear ----------------------------------------------------------------
  * The reference wraps q_proj / v_proj (key / query / value for BERT retrievers) in peft LoRA adapters, r = 8, alpha = 16,

@@ -91,6 +91,62 @@ def test_swiglu_kernel_vs_eager_chain(dev, shape, dtype):
         assert frac < 1e-3, f"{name}: {frac:.2e} of the elements differ from the eager chain"
 
 
+NORM_CASES = [(R, D, dt) for dt in (torch.bfloat16, torch.float32)
+              for R, D in [(4608, 4096), (7, 4096), (33, 1024), (5, 8192), (9, 40), (3, 4544)]
+              if not (dt == torch.float32 and D > 4096)]          # f32 rows are supported up to 4096 elements
+
+
+@pytest.mark.parametrize("R,D,dtype", NORM_CASES)
+@pytest.mark.parametrize("with_add", [False, True])
+def test_rms_norm_kernels_vs_llama_rms_norm(dev, R, D, dtype, with_add):
+    """forward against transformers' LlamaRMSNorm (and the eager residual add in front of it): the same two roundings, so equal
+    up to the f32 summation order of mean(x^2) - at most one bf16 ulp on a vanishing fraction of elements; backward (dx, with
+    the residual-path gradient folded in) against autograd through a float64 copy of the same chain."""
+    from transformers.models.llama.modeling_llama import LlamaRMSNorm
+
+    from dalm_amd.models import tower_ops
+
+    g = torch.Generator().manual_seed(R + D)
+    x = torch.randn(R, D, generator=g).to(dtype).to(dev)
+    delta = torch.randn(R, D, generator=g).to(dtype).to(dev) if with_add else None
+    norm = LlamaRMSNorm(D, eps=1e-5).to(dev)
+    with torch.no_grad():
+        norm.weight.copy_(1 + 0.1 * torch.randn(D, generator=g))
+    norm = norm.to(dtype)
+    up_h = torch.randn(R, D, generator=g).to(dtype).to(dev)
+    up_y = torch.randn(R, D, generator=g).to(dtype).to(dev)
+    assert tower_ops.rms_norm_supported(x, norm.weight)
+    x1 = x.clone().requires_grad_(True)
+    d1 = delta.clone().requires_grad_(True) if with_add else None
+    h1, y1 = tower_ops.add_rms_norm(x1, d1, norm.weight, 1e-5)
+    torch.autograd.backward([h1, y1], [up_h, up_y])
+    # eager chain in the tensor dtype: forward values
+    with torch.no_grad():
+        h0 = x + delta if with_add else x
+        y0 = norm(h0)
+    assert torch.equal(h1.detach(), h0)
+    diff = (y1.detach().float() - y0.float()).abs()
+    if dtype == torch.float32:
+        torch.testing.assert_close(y1.detach(), y0, rtol=2e-6, atol=1e-6)
+    else:
+        # a last-bit difference of rstd can move the inner rounding by one ulp; the weight (|w| ~ 1.1) and the outer rounding can
+        # turn that into two
+        worst = float((diff / (y0.float().abs() + 1e-30)).max())
+        assert worst <= 2.0 ** -6, f"more than two bf16 ulps apart ({worst:.3e} relative)"
+        assert float((diff > 0).float().mean()) < 2e-3
+    # float64 chain: gradients
+    x64 = x.double().requires_grad_(True)
+    d64 = delta.double().requires_grad_(True) if with_add else None
+    h64 = x64 + d64 if with_add else x64
+    y64 = norm.weight.double() * (h64 * torch.rsqrt(h64.pow(2).mean(-1, keepdim=True) + 1e-5))
+    torch.autograd.backward([h64, y64], [up_h.double(), up_y.double()])
+    tol = 2e-6 if dtype == torch.float32 else 4e-3
+    rel = lambda a, b: float((a.double() - b).norm() / b.norm())
+    assert rel(x1.grad, x64.grad) < tol
+    if with_add:
+        assert rel(d1.grad, d64.grad) < tol
+
+
 def test_patched_llama_layer_matches_transformers(dev):
     """A 2-layer Llama (head_dim 128) with the rotary and SwiGLU kernels patched in against the unpatched module: logits and
     every parameter gradient, bf16 autocast and fp32."""
@@ -105,6 +161,7 @@ def test_patched_llama_layer_matches_transformers(dev):
     new = LlamaForCausalLM(cfg).to(dev)
     new.load_state_dict(ref.state_dict())
     assert fastpath.use_swiglu_kernel(new) == 2
+    assert fastpath.use_fused_residual_norm(new) == 2
     ids = torch.randint(1, 300, (3, 17), device=dev)
     mask = torch.ones_like(ids)
     mask[1, :5] = 0
