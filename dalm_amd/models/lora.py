@@ -66,15 +66,25 @@ class LoRALinear(nn.Module):
         if x.is_cuda and _FUSED:
             from . import lora_ops
 
-            if lora_ops.supported(x, self.base_layer, a.weight, b.weight) and not self.base_layer.weight.requires_grad:
+            if lora_ops.branch_supported(x, a.weight, b.weight):
                 drop = self.lora_dropout["default"]
                 p = float(getattr(drop, "p", 0.0)) if self.training else 0.0
                 # salt: this module's id in the upper bits, a host call counter below it (graph replays re-use the captured
                 # salt; there the device-side seed word, advanced once per step, changes the masks)
                 self._calls = getattr(self, "_calls", 0) + 1
                 salt = (self._uid << 12) ^ (self._calls & 0xFFF)
-                return lora_ops.lora_linear(x, self.base_layer, a.weight, b.weight, self.scaling, p, salt)
-        out = self.base_layer(x)
+                base = self.base_layer
+                if lora_ops.supported(x, base, a.weight, b.weight) and not base.weight.requires_grad:
+                    return lora_ops.lora_linear(x, base, a.weight, b.weight, self.scaling, p, salt)
+                if hasattr(base, "qweight") or isinstance(base, nn.Linear):      # nf4 storage / a Linear subclass
+                    out = base(x)                                                # its own module, its own backward
+                    if out.dtype in (torch.float32, torch.bfloat16) and out.is_contiguous():
+                        return lora_ops.lora_branch_(out, x, a.weight, b.weight, self.scaling, p, salt)   # out += ..., in place
+                    return self._eager_branch(out, x)
+        return self._eager_branch(self.base_layer(x), x)
+
+    def _eager_branch(self, out: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        a, b = self.lora_A["default"], self.lora_B["default"]
         z = self.lora_dropout["default"](x)
         if not torch.is_autocast_enabled() and z.dtype != a.weight.dtype:
             z = z.to(a.weight.dtype)  # outside autocast the fp32 adapters need fp32 activations

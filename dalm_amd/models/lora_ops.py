@@ -45,11 +45,18 @@ def advance_dropout_seed(device: Optional[torch.device] = None) -> None:
     dropout_seed(dev).add_(0x9E3779B97F4A7C15 - (1 << 64))     # += golden-ratio increment (as a signed 64-bit value)
 
 
-def supported(x: torch.Tensor, base, a: torch.Tensor, b: torch.Tensor) -> bool:
+def branch_supported(x: torch.Tensor, a: torch.Tensor, b: torch.Tensor) -> bool:
+    """The low-rank branch alone (any base layer): shapes and dtypes the kernels take."""
     r = a.shape[0]
-    return (x.is_cuda and isinstance(base, torch.nn.Linear) and r in (8, 16) and a.shape[1] % 8 == 0 and b.shape[0] % 8 == 0
+    return (x.is_cuda and r in (8, 16) and a.shape[1] % 8 == 0 and b.shape[0] % 8 == 0
             and a.dtype == torch.float32 and b.dtype == torch.float32 and a.is_contiguous() and b.is_contiguous()
-            and base.weight.dtype in (torch.float32, torch.bfloat16) and x.dtype in (torch.float32, torch.bfloat16))
+            and x.dtype in (torch.float32, torch.bfloat16))
+
+
+def supported(x: torch.Tensor, base, a: torch.Tensor, b: torch.Tensor) -> bool:
+    """Base GEMM and branch as one autograd node: plain nn.Linear bases only (a subclass may override forward)."""
+    return (branch_supported(x, a, b) and type(base) is torch.nn.Linear
+            and base.weight.dtype in (torch.float32, torch.bfloat16))
 
 
 def _rowdot(x2, w, kmajor, rank, scale, p, seed, salt):
@@ -119,6 +126,52 @@ class _LoRALinearFn(torch.autograd.Function):
                 dx = dx.to(xdtype)
         dbias = g2.sum(0) if ctx.needs_input_grad[2] else None
         return dx, None, dbias, da, db, None, None, None
+
+
+class _LoRABranchFn(torch.autograd.Function):
+    """out = base_out + s * B(A(dropout(x))) for a base layer that runs as its own module (nf4 storage, a Linear subclass):
+    the branch is added to the base layer's output in place; the backward passes g through to the base layer untouched and
+    returns the branch's own dx, dA, dB."""
+
+    @staticmethod
+    def forward(ctx, base_out, x, a, b, scaling, p, salt):
+        K, N, rank = a.shape[1], b.shape[0], a.shape[0]
+        cdt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else None
+        x2 = x.reshape(-1, K)
+        if cdt is not None and x2.dtype != cdt:
+            x2 = x2.to(cdt)
+        x2 = x2.contiguous()
+        seed = dropout_seed(x2.device) if p > 0 else None
+        z = _rowdot(x2, a, True, rank, 1.0 / (1.0 - p), p, seed, salt)
+        _rankupd_(base_out.view(-1, N), z, b, True, rank, scaling, 0.0, None, 0)
+        ctx.mark_dirty(base_out)
+        ctx.save_for_backward(x2, a, b, z)
+        ctx.meta = (scaling, p, salt, x.shape, x.dtype, rank)
+        return base_out
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, a, b, z = ctx.saved_tensors
+        scaling, p, salt, xshape, xdtype, rank = ctx.meta
+        g2 = g.reshape(-1, b.shape[0]).contiguous()
+        seed = dropout_seed(x2.device) if p > 0 else None
+        keep = 1.0 / (1.0 - p)
+        dz = _rowdot(g2, b, False, rank, scaling, 0.0, None, 0)
+        db = _colacc(g2, z, rank, scaling, 0.0, None, 0, False) if ctx.needs_input_grad[3] else None
+        da = _colacc(x2, dz, rank, keep, p, seed, salt, True) if ctx.needs_input_grad[2] else None
+        dx = None
+        if ctx.needs_input_grad[1]:
+            dx = _rankupd_(torch.zeros_like(x2), dz, a, False, rank, keep, p, seed, salt).view(xshape)
+            if dx.dtype != xdtype:
+                dx = dx.to(xdtype)
+        return g, dx, da, db, None, None, None
+
+
+def lora_branch_(base_out, x, a, b, scaling: float, p: float, salt: int):
+    """base_out += scaling * B(A(dropout_p(x))), in place, differentiable in x, a, b (and base_out)."""
+    if base_out.dtype not in (torch.float32, torch.bfloat16) or not base_out.is_contiguous():
+        raise TypeError("lora_branch_: the base layer's output must be a contiguous float32 / bfloat16 tensor")
+    return _LoRABranchFn.apply(base_out, x, a, b, float(scaling), float(p), int(salt) & 0xFFFFFFFF)
 
 
 def lora_linear(x, base: torch.nn.Linear, a: torch.Tensor, b: torch.Tensor, scaling: float, p: float, salt: int):

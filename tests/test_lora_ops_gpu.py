@@ -97,7 +97,12 @@ def test_dropout_mask_is_the_same_in_all_three_kernels(dev, R, K, rank, dtype):
     assert not torch.equal(moved, cnt) or K < 64
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16-autocast", "bf16-weights-autocast"])
+class _LinearSubclass(torch.nn.Linear):
+    """Not `type(...) is nn.Linear`: LoRALinear must run it as its own module and add only the low-rank branch (the route nf4
+    bases take as well)."""
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16-autocast", "bf16-weights-autocast", "fp32-subclass", "bf16-autocast-subclass"])
 def test_fused_lora_linear_matches_the_eager_branch(dev, mode):
     """LoRALinear through lora_ops (the GPU default) against the same module with DALM_LORA_KERNEL=0 semantics (its eager
     branch), dropout off: outputs, dx, dA, dB."""
@@ -106,9 +111,11 @@ def test_fused_lora_linear_matches_the_eager_branch(dev, mode):
     torch.manual_seed(0)
     K, N, R = 1024, 768, 300
     base = torch.nn.Linear(K, N, bias=True)
+    cls = _LinearSubclass if mode.endswith("subclass") else torch.nn.Linear
+    mode = mode.replace("-subclass", "")
     mods = []
     for fused in (False, True):
-        b = torch.nn.Linear(K, N, bias=True)
+        b = cls(K, N, bias=True)
         b.load_state_dict(base.state_dict())
         if mode == "bf16-weights-autocast":
             b = b.to(torch.bfloat16)
