@@ -470,7 +470,19 @@ inline DropArgs drop_args(float p, const void* seed, unsigned int salt) {
   d.thr16 = static_cast<unsigned int>(p * 65536.0f + 0.5f);
   return d;
 }
-constexpr int kColSplitRows = 576;   // rows per colacc split (>= 18 row steps per thread)
+// colacc: rows per split.  About 512 workgroups (slabs x splits) keep the chip busy: the generator's 64 slabs of a 4096-wide
+// activation take 8 splits of 576 rows at cfg3; a 1024-wide BERT activation (16 slabs) takes 32 splits of its 2304 rows
+// instead of 4 (64 workgroups measured 24 us for 4.7 MB)
+inline int colacc_rows_per_split(int64_t R, int64_t C) {
+  const int64_t slabs = (C + 63) / 64;
+  int64_t splits = (512 + slabs - 1) / slabs;
+  const int64_t max_splits = (R + 63) / 64;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int64_t rows = (R + splits - 1) / splits;
+  rows = (rows + 31) / 32 * 32;
+  return static_cast<int>(rows);
+}
 // rowdot / rankupd: one 512-thread workgroup per CU at a time (its W slice and rows in flight fill the register file), so the
 // row count per workgroup is chosen to make the grid a whole number of 256-workgroup rounds (R = 4608: 256 x 18 rows)
 inline int lora_rows_per_wg(int64_t R) {
@@ -553,7 +565,8 @@ extern "C" int dalm_lora_rankupd(void* y, int dtype, const float* z, const float
 
 extern "C" size_t dalm_lora_colacc_workspace_bytes(int64_t R, int64_t C, int rank) {
   if (R <= 0 || C <= 0 || rank <= 0) return 0;
-  const int64_t splits = (R + kColSplitRows - 1) / kColSplitRows;
+  const int64_t rps = colacc_rows_per_split(R, C);
+  const int64_t splits = (R + rps - 1) / rps;
   return static_cast<size_t>(splits) * C * rank * sizeof(float);
 }
 
@@ -564,7 +577,8 @@ extern "C" int dalm_lora_colacc(const void* x, int dtype, const float* z, int64_
   DALM_LORA_COMMON_CHECKS(R, C);
   DALM_REQUIRE(al16(x) && al16(z), DALM_E_ALIGN, "x / z must be 16-byte aligned");
   DALM_REQUIRE(ws_bytes >= dalm_lora_colacc_workspace_bytes(R, C, rank), DALM_E_WORKSPACE, "workspace too small");
-  const int64_t splits = (R + kColSplitRows - 1) / kColSplitRows;
+  const int rps = colacc_rows_per_split(R, C);
+  const int64_t splits = (R + rps - 1) / rps;
   DALM_REQUIRE(splits <= 65535, DALM_E_SHAPE, "too many rows for one launch");
   const dim3 grid(static_cast<unsigned>((C + 63) / 64), static_cast<unsigned>(splits));
   const DropArgs d = drop_args(p, seed, salt);
@@ -572,7 +586,7 @@ extern "C" int dalm_lora_colacc(const void* x, int dtype, const float* z, int64_
   float* part = static_cast<float*>(ws);
 #define DALM_COLACC(TT, RK, DR) \
   hipLaunchKernelGGL((lora_colacc_kernel<TT, RK, DR>), grid, dim3(256), 0, s, static_cast<const TT*>(x), z, part, \
-                     static_cast<int>(R), static_cast<int>(C), kColSplitRows, d)
+                     static_cast<int>(R), static_cast<int>(C), rps, d)
 #define DALM_COLACC_DR(TT, RK) do { if (p > 0.f) DALM_COLACC(TT, RK, true); else DALM_COLACC(TT, RK, false); } while (0)
 #define DALM_COLACC_RK(TT) do { if (rank == 8) DALM_COLACC_DR(TT, 8); else DALM_COLACC_DR(TT, 16); } while (0)
   if (dtype == DALM_F32) DALM_COLACC_RK(float); else DALM_COLACC_RK(bf16_t);

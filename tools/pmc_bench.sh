@@ -17,7 +17,7 @@ cat $OUT/pmc_loss_kernels.txt
 t=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
 # the TIMED steps only (round 4): initialisation kernels, warm-up steps and post-run probes are cut out of the trace
 python tools/summarize_step_window.py "$t" --warmup 2 --steps 5 --top 50 > $OUT/bench_kernel_stats.txt; tail -25 $OUT/bench_kernel_stats.txt
-python tools/summarize_trace.py "$t" "dalm|marg_ce|small_|pool_|flash|gemm_f32|rag_loss|ce_" 60 > $OUT/dalm_kernels_per_shape.txt; cat $OUT/dalm_kernels_per_shape.txt
+python tools/summarize_trace.py "$t" "dalm|marg_ce|small_|pool_|flash|gemm_f32|rag_loss|ce_|lora_|rope_|swiglu_|rms_norm" 80 > $OUT/dalm_kernels_per_shape.txt; cat $OUT/dalm_kernels_per_shape.txt
 grep '^{' $OUT/trace.log | tail -1 > $OUT/bench_line_under_rocprof.json || true
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*counter_collection.csv" -size +6M -delete

@@ -78,7 +78,7 @@ def main():
         elif any(x in k for x in ("attention", "attn", "fmha", "flash_fwd", "flash_bwd", "sdpa", "bwd_kernel_dk_dv", "bwd_kernel_dq",
                                   "bwd_kernel_fuse", "bwd_preprocess")):
             groups["attention (SDPA)"] += t
-        elif any(x in k for x in ("marg_ce", "pool_", "small_", "rag_loss", "ce_prep", "ce_finalize", "rms_norm", "nf4", "l2norm",
+        elif "dalm::" in k or any(x in k for x in ("marg_ce", "pool_", "small_", "rag_loss", "ce_prep", "ce_finalize", "rms_norm", "nf4", "l2norm",
                                   "sim_", "scale_inplace", "contrastive")):
             groups["dalm_* (this library)"] += t
         elif k.startswith("aten::") or "at::native" in k or "elementwise" in k:
