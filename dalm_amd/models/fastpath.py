@@ -70,14 +70,15 @@ def _rope_hip(q, k, cos, sin, position_ids=None, unsqueeze_dim=1):
 
 
 def use_roll_rope(model: torch.nn.Module) -> bool:
-    """Swap the module-level apply_rotary_pos_emb of the model's own modeling file (Llama family only)."""
+    """Swap the module-level apply_rotary_pos_emb of the model's own modeling file (Llama and Falcon)."""
     if os.environ.get("DALM_FAST_ROPE", "1") == "0":
         return False
     fn = _rope_roll if os.environ.get("DALM_ROPE_KERNEL", "1") == "0" else _rope_hip
     import importlib
 
     mod_name = type(getattr(model, "base_model", model)).__module__
-    if not mod_name.endswith("modeling_llama"):
+    # modeling files whose apply_rotary_pos_emb is the formula above, word for word (Falcon calls it only without alibi)
+    if not mod_name.endswith(("modeling_llama", "modeling_falcon")):
         return False
     mod = importlib.import_module(mod_name)
     if not hasattr(mod, "apply_rotary_pos_emb"):

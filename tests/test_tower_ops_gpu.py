@@ -32,7 +32,8 @@ def _cos_sin(B, T, hd, dtype, dev, g):
     return emb.cos().to(dtype).to(dev), emb.sin().to(dtype).to(dev)
 
 
-ROPE = [(18, 32, 32, 256, 128), (2, 4, 2, 7, 64), (3, 2, 2, 5, 8), (1, 3, 1, 9, 6), (2, 8, 8, 33, 96)]
+ROPE = [(18, 32, 32, 256, 128), (2, 4, 2, 7, 64), (3, 2, 2, 5, 8), (1, 3, 1, 9, 6), (2, 8, 8, 33, 96),
+        (2, 71, 1, 19, 64)]       # Falcon-7B: 71 query heads, one shared key head
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
