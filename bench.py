@@ -70,6 +70,25 @@ def build_models(device, dtype, bert_layers=24, llama_layers=32, lora=True, gene
                                            use_bnb=Mode(use_bnb) if use_bnb else None)
 
 
+def _tower_kernels(model) -> dict:
+    """Which of this library's tower-side kernels the generator actually runs on (models/fastpath.py, models/lora.py): read
+    off the patched modules, not off the environment."""
+    from dalm_amd.models import lora as lora_mod
+
+    gen = model.generator_model
+    names = {type(m).__name__ for m in gen.modules()}
+    fwd = lambda cls: [getattr(m.forward, "__func__", m.forward).__name__ for m in gen.modules() if type(m).__name__ == cls]
+    import importlib
+
+    rope = getattr(getattr(importlib.import_module(type(getattr(gen, "base_model", gen)).__module__), "apply_rotary_pos_emb", None),
+                   "__name__", None)
+    return {"lora_branch": "dalm_lora_* (fused node / in-place branch)" if lora_mod._FUSED and "LoRALinear" in names else "eager",
+            "rotary": {"_rope_hip": "dalm_rope_qk", "_rope_roll": "roll + addcmul (torch)"}.get(rope, "transformers"),
+            "swiglu": "dalm_swiglu_*" if "_swiglu_mlp_forward" in fwd("LlamaMLP") else "transformers",
+            "residual_norm": "dalm_rms_norm_*" if "_llama_layer_forward" in fwd("LlamaDecoderLayer") else "transformers / torch",
+            "use_cache": False}
+
+
 def _resident_weight_bytes(model):
     from dalm_amd.models import nf4
 
@@ -661,6 +680,7 @@ def main():
                                     else "fused with the CE in sample chunks (no logits tensor)") if args.fuse_lm_head
                                    else f"logits materialised ({args.dtype})"),
                        "tower_gemms": "pre-tuned solution table (dalm_amd/tuning)" if args.tuned_gemms else "library defaults",
+                       "tower_kernels": _tower_kernels(model),
                        "launch": ("hipGraph replay of the whole step" if (use_graph and getattr(step, "graph", None) is not None)
                                   else ("hipGraph replay of tower fwd/bwd, eager collectives+loss+optimizer"
                                         if getattr(step, "towers", None) is not None else

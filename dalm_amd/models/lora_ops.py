@@ -16,7 +16,6 @@ between devices or libraries anyway); `p` and the 1 / (1-p) rescaling are peft's
 """
 from __future__ import annotations
 
-import itertools
 from typing import Dict, Optional
 
 import torch
@@ -25,7 +24,6 @@ import torch.nn.functional as F
 from .. import hip
 
 _seed_words: Dict[int, torch.Tensor] = {}
-_salt_counter = itertools.count(1)
 
 
 def dropout_seed(device: torch.device) -> torch.Tensor:
@@ -33,7 +31,10 @@ def dropout_seed(device: torch.device) -> torch.Tensor:
     idx = device.index if device.index is not None else torch.cuda.current_device()
     t = _seed_words.get(idx)
     if t is None:
-        first = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+        # derived from torch's seed WITHOUT drawing from the global generator (a draw here would shift every later random
+        # number of the program - shuffles, initialisations - depending on whether a LoRA layer happened to run first)
+        g = torch.Generator().manual_seed((torch.initial_seed() ^ 0x5DA1A0D5EED) & (2 ** 63 - 1))
+        first = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, generator=g).item())
         t = torch.full((1,), first, dtype=torch.int64, device=torch.device("cuda", idx))
         _seed_words[idx] = t
     return t
@@ -181,6 +182,3 @@ def lora_linear(x, base: torch.nn.Linear, a: torch.Tensor, b: torch.Tensor, scal
         raise RuntimeError("lora_linear: the base weight must be frozen (LoRA trains A and B only)")
     return _LoRALinearFn.apply(x, base.weight, base.bias, a, b, float(scaling), float(p), int(salt) & 0xFFFFFFFF)
 
-
-def next_salt() -> int:
-    return next(_salt_counter)

@@ -745,3 +745,91 @@ def test_progress_counts_reports_and_checkpoints_the_flush_step_like_any_other()
     assert common.parse_resume("/out/step_3", per_epoch, nb, N, saved["step_3"]) == (0, 10, 3)
     assert common.parse_resume("/out/step_3", per_epoch, nb, N) == (1, 0, 3)
     assert common.parse_resume("/out/step_4", per_epoch, nb, N, saved["step_4"]) == (1, 4, 4) == common.parse_resume("/out/step_4", per_epoch, nb, N)
+
+
+# ---- round 4: tower / LoRA kernel plumbing (host side; the kernels themselves are tests/test_{tower,lora}_ops_gpu.py) ----
+def _tiny_llama(layers=2):
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    torch.manual_seed(0)
+    return LlamaForCausalLM(LlamaConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=layers, num_attention_heads=4,
+                                        num_key_value_heads=4, vocab_size=50, attention_dropout=0.0))
+
+
+def test_tower_patches_leave_cpu_results_untouched_and_are_guarded():
+    """Every fastpath patch falls back to transformers' own code for CPU tensors (same logits and gradients), patches only the
+    module types / signatures it was written against, and can be switched off by its environment variable."""
+    import os
+
+    from dalm_amd.models import fastpath
+
+    ref, new = _tiny_llama(), _tiny_llama()
+    new.load_state_dict(ref.state_dict())
+    assert fastpath.use_roll_rope(new) and fastpath.use_swiglu_kernel(new) == 2 and fastpath.use_fused_residual_norm(new) == 2
+    ids = torch.randint(1, 50, (2, 9))
+    a = ref(input_ids=ids).logits
+    b = new(input_ids=ids, use_cache=False).logits
+    torch.testing.assert_close(b, a, rtol=1e-6, atol=1e-6)
+    a.square().mean().backward()
+    b.square().mean().backward()
+    for (n, p), (_, q) in zip(ref.named_parameters(), new.named_parameters()):
+        torch.testing.assert_close(q.grad, p.grad, rtol=1e-5, atol=1e-7, msg=n)
+
+    # a decoder layer whose forward has another signature is left alone
+    class LlamaDecoderLayer(torch.nn.Module):          # same class NAME, different interface
+        def __init__(self):
+            super().__init__()
+            self.input_layernorm = self.post_attention_layernorm = torch.nn.LayerNorm(4)
+
+        def forward(self, x, something_else=None):
+            return x
+
+    holder = torch.nn.Sequential(LlamaDecoderLayer())
+    assert fastpath.use_fused_residual_norm(holder) == 0
+
+    # a gated MLP with another activation is not SwiGLU
+    other = _tiny_llama(1)
+    other.model.layers[0].mlp.act_fn = torch.nn.GELU()
+    assert fastpath.use_swiglu_kernel(other) == 0
+    for var, fn in (("DALM_SWIGLU_KERNEL", fastpath.use_swiglu_kernel), ("DALM_NORM_KERNEL", fastpath.use_fused_residual_norm)):
+        os.environ[var] = "0"
+        try:
+            assert fn(_tiny_llama(1)) == 0
+        finally:
+            del os.environ[var]
+
+
+def test_lora_linear_path_selection_and_seed_word():
+    """CPU tensors take the eager branch; the fused node is for plain nn.Linear bases only (a subclass may override forward);
+    the dropout seed word is derived from torch's seed without drawing from the global generator."""
+    from dalm_amd.models import lora, lora_ops
+
+    base = torch.nn.Linear(16, 24).requires_grad_(False)
+    m = lora.LoRALinear(base, r=8, lora_alpha=16, lora_dropout=0.0)
+    with torch.no_grad():
+        m.lora_B["default"].weight.normal_()
+    x = torch.randn(3, 16)
+    want = base(x) + 2.0 * (x @ m.lora_A["default"].weight.t()) @ m.lora_B["default"].weight.t()
+    torch.testing.assert_close(m(x), want, rtol=1e-5, atol=1e-6)
+
+    class Sub(torch.nn.Linear):
+        pass
+
+    a, b = m.lora_A["default"].weight, m.lora_B["default"].weight
+    assert not lora_ops.supported(x, base, a, b)                       # CPU tensor
+    fake_cuda = type("T", (), {"is_cuda": True, "dtype": torch.float32})()
+    assert lora_ops.supported(fake_cuda, base, a, b)
+    assert not lora_ops.supported(fake_cuda, Sub(16, 24), a, b)         # subclass: its own forward must run
+    assert lora_ops.branch_supported(fake_cuda, a, b)
+    assert not lora_ops.branch_supported(fake_cuda, a[:4], b)            # rank 4: no kernel
+    assert not lora_ops.branch_supported(fake_cuda, a.double(), b)
+
+    torch.manual_seed(123)
+    before = torch.get_rng_state()
+    g = torch.Generator().manual_seed((torch.initial_seed() ^ 0x5DA1A0D5EED) & (2 ** 63 - 1))
+    first = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, generator=g).item())
+    assert torch.equal(torch.get_rng_state(), before)                  # the derivation lora_ops uses leaves the global stream alone
+    assert 0 <= first < 2 ** 62
+    import inspect
+
+    assert "generator=g" in inspect.getsource(lora_ops.dropout_seed)
