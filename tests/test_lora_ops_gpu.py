@@ -5,9 +5,14 @@ branch peft evaluates for the reference (dalm/models/rag_e2e_base_model.py:145-1
   branch is accumulated in f32 and rounded once, so it is at least as close to float64 as the eager bf16 chain is).
 * p > 0: the mask is never stored, three kernels regenerate it - adjoint identities <L x, u> = <x, L^T u> prove that forward,
   dx and dA saw the SAME mask; keep rate and rescaling are checked statistically; the seed word changes the mask."""
+import sys
+from pathlib import Path
+
+import numpy as np
 import pytest
 import torch
 
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "oracle"))
 pytestmark = pytest.mark.gpu
 
 
@@ -174,3 +179,47 @@ def test_training_mode_draws_new_masks_per_step_and_backward_sees_the_forward_ma
         torch.testing.assert_close(out.detach(), ref, rtol=1e-4, atol=1e-4)
         assert 0.4 < float(mask.mean()) < 0.6
     assert not torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("p", [0.05, 0.5])
+def test_every_mask_bit_of_every_kernel_equals_the_numpy_restatement(dev, dtype, p):
+    """oracle/lora_mask.py restates the mask function in numpy integer arithmetic.  Each kernel is driven with powers of two so
+    that its output spells the mask of a whole [128, 128] activation in binary: rowdot (VALU for f32, matrix cores for bf16)
+    sums 2^(k % 16) over 16-column groups, colacc sums 2^(row % 16) over 16-row groups, rankupd writes the mask itself."""
+    import lora_mask as O
+
+    from dalm_amd.models import lora_ops as L
+
+    R = K = 128
+    rank = 8
+    seed = L.dropout_seed(dev)
+    L.advance_dropout_seed(dev)
+    salt = 0xBEEF01
+    want = O.keep_mask(int(seed.item()), salt, R, K, p)
+    pow2 = (2.0 ** (torch.arange(K) % 16)).to(dtype)
+    group = torch.arange(K) // 16                                                   # 8 groups of 16 -> the 8 rank slots
+
+    # rankupd: y = 0 + 1 * mask * sum_j 1 * 1
+    y = L._rankupd_(torch.zeros(R, K, device=dev, dtype=dtype), torch.ones(R, rank, device=dev),
+                    torch.ones(rank, K, device=dev), False, rank, 1.0, p, seed, salt)
+    assert np.array_equal((y.float() > 0).cpu().numpy(), want)
+
+    # rowdot: z[row, j] = sum over the 16 columns of group j of mask * 2^(k % 16)
+    x = pow2.unsqueeze(0).expand(R, K).contiguous().to(dev)
+    A = (group.unsqueeze(0) == torch.arange(rank).unsqueeze(1)).float().to(dev)       # [rank, K]
+    z = L._rowdot(x, A, True, rank, 1.0, p, seed, salt).cpu().numpy().astype(np.int64)   # [R, rank], exact integers < 2^16
+    got = np.zeros((R, K), dtype=bool)
+    for k in range(K):
+        got[:, k] = (z[:, k // 16] >> (k % 16)) & 1
+    assert np.array_equal(got, want)
+
+    # colacc: out[j, c] = sum over the 16 rows of group j of mask * 2^(row % 16)
+    xr = (2.0 ** (torch.arange(R) % 16)).to(dtype).unsqueeze(1).expand(R, K).contiguous().to(dev)
+    zsel = ((torch.arange(R) // 16).unsqueeze(1) == torch.arange(rank).unsqueeze(0)).float().to(dev)   # [R, rank]
+    out = L._colacc(xr, zsel, rank, 1.0, p, seed, salt, True).cpu().numpy().astype(np.int64)             # [rank, K]
+    got = np.zeros((R, K), dtype=bool)
+    for r in range(R):
+        got[r, :] = (out[r // 16, :] >> (r % 16)) & 1
+    assert np.array_equal(got, want)
+    assert abs(want.mean() - (1 - p)) < 0.02

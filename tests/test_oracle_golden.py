@@ -1,5 +1,6 @@
 """Pin the CPU oracle to the reference: every oracle function vs the golden vectors that
 oracle/make_golden.py dumped from the reference's own code."""
+import numpy as np
 import pytest
 import torch
 
@@ -142,3 +143,29 @@ def test_topk_marginalisation_reduces_to_the_reference_at_k1():
             continue      # (left-padded rows whose cut falls into the padding: not the layout this helper states)
         got = O.closed_gen_loss_topk(lp.unsqueeze(1), m.unsqueeze(1), cut.unsqueeze(1), doc.unsqueeze(1))
         assert abs(float(got["generator"]) - float(z["ref64_generator"])) <= 1e-12 * abs(float(z["ref64_generator"]))
+
+
+def test_lora_mask_oracle_is_a_deterministic_well_mixed_function():
+    """oracle/lora_mask.py (the numpy restatement the GPU tests pin the LoRA dropout kernels to): same inputs -> same mask;
+    seed word, salt and position each change it; the keep rate is 1 - p to binomial accuracy; known bits for one input (so an
+    edit of the restatement cannot go unnoticed when no GPU is around)."""
+    import lora_mask as O
+
+    m = O.keep_mask(0x0123456789ABCDEF, 42, 256, 1024, 0.05)
+    assert m.shape == (256, 1024) and np.array_equal(m, O.keep_mask(0x0123456789ABCDEF, 42, 256, 1024, 0.05))
+    n = m.size
+    assert abs(m.mean() - 0.95) < 4 * (0.05 * 0.95 / n) ** 0.5 + 1e-4
+    for other in (O.keep_mask(0x0123456789ABCDEE, 42, 256, 1024, 0.05), O.keep_mask(0x0123456789ABCDEF, 43, 256, 1024, 0.05),
+                  O.keep_mask(0x1123456789ABCDEF, 42, 256, 1024, 0.05)):
+        agree = (other == m).mean()                       # two independent masks agree on 0.95^2 + 0.05^2 = 0.905 of the elements
+        assert 0.89 < agree < 0.92, agree
+    rows = m.mean(1)
+    assert rows.min() > 0.9 and m.mean(0).min() > 0.85           # no dead rows / columns
+    half = O.keep_mask(7, 7, 64, 64, 0.5)
+    assert abs(half.mean() - 0.5) < 0.04
+    assert O.threshold(0.05) == 3277 and O.threshold(0.5) == 32768 and O.threshold(0.0) == 0
+    assert O.keep_mask(1, 2, 2, 8, 0.0).all()
+    assert int(np.packbits(O.keep_mask(0xDEADBEEF, 5, 1, 64, 0.5)).astype(np.uint64).sum()) == KNOWN_LORA_MASK_BYTESUM
+
+
+KNOWN_LORA_MASK_BYTESUM = 888
