@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--by-stream", action="store_true",
                     help="also: kernel time per HIP stream / queue inside the window, its busiest kernels, and the small launches "
                          "(< 8 us) by name and grid - which stream is the long pole of the step, and what fills it")
+    ap.add_argument("--marker", default="marg_ce_row|marg_ce_stream",
+                    help="regex of a kernel launched exactly once per step (retriever-only steps: small_grad_kernel)")
     ap.add_argument("--sequence", type=int, default=0, help="with --by-stream: print this many consecutive launches of the busiest stream, forward and backward")
     a = ap.parse_args()
     rows, lanes = [], {}
@@ -35,7 +37,10 @@ def main():
             grid = "x".join(str(r.get(k, "?")) for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"))
             lanes[(rows[-1][0], rows[-1][1])] = (lane, grid)
     rows.sort()
-    ce = [s for s, e, n in rows if "marg_ce_row" in n or "marg_ce_stream" in n]
+    import re
+
+    mark = re.compile(a.marker)
+    ce = [s for s, e, n in rows if mark.search(n)]
     adam = [(s, e) for s, e, n in rows if "multi_tensor_apply" in n]
     need = a.warmup + a.steps
     if len(ce) < need:
