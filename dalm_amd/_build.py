@@ -14,8 +14,8 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = CSRC / "libdalm_hip.so"
-SOURCES = ["lib.hip", "ce.hip", "sim.hip", "sim_small.hip", "pool.hip", "comm.hip", "lmhead.hip", "nf4.hip", "tower.hip", "lora.hip"]
-HEADERS = [CSRC / "common.hpp", CSRC.parent.parent / "include" / "dalm_hip.h"]
+SOURCES = ["lib.hip", "ce.hip", "sim.hip", "sim_small.hip", "pool.hip", "comm.hip", "lmhead.hip", "nf4.hip", "tower.hip", "lora.hip", "lora2.hip"]
+HEADERS = [CSRC / "common.hpp", CSRC / "lora_common.hpp", CSRC.parent.parent / "include" / "dalm_hip.h"]
 ARCH = "gfx950"
 
 
@@ -39,13 +39,17 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         return LIB
     cc = hipcc_path()
     objs = []
+    newest_header = max(h.stat().st_mtime for h in HEADERS)
     for src in SOURCES:
         obj = CSRC / (Path(src).stem + ".o")
+        objs.append(str(obj))
+        # an object newer than its source and every header is reused (a one-file edit recompiles one file, not eleven)
+        if not force and obj.exists() and obj.stat().st_mtime > max((CSRC / src).stat().st_mtime, newest_header):
+            continue
         cmd = [cc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print("[dalm_amd build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-        objs.append(str(obj))
     cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-ldl", "-o", str(LIB)]
     if verbose:
         print("[dalm_amd build]", " ".join(cmd), flush=True)

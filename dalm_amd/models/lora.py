@@ -36,8 +36,13 @@ class LoRALinear(nn.Module):
         self.lora_A = nn.ModuleDict({"default": nn.Linear(base.in_features, r, bias=False, device=dev, dtype=torch.float32)})
         self.lora_B = nn.ModuleDict({"default": nn.Linear(r, base.out_features, bias=False, device=dev, dtype=torch.float32)})
         nn.init.kaiming_uniform_(self.lora_A["default"].weight, a=math.sqrt(5))
-        nn.init.zeros_(self.lora_B["default"].weight)
+        # lora_B.weight is [out_features, r] (peft's shape, what the adapter files hold) but lives in [r, out_features]-major
+        # memory: every LoRA kernel then reads A and B the same way (rank rows, 16-byte loads along the long dimension - the
+        # [N][r] layout cost dalm_lora_rowdot 8 dword loads per MFMA step).  Shape, state_dict keys and values are unchanged;
+        # gradients and optimizer state follow the parameter's strides (torch's gradient layout contract).
+        self.lora_B["default"].weight = nn.Parameter(torch.zeros(r, base.out_features, device=dev, dtype=torch.float32).t())
         self.merged = False
+        self._group = None            # LoRAGroup of the projections that read the same input (build_groups)
         LoRALinear._count += 1
         self._uid = LoRALinear._count
 
@@ -66,15 +71,17 @@ class LoRALinear(nn.Module):
         if x.is_cuda and _FUSED:
             from . import lora_ops
 
+            if self._group is not None:
+                out = self._group.fetch(self, x)          # q / k / v of one block: one autograd node for all of them
+                if out is not None:
+                    return out
             if lora_ops.branch_supported(x, a.weight, b.weight):
-                drop = self.lora_dropout["default"]
-                p = float(getattr(drop, "p", 0.0)) if self.training else 0.0
-                # salt: this module's id in the upper bits, a host call counter below it (graph replays re-use the captured
-                # salt; there the device-side seed word, advanced once per step, changes the masks)
-                self._calls = getattr(self, "_calls", 0) + 1
-                salt = (self._uid << 12) ^ (self._calls & 0xFFF)
+                p, salt = self.next_mask_key()
                 base = self.base_layer
                 if lora_ops.supported(x, base, a.weight, b.weight) and not base.weight.requires_grad:
+                    member = (base.weight, base.bias, a.weight, b.weight, self.scaling, p, salt)
+                    if lora_ops.group_supported(x, [member]):                 # bf16 activations: the round-5 kernels
+                        return lora_ops.lora_group_forward(x, [member])[0]
                     return lora_ops.lora_linear(x, base, a.weight, b.weight, self.scaling, p, salt)
                 if hasattr(base, "qweight") or isinstance(base, nn.Linear):      # nf4 storage / a Linear subclass
                     out = base(x)                                                # its own module, its own backward
@@ -82,6 +89,14 @@ class LoRALinear(nn.Module):
                         return lora_ops.lora_branch_(out, x, a.weight, b.weight, self.scaling, p, salt)   # out += ..., in place
                     return self._eager_branch(out, x)
         return self._eager_branch(self.base_layer(x), x)
+
+    def next_mask_key(self):
+        """(p, salt) of this call.  salt: this module's id in the upper bits, a host call counter below it (graph replays re-use
+        the captured salt; there the device-side seed word, advanced once per step, changes the masks)."""
+        drop = self.lora_dropout["default"]
+        p = float(getattr(drop, "p", 0.0)) if self.training else 0.0
+        self._calls = getattr(self, "_calls", 0) + 1
+        return p, (self._uid << 12) ^ (self._calls & 0xFFF)
 
     def _eager_branch(self, out: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
         a, b = self.lora_A["default"], self.lora_B["default"]
@@ -98,6 +113,99 @@ class LoRALinear(nn.Module):
             base = base.to_linear()
         base.weight.add_(delta.to(base.weight.dtype))
         return base
+
+
+# ---- projections that read the same input ------------------------------------------------------------------------------
+# transformers calls q_proj / k_proj / v_proj (query / key / value) of one attention module on the SAME tensor object, one after
+# the other.  A LoRAGroup lets the first of those calls evaluate all of them as one autograd node (lora_ops.lora_group_forward:
+# x streamed once for every adapter, one dx) and hands the siblings their outputs when they are called with that very tensor.
+# Nothing in transformers is patched: a sibling called with another tensor (cross attention) simply computes on its own, and a
+# group whose stash is left unclaimed switches itself off.
+SHARED_INPUT_NAMES = (("q_proj", "k_proj", "v_proj"), ("query", "key", "value"))
+_GROUPS = os.environ.get("DALM_LORA_GROUP", "1") != "0"
+
+
+class GroupedLinear(nn.Linear):
+    """A plain (frozen) nn.Linear that sits between LoRA-wrapped siblings (k_proj between q_proj and v_proj): same parameters,
+    same state_dict keys; forward asks the group first."""
+
+    _group = None
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self._group is not None and x.is_cuda:
+            out = self._group.fetch(self, x)
+            if out is not None:
+                return out
+        return super().forward(x)
+
+
+class LoRAGroup:
+    def __init__(self, members):
+        self.members = list(members)
+        self.enabled = True
+        self._x = None
+        self._outs = {}
+
+    def _member_args(self, m):
+        if isinstance(m, LoRALinear):
+            p, salt = m.next_mask_key()
+            return (m.base_layer.weight, m.base_layer.bias, m.lora_A["default"].weight, m.lora_B["default"].weight,
+                    m.scaling, p, salt)
+        return (m.weight, m.bias, None, None, 0.0, 0.0, 0)
+
+    def fetch(self, module, x):
+        """The output of `module` for input x, or None (the caller computes it itself)."""
+        if not self.enabled or not _GROUPS or not _FUSED:
+            return None
+        if self._x is x:
+            out = self._outs.pop(id(module), None)
+            if not self._outs:
+                self._x = None
+            return out
+        if self._outs:                       # an earlier stash was never claimed: this model does not share inputs here
+            self.enabled = False
+            self._x, self._outs = None, {}
+            return None
+        from . import lora_ops
+
+        if any(isinstance(m, LoRALinear) and m.merged for m in self.members):
+            return None
+        for m in self.members:               # the plain-Linear path of a member must be exactly F.linear
+            base = m.base_layer if isinstance(m, LoRALinear) else m
+            if type(base) not in (nn.Linear, GroupedLinear):
+                return None
+        args = [self._member_args(m) for m in self.members]
+        if not lora_ops.group_supported(x, args):
+            return None
+        outs = lora_ops.lora_group_forward(x, args)
+        self._x = x
+        self._outs = {id(m): o for m, o in zip(self.members, outs)}
+        out = self._outs.pop(id(module))
+        if not self._outs:
+            self._x = None
+        return out
+
+
+def build_groups(model: nn.Module) -> int:
+    """Link LoRA-wrapped projections (and the plain Linears between them) that read the same input; returns the group count."""
+    n = 0
+    for parent in model.modules():
+        kids = dict(parent.named_children())
+        for names in SHARED_INPUT_NAMES:
+            mods = [kids[k] for k in names if k in kids]
+            if len(mods) < 2 or not any(isinstance(m, LoRALinear) for m in mods):
+                continue
+            if any(not (isinstance(m, LoRALinear) or type(m) in (nn.Linear, GroupedLinear)) for m in mods):
+                continue
+            if len({m.in_features for m in mods}) != 1:
+                continue
+            grp = LoRAGroup(mods)
+            for m in mods:
+                if type(m) is nn.Linear:
+                    m.__class__ = GroupedLinear
+                m._group = grp
+            n += 1
+    return n
 
 
 def _is_linear(m: nn.Module) -> bool:
@@ -145,6 +253,7 @@ def inject_lora(model: nn.Module, target_modules: List[str], r: int = 8, lora_al
         raise ValueError(f"Target modules {target_modules} not found in the base model.")
     model._dalm_lora_config = {"r": r, "lora_alpha": lora_alpha, "lora_dropout": lora_dropout, "bias": "none",
                                "target_modules": list(target_modules), "peft_type": "LORA"}
+    build_groups(model)
     return model
 
 

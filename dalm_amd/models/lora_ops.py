@@ -8,7 +8,14 @@ backward = base GEMM (dx = g W) + `rowdot` (dz = s g B) + 2 x `colacc` (dB = s g
 `rankupd` (dx += mask (dz A) / (1-p), in place).  A, B and every [rows, r] tensor stay in float32: no autocast casts of the
 adapter weights, no gradient casts back.
 
-Dropout: the mask is never stored; the kernels regenerate it from (a 64-bit seed word in DEVICE memory, a per-call salt, the
+Round 5 (`dalm_lora2_*`, dalm_amd/csrc/lora2.hip): bf16 activations take the stacked kernels - projections that read the
+same tensor (q_proj / v_proj of a Llama block, query / key / value of a BERT block) run as ONE autograd node
+(`lora_group_forward`): x is streamed once for all their z, once for all their dA, dx gets every rank update in one pass, the
+base GEMMs of the backward accumulate into one dx (no autograd add kernels), and the dropout mask is computed once in the
+forward and kept as bits (the backward no longer reads the seed word).  lora_B is held in [r, N]-major memory (models/lora.py) so
+that every weight operand is K-major.  float32 activations keep the round-4 kernels below.
+
+Dropout (float32 path): the mask is never stored; the kernels regenerate it from (a 64-bit seed word in DEVICE memory, a per-call salt, the
 element index).  `advance_dropout_seed()` bumps the seed word with a device op, so it can be captured into the step's
 hipGraph: every replay draws new masks.  The per-call salt (module id and a host call counter) separates the modules and -
 outside graphs - successive calls.  The random stream is this library's own, not torch's (dropout masks never agreed
@@ -50,8 +57,22 @@ def branch_supported(x: torch.Tensor, a: torch.Tensor, b: torch.Tensor) -> bool:
     """The low-rank branch alone (any base layer): shapes and dtypes the kernels take."""
     r = a.shape[0]
     return (x.is_cuda and r in (8, 16) and a.shape[1] % 8 == 0 and b.shape[0] % 8 == 0
-            and a.dtype == torch.float32 and b.dtype == torch.float32 and a.is_contiguous() and b.is_contiguous()
+            and a.dtype == torch.float32 and b.dtype == torch.float32 and a.is_contiguous()
+            and (b.is_contiguous() or b.t().is_contiguous())
             and x.dtype in (torch.float32, torch.bfloat16))
+
+
+def _b_cmajor(b: torch.Tensor) -> bool:
+    """lora_B.weight [N, r]: True when its memory is [N][r] (a plain contiguous Linear weight), False for the [r][N]-major form
+    models/lora.py creates (then `b.t()` is the contiguous [r, N] matrix every kernel wants)."""
+    return b.is_contiguous() and not (b.shape[1] > 1 and b.t().is_contiguous())
+
+
+def _colacc_b(g2, z, rank, scale, b):
+    """dB with the memory layout of b."""
+    if _b_cmajor(b):
+        return _colacc(g2, z, rank, scale, 0.0, None, 0, False)
+    return _colacc(g2, z, rank, scale, 0.0, None, 0, True).t()
 
 
 def supported(x: torch.Tensor, base, a: torch.Tensor, b: torch.Tensor) -> bool:
@@ -96,9 +117,12 @@ class _LoRALinearFn(torch.autograd.Function):
         bia = bias if bias is None or bias.dtype == x2.dtype else bias.to(x2.dtype)
         with torch.autocast("cuda", enabled=False):
             out = F.linear(x2, w, bia)                                                    # [R, N], the library's GEMM
-        seed = dropout_seed(x2.device) if p > 0 else None
+        # the seed word as the forward saw it (8-byte device copy, capturable): the backward regenerates the mask from THIS word,
+        # whatever advanced the live one in between
+        seed = dropout_seed(x2.device).clone() if p > 0 else None
         z = _rowdot(x2, a, True, rank, 1.0 / (1.0 - p), p, seed, salt)                    # dropout(x) A^T / (1-p)
-        _rankupd_(out, z, b, True, rank, scaling, 0.0, None, 0)                           # out += s z B^T
+        _rankupd_(out, z, b, _b_cmajor(b), rank, scaling, 0.0, None, 0)                   # out += s z B^T
+        ctx.seed = seed
         ctx.save_for_backward(x2, w, a, b, z)      # w: the weight in the compute dtype (the parameter itself when they agree)
         ctx.meta = (scaling, p, salt, x.shape, x.dtype, rank)
         return out.view(*x.shape[:-1], N)
@@ -112,10 +136,10 @@ class _LoRALinearFn(torch.autograd.Function):
         if g2.dtype != x2.dtype:
             g2 = g2.to(x2.dtype)
         g2 = g2.contiguous()
-        seed = dropout_seed(x2.device) if p > 0 else None
+        seed = ctx.seed
         keep = 1.0 / (1.0 - p)
-        dz = _rowdot(g2, b, False, rank, scaling, 0.0, None, 0)                           # s g B          [R, r]
-        db = _colacc(g2, z, rank, scaling, 0.0, None, 0, False) if ctx.needs_input_grad[4] else None      # s g^T z  [N, r]
+        dz = _rowdot(g2, b, not _b_cmajor(b), rank, scaling, 0.0, None, 0)                # s g B          [R, r]
+        db = _colacc_b(g2, z, rank, scaling, b) if ctx.needs_input_grad[4] else None                      # s g^T z  [N, r]
         da = _colacc(x2, dz, rank, keep, p, seed, salt, True) if ctx.needs_input_grad[3] else None        # [r, K]
         dx = None
         if ctx.needs_input_grad[0]:
@@ -142,10 +166,11 @@ class _LoRABranchFn(torch.autograd.Function):
         if cdt is not None and x2.dtype != cdt:
             x2 = x2.to(cdt)
         x2 = x2.contiguous()
-        seed = dropout_seed(x2.device) if p > 0 else None
+        seed = dropout_seed(x2.device).clone() if p > 0 else None
         z = _rowdot(x2, a, True, rank, 1.0 / (1.0 - p), p, seed, salt)
-        _rankupd_(base_out.view(-1, N), z, b, True, rank, scaling, 0.0, None, 0)
+        _rankupd_(base_out.view(-1, N), z, b, _b_cmajor(b), rank, scaling, 0.0, None, 0)
         ctx.mark_dirty(base_out)
+        ctx.seed = seed
         ctx.save_for_backward(x2, a, b, z)
         ctx.meta = (scaling, p, salt, x.shape, x.dtype, rank)
         return base_out
@@ -155,10 +180,10 @@ class _LoRABranchFn(torch.autograd.Function):
         x2, a, b, z = ctx.saved_tensors
         scaling, p, salt, xshape, xdtype, rank = ctx.meta
         g2 = g.reshape(-1, b.shape[0]).contiguous()
-        seed = dropout_seed(x2.device) if p > 0 else None
+        seed = ctx.seed
         keep = 1.0 / (1.0 - p)
-        dz = _rowdot(g2, b, False, rank, scaling, 0.0, None, 0)
-        db = _colacc(g2, z, rank, scaling, 0.0, None, 0, False) if ctx.needs_input_grad[3] else None
+        dz = _rowdot(g2, b, not _b_cmajor(b), rank, scaling, 0.0, None, 0)
+        db = _colacc_b(g2, z, rank, scaling, b) if ctx.needs_input_grad[3] else None
         da = _colacc(x2, dz, rank, keep, p, seed, salt, True) if ctx.needs_input_grad[2] else None
         dx = None
         if ctx.needs_input_grad[1]:
@@ -182,3 +207,248 @@ def lora_linear(x, base: torch.nn.Linear, a: torch.Tensor, b: torch.Tensor, scal
         raise RuntimeError("lora_linear: the base weight must be frozen (LoRA trains A and B only)")
     return _LoRALinearFn.apply(x, base.weight, base.bias, a, b, float(scaling), float(p), int(salt) & 0xFFFFFFFF)
 
+
+
+# =====================================================================================================================
+# round 5: stacked kernels (dalm_lora2_*), bf16 activations
+# =====================================================================================================================
+_tickets2: Dict[tuple, torch.Tensor] = {}
+
+
+def _colacc_tickets(dev: torch.device, words: int) -> torch.Tensor:
+    """Arrival tickets of `dalm_lora2_colacc`: zeroed once, left zero by every call.  One buffer per (device, stream): calls that
+    share it are ordered on that stream (the retriever towers run on their own streams beside the generator's)."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    buf = _tickets2.get(key)
+    if buf is None or buf.numel() < words:
+        buf = torch.zeros((max(words, 4096),), device=dev, dtype=torch.int32)
+        _tickets2[key] = buf
+    return buf
+
+
+def v2_supported(x2: torch.Tensor, rank: int) -> bool:
+    import os
+
+    return (x2.is_cuda and x2.dtype == torch.bfloat16 and rank in (8, 16) and x2.shape[1] % 32 == 0
+            and os.environ.get("DALM_LORA_V2", "1") != "0")
+
+
+def _bt(b: torch.Tensor) -> torch.Tensor:
+    """lora_B.weight [N, r] -> the contiguous [r, N] matrix (a view when models/lora.py created the parameter)."""
+    t = b.t()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def rowdot2(xs, Ws, rank: int, scale: float, p: float, salts, mode: int):
+    """mode 1: ([x], [W]) -> [z];  mode 2: ([x], [W0, W1]) -> [z0, z1] from ONE pass over x;  mode 3: ([x0, x1], [W0, W1]).
+    Returns (zs, bits): bits[t] is the [R, K/8] uint8 keep mask of slot t (None without dropout)."""
+    x0 = xs[0]
+    R, K = x0.shape
+    n = 1 if mode == 1 else 2
+    dev = x0.device
+    zs = [torch.empty(R, rank, device=dev, dtype=torch.float32) for _ in range(n)]
+    bits = [torch.empty(R, K // 8, device=dev, dtype=torch.uint8) if p > 0 else None for _ in range(n)]
+    seed = dropout_seed(dev) if p > 0 else None
+    x1 = xs[1] if mode == 3 else None
+    hip.call("dalm_lora2_rowdot", hip.ptr(x0), hip.ptr(x1), hip.ptr(Ws[0]), hip.ptr(Ws[1]) if n == 2 else None,
+             hip.ptr(zs[0]), hip.ptr(zs[1]) if n == 2 else None, hip.ptr(bits[0]), hip.ptr(bits[1]) if n == 2 else None,
+             R, K, rank, float(scale), float(p), hip.ptr(seed), int(salts[0]) & 0xFFFFFFFF,
+             (int(salts[1]) & 0xFFFFFFFF) if n == 2 else 0, mode, hip.stream())
+    return zs, bits
+
+
+def rankupd2_(ys, zs, Ws, bits, rank: int, scale: float, mode: int):
+    """mode 1: y += scale m (z W);  mode 2: ONE y += both terms;  mode 3: two independent (y, z, W)."""
+    y0 = ys[0]
+    R, C = y0.shape
+    n = 1 if mode == 1 else 2
+    hip.call("dalm_lora2_rankupd", hip.ptr(y0), hip.ptr(ys[1]) if mode == 3 else None, hip.ptr(zs[0]),
+             hip.ptr(zs[1]) if n == 2 else None, hip.ptr(Ws[0]), hip.ptr(Ws[1]) if n == 2 else None,
+             hip.ptr(bits[0]) if bits is not None else None, hip.ptr(bits[1]) if (bits is not None and n == 2) else None,
+             R, C, rank, float(scale), mode, hip.stream())
+    return ys
+
+
+def colacc2(xs, zs, bits, rank: int, scale: float, mode: int):
+    """out_t [rank, C] = scale * sum_row m_t x_t[row, :] (x) z_t[row, :]; mode as in rowdot2 (mode 2: one pass over x)."""
+    x0 = xs[0]
+    R, C = x0.shape
+    n = 1 if mode == 1 else 2
+    dev = x0.device
+    lib = hip.load()
+    outs = [torch.empty(rank, C, device=dev, dtype=torch.float32) for _ in range(n)]
+    nbytes = lib.dalm_lora2_colacc_workspace_bytes(R, C, rank, mode)
+    ws = torch.empty(max(nbytes, 8), device=dev, dtype=torch.uint8)
+    tickets = _colacc_tickets(dev, lib.dalm_lora2_colacc_ticket_words(C, mode))
+    hip.call("dalm_lora2_colacc", hip.ptr(x0), hip.ptr(xs[1]) if mode == 3 else None, hip.ptr(zs[0]),
+             hip.ptr(zs[1]) if n == 2 else None, hip.ptr(bits[0]) if bits is not None else None,
+             hip.ptr(bits[1]) if (bits is not None and n == 2) else None, hip.ptr(outs[0]), hip.ptr(outs[1]) if n == 2 else None,
+             R, C, rank, float(scale), mode, hip.ptr(ws), nbytes, hip.ptr(tickets), hip.stream())
+    return outs
+
+
+def _pairs(idx):
+    """[0, 1, 2] -> [(0, 1), (2,)]: the launches of a group of projections."""
+    return [tuple(idx[i:i + 2]) for i in range(0, len(idx), 2)]
+
+
+class _LoRAGroupFn(torch.autograd.Function):
+    """(out_0, ..., out_{n-1}) = (W_i x + b_i [+ s_i B_i A_i dropout_i(x)])_i for projections that read the same x.
+    Tensor arguments after x, per member: weight, bias or None, lora_A or None, lora_B^T ([r, N] contiguous) or None.
+    meta: per member (scaling, p, salt) or None for a plain Linear."""
+
+    @staticmethod
+    def forward(ctx, x, meta, *flat):
+        n = len(meta)
+        Ws, bs, As, Bts = flat[0::4], flat[1::4], flat[2::4], flat[3::4]
+        K = Ws[0].shape[1]
+        cdt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else None
+        x2 = x.reshape(-1, K)
+        if cdt is not None and x2.dtype != cdt:
+            x2 = x2.to(cdt)
+        x2 = x2.contiguous()
+        wc = [w if w.dtype == x2.dtype else w.to(x2.dtype) for w in Ws]
+        outs = []
+        with torch.autocast("cuda", enabled=False):
+            for i in range(n):
+                bi = bs[i] if bs[i] is None or bs[i].dtype == x2.dtype else bs[i].to(x2.dtype)
+                outs.append(torch.nn.functional.linear(x2, wc[i], bi))
+        lora = [i for i in range(n) if meta[i] is not None]
+        rank = As[lora[0]].shape[0]
+        zs, bits = [None] * n, [None] * n
+        # one pass over x per pair of adapters (one pass for q + v); members with different dropout rates cannot share a launch
+        for grp in _pairs(lora):
+            p = meta[grp[0]][1]
+            if len(grp) == 2 and rank == 8 and meta[grp[1]][1] == p:
+                z, bt = rowdot2([x2], [As[grp[0]], As[grp[1]]], rank, 1.0 / (1.0 - p), p, [meta[grp[0]][2], meta[grp[1]][2]], 2)
+                zs[grp[0]], zs[grp[1]], bits[grp[0]], bits[grp[1]] = z[0], z[1], bt[0], bt[1]
+            else:
+                for i in grp:
+                    pi = meta[i][1]
+                    z, bt = rowdot2([x2], [As[i]], rank, 1.0 / (1.0 - pi), pi, [meta[i][2]], 1)
+                    zs[i], bits[i] = z[0], bt[0]
+        for grp in _pairs(lora):
+            same = len(grp) == 2 and outs[grp[0]].shape == outs[grp[1]].shape and meta[grp[0]][0] == meta[grp[1]][0]
+            if same:
+                rankupd2_([outs[grp[0]], outs[grp[1]]], [zs[grp[0]], zs[grp[1]]], [Bts[grp[0]], Bts[grp[1]]], None, rank,
+                          meta[grp[0]][0], 3)
+            else:
+                for i in grp:
+                    rankupd2_([outs[i]], [zs[i]], [Bts[i]], None, rank, meta[i][0], 1)
+        ctx.meta, ctx.lora, ctx.n, ctx.rank = meta, lora, n, rank
+        ctx.xshape, ctx.xdtype = x.shape, x.dtype
+        ctx.set_materialize_grads(False)          # an output nobody differentiated arrives as None, not as a zero tensor
+        ctx.save_for_backward(x2, *wc, *[As[i] for i in lora], *[Bts[i] for i in lora], *[zs[i] for i in lora],
+                              *[b for b in (bits[i] for i in lora) if b is not None])
+        ctx.has_bits = [bits[i] is not None for i in lora]
+        return tuple(o.view(*x.shape[:-1], o.shape[-1]) for o in outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n, lora, meta, rank = ctx.n, ctx.lora, ctx.meta, ctx.rank
+        sv = ctx.saved_tensors
+        x2, wc = sv[0], sv[1:1 + n]
+        m = len(lora)
+        As = dict(zip(lora, sv[1 + n:1 + n + m]))
+        Bts = dict(zip(lora, sv[1 + n + m:1 + n + 2 * m]))
+        zs = dict(zip(lora, sv[1 + n + 2 * m:1 + n + 3 * m]))
+        rest = list(sv[1 + n + 3 * m:])
+        bits = {i: (rest.pop(0) if hb else None) for i, hb in zip(lora, ctx.has_bits)}
+        g2 = []
+        for i in range(n):
+            g = gs[i]
+            if g is None:
+                g2.append(None)
+                continue
+            g = g.reshape(-1, wc[i].shape[0])
+            if g.dtype != x2.dtype:
+                g = g.to(x2.dtype)
+            g2.append(g.contiguous())
+        live = [i for i in lora if g2[i] is not None]
+        dz, dA, dBt = {}, {}, {}
+        for grp in _pairs(live):
+            same = len(grp) == 2 and g2[grp[0]].shape == g2[grp[1]].shape and meta[grp[0]][0] == meta[grp[1]][0]
+            if same:                                       # dz = s g B and dB^T = s z^T g for both adapters, one launch each
+                z2, _ = rowdot2([g2[grp[0]], g2[grp[1]]], [Bts[grp[0]], Bts[grp[1]]], rank, meta[grp[0]][0], 0.0, [0, 0], 3)
+                d2 = colacc2([g2[grp[0]], g2[grp[1]]], [zs[grp[0]], zs[grp[1]]], None, rank, meta[grp[0]][0], 3)
+                for k, i in enumerate(grp):
+                    dz[i], dBt[i] = z2[k], d2[k]
+            else:
+                for i in grp:
+                    dz[i] = rowdot2([g2[i]], [Bts[i]], rank, meta[i][0], 0.0, [0], 1)[0][0]
+                    dBt[i] = colacc2([g2[i]], [zs[i]], None, rank, meta[i][0], 1)[0]
+        for grp in _pairs(live):                           # dA = dz^T (mask x) / (1-p): x streamed once per pair
+            p = meta[grp[0]][1]
+            both = len(grp) == 2 and rank == 8 and meta[grp[1]][1] == p and (bits[grp[0]] is None) == (bits[grp[1]] is None)
+            if both:
+                bt = [bits[grp[0]], bits[grp[1]]] if bits[grp[0]] is not None else None
+                d2 = colacc2([x2], [dz[grp[0]], dz[grp[1]]], bt, rank, 1.0 / (1.0 - p), 2)
+                dA[grp[0]], dA[grp[1]] = d2[0], d2[1]
+            else:
+                for i in grp:
+                    pi = meta[i][1]
+                    dA[i] = colacc2([x2], [dz[i]], [bits[i]] if bits[i] is not None else None, rank, 1.0 / (1.0 - pi), 1)[0]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            for i in range(n):                             # the base GEMMs accumulate into one dx
+                if g2[i] is None:
+                    continue
+                if dx is None:
+                    dx = torch.mm(g2[i], wc[i])
+                else:
+                    dx.addmm_(g2[i], wc[i])
+            if dx is None:
+                dx = torch.zeros_like(x2)
+            for grp in _pairs(live):                       # += mask (dz A) / (1-p), every adapter of a pair in one pass
+                p = meta[grp[0]][1]
+                both = len(grp) == 2 and rank == 8 and meta[grp[1]][1] == p and (bits[grp[0]] is None) == (bits[grp[1]] is None)
+                if both:
+                    bt = [bits[grp[0]], bits[grp[1]]] if bits[grp[0]] is not None else None
+                    rankupd2_([dx], [dz[grp[0]], dz[grp[1]]], [As[grp[0]], As[grp[1]]], bt, rank, 1.0 / (1.0 - p), 2)
+                else:
+                    for i in grp:
+                        pi = meta[i][1]
+                        rankupd2_([dx], [dz[i]], [As[i]], [bits[i]] if bits[i] is not None else None, rank, 1.0 / (1.0 - pi), 1)
+            dx = dx.view(ctx.xshape)
+            if dx.dtype != ctx.xdtype:
+                dx = dx.to(ctx.xdtype)
+        grads = [dx, None]
+        for i in range(n):
+            grads += [None, None, dA.get(i), dBt.get(i)]
+        return tuple(grads)
+
+
+def lora_group_forward(x, members):
+    """members: list of (weight, bias, lora_A or None, lora_B or None, scaling, p, salt).  Returns the tuple of outputs."""
+    meta, flat = [], []
+    for (w, bias, a, b, scaling, p, salt) in members:
+        if a is None:
+            meta.append(None)
+            flat += [w, bias, None, None]
+        else:
+            meta.append((float(scaling), float(p), int(salt) & 0xFFFFFFFF))
+            flat += [w, bias, a, _bt(b)]
+    return _LoRAGroupFn.apply(x, tuple(meta), *flat)
+
+
+def group_supported(x, members) -> bool:
+    """All members plain frozen Linears (bf16 / f32 weights), adapters of one rank with f32 contiguous A and [r, N]-major B, and an
+    activation the stacked kernels take (bf16, or autocast to bf16)."""
+    if not x.is_cuda:
+        return False
+    cdt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
+    if cdt != torch.bfloat16:
+        return False
+    ranks = set()
+    for (w, bias, a, b, scaling, p, salt) in members:
+        if w.requires_grad or (bias is not None and bias.requires_grad) or w.dtype not in (torch.float32, torch.bfloat16):
+            return False
+        if a is not None:
+            if not (a.dtype == torch.float32 and b.dtype == torch.float32 and a.is_contiguous() and b.t().is_contiguous()):
+                return False
+            if a.shape[1] % 32 != 0 or b.shape[0] % 8 != 0:
+                return False
+            ranks.add(a.shape[0])
+    import os
+
+    return len(ranks) == 1 and next(iter(ranks)) in (8, 16) and os.environ.get("DALM_LORA_V2", "1") != "0"

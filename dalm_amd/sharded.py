@@ -125,8 +125,18 @@ def allreduce_grads(params: Iterable[torch.nn.Parameter], comm) -> None:
     off = 0
     for p in ps:
         n = p.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        p.grad.copy_(flat[off:off + n].view(p.grad.shape))
         off += n
+
+
+def _view_like(flat: torch.Tensor, p: torch.Tensor) -> torch.Tensor:
+    """A view of the 1-D slice `flat` with the SHAPE AND STRIDES of `p`: lora_B parameters live in transposed ([r, N]-major)
+    memory (models/lora.py), and the fused optimizer wants parameter and gradient laid out alike."""
+    if p.is_contiguous():
+        return flat.view_as(p)
+    if p.dim() == 2 and p.t().is_contiguous():
+        return flat.view(p.shape[1], p.shape[0]).t()
+    raise ValueError(f"GradBucket: parameter layout {tuple(p.shape)} / {p.stride()} is neither dense nor transposed-dense")
 
 
 class _Bucket:
@@ -171,7 +181,7 @@ class GradBucket:
         per = max(int(bucket_bytes) // 4, 1)
         for p in self.params:
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
+            p.grad = _view_like(self.flat[off:off + n], p)
             self._bucket_of.append(len(self.buckets))
             off += n
             count += 1
@@ -251,7 +261,7 @@ class GradBucket:
         for p in self.params:  # re-attach in case something replaced .grad (e.g. set_to_none)
             n = p.numel()
             if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * off:
-                p.grad = self.flat[off:off + n].view_as(p)
+                p.grad = _view_like(self.flat[off:off + n], p)
             off += n
 
 

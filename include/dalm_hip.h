@@ -464,6 +464,36 @@ int dalm_lora_colacc(const void* x, int dtype, const float* z, int64_t R, int64_
                      const void* seed, uint32_t salt, float* out, int out_jmajor, void* ws, size_t ws_bytes,
                      dalm_stream_t stream);
 
+/* ---- round 5: the same branch for projections that SHARE their input, bf16 activations, mask stored as bits ------------
+ * (q_proj / v_proj of one attention block read the same normed hidden states, query / key / value of a BERT block likewise:
+ * dalm/models/rag_e2e_base_model.py:61-80.)  `mode` selects how the two operand slots are used:
+ *   1  one problem (slot 0);
+ *   2  two terms over ONE activation (slot 0's x / y): rowdot reads x once for z_0 and z_1, colacc reads x once for out_0 and
+ *      out_1, rankupd adds both rank updates in one pass over y.  rank 8 only;
+ *   3  two independent problems of one shape in one launch (slots 0 and 1).
+ * Every W is [rank][K] row-major f32 (lora_A as stored; lora_B transposed - models/lora.py keeps it that way in memory), z and
+ * out f32, x / y bf16 row-major, 16-byte aligned, columns a multiple of 8 (rowdot: of 32).
+ * Dropout (mask v2, restated in oracle/lora_mask.py::keep_mask_v2): dalm_lora2_rowdot computes the keep mask of slot t from
+ * (the 64-bit word at `seed`, salt_t, flat element index) ONCE and writes it to bits_t, [R][K / 8] bytes, bit e of byte
+ * (row, c) = element 8 c + e of the row survives; rankupd / colacc take bits_t (NULL = no mask) - the backward never depends on
+ * the seed word again.  1 / (1 - p) is folded into `scale` by the caller.
+ *   dalm_lora2_rowdot :  out_t[row][j]  = scale * sum_k m_t x_t[row][k] W_t[j][k]
+ *   dalm_lora2_rankupd:  y[row][c]     += scale * sum_t m_t sum_j z_t[row][j] W_t[j][c]        (mode 3: y_t, one term each)
+ *   dalm_lora2_colacc :  out_t[j][c]    = scale * sum_row m_t x_t[row][c] z_t[row][j]          ([rank][C], finished in the launch)
+ * colacc: `ws` >= dalm_lora2_colacc_workspace_bytes, 8-byte aligned; `tickets`: dalm_lora2_colacc_ticket_words 32-bit words,
+ * ZERO on entry and left zero (calls that share the buffer must be ordered on one stream).  Fixed summation orders. */
+int dalm_lora2_rowdot(const void* x0, const void* x1, const float* W0, const float* W1, float* out0, float* out1, void* bits0,
+                      void* bits1, int64_t R, int64_t K, int rank, float scale, float p, const void* seed, uint32_t salt0,
+                      uint32_t salt1, int mode, dalm_stream_t stream);
+int dalm_lora2_rankupd(void* y0, void* y1, const float* z0, const float* z1, const float* W0, const float* W1,
+                       const void* bits0, const void* bits1, int64_t R, int64_t C, int rank, float scale, int mode,
+                       dalm_stream_t stream);
+size_t dalm_lora2_colacc_workspace_bytes(int64_t R, int64_t C, int rank, int mode);
+size_t dalm_lora2_colacc_ticket_words(int64_t C, int mode);
+int dalm_lora2_colacc(const void* x0, const void* x1, const float* z0, const float* z1, const void* bits0, const void* bits1,
+                      float* out0, float* out1, int64_t R, int64_t C, int rank, float scale, int mode, void* ws,
+                      size_t ws_bytes, uint32_t* tickets, dalm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

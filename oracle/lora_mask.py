@@ -12,6 +12,13 @@ kernels' mask to something written independently of them:
     element 2i   is kept iff  (h(i) & 0xFFFF) >= thr      element 2i+1 iff (h(i) >> 16) >= thr,   thr = round(p * 65536)
     mix(x): x ^= x >> 16; x *= 0x7FEB352D; x ^= x >> 15; x *= 0x846CA68B; x ^= x >> 16        (all modulo 2^32)
 
+Round 5 (dalm_amd/csrc/lora2.hip, bf16 activations): mask v2 - the same keys, pair index and 16-bit threshold test, with a
+two-multiply hash; the forward kernel computes it ONCE and stores it as bits (byte (row, c) bit e = element 8 c + e survives),
+the backward kernels read the bits:
+
+    h(i)  = mix2(i ^ key.a, key.b)
+    mix2(x, b): x ^= x >> 16; x *= 0x7FEB352D; x ^= x >> 15; x += b; x *= 0x846CA68B; x ^= x >> 16   (all modulo 2^32)
+
 PARITY: not a reference algorithm (see above) - what is pinned is kernel == this restatement for every element, the keep rate,
 and that the three kernels agree with each other (tests/test_lora_ops_gpu.py).
 """
@@ -51,3 +58,35 @@ def keep_mask(seed: int, salt: int, rows: int, cols: int, p: float) -> np.ndarra
     out[0::2] = (h & np.uint64(0xFFFF)) >= thr
     out[1::2] = (h >> np.uint64(16)) >= thr
     return out.reshape(rows, cols)
+
+
+def _mix2(x: np.ndarray, b) -> np.ndarray:
+    x = x.astype(np.uint64) & M32
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x7FEB352D)) & M32
+    x ^= x >> np.uint64(15)
+    x = (x + np.uint64(b)) & M32
+    x = (x * np.uint64(0x846CA68B)) & M32
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def keep_mask_v2(seed: int, salt: int, rows: int, cols: int, p: float) -> np.ndarray:
+    """bool [rows, cols], mask v2 (dalm_lora2_rowdot)."""
+    seed &= (1 << 64) - 1
+    salt &= 0xFFFFFFFF
+    a = _mix(np.array([(seed & 0xFFFFFFFF) ^ ((salt * 0x9E3779B9) & 0xFFFFFFFF)], dtype=np.uint64))[0]
+    b = _mix(np.array([((seed >> 32) + salt + 0x85EBCA6B) & 0xFFFFFFFF], dtype=np.uint64))[0] | np.uint64(1)
+    n = rows * cols
+    pair = (np.arange(0, n, 2, dtype=np.uint64) & M32) >> np.uint64(1)
+    h = _mix2(pair ^ a, b)
+    thr = np.uint64(threshold(p))
+    out = np.empty(n, dtype=bool)
+    out[0::2] = (h & np.uint64(0xFFFF)) >= thr
+    out[1::2] = (h >> np.uint64(16)) >= thr
+    return out.reshape(rows, cols)
+
+
+def pack_bits(mask: np.ndarray) -> np.ndarray:
+    """bool [rows, cols] -> uint8 [rows, cols / 8], bit e of byte c = mask[row, 8 c + e] (the layout dalm_lora2_rowdot writes)."""
+    return np.packbits(mask.astype(np.uint8), axis=1, bitorder="little")

@@ -1,0 +1,342 @@
+"""`dalm_lora2_{rowdot,rankupd,colacc}` (dalm_amd/csrc/lora2.hip) and the shared-input LoRA node built on them
+(`lora_ops.lora_group_forward`, `lora.LoRAGroup`), against the formula peft evaluates for the reference
+(dalm/models/rag_e2e_base_model.py:61-80,145-160: r = 8, alpha = 16, dropout 0.05 on q_proj / v_proj, key / query / value):
+    out_i = W_i x + s * B_i(A_i(dropout_i(x)))
+* every mode of every kernel against a float64 evaluation (operands bf16, weights f32; sums in f32);
+* dropout: the bits the forward kernel stores equal oracle/lora_mask.py::keep_mask_v2 BIT FOR BIT, z equals the float64
+  product under that mask, and the backward kernels apply exactly those bits;
+* the group node against the same modules evaluated one by one through their eager branch (outputs, dx, dA, dB);
+* the group protocol: siblings receive the stashed outputs, an unclaimed stash switches the group off, the backward does not
+  depend on the live seed word."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "oracle"))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _data(R, K, N, rank, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(R, K, generator=g).bfloat16()
+    y = torch.randn(R, N, generator=g).bfloat16()
+    A = torch.randn(rank, K, generator=g) / K ** 0.5
+    Bt = torch.randn(rank, N, generator=g) / rank ** 0.5
+    return x, y, A, Bt
+
+
+SHAPES = [(4608, 4096, 4096, 8), (2304, 1024, 1024, 8), (37, 64, 40, 8), (5, 4128, 8200, 8), (300, 96, 72, 16), (1, 32, 8, 16),
+          (19, 512, 512, 8)]
+
+
+@pytest.mark.parametrize("R,K,N,rank", SHAPES)
+def test_rowdot_modes_vs_float64(dev, R, K, N, rank):
+    from dalm_amd.models import lora_ops as L
+
+    x, y, A, Bt = _data(R, K, N, rank, R + K)
+    x2, _, A2, _ = _data(R, K, N, rank, R + K + 1)
+    xd, x2d, Ad, A2d = x.to(dev), x2.to(dev), A.to(dev), A2.to(dev)
+    tol = 2e-5
+    z, bits = L.rowdot2([xd], [Ad], rank, 1.5, 0.0, [0], 1)
+    assert bits[0] is None and _rel(z[0], 1.5 * x.double() @ A.double().t()) < tol
+    z = L.rowdot2([xd, x2d], [Ad, A2d], rank, 0.5, 0.0, [0, 0], 3)[0]
+    assert _rel(z[0], 0.5 * x.double() @ A.double().t()) < tol and _rel(z[1], 0.5 * x2.double() @ A2.double().t()) < tol
+    if rank == 8:
+        z = L.rowdot2([xd], [Ad, A2d], rank, 2.0, 0.0, [0, 0], 2)[0]
+        assert _rel(z[0], 2.0 * x.double() @ A.double().t()) < tol and _rel(z[1], 2.0 * x.double() @ A2.double().t()) < tol
+
+
+@pytest.mark.parametrize("p", [0.05, 0.5])
+@pytest.mark.parametrize("R,K,rank,mode", [(4608, 4096, 8, 2), (333, 1024, 8, 2), (333, 1024, 8, 1), (64, 8224, 8, 2), (200, 96, 16, 1),
+                                           (7, 64, 8, 2)])
+def test_rowdot_dropout_bits_equal_the_numpy_restatement(dev, R, K, rank, mode, p):
+    import lora_mask as O
+
+    from dalm_amd.models import lora_ops as L
+
+    x, _, A, _ = _data(R, K, 8, rank, R + K)
+    _, _, A2, _ = _data(R, K, 8, rank, R + K + 5)
+    xd = x.to(dev)
+    L.advance_dropout_seed(dev)
+    seed = int(L.dropout_seed(dev).item())
+    salts = [0xBEEF01, 0x1234567]
+    Ws = [A.to(dev)] if mode == 1 else [A.to(dev), A2.to(dev)]
+    z, bits = L.rowdot2([xd], Ws, rank, 1.0 / (1.0 - p), p, salts, mode)
+    torch.cuda.synchronize()
+    for t, W in enumerate([A, A2][:len(Ws)]):
+        want = O.keep_mask_v2(seed, salts[t], R, K, p)
+        assert np.array_equal(bits[t].cpu().numpy(), O.pack_bits(want)), f"mask bits of slot {t}"
+        ref = (x.double() * torch.from_numpy(want).double()) @ W.double().t() / (1.0 - p)
+        assert _rel(z[t], ref) < 2e-5
+        assert abs(want.mean() - (1 - p)) < 4 * (p * (1 - p) / want.size) ** 0.5 + 1e-4
+    if mode == 2:
+        assert not np.array_equal(bits[0].cpu().numpy(), bits[1].cpu().numpy())
+    # same (seed, salt): the same bits; an advanced seed word: other bits
+    again = L.rowdot2([xd], Ws, rank, 1.0 / (1.0 - p), p, salts, mode)[1]
+    assert torch.equal(again[0], bits[0])
+    L.advance_dropout_seed(dev)
+    moved = L.rowdot2([xd], Ws, rank, 1.0 / (1.0 - p), p, salts, mode)[1]
+    assert not torch.equal(moved[0], bits[0]) or R * K < 512
+
+
+def _rand_bits(R, C, gen, dev):
+    m = torch.rand(R, C, generator=gen) > 0.3
+    packed = np.packbits(m.numpy().astype(np.uint8), axis=1, bitorder="little")
+    return m.double(), torch.from_numpy(packed).to(dev)
+
+
+@pytest.mark.parametrize("with_bits", [False, True])
+@pytest.mark.parametrize("R,K,N,rank", SHAPES)
+def test_rankupd_modes_vs_float64(dev, R, K, N, rank, with_bits):
+    from dalm_amd.models import lora_ops as L
+
+    x, y, A, Bt = _data(R, K, N, rank, R + N)
+    g = torch.Generator().manual_seed(R)
+    z0, z1 = torch.randn(R, rank, generator=g), torch.randn(R, rank, generator=g)
+    _, y1, _, Bt1 = _data(R, K, N, rank, R + N + 3)
+    m0, b0 = _rand_bits(R, N, g, dev) if with_bits else (1.0, None)
+    m1, b1 = _rand_bits(R, N, g, dev) if with_bits else (1.0, None)
+    rt = 4e-3                                                # one rounding of the bf16 result
+    out = L.rankupd2_([y.to(dev)], [z0.to(dev)], [Bt.to(dev)], [b0] if with_bits else None, rank, 2.0, 1)[0]
+    assert _rel(out, y.double() + 2.0 * m0 * (z0.double() @ Bt.double())) < rt
+    outs = L.rankupd2_([y.to(dev), y1.to(dev)], [z0.to(dev), z1.to(dev)], [Bt.to(dev), Bt1.to(dev)],
+                       [b0, b1] if with_bits else None, rank, 0.5, 3)
+    assert _rel(outs[0], y.double() + 0.5 * m0 * (z0.double() @ Bt.double())) < rt
+    assert _rel(outs[1], y1.double() + 0.5 * m1 * (z1.double() @ Bt1.double())) < rt
+    if rank == 8:
+        out = L.rankupd2_([y.to(dev)], [z0.to(dev), z1.to(dev)], [Bt.to(dev), Bt1.to(dev)], [b0, b1] if with_bits else None,
+                          rank, 1.25, 2)[0]
+        ref = y.double() + 1.25 * (m0 * (z0.double() @ Bt.double()) + m1 * (z1.double() @ Bt1.double()))
+        assert _rel(out, ref) < rt
+    # exactness of the mask: where both masks drop an element, y comes back untouched
+    if with_bits and rank == 8:
+        keep = ((m0 + m1) > 0)
+        assert torch.equal(out.cpu()[~keep], y[~keep])
+
+
+@pytest.mark.parametrize("with_bits", [False, True])
+@pytest.mark.parametrize("R,K,N,rank", SHAPES)
+def test_colacc_modes_vs_float64_and_tickets_are_left_zero(dev, R, K, N, rank, with_bits):
+    from dalm_amd.models import lora_ops as L
+
+    x, y, _, _ = _data(R, K, N, rank, R + N)
+    x1 = _data(R, K, N, rank, R + N + 9)[0]
+    g = torch.Generator().manual_seed(R + 1)
+    z0, z1 = torch.randn(R, rank, generator=g), torch.randn(R, rank, generator=g)
+    m0, b0 = _rand_bits(R, K, g, dev) if with_bits else (1.0, None)
+    m1, b1 = _rand_bits(R, K, g, dev) if with_bits else (1.0, None)
+    tol = 3e-6
+    for _ in range(2):                                       # twice: the second call finds the tickets the first one left
+        o = L.colacc2([x.to(dev)], [z0.to(dev)], [b0] if with_bits else None, rank, 2.0, 1)[0]
+        assert _rel(o, 2.0 * z0.double().t() @ (m0 * x.double())) < tol
+        o = L.colacc2([x.to(dev), x1.to(dev)], [z0.to(dev), z1.to(dev)], [b0, b1] if with_bits else None, rank, 0.5, 3)
+        assert _rel(o[0], 0.5 * z0.double().t() @ (m0 * x.double())) < tol
+        assert _rel(o[1], 0.5 * z1.double().t() @ (m1 * x1.double())) < tol
+        if rank == 8:
+            o = L.colacc2([x.to(dev)], [z0.to(dev), z1.to(dev)], [b0, b1] if with_bits else None, rank, 1.5, 2)
+            assert _rel(o[0], 1.5 * z0.double().t() @ (m0 * x.double())) < tol
+            assert _rel(o[1], 1.5 * z1.double().t() @ (m1 * x.double())) < tol
+    torch.cuda.synchronize()
+    for buf in L._tickets2.values():
+        assert int(buf.abs().sum()) == 0
+
+
+def test_colacc_is_bitwise_reproducible(dev):
+    from dalm_amd.models import lora_ops as L
+
+    x = _data(4608, 4096, 8, 8, 3)[0].to(dev)
+    z = torch.randn(4608, 8, generator=torch.Generator().manual_seed(4)).to(dev)
+    a = L.colacc2([x], [z, z.flip(0)], None, 8, 1.0, 2)
+    for _ in range(3):
+        b = L.colacc2([x], [z, z.flip(0)], None, 8, 1.0, 2)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the shared-input node
+# ---------------------------------------------------------------------------------------------------------------------
+class _Attn(torch.nn.Module):
+    """The call pattern of transformers' attention modules: three projections of the SAME tensor."""
+
+    def __init__(self, K, Nq, Nkv, names, bias):
+        super().__init__()
+        self.names = names
+        for n, N in zip(names, (Nq, Nkv, Nkv)):
+            setattr(self, n, torch.nn.Linear(K, N, bias=bias))
+
+    def forward(self, h):
+        return tuple(getattr(self, n)(h) for n in self.names)
+
+
+def _build(dev, names, targets, K, Nq, Nkv, bias, wdtype, seed=0):
+    from dalm_amd.models import lora as lora_mod
+
+    torch.manual_seed(seed)
+    m = _Attn(K, Nq, Nkv, names, bias).to(wdtype).to(dev)
+    lora_mod.inject_lora(m, targets, r=8, lora_alpha=16, lora_dropout=0.05)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, lora_mod.LoRALinear):
+                mod.lora_B["default"].weight.normal_(0, 0.1)
+    return m
+
+
+@pytest.mark.parametrize("names,targets,Nq,Nkv,bias", [
+    (("q_proj", "k_proj", "v_proj"), ["q_proj", "v_proj"], 1024, 1024, False),      # Llama: adapters on q and v, k plain
+    (("q_proj", "k_proj", "v_proj"), ["q_proj", "v_proj"], 1024, 256, False),       # grouped-query: v narrower than q
+    (("query", "key", "value"), ["key", "query", "value"], 768, 768, True),         # BERT: three adapters, biases
+])
+@pytest.mark.parametrize("mode", ["bf16-weights", "f32-weights-autocast"])
+def test_group_node_matches_the_modules_evaluated_one_by_one(dev, names, targets, Nq, Nkv, bias, mode):
+    from dalm_amd.models import lora as lora_mod
+
+    K, R = 1024, 384
+    wdtype = torch.bfloat16 if mode == "bf16-weights" else torch.float32
+    m = _build(dev, names, targets, K, Nq, Nkv, bias, wdtype).eval()            # eval: dropout off
+    groups = {id(getattr(m, n)._group) for n in names}
+    assert len(groups) == 1 and None not in [getattr(m, n)._group for n in names]
+    x = torch.randn(4, R // 4, K, generator=torch.Generator().manual_seed(2)).to(dev)
+    ups = [torch.randn(4, R // 4, N, generator=torch.Generator().manual_seed(3 + i)).to(dev) for i, N in enumerate((Nq, Nkv, Nkv))]
+    res = []
+    for grouped in (False, True):
+        lora_mod._GROUPS = grouped
+        lora_mod._FUSED = grouped                                  # reference: every module through its eager branch
+        try:
+            for p in m.parameters():
+                p.grad = None
+            xi = x.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                outs = m(xi)
+            sum((o.float() * u).sum() for o, u in zip(outs, ups)).backward()
+            grads = {n: p.grad.float().clone() for n, p in m.named_parameters() if p.grad is not None}
+            res.append(([o.detach().float() for o in outs], xi.grad.float(), grads))
+        finally:
+            lora_mod._GROUPS, lora_mod._FUSED = True, True
+    (o_ref, dx_ref, g_ref), (o_new, dx_new, g_new) = res
+    # the group accumulates the branch in f32 and rounds once; the eager chain rounds every intermediate to bf16.  Measured
+    # (profiles/r05_lora2_tests.txt): out 2.6e-3, dx 4.5e-3, dA 5e-3, dB 3.4e-3
+    for a, b in zip(o_new, o_ref):
+        assert a.dtype == b.dtype and _rel(a, b) < 8e-3
+    assert _rel(dx_new, dx_ref) < 1.2e-2
+    assert sorted(g_new) == sorted(g_ref) and len(g_new) == 2 * len(targets)
+    for k in g_ref:
+        assert g_new[k].shape == g_ref[k].shape and _rel(g_new[k], g_ref[k]) < 1.5e-2, k
+
+
+def test_group_node_vs_float64(dev):
+    """The same comparison against a float64 evaluation of the formula (what both of the above approximate)."""
+    from dalm_amd.models import lora as lora_mod
+
+    K, N, R = 1024, 1024, 512
+    m = _build(dev, ("q_proj", "k_proj", "v_proj"), ["q_proj", "v_proj"], K, N, N, False, torch.bfloat16).eval()
+    x = torch.randn(R, K, generator=torch.Generator().manual_seed(5)).bfloat16().to(dev).requires_grad_(True)
+    ups = [torch.randn(R, N, generator=torch.Generator().manual_seed(6 + i)).bfloat16().to(dev) for i in range(3)]
+    outs = m(x)
+    sum((o.float() * u.float()).sum() for o, u in zip(outs, ups)).backward()
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    tot = 0.0
+    refs = []
+    params64 = {}
+    for n, u in zip(("q_proj", "k_proj", "v_proj"), ups):
+        mod = getattr(m, n)
+        if isinstance(mod, lora_mod.LoRALinear):
+            W = mod.base_layer.weight.detach().double().cpu()
+            A = mod.lora_A["default"].weight.detach().double().cpu().requires_grad_(True)
+            Bm = mod.lora_B["default"].weight.detach().double().cpu().requires_grad_(True)
+            params64[n] = (A, Bm)
+            o = x64 @ W.t() + mod.scaling * (x64 @ A.t()) @ Bm.t()
+        else:
+            o = x64 @ mod.weight.detach().double().cpu().t()
+        refs.append(o)
+        tot = tot + (o * u.double().cpu()).sum()
+    tot.backward()
+    for o, r in zip(outs, refs):
+        assert _rel(o, r) < 4e-3                                   # one bf16 rounding of the output
+    assert _rel(x.grad, x64.grad) < 4e-3
+    for n, (A, Bm) in params64.items():
+        mod = getattr(m, n)
+        assert _rel(mod.lora_A["default"].weight.grad, A.grad) < 3e-5
+        assert _rel(mod.lora_B["default"].weight.grad, Bm.grad) < 3e-5
+        assert mod.lora_B["default"].weight.grad.stride() == mod.lora_B["default"].weight.stride()
+
+
+def test_group_protocol(dev):
+    from dalm_amd.models import lora as lora_mod
+
+    m = _build(dev, ("q_proj", "k_proj", "v_proj"), ["q_proj", "v_proj"], 256, 256, 256, False, torch.bfloat16).eval()
+    grp = m.q_proj._group
+    x = torch.randn(16, 256, device=dev, dtype=torch.bfloat16)
+    q = m.q_proj(x)
+    assert grp._x is x and len(grp._outs) == 2                      # k and v wait in the stash
+    k, v = m.k_proj(x), m.v_proj(x)
+    assert grp._x is None and not grp._outs and grp.enabled
+    lora_mod._GROUPS = False
+    try:
+        q1, k1, v1 = m(x)
+    finally:
+        lora_mod._GROUPS = True
+    assert torch.equal(k, k1) and _rel(q, q1) < 1e-4 and _rel(v, v1) < 1e-4   # one member per launch: the same values
+    # a sibling called with ANOTHER tensor computes on its own; the stash it left behind switches the group off at the next call
+    q = m.q_proj(x)
+    k2 = m.k_proj(x.clone())
+    assert torch.equal(k2, k1) and grp.enabled
+    q = m.q_proj(x.clone())
+    assert not grp.enabled and grp._x is None and not grp._outs
+    assert torch.equal(q, q1)
+    assert type(m.k_proj) is lora_mod.GroupedLinear and sorted(m.state_dict()) == sorted(
+        ["q_proj.base_layer.weight", "q_proj.lora_A.default.weight", "q_proj.lora_B.default.weight", "k_proj.weight",
+         "v_proj.base_layer.weight", "v_proj.lora_A.default.weight", "v_proj.lora_B.default.weight"])
+
+
+def test_training_masks_differ_per_adapter_and_step_and_backward_ignores_the_live_seed(dev):
+    from dalm_amd.models import lora as lora_mod
+    from dalm_amd.models import lora_ops as L
+
+    torch.manual_seed(0)
+    K = N = 256
+    m = _Attn(K, N, N, ("q_proj", "k_proj", "v_proj"), False).to(torch.bfloat16).to(dev)
+    with torch.no_grad():
+        for n in ("q_proj", "k_proj", "v_proj"):
+            getattr(m, n).weight.zero_()                                # only the low-rank branches are left
+    lora_mod.inject_lora(m, ["q_proj", "v_proj"], r=8, lora_alpha=16, lora_dropout=0.5)
+    with torch.no_grad():                                               # positive adapters: no column of s B A is near zero
+        for n in ("q_proj", "v_proj"):
+            getattr(m, n).lora_B["default"].weight.uniform_(0.5, 1.5)
+            getattr(m, n).lora_A["default"].weight.uniform_(0.5, 1.5)
+    m.train()
+    x = torch.ones(64, K, device=dev, dtype=torch.bfloat16, requires_grad=True)
+    masks = []
+    for _ in range(2):
+        L.advance_dropout_seed(dev)
+        q, k, v = m(x)
+        L.advance_dropout_seed(dev)                                     # the live seed moves between forward and backward
+        for name, out in (("q_proj", q), ("v_proj", v)):
+            mod = getattr(m, name)
+            x.grad = None
+            out.float().sum().backward(retain_graph=True)
+            # d out.sum() / dx[r, k] = mask[r, k] / (1 - p) * sum_c (s B A)[c, k]: zero exactly where the forward dropped x[r, k]
+            col = (mod.scaling * mod.lora_B["default"].weight @ mod.lora_A["default"].weight).sum(0)
+            mask = (x.grad.float() / (col / 0.5)).round()
+            assert set(mask.unique().tolist()) <= {0.0, 1.0} and 0.4 < float(mask.mean()) < 0.6
+            z_ref = (mask * x.detach().float() / 0.5) @ mod.lora_A["default"].weight.t()
+            ref = mod.scaling * z_ref @ mod.lora_B["default"].weight.t()
+            torch.testing.assert_close(out.detach().float(), ref, rtol=2e-2, atol=2e-2)   # out is bf16
+            masks.append(mask)
+        assert float(k.abs().max()) == 0.0
+    assert not torch.equal(masks[0], masks[1])                          # q and v of one step
+    assert not torch.equal(masks[0], masks[2])                          # q of step 1 and q of step 2
