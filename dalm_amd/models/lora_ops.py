@@ -216,7 +216,7 @@ _tickets2: Dict[tuple, torch.Tensor] = {}
 
 
 def _colacc_tickets(dev: torch.device, words: int) -> torch.Tensor:
-    """Arrival tickets of `dalm_lora2_colacc`: zeroed once, left zero by every call.  One buffer per (device, stream): calls that
+    """Arrival tickets of `dalm_lora2_rowdot` / `dalm_lora2_colacc`: zeroed once, left zero by every call.  One buffer per (device, stream): calls that
     share it are ordered on that stream (the retriever towers run on their own streams beside the generator's)."""
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
     buf = _tickets2.get(key)
@@ -250,10 +250,14 @@ def rowdot2(xs, Ws, rank: int, scale: float, p: float, salts, mode: int):
     bits = [torch.empty(R, K // 8, device=dev, dtype=torch.uint8) if p > 0 else None for _ in range(n)]
     seed = dropout_seed(dev) if p > 0 else None
     x1 = xs[1] if mode == 3 else None
+    lib = hip.load()
+    nbytes = lib.dalm_lora2_rowdot_workspace_bytes(R, K, mode)
+    ws = torch.empty(nbytes, device=dev, dtype=torch.uint8) if nbytes else None
+    tickets = _colacc_tickets(dev, lib.dalm_lora2_rowdot_ticket_words(R, mode)) if nbytes else None
     hip.call("dalm_lora2_rowdot", hip.ptr(x0), hip.ptr(x1), hip.ptr(Ws[0]), hip.ptr(Ws[1]) if n == 2 else None,
              hip.ptr(zs[0]), hip.ptr(zs[1]) if n == 2 else None, hip.ptr(bits[0]), hip.ptr(bits[1]) if n == 2 else None,
              R, K, rank, float(scale), float(p), hip.ptr(seed), int(salts[0]) & 0xFFFFFFFF,
-             (int(salts[1]) & 0xFFFFFFFF) if n == 2 else 0, mode, hip.stream())
+             (int(salts[1]) & 0xFFFFFFFF) if n == 2 else 0, mode, hip.ptr(ws), nbytes, hip.ptr(tickets), hip.stream())
     return zs, bits
 
 

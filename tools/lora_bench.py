@@ -4,7 +4,7 @@ projection per launch, mask recomputed) next to the round-5 ones (`dalm_lora2_*`
     python tools/lora_bench.py [--rows 4608 --cols 4096] [--sets 8]
 
 Every timed call cycles through `--sets` different activation buffers (8 x 37.7 MB > the 256 MB Infinity Cache) so that a
-kernel is not timed on data its own previous launch left on die.  Times are HIP-event averages over `--iters` launches."""
+kernel is not timed on data its own previous launch left on die.  Times are HIP-event averages over 3 replays of a hipGraph holding `--iters` launches."""
 from __future__ import annotations
 
 import argparse
@@ -19,17 +19,31 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from dalm_amd.models import lora_ops as L  # noqa: E402
 
 
-def timed(fn, sets, iters, warmup=5):
+def timed(fn, sets, iters, warmup=3):
+    """us per call: `iters` calls captured into ONE hipGraph and replayed (a python call of these ops costs 20-40 us of host
+    time - launched eagerly the loop would measure the host, as the first version of this tool did)."""
     for i in range(warmup):
         fn(i % sets)
     torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn(0)                                          # per-stream buffers (tickets) exist before the capture
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        for i in range(iters):
+            fn(i % sets)
+    graph.replay()
+    torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for i in range(iters):
-        fn(i % sets)
+    for _ in range(3):
+        graph.replay()
     b.record()
     torch.cuda.synchronize()
-    return a.elapsed_time(b) * 1e3 / iters
+    return a.elapsed_time(b) * 1e3 / (3 * iters)
 
 
 def main():
