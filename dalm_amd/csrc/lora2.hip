@@ -30,8 +30,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
-// ---- mask v2: pair index i = flat element index >> 1;  h = mix2(i ^ key.a, key.b);  element 2i kept iff (h & 0xffff) >= thr,
-// element 2i+1 iff (h >> 16) >= thr.  mix2 = lowbias32 with key.b added between its two multiplies.
+// ---- mask v2: chunk index c = flat element index >> 3 (8 elements);  w_0 = mix2(c ^ key.a, key.b),  w_{q+1} = xorshift32(w_q);
+// element 8c + 2q is kept iff (w_q & 0xffff) >= thr, element 8c + 2q + 1 iff (w_q >> 16) >= thr.  mix2 = lowbias32 with key.b
+// added between its two multiplies; xorshift32: w ^= w << 13; w ^= w >> 17; w ^= w << 5.  (One two-multiply hash per word - the
+// first form - cost the forward kernel 16.5 us of integer VALU at [4608, 4096] x 2 adapters: profiles/r05_lora_rowdot_ablation.txt.)
 __device__ __forceinline__ unsigned int mix2(unsigned int x, unsigned int b) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x += b; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
@@ -42,9 +44,10 @@ __device__ __forceinline__ unsigned int mask8(const DropKey& k, unsigned int e0,
   unsigned int wds[4] = {v.x, v.y, v.z, v.w};
   unsigned int packed = 0;
   const u16x2 zero = {0, 0};
+  unsigned int h = mix2((e0 >> 3) ^ k.a, k.b);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const unsigned int h = mix2(((e0 >> 1) + q) ^ k.a, k.b);
+    if (q) { h ^= h << 13; h ^= h >> 17; h ^= h << 5; }
     // packed 16-bit ops (v_pk_sub_u16 clamp, v_pk_min_u16, v_pk_sub_u16); the min is written as an instruction because the
     // optimiser folds min(sat_sub, 1) back into two compares and two selects per word
     const u16x2 g = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, h), __builtin_bit_cast(u16x2, thr_m1));
@@ -70,163 +73,106 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned int& hi, u
 
 // ---------------------------------------------------------------------------------------------------
 // rowdot: out_t[row][j] = scale * sum_k m_t x_t[row][k] W_t[j][k]   on v_mfma_f32_16x16x32_bf16.
-//   MODE 1: one problem, 16-row tiles.   MODE 3: two independent problems of one shape (blockIdx.z)
+//   MODE 1: one problem, 16-row tiles.   MODE 3: two independent problems of one shape (blockIdx.y), no dropout needed by callers
 //   MODE 2: two projections of ONE x (rank 8): 8-row tiles, see the file header.
-// W-STATIONARY: a workgroup owns a slab of 256 columns (8 MFMA steps) x 128 rows.  Its 4 waves split W's slab into bf16 high / low
-// B fragments ONCE (64 registers) and then stream row tiles: 8 sixteen-byte loads per tile and lane, the next tile's loads in
-// flight while the current one is multiplied.  (The first form of this kernel - every workgroup walking whole rows and re-reading
-// all of W - moved 4 x the activation bytes of W from the L2, all workgroups asking for the same lines at the same time:
-// 34.8 us without dropout for q + v at [4608, 4096], slower than round 4; profiles/r05_lora_kernels_first_form.txt.)
-// The K slabs' partial 16 x 16 tiles leave through agent-scope stores; the last slab of a row block to arrive (one ticket per
-// row block and problem) adds them in slab order, scales and writes z.  K <= 256: one slab, written directly.
+// 256 threads; wave w takes the 32-column steps w, w + 4, ... in batches of UN with the next batch's loads in flight.
+// Tried and dropped (profiles/r05_lora_rowdot_ablation.txt): a W-stationary form - workgroup = 256-column slab x 128 rows, W split
+// into B fragments once, the K slabs' partial tiles added in the launch by the last slab to arrive.  Its loads and MFMAs ran at
+// 4.2 TB/s (18 us for two projections), but the write-through partial tiles + ticket + last-arriver pass cost another 13-18 us
+// at the end of the kernel, and an EMPTY kernel of either shape takes 6-7 us in a hipGraph: at 37.7 MB per activation the
+// launch itself is half of the 0.55-of-HBM budget, so the lever that is left is more projections per launch.
 // ---------------------------------------------------------------------------------------------------
-constexpr int kSlabSteps = 8;      // 32-column steps per K slab
-constexpr int kRowBlock = 128;     // rows per workgroup
-
 template <int MODE, bool DROP>
 __global__ __launch_bounds__(256) void lora2_rowdot_kernel(
     const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1, const float* __restrict__ W0, const float* __restrict__ W1,
     float* __restrict__ out0, float* __restrict__ out1, unsigned char* __restrict__ bits0, unsigned char* __restrict__ bits1,
     const unsigned long long* __restrict__ seed, unsigned int salt0, unsigned int salt1, unsigned int thr16, int R, int K,
-    int rank, float scale, float* __restrict__ part /* [nprob][nslab][Rp][16] */, unsigned int* __restrict__ tickets) {
-  __shared__ unsigned int slot;
-  constexpr int TR = MODE == 2 ? 8 : 16;                      // rows per MFMA tile
-  constexpr int NTILE = kRowBlock / TR;
+    int rank, float scale) {
+  __shared__ float red[4][16][17];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, kg = lane >> 4;
-  const int prob = MODE == 3 ? static_cast<int>(blockIdx.z) : 0;
-  const int slab = blockIdx.x, nslab = gridDim.x, rb = blockIdx.y, nrb = gridDim.y;
-  const int k_lo = slab * (kSlabSteps * 32);
-  const int nst = min(kSlabSteps, (K - k_lo) >> 5);
+  const int prob = MODE == 3 ? static_cast<int>(blockIdx.y) : 0;
   const int lp = MODE == 2 ? (i >> 3) : prob;                 // the projection this lane's operand row / column belongs to
   const int li = MODE == 2 ? (i & 7) : i;                     // row within the tile / rank index
-  // ---- this lane's B fragments of the slab: W[li][k_lo + 32 s + 8 kg .. +8], split once ----
-  uint4 bh[kSlabSteps], bl[kSlabSteps];
-  {
-    const float* wr = (lp ? W1 : W0) + static_cast<int64_t>(min(li, rank - 1)) * K + k_lo + kg * 8;
-    const bool wv = li < rank;
-#pragma unroll
-    for (int s = 0; s < kSlabSteps; ++s) {
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-      if (wv && s < nst) {
-        a = *reinterpret_cast<const float4*>(wr + s * 32);
-        b = *reinterpret_cast<const float4*>(wr + s * 32 + 4);
-      }
-      unsigned int hi[4], lo[4];
-      split_pair(a.x, a.y, hi[0], lo[0]);
-      split_pair(a.z, a.w, hi[1], lo[1]);
-      split_pair(b.x, b.y, hi[2], lo[2]);
-      split_pair(b.z, b.w, hi[3], lo[3]);
-      bh[s] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-      bl[s] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-    }
-  }
+  const int row = static_cast<int>(blockIdx.x) * (MODE == 2 ? 8 : 16) + li;
+  const int rowc = min(row, R - 1);
+  const bf16_t* xr = ((MODE == 3 && prob) ? x1 : x0) + static_cast<int64_t>(rowc) * K + kg * 8;
+  const bool wv = li < rank;                                  // this lane's B-operand column is a real rank index
+  const float* wr = (lp ? W1 : W0) + static_cast<int64_t>(min(li, rank - 1)) * K + kg * 8;
   DropKey key{0u, 1u};
+  unsigned char* bp = nullptr;
   unsigned int thr_m1 = 0;
   if constexpr (DROP) {
     key = drop_key2(seed, lp ? salt1 : salt0);
+    bp = (lp ? bits1 : bits0) + static_cast<int64_t>(rowc) * (K >> 3) + kg;
     thr_m1 = (thr16 - 1u) * 0x00010001u;
   }
-  const bf16_t* xb = ((MODE == 3 && prob) ? x1 : x0) + k_lo + kg * 8;
-  unsigned char* bb = nullptr;
-  if constexpr (DROP) bb = (lp ? bits1 : bits0) + (k_lo >> 3) + kg;
-  const int Rp = nrb * kRowBlock;
-  const bool direct = nslab == 1;
-  float* pbase = part + (static_cast<int64_t>(prob) * nslab + slab) * Rp * 16;
+  const unsigned int ebase = static_cast<unsigned int>(rowc) * static_cast<unsigned int>(K) + kg * 8;
+  const int nsteps = K >> 5;
+  constexpr int UN = 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 
-  auto issue = [&](uint4 (&xa)[kSlabSteps], int t) __attribute__((always_inline)) {
-    const int rowc = min(rb * kRowBlock + t * TR + li, R - 1);
-    const bf16_t* xr = xb + static_cast<int64_t>(rowc) * K;
+  auto issue = [&](uint4 (&xa)[UN], float4 (&wa)[UN][2], int s0) __attribute__((always_inline)) {
 #pragma unroll
-    for (int s = 0; s < kSlabSteps; ++s) xa[s] = *reinterpret_cast<const uint4*>(xr + min(s, nst - 1) * 32);
+    for (int u = 0; u < UN; ++u) {
+      const int k = min(s0 + 4 * u, nsteps - 1) * 32;           // clamped: the extra steps are skipped in process()
+      xa[u] = *reinterpret_cast<const uint4*>(xr + k);
+      if (MODE == 2 || wv) {                                    // the other lanes' columns are never written out: any value does
+        wa[u][0] = *reinterpret_cast<const float4*>(wr + k);
+        wa[u][1] = *reinterpret_cast<const float4*>(wr + k + 4);
+      }
+    }
   };
-  auto process = [&](uint4 (&xa)[kSlabSteps], int t) __attribute__((always_inline)) {
-    const int row0 = rb * kRowBlock + t * TR;
-    const int row = row0 + li, rowc = min(row, R - 1);
-    const unsigned int ebase = static_cast<unsigned int>(rowc) * static_cast<unsigned int>(K) + k_lo + kg * 8;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  auto process = [&](uint4 (&xa)[UN], float4 (&wa)[UN][2], int s0) __attribute__((always_inline)) {
 #pragma unroll
-    for (int s = 0; s < kSlabSteps; ++s) {
-      if (s >= nst) continue;                                  // workgroup-uniform
-      uint4 v = xa[s];
+    for (int u = 0; u < UN; ++u) {
+      const int st = s0 + 4 * u;
+      if (st >= nsteps) continue;                               // wave-uniform
+      uint4 v = xa[u];
       if constexpr (DROP) {
-        const unsigned int byte = mask8(key, ebase + s * 32u, thr_m1, v);
-        if (row < R) bb[static_cast<int64_t>(rowc) * (K >> 3) + s * 4] = static_cast<unsigned char>(byte);
+        const unsigned int byte = mask8(key, ebase + static_cast<unsigned int>(st) * 32u, thr_m1, v);
+        if (row < R) bp[st * 4] = static_cast<unsigned char>(byte);
       }
+      unsigned int hi[4], lo[4];
+      split_pair(wa[u][0].x, wa[u][0].y, hi[0], lo[0]);
+      split_pair(wa[u][0].z, wa[u][0].w, hi[1], lo[1]);
+      split_pair(wa[u][1].x, wa[u][1].y, hi[2], lo[2]);
+      split_pair(wa[u][1].z, wa[u][1].w, hi[3], lo[3]);
       const bf16x8 a8 = __builtin_bit_cast(bf16x8, v);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(bf16x8, bl[s]), acc, 0, 0, 0);   // small part first
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(bf16x8, bh[s]), acc, 0, 0, 0);
-    }
-    // accumulator tile: lane L holds A-operand rows m = 4 (L / 16) + r, column j = L % 16
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = kg * 4 + r;
-      bool ok;
-      int orow;
-      if constexpr (MODE == 2) {
-        ok = (m >> 3) == (i >> 3);                             // the two diagonal 8 x 8 blocks
-        orow = row0 + (m & 7);
-      } else {
-        ok = i < rank;
-        orow = row0 + m;
-      }
-      if (!ok || orow >= R) continue;
-      if (direct) {
-        if constexpr (MODE == 2) ((i >> 3) ? out1 : out0)[static_cast<int64_t>(orow) * 8 + (i & 7)] = scale * acc[r];
-        else (prob ? out1 : out0)[static_cast<int64_t>(orow) * rank + i] = scale * acc[r];
-      } else {
-        st_agent(pbase + static_cast<int64_t>(orow) * 16 + i, acc[r]);
-      }
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(bf16x8, make_uint4(lo[0], lo[1], lo[2], lo[3])), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(bf16x8, make_uint4(hi[0], hi[1], hi[2], hi[3])), acc, 0, 0, 0);
     }
   };
 
-  {
-    uint4 xa0[kSlabSteps], xa1[kSlabSteps];
-    const int t_first = wave;
-    if (rb * kRowBlock + t_first * TR < R) issue(xa0, t_first);
-    for (int t = t_first; t < NTILE && rb * kRowBlock + t * TR < R; t += 8) {
-      const int t1 = t + 4, t2 = t + 8;
-      const bool h1 = t1 < NTILE && rb * kRowBlock + t1 * TR < R;
-      if (h1) issue(xa1, t1);
+  uint4 xa0[UN], xa1[UN];
+  float4 wa0[UN][2], wa1[UN][2];
+  issue(xa0, wa0, wave);
+  for (int s0 = wave; s0 < nsteps; s0 += 8 * UN) {
+    const int s1 = s0 + 4 * UN, s2 = s0 + 8 * UN;
+    if (s1 < nsteps) issue(xa1, wa1, s1);
+    __builtin_amdgcn_sched_barrier(0);
+    process(xa0, wa0, s0);
+    if (s1 < nsteps) {
+      if (s2 < nsteps) issue(xa0, wa0, s2);
       __builtin_amdgcn_sched_barrier(0);
-      process(xa0, t);
-      if (h1) {
-        if (t2 < NTILE && rb * kRowBlock + t2 * TR < R) issue(xa0, t2);
-        __builtin_amdgcn_sched_barrier(0);
-        process(xa1, t1);
-      }
+      process(xa1, wa1, s1);
     }
   }
-  if (direct) return;
-  unsigned int* tk = tickets + prob * nrb + rb;
-  if (draw_ticket(tk, &slot) != static_cast<unsigned int>(nslab - 1)) return;
-  if (tid == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // the last slab of this row block: add the slabs' tiles in slab order (pairs of adjacent columns, 8-byte agent-scope loads)
-  const unsigned long long* src0 = reinterpret_cast<const unsigned long long*>(part + static_cast<int64_t>(prob) * nslab * Rp * 16);
-  const int64_t plane = static_cast<int64_t>(Rp) * 8;          // pairs per slab
-  for (int v = tid; v < kRowBlock * 8; v += 256) {
-    const int row = rb * kRowBlock + (v >> 3), col = (v & 7) * 2;
-    if (row >= R) continue;
-    if (MODE != 2 && col >= rank) continue;
-    const unsigned long long* src = src0 + static_cast<int64_t>(row) * 8 + (v & 7);
-    float a = 0.f, b = 0.f;
-    for (int s0 = 0; s0 < nslab; s0 += 8) {
-      float va[8], vb[8];
+  // accumulator tile: lane L holds rows 4 (L / 16) + r, column L % 16
 #pragma unroll
-      for (int u = 0; u < 8; ++u) ld_pair(src + static_cast<int64_t>(min(s0 + u, nslab - 1)) * plane, va[u], vb[u]);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        a += (s0 + u < nslab) ? va[u] : 0.f;
-        b += (s0 + u < nslab) ? vb[u] : 0.f;
-      }
-    }
+  for (int r = 0; r < 4; ++r) red[wave][kg * 4 + r][i] = acc[r];
+  __syncthreads();
+  {
+    const int m = tid >> 4, j = tid & 15;
+    const float s = ((red[0][m][j] + red[1][m][j]) + red[2][m][j]) + red[3][m][j];     // fixed order
     if constexpr (MODE == 2) {
-      float* o = ((col >> 3) ? out1 : out0) + static_cast<int64_t>(row) * 8 + (col & 7);
-      o[0] = scale * a; o[1] = scale * b;
+      const int pm = m >> 3;
+      const int orow = static_cast<int>(blockIdx.x) * 8 + (m & 7);
+      if (pm == (j >> 3) && orow < R) (pm ? out1 : out0)[static_cast<int64_t>(orow) * 8 + (j & 7)] = scale * s;
     } else {
-      float* o = (prob ? out1 : out0) + static_cast<int64_t>(row) * rank + col;
-      o[0] = scale * a; o[1] = scale * b;
+      const int orow = static_cast<int>(blockIdx.x) * 16 + m;
+      if (j < rank && orow < R) (prob ? out1 : out0)[static_cast<int64_t>(orow) * rank + j] = scale * s;
     }
   }
 }
@@ -595,21 +541,9 @@ using namespace dalm;
   DALM_REQUIRE(mode >= 1 && mode <= 3, DALM_E_SHAPE, "mode must be 1 (one problem), 2 (two terms, shared activation) or 3 (two problems)"); \
   DALM_REQUIRE(mode != 2 || (rank) == 8, DALM_E_SHAPE, "stacked projections need rank 8")
 
-extern "C" size_t dalm_lora2_rowdot_workspace_bytes(int64_t R, int64_t K, int mode) {
-  if (R <= 0 || K <= 0 || mode < 1 || mode > 3) return 0;
-  const int64_t nslab = (K + kSlabSteps * 32 - 1) / (kSlabSteps * 32), nrb = (R + kRowBlock - 1) / kRowBlock;
-  if (nslab <= 1) return 0;
-  return static_cast<size_t>(mode == 3 ? 2 : 1) * nslab * nrb * kRowBlock * 16 * sizeof(float);
-}
-extern "C" size_t dalm_lora2_rowdot_ticket_words(int64_t R, int mode) {
-  if (R <= 0) return 0;
-  return static_cast<size_t>((R + kRowBlock - 1) / kRowBlock) * (mode == 3 ? 2 : 1);
-}
-
 extern "C" int dalm_lora2_rowdot(const void* x0, const void* x1, const float* W0, const float* W1, float* out0, float* out1,
                                  void* bits0, void* bits1, int64_t R, int64_t K, int rank, float scale, float p,
-                                 const void* seed, uint32_t salt0, uint32_t salt1, int mode, void* ws, size_t ws_bytes,
-                                 uint32_t* tickets, dalm_stream_t stream) {
+                                 const void* seed, uint32_t salt0, uint32_t salt1, int mode, dalm_stream_t stream) {
   DALM_LORA2_SHAPE(R, K, rank);
   DALM_REQUIRE(K % 32 == 0, DALM_E_SHAPE, "the contraction length must be a multiple of 32");
   DALM_REQUIRE(p >= 0.f && p < 1.f, DALM_E_SHAPE, "dropout probability must be in [0, 1)");
@@ -620,9 +554,6 @@ extern "C" int dalm_lora2_rowdot(const void* x0, const void* x1, const float* W0
   DALM_REQUIRE(!drop || (seed && bits0 && (!two || bits1)), DALM_E_NULL, "dropout needs the seed word and the mask buffers");
   const unsigned int thr16 = static_cast<unsigned int>(p * 65536.0f + 0.5f);
   DALM_REQUIRE(!drop || thr16 >= 1, DALM_E_SHAPE, "dropout probability below 2^-17 rounds to no dropout: pass 0");
-  const size_t need = dalm_lora2_rowdot_workspace_bytes(R, K, mode);
-  DALM_REQUIRE(need == 0 || (ws && tickets && ws_bytes >= need && (reinterpret_cast<uintptr_t>(ws) & 7) == 0), DALM_E_WORKSPACE,
-               "workspace (8-byte aligned, dalm_lora2_rowdot_workspace_bytes) and tickets are required when K > 256");
   const bf16_t* xa0 = static_cast<const bf16_t*>(x0);
   const bf16_t* xa1 = static_cast<const bf16_t*>(mode == 3 ? x1 : x0);
   const float* Wa1 = two ? W1 : W0;
@@ -632,16 +563,12 @@ extern "C" int dalm_lora2_rowdot(const void* x0, const void* x1, const float* W0
   const unsigned long long* sd = static_cast<const unsigned long long*>(seed);
   const int Ri = static_cast<int>(R), Ki = static_cast<int>(K);
   hipStream_t s = as_stream(stream);
-  const unsigned nslab = static_cast<unsigned>((K + kSlabSteps * 32 - 1) / (kSlabSteps * 32));
-  const unsigned nrb = static_cast<unsigned>((R + kRowBlock - 1) / kRowBlock);
-  DALM_REQUIRE(nrb <= 65535, DALM_E_SHAPE, "too many rows for one launch");
-  const dim3 grid(nslab, nrb, mode == 3 ? 2u : 1u);
-  float* part = static_cast<float*>(ws);
-#define DALM_RD2(MODE, DR) hipLaunchKernelGGL((lora2_rowdot_kernel<MODE, DR>), grid, dim3(256), 0, s, xa0, xa1, W0, Wa1, \
-    out0, oa1, ba0, ba1, sd, salt0, salt1, thr16, Ri, Ki, rank, scale, part, tickets)
-  if (mode == 1) { if (drop) DALM_RD2(1, true); else DALM_RD2(1, false); }
-  else if (mode == 2) { if (drop) DALM_RD2(2, true); else DALM_RD2(2, false); }
-  else { if (drop) DALM_RD2(3, true); else DALM_RD2(3, false); }
+  const unsigned tiles16 = static_cast<unsigned>((R + 15) / 16), tiles8 = static_cast<unsigned>((R + 7) / 8);
+#define DALM_RD2(MODE, DR, GRID) hipLaunchKernelGGL((lora2_rowdot_kernel<MODE, DR>), GRID, dim3(256), 0, s, xa0, xa1, W0, Wa1, \
+    out0, oa1, ba0, ba1, sd, salt0, salt1, thr16, Ri, Ki, rank, scale)
+  if (mode == 1) { if (drop) DALM_RD2(1, true, dim3(tiles16)); else DALM_RD2(1, false, dim3(tiles16)); }
+  else if (mode == 2) { if (drop) DALM_RD2(2, true, dim3(tiles8)); else DALM_RD2(2, false, dim3(tiles8)); }
+  else { if (drop) DALM_RD2(3, true, dim3(tiles16, 2)); else DALM_RD2(3, false, dim3(tiles16, 2)); }
 #undef DALM_RD2
   return check_launch(__func__);
 }
@@ -663,7 +590,9 @@ extern "C" int dalm_lora2_rankupd(void* y0, void* y1, const float* z0, const flo
   const unsigned char* ba1 = static_cast<const unsigned char*>(two ? bits1 : bits0);
   const int Ri = static_cast<int>(R), Ci = static_cast<int>(C);
   const int64_t slabs = (C + 511) / 512, nprob = mode == 3 ? 2 : 1;
-  int64_t S = 1536 / (slabs * nprob);
+  // one resident round of workgroups (2 per CU with two terms' W slices in registers, 3 with one): every workgroup pays its W
+  // loads and mask stage once (1536 workgroups of 24 rows measured no faster than round 4's kernel)
+  int64_t S = (mode == 2 ? 512 : 768) / (slabs * nprob);
   const int64_t max_s = (R + 3) / 4, min_s = (R + 255) / 256;       // at most 256 rows per workgroup (the LDS mask stage)
   if (S > max_s) S = max_s;
   if (S < min_s) S = min_s;

@@ -96,10 +96,8 @@ SIGNATURES = {
     "dalm_lora_rankupd": (_int, [_vp, _int, _vp, _vp, _int, _i64, _i64, _int, _f32, _f32, _vp, C.c_uint32, _vp]),
     "dalm_lora_colacc_workspace_bytes": (_sz, [_i64, _i64, _int]),
     "dalm_lora_colacc": (_int, [_vp, _int, _vp, _i64, _i64, _int, _f32, _f32, _vp, C.c_uint32, _vp, _int, _vp, _sz, _vp]),
-    "dalm_lora2_rowdot_workspace_bytes": (_sz, [_i64, _i64, _int]),
-    "dalm_lora2_rowdot_ticket_words": (_sz, [_i64, _int]),
     "dalm_lora2_rowdot": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _f32, _f32, _vp, C.c_uint32, C.c_uint32,
-                                 _int, _vp, _sz, _vp, _vp]),
+                                 _int, _vp]),
     "dalm_lora2_rankupd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _f32, _int, _vp]),
     "dalm_lora2_colacc_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
     "dalm_lora2_colacc_ticket_words": (_sz, [_i64, _int]),

@@ -213,10 +213,11 @@ def lora_linear(x, base: torch.nn.Linear, a: torch.Tensor, b: torch.Tensor, scal
 # round 5: stacked kernels (dalm_lora2_*), bf16 activations
 # =====================================================================================================================
 _tickets2: Dict[tuple, torch.Tensor] = {}
+_FWD_STACKED = __import__("os").environ.get("DALM_LORA_FWD_STACKED", "0") == "1"      # A/B: mode 2 in the forward
 
 
 def _colacc_tickets(dev: torch.device, words: int) -> torch.Tensor:
-    """Arrival tickets of `dalm_lora2_rowdot` / `dalm_lora2_colacc`: zeroed once, left zero by every call.  One buffer per (device, stream): calls that
+    """Arrival tickets of `dalm_lora2_colacc`: zeroed once, left zero by every call.  One buffer per (device, stream): calls that
     share it are ordered on that stream (the retriever towers run on their own streams beside the generator's)."""
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
     buf = _tickets2.get(key)
@@ -250,14 +251,10 @@ def rowdot2(xs, Ws, rank: int, scale: float, p: float, salts, mode: int):
     bits = [torch.empty(R, K // 8, device=dev, dtype=torch.uint8) if p > 0 else None for _ in range(n)]
     seed = dropout_seed(dev) if p > 0 else None
     x1 = xs[1] if mode == 3 else None
-    lib = hip.load()
-    nbytes = lib.dalm_lora2_rowdot_workspace_bytes(R, K, mode)
-    ws = torch.empty(nbytes, device=dev, dtype=torch.uint8) if nbytes else None
-    tickets = _colacc_tickets(dev, lib.dalm_lora2_rowdot_ticket_words(R, mode)) if nbytes else None
     hip.call("dalm_lora2_rowdot", hip.ptr(x0), hip.ptr(x1), hip.ptr(Ws[0]), hip.ptr(Ws[1]) if n == 2 else None,
              hip.ptr(zs[0]), hip.ptr(zs[1]) if n == 2 else None, hip.ptr(bits[0]), hip.ptr(bits[1]) if n == 2 else None,
              R, K, rank, float(scale), float(p), hip.ptr(seed), int(salts[0]) & 0xFFFFFFFF,
-             (int(salts[1]) & 0xFFFFFFFF) if n == 2 else 0, mode, hip.ptr(ws), nbytes, hip.ptr(tickets), hip.stream())
+             (int(salts[1]) & 0xFFFFFFFF) if n == 2 else 0, mode, hip.stream())
     return zs, bits
 
 
@@ -323,8 +320,13 @@ class _LoRAGroupFn(torch.autograd.Function):
         # one pass over x per pair of adapters (one pass for q + v); members with different dropout rates cannot share a launch
         for grp in _pairs(lora):
             p = meta[grp[0]][1]
-            if len(grp) == 2 and rank == 8 and meta[grp[1]][1] == p:
-                z, bt = rowdot2([x2], [As[grp[0]], As[grp[1]]], rank, 1.0 / (1.0 - p), p, [meta[grp[0]][2], meta[grp[1]][2]], 2)
+            if len(grp) == 2 and meta[grp[1]][1] == p:
+                # both adapters in one launch.  Mode 3 with the SAME x in both slots (16-row tiles, the second read of x comes
+                # from the caches) measured faster than mode 2's 8-row stacked tiles, which pull all of A_q and A_v through every
+                # workgroup: 37 vs 45 us at [4608, 4096] with dropout (profiles/r05_lora_bench_4608x4096.txt)
+                fwd_mode = 2 if (rank == 8 and _FWD_STACKED) else 3
+                z, bt = rowdot2([x2, x2], [As[grp[0]], As[grp[1]]], rank, 1.0 / (1.0 - p), p, [meta[grp[0]][2], meta[grp[1]][2]],
+                                fwd_mode)
                 zs[grp[0]], zs[grp[1]], bits[grp[0]], bits[grp[1]] = z[0], z[1], bt[0], bt[1]
             else:
                 for i in grp:

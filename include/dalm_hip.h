@@ -480,14 +480,11 @@ int dalm_lora_colacc(const void* x, int dtype, const float* z, int64_t R, int64_
  *   dalm_lora2_rowdot :  out_t[row][j]  = scale * sum_k m_t x_t[row][k] W_t[j][k]
  *   dalm_lora2_rankupd:  y[row][c]     += scale * sum_t m_t sum_j z_t[row][j] W_t[j][c]        (mode 3: y_t, one term each)
  *   dalm_lora2_colacc :  out_t[j][c]    = scale * sum_row m_t x_t[row][c] z_t[row][j]          ([rank][C], finished in the launch)
- * rowdot (K > 256: the K slabs of a row block are added in the launch) and colacc: `ws` >= the _workspace_bytes query, 8-byte
- * aligned; `tickets`: the _ticket_words query in 32-bit words, ZERO on entry and left zero (calls that share the buffer must be
- * ordered on one stream).  Fixed summation orders. */
-size_t dalm_lora2_rowdot_workspace_bytes(int64_t R, int64_t K, int mode);
-size_t dalm_lora2_rowdot_ticket_words(int64_t R, int mode);
+ * colacc: `ws` >= dalm_lora2_colacc_workspace_bytes, 8-byte aligned; `tickets`: dalm_lora2_colacc_ticket_words 32-bit words,
+ * ZERO on entry and left zero (calls that share the buffer must be ordered on one stream).  Fixed summation orders. */
 int dalm_lora2_rowdot(const void* x0, const void* x1, const float* W0, const float* W1, float* out0, float* out1, void* bits0,
                       void* bits1, int64_t R, int64_t K, int rank, float scale, float p, const void* seed, uint32_t salt0,
-                      uint32_t salt1, int mode, void* ws, size_t ws_bytes, uint32_t* tickets, dalm_stream_t stream);
+                      uint32_t salt1, int mode, dalm_stream_t stream);
 int dalm_lora2_rankupd(void* y0, void* y1, const float* z0, const float* z1, const float* W0, const float* W1,
                        const void* bits0, const void* bits1, int64_t R, int64_t C, int rank, float scale, int mode,
                        dalm_stream_t stream);

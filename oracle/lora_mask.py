@@ -12,11 +12,13 @@ kernels' mask to something written independently of them:
     element 2i   is kept iff  (h(i) & 0xFFFF) >= thr      element 2i+1 iff (h(i) >> 16) >= thr,   thr = round(p * 65536)
     mix(x): x ^= x >> 16; x *= 0x7FEB352D; x ^= x >> 15; x *= 0x846CA68B; x ^= x >> 16        (all modulo 2^32)
 
-Round 5 (dalm_amd/csrc/lora2.hip, bf16 activations): mask v2 - the same keys, pair index and 16-bit threshold test, with a
-two-multiply hash; the forward kernel computes it ONCE and stores it as bits (byte (row, c) bit e = element 8 c + e survives),
-the backward kernels read the bits:
+Round 5 (dalm_amd/csrc/lora2.hip, bf16 activations): mask v2 - the same keys and 16-bit threshold test; ONE two-multiply hash
+per chunk of 8 elements, its four words chained by xorshift32; the forward kernel computes it ONCE and stores it as bits (byte
+(row, c) bit e = element 8 c + e survives), the backward kernels read the bits:
 
-    h(i)  = mix2(i ^ key.a, key.b)
+    w_0(c) = mix2(c ^ key.a, key.b)      for the chunk index c = flat_element_index >> 3
+    w_{q+1} = xorshift32(w_q):  w ^= w << 13; w ^= w >> 17; w ^= w << 5
+    element 8c + 2q is kept iff (w_q & 0xFFFF) >= thr,  element 8c + 2q + 1 iff (w_q >> 16) >= thr
     mix2(x, b): x ^= x >> 16; x *= 0x7FEB352D; x ^= x >> 15; x += b; x *= 0x846CA68B; x ^= x >> 16   (all modulo 2^32)
 
 PARITY: not a reference algorithm (see above) - what is pinned is kernel == this restatement for every element, the keep rate,
@@ -78,12 +80,17 @@ def keep_mask_v2(seed: int, salt: int, rows: int, cols: int, p: float) -> np.nda
     a = _mix(np.array([(seed & 0xFFFFFFFF) ^ ((salt * 0x9E3779B9) & 0xFFFFFFFF)], dtype=np.uint64))[0]
     b = _mix(np.array([((seed >> 32) + salt + 0x85EBCA6B) & 0xFFFFFFFF], dtype=np.uint64))[0] | np.uint64(1)
     n = rows * cols
-    pair = (np.arange(0, n, 2, dtype=np.uint64) & M32) >> np.uint64(1)
-    h = _mix2(pair ^ a, b)
+    chunk = (np.arange(0, n, 8, dtype=np.uint64) & M32) >> np.uint64(3)
+    w = _mix2(chunk ^ a, b)
     thr = np.uint64(threshold(p))
     out = np.empty(n, dtype=bool)
-    out[0::2] = (h & np.uint64(0xFFFF)) >= thr
-    out[1::2] = (h >> np.uint64(16)) >= thr
+    for q in range(4):
+        if q:
+            w ^= (w << np.uint64(13)) & M32
+            w ^= w >> np.uint64(17)
+            w ^= (w << np.uint64(5)) & M32
+        out[2 * q::8] = (w & np.uint64(0xFFFF)) >= thr
+        out[2 * q + 1::8] = (w >> np.uint64(16)) >= thr
     return out.reshape(rows, cols)
 
 

@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--p", type=float, default=0.05)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--only", default=None, help="substring of the line names to run")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     R, C, S, p, rank = a.rows, a.cols, a.sets, a.p, 8
@@ -75,47 +76,35 @@ def main():
                      "note": note})
         print(f"{name:58s} {us:8.2f} us  {bytes_mb:7.1f} MB  {tbs:5.2f} TB/s  {tbs / 8:5.3f} of 8 TB/s  {note}", flush=True)
 
+    def run(name, fn, bytes_mb, note=""):
+        if a.only is None or a.only in name:
+            line(name, timed(fn, S, a.iters), bytes_mb, note)
+
     print(f"# [{R}, {C}] bf16, rank 8, p = {p}, {S} buffer sets, {a.iters} launches per line")
     # ---- forward: z = dropout(x) A^T for q and v ----
-    t = timed(lambda i: L._rowdot(xs[i], A0, True, rank, keep, p, seed, 1), S, a.iters)
-    line("r4 rowdot (x, A) dropout, ONE projection", t, mb)
-    t = timed(lambda i: L.rowdot2([xs[i]], [A0], rank, keep, p, [1], 1), S, a.iters)
-    line("r5 rowdot2 mode 1 dropout (+bits), ONE projection", t, mb * (1 + 1 / 16))
-    t = timed(lambda i: L.rowdot2([xs[i]], [A0, A1], rank, keep, p, [1, 2], 2), S, a.iters)
-    line("r5 rowdot2 mode 2 dropout (+bits), q AND v, one x pass", t, mb * (1 + 2 / 16), "r4 needs 2 launches")
-    t = timed(lambda i: L.rowdot2([xs[i]], [A0, A1], rank, 1.0, 0.0, [0, 0], 2), S, a.iters)
-    line("r5 rowdot2 mode 2 no dropout, q AND v", t, mb)
+    run("r4 rowdot (x, A) dropout, ONE projection", lambda i: L._rowdot(xs[i], A0, True, rank, keep, p, seed, 1), mb)
+    run("r5 rowdot2 mode 1 dropout (+bits), ONE projection", lambda i: L.rowdot2([xs[i]], [A0], rank, keep, p, [1], 1), mb * (1 + 1 / 16))
+    run("r5 rowdot2 mode 2 dropout (+bits), q AND v, one x pass", lambda i: L.rowdot2([xs[i]], [A0, A1], rank, keep, p, [1, 2], 2), mb * (1 + 2 / 16), "r4 needs 2 launches")
+    run("r5 rowdot2 mode 3 dropout (+bits), q AND v, SAME x in both slots", lambda i: L.rowdot2([xs[i], xs[i]], [A0, A1], rank, keep, p, [1, 2], 3), mb * (1 + 2 / 16), "x read twice, the second time from the caches")
+    run("r5 rowdot2 mode 2 no dropout, q AND v", lambda i: L.rowdot2([xs[i]], [A0, A1], rank, 1.0, 0.0, [0, 0], 2), mb)
     # ---- backward: dz = s g B ----
-    t = timed(lambda i: L._rowdot(ys[i], B0, False, rank, 2.0, 0.0, None, 0), S, a.iters)
-    line("r4 rowdot (g, B [N,r]), ONE projection", t, mb)
-    t = timed(lambda i: L.rowdot2([ys[i], ys[(i + 1) % S]], [A0, A1], rank, 2.0, 0.0, [0, 0], 3), S, a.iters)
-    line("r5 rowdot2 mode 3 (g_q, g_v; B^T [r,N]), TWO projections", t, 2 * mb)
+    run("r4 rowdot (g, B [N,r]), ONE projection", lambda i: L._rowdot(ys[i], B0, False, rank, 2.0, 0.0, None, 0), mb)
+    run("r5 rowdot2 mode 3 (g_q, g_v; B^T [r,N]), TWO projections", lambda i: L.rowdot2([ys[i], ys[(i + 1) % S]], [A0, A1], rank, 2.0, 0.0, [0, 0], 3), 2 * mb)
     # ---- out += s z B^T ----
-    t = timed(lambda i: L._rankupd_(ys[i], z0, B0, True, rank, 2.0, 0.0, None, 0), S, a.iters)
-    line("r4 rankupd forward, ONE projection", t, 2 * mb)
-    t = timed(lambda i: L.rankupd2_([ys[i], ys[(i + 1) % S]], [z0, z1], [A0, A1], None, rank, 2.0, 3), S, a.iters)
-    line("r5 rankupd2 mode 3 forward, TWO projections", t, 4 * mb)
-    t = timed(lambda i: L.rankupd2_([ys[i]], [z0], [A0], None, rank, 2.0, 1), S, a.iters)
-    line("r5 rankupd2 mode 1 forward, ONE projection", t, 2 * mb)
+    run("r4 rankupd forward, ONE projection", lambda i: L._rankupd_(ys[i], z0, B0, True, rank, 2.0, 0.0, None, 0), 2 * mb)
+    run("r5 rankupd2 mode 3 forward, TWO projections", lambda i: L.rankupd2_([ys[i], ys[(i + 1) % S]], [z0, z1], [A0, A1], None, rank, 2.0, 3), 4 * mb)
+    run("r5 rankupd2 mode 1 forward, ONE projection", lambda i: L.rankupd2_([ys[i]], [z0], [A0], None, rank, 2.0, 1), 2 * mb)
     # ---- dx += mask (dz A) ----
-    t = timed(lambda i: L._rankupd_(xs[i], z0, A0, False, rank, keep, p, seed, 1), S, a.iters)
-    line("r4 rankupd backward (mask hashed), ONE projection", t, 2 * mb)
-    t = timed(lambda i: L.rankupd2_([xs[i]], [z0, z1], [A0, A1], bits, rank, keep, 2), S, a.iters)
-    line("r5 rankupd2 mode 2 backward (mask bits), q AND v on one dx", t, 2 * mb * (1 + 1 / 16), "r4 needs 2 launches")
+    run("r4 rankupd backward (mask hashed), ONE projection", lambda i: L._rankupd_(xs[i], z0, A0, False, rank, keep, p, seed, 1), 2 * mb)
+    run("r5 rankupd2 mode 2 backward (mask bits), q AND v on one dx", lambda i: L.rankupd2_([xs[i]], [z0, z1], [A0, A1], bits, rank, keep, 2), 2 * mb * (1 + 1 / 16), "r4 needs 2 launches")
     # ---- dB / dA ----
-    t = timed(lambda i: L._colacc(ys[i], z0, rank, 2.0, 0.0, None, 0, False), S, a.iters)
-    line("r4 colacc dB (2 launches), ONE projection", t, mb)
-    t = timed(lambda i: L.colacc2([ys[i], ys[(i + 1) % S]], [z0, z1], None, rank, 2.0, 3), S, a.iters)
-    line("r5 colacc2 mode 3 dB, TWO projections, one launch", t, 2 * mb)
-    t = timed(lambda i: L._colacc(xs[i], z0, rank, keep, p, seed, 1, True), S, a.iters)
-    line("r4 colacc dA (mask hashed, 2 launches), ONE projection", t, mb)
-    t = timed(lambda i: L.colacc2([xs[i]], [z0, z1], bits, rank, keep, 2), S, a.iters)
-    line("r5 colacc2 mode 2 dA (mask bits), q AND v, one x pass", t, mb * (1 + 2 / 16), "r4 needs 4 launches")
-    t = timed(lambda i: L.colacc2([xs[i]], [z0], [bits[0]], rank, keep, 1), S, a.iters)
-    line("r5 colacc2 mode 1 dA (mask bits), ONE projection", t, mb * (1 + 1 / 16))
+    run("r4 colacc dB (2 launches), ONE projection", lambda i: L._colacc(ys[i], z0, rank, 2.0, 0.0, None, 0, False), mb)
+    run("r5 colacc2 mode 3 dB, TWO projections, one launch", lambda i: L.colacc2([ys[i], ys[(i + 1) % S]], [z0, z1], None, rank, 2.0, 3), 2 * mb)
+    run("r4 colacc dA (mask hashed, 2 launches), ONE projection", lambda i: L._colacc(xs[i], z0, rank, keep, p, seed, 1, True), mb)
+    run("r5 colacc2 mode 2 dA (mask bits), q AND v, one x pass", lambda i: L.colacc2([xs[i]], [z0, z1], bits, rank, keep, 2), mb * (1 + 2 / 16), "r4 needs 4 launches")
+    run("r5 colacc2 mode 1 dA (mask bits), ONE projection", lambda i: L.colacc2([xs[i]], [z0], [bits[0]], rank, keep, 1), mb * (1 + 1 / 16))
     # ---- a plain read of the same bytes for scale ----
-    t = timed(lambda i: xs[i].sum(dtype=torch.float32), S, a.iters)
-    line("torch sum over the activation (a read-only pass)", t, mb)
+    run("torch sum over the activation (a read-only pass)", lambda i: xs[i].sum(dtype=torch.float32), mb)
     if a.json:
         Path(a.json).write_text(json.dumps({"rows": R, "cols": C, "p": p, "lines": rows}, indent=1))
 
