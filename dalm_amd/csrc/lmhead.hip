@@ -6,8 +6,10 @@
 // for rows that carry loss.  Each workgroup owns a 128 x 128 tile of (row, vocabulary) pairs, contracts it over the
 // hidden width on v_mfma_f32_32x32x16_bf16 and reduces the tile IN REGISTERS to a per-row (max, sum exp) pair per 64
 // columns plus the label's logit; lm_head_lse_merge_kernel folds the 2*V/128 partials of a row.
-// The backward is NOT fused this way (it needs the finished log-sum-exp before any softmax * W product exists, i.e. a
-// third GEMM - see DESIGN.md section 9 f1): training keeps the chunked hipBLASLt path of dalm_amd/fused.py.
+// Round 5: the backward on the same core (dalm_lm_head_dlogits / dalm_lm_head_dhidden below): with the finished row
+// log-sum-exp the logits tile is RECOMPUTED per vocabulary chunk, turned into coef * (softmax - onehot) in registers, staged
+// in bf16 in a chunk-sized workspace and contracted with the (transposed) chunk of W for d(hidden) - a logits-free training
+// step that is hand-written end to end.
 //
 // Data flow per K step of 64: 16-byte global loads (full 128-byte lines per row) -> registers -> ds_write_b128 into
 // rows padded to 144 bytes (conflict-free 16-byte fragment reads) -> ds_read_b128 fragments -> MFMA.  Both operands are
@@ -218,9 +220,18 @@ struct Lm8Params {
   float* pm;                 // [4*NT, R]
   float* pl;                 // [4*NT, R]
   float* z;                  // [R]
+  // EPI_DLOGITS / EPI_CSTORE (round 5: the backward of the fused head)
+  const float* row_lse;      // [R] log-sum-exp of every row over the WHOLE vocabulary
+  const float* coef;         // [R] d loss / d log-prob of the row's label (0 for rows without loss)
+  int col_base;              // first vocabulary entry of this chunk (labels are global ids)
+  void* out;                 // EPI_DLOGITS: bf16 [R][out_pitch];  EPI_CSTORE: f32 [R][out_pitch]
+  int64_t out_pitch;         // elements
+  int out_cols;              // columns that exist in `out` (EPI_DLOGITS: zero-filled from V up to here)
+  int accumulate;            // EPI_CSTORE: add to what `out` holds
 };
 
 constexpr int L8_BUF = 65536;
+constexpr int EPI_LSE = 0, EPI_DLOGITS = 2, EPI_CSTORE = 3;
 
 // Tile order.  The ordered tile list walks the output in bands of gh row tiles - within a band vocabulary tile by vocabulary
 // tile, the band's row tiles innermost - and every XCD (workgroup L runs on XCD L % 8, own 4 MB L2) works through ONE
@@ -404,6 +415,101 @@ __device__ __forceinline__ void lm_tile_epilogue_gmax(const Lm8Params& p, f32x16
   }
 }
 
+// EPI_DLOGITS: the 256 x 256 logits tile becomes coef_r * (exp(x - lse_r) - [column == label_r]) in registers and leaves as
+// bf16 into the chunk workspace out[row][c0 + column] (columns >= V up to out_cols are written as zeros: the workspace is the A
+// operand of the d(hidden) contraction).  Reference math: dalm/training/utils/train_utils.py:113-138 differentiated (SURVEY 8a:
+// dL/dlogits[b,t,:] = (m_bt / M) (softmax - onehot)); coef carries m_bt / M.  Lanes l and l ^ 1 hold adjacent columns: one DPP
+// exchange per pair of accumulator registers lets every lane store one dword (2 bf16) instead of two shorts.
+__device__ __forceinline__ void lm_tile_epilogue_dlogits(const Lm8Params& p, f32x16 (&acc)[4][4], unsigned char* lds, int r0, int c0,
+                                                         int wr, int wc, int tid) {
+  const int lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+  float* lse_s = reinterpret_cast<float*>(lds);              // [256] -lse * log2(e)
+  float* cf_s = lse_s + 256;                                  // [256] coef
+  int* lab_s = reinterpret_cast<int*>(lse_s + 512);           // [256] label - c0 (or -1)
+  {
+    const int r = r0 + tid;
+    float l = 0.f, c = 0.f;
+    int y = -1;
+    if (r < p.R) {
+      l = -p.row_lse[r] * kLog2e;
+      c = p.coef[r];
+      const int64_t yl = p.labels[r] - p.col_base - c0;
+      y = (yl >= 0 && yl < 256 && yl + c0 < p.V) ? static_cast<int>(yl) : -1;
+    }
+    lse_s[tid] = l; cf_s[tid] = c; lab_s[tid] = y;
+  }
+  __syncthreads();
+  const int colw = wc * 128 + l31;                            // column of accumulator tile j = colw + 32 j, relative to c0
+  const bool odd = (lane & 1) != 0;
+  unsigned short* outp = static_cast<unsigned short*>(p.out);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int rl4 = wr * 128 + i * 32 + 8 * g + 4 * lhi;     // rows rl4 .. rl4 + 3 = accumulator registers 4 g .. 4 g + 3
+      const float4 l4 = *reinterpret_cast<const float4*>(lse_s + rl4);
+      const float4 c4 = *reinterpret_cast<const float4*>(cf_s + rl4);
+      const int4 y4 = *reinterpret_cast<const int4*>(lab_s + rl4);
+      const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, cs[4] = {c4.x, c4.y, c4.z, c4.w};
+      const int ys[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = colw + 32 * j;
+        const bool live = c0 + col < p.V;
+        float v[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[i][j][4 * g + rr], kLog2e, ls[rr]));
+          v[rr] = live ? cs[rr] * (pr - (ys[rr] == col ? 1.f : 0.f)) : 0.f;
+        }
+        // register pairs (0, 1) and (2, 3): the even lane stores row a (its column and the odd neighbour's), the odd lane row b
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float mine_a = v[2 * h], mine_b = v[2 * h + 1];
+          const float send = odd ? mine_a : mine_b;
+          const float got = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(send), 0xB1, 0xf, 0xf, false));
+          const unsigned int word = odd ? pack_bf16x2(got, mine_b) : pack_bf16x2(mine_a, got);
+          const int row = r0 + rl4 + 2 * h + (odd ? 1 : 0);
+          const int ce = c0 + (col & ~1);                      // even column of the pair, relative to the chunk
+          if (row < p.R && ce < p.out_cols)
+            *reinterpret_cast<unsigned int*>(outp + static_cast<int64_t>(row) * p.out_pitch + ce) = word;
+        }
+      }
+    }
+  }
+}
+
+// EPI_CSTORE: the 256 x 256 tile is stored (or added) as f32 into out[row][c0 + column]: d(hidden) += dlogits_chunk . W_chunk
+__device__ __forceinline__ void lm_tile_epilogue_cstore(const Lm8Params& p, f32x16 (&acc)[4][4], int r0, int c0, int wr, int wc,
+                                                        int tid) {
+  const int lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+  const int col0 = c0 + wc * 128 + l31;
+  float* base = static_cast<float*>(p.out) + col0;
+  const int pitch = static_cast<int>(p.out_pitch);
+  const bool ok0 = col0 < p.out_cols, ok1 = col0 + 32 < p.out_cols, ok2 = col0 + 64 < p.out_cols, ok3 = col0 + 96 < p.out_cols;
+  const bool add = p.accumulate != 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = r0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      if (row >= p.R) continue;
+      float* dst = base + static_cast<int64_t>(row) * pitch;
+      float v0 = acc[i][0][r], v1 = acc[i][1][r], v2 = acc[i][2][r], v3 = acc[i][3][r];
+      if (add) {
+        if (ok0) v0 += dst[0];
+        if (ok1) v1 += dst[32];
+        if (ok2) v2 += dst[64];
+        if (ok3) v3 += dst[96];
+      }
+      if (ok0) dst[0] = v0;
+      if (ok1) dst[32] = v1;
+      if (ok2) dst[64] = v2;
+      if (ok3) dst[96] = v3;
+    }
+  }
+}
+
 // N3 / N0 / N1 / N2: load pieces issued in k-step 3 (right after the barrier) / 0 / 1 / 2; measured best: 8, 8, 0, 0.
 // ABL (measurement only, results are garbage unless 0): 1 = no loads in the loop, 2 = no fragment reads, 32 = no barrier,
 // 64 = no epilogue.
@@ -411,7 +517,7 @@ __device__ __forceinline__ void lm_tile_epilogue_gmax(const Lm8Params& p, f32x16
 // lo) bf16 thirds of an f32 matrix side by side; the contraction walks SIX segments of D - the six significant products of
 // (hi + mid + lo) x (hi + mid + lo), smallest first - and K tile u reads third segA[u / tpd] of H against third segB[u / tpd]
 // of W: the same main loop, only the K offset of a tile is looked up instead of being u * 128.
-template <int N3, int N0, int N1, int N2, int ABL = 0, bool SPLIT3 = false, bool GMAX = false>
+template <int N3, int N0, int N1, int N2, int ABL = 0, bool SPLIT3 = false, bool GMAX = false, int EPI = EPI_LSE>
 __global__ __launch_bounds__(256, 1) void lm_head_lse4w_kernel(const Lm8Params p) {
   static_assert(N3 + N0 + N1 + N2 == 16, "16 load pieces per K tile and wave");
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * L8_BUF];
@@ -535,7 +641,9 @@ __global__ __launch_bounds__(256, 1) void lm_head_lse4w_kernel(const Lm8Params p
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // tail re-reads still target the LDS about to be reused
   __builtin_amdgcn_s_barrier();
 
-  if constexpr (GMAX) lm_tile_epilogue_gmax(p, acc, r0, c0, wr, wc, tid);
+  if constexpr (EPI == EPI_DLOGITS) lm_tile_epilogue_dlogits(p, acc, lds, r0, c0, wr, wc, tid);
+  else if constexpr (EPI == EPI_CSTORE) lm_tile_epilogue_cstore(p, acc, r0, c0, wr, wc, tid);
+  else if constexpr (GMAX) lm_tile_epilogue_gmax(p, acc, r0, c0, wr, wc, tid);
   else lm_tile_epilogue<ABL>(p, acc, lds, r0, c0, nt, wr, wc, tid);
 }
 
@@ -623,6 +731,36 @@ __global__ __launch_bounds__(256) void split3_bf16_kernel(const float* __restric
   *reinterpret_cast<uint4*>(o) = make_uint4(pack_bf16x2(h[0], h[1]), pack_bf16x2(h[2], h[3]), pack_bf16x2(h[4], h[5]), pack_bf16x2(h[6], h[7]));
   *reinterpret_cast<uint4*>(o + D) = make_uint4(pack_bf16x2(m[0], m[1]), pack_bf16x2(m[2], m[3]), pack_bf16x2(m[4], m[5]), pack_bf16x2(m[6], m[7]));
   *reinterpret_cast<uint4*>(o + 2 * D) = make_uint4(pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3]), pack_bf16x2(l[4], l[5]), pack_bf16x2(l[6], l[7]));
+}
+
+// dst[c][r] = src[r][c] for a [rows, cols] bf16 matrix (rows of `ld_src` elements) -> [cols][ld_dst], columns r >= rows of dst
+// zero-filled up to ld_dst: a vocabulary chunk of the lm_head weight [Vc, K] becomes the K-contiguous B operand [K, Vc_pad] of the
+// d(hidden) contraction.  64 x 64 tiles through LDS, 128-byte rows on both sides.
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const unsigned short* __restrict__ src, int rows, int cols, int64_t ld_src,
+                                                             unsigned short* __restrict__ dst, int64_t ld_dst) {
+  __shared__ unsigned short tile[64][66];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c_in = blockIdx.x * 64 + tx;                      // source column
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int r = blockIdx.y * 64 + ty + 4 * k;               // source row
+    tile[ty + 4 * k][tx] = (r < rows && c_in < cols) ? src[static_cast<int64_t>(r) * ld_src + c_in] : static_cast<unsigned short>(0);
+  }
+  __syncthreads();
+  const int r_out = blockIdx.y * 64 + tx;                     // destination column = source row
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int c_out = blockIdx.x * 64 + ty + 4 * k;           // destination row = source column
+    if (c_out < cols && r_out < ld_dst) dst[static_cast<int64_t>(c_out) * ld_dst + r_out] = tile[tx][ty + 4 * k];
+  }
+}
+
+// dst (bf16) = src (f32) * scale, 8 elements per thread
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int64_t n8) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const float4 a = *reinterpret_cast<const float4*>(src + i * 8), b = *reinterpret_cast<const float4*>(src + i * 8 + 4);
+  *reinterpret_cast<uint4*>(dst + i * 8) = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
 }
 
 }  // namespace
@@ -834,5 +972,90 @@ extern "C" int dalm_x3_group_max(const float* A, const float* Bm, int64_t m, int
   q.gmax = gmax; q.ng = static_cast<int>(ng);
   DALM_REQUIRE(static_cast<int64_t>(q.MT) * q.NT <= 0x7fffffffll, DALM_E_SHAPE, "too many tiles for one launch");
   hipLaunchKernelGGL((lm_head_lse4w_kernel<8, 8, 0, 0, 0, true, true>), dim3(static_cast<unsigned>(q.MT) * q.NT), dim3(256), 0, s, q);
+  return check_launch(__func__);
+}
+
+
+// ---- round 5: the backward of the fused head -----------------------------------------------------------------
+namespace {
+inline void lm8_geometry(Lm8Params& q, int64_t R, int64_t V) {
+  q.R = static_cast<int>(R); q.V = static_cast<int>(V);
+  q.MT = static_cast<int>((R + 255) / 256); q.NT = static_cast<int>((V + 255) / 256);
+  static const char* xcd_env8 = getenv("DALM_LM_HEAD_XCD");
+  q.xcd_order = xcd_env8 ? atoi(xcd_env8) != 0 : 1;
+  const int bands = (q.MT + 7) / 8;
+  q.gh = (q.MT + bands - 1) / bands;
+  if (q.gh < 1 || q.gh > q.MT) q.gh = q.MT;
+  q.tpd = 0; q.tpd_inv = 0; q.seg_bytes = 0; q.gmax = nullptr; q.ng = 0;
+  q.pm = q.pl = q.z = nullptr;
+}
+}  // namespace
+
+extern "C" int dalm_lm_head_dlogits(const void* hidden, const void* weight_chunk, const int64_t* labels, const float* row_lse,
+                                    const float* coef, int64_t R, int64_t Vc, int64_t K, int64_t col_base, void* dl,
+                                    int64_t pitch, dalm_stream_t stream) {
+  DALM_REQUIRE(hidden && weight_chunk && labels && row_lse && coef && dl, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(R > 0 && Vc > 0 && K > 0 && K % 64 == 0 && col_base >= 0, DALM_E_SHAPE, "need R, Vc > 0 and K a positive multiple of 64");
+  DALM_REQUIRE(pitch >= Vc && pitch % 64 == 0 && pitch <= (Vc + 255) / 256 * 256, DALM_E_SHAPE,
+               "pitch must be a multiple of 64 in [Vc, round_up(Vc, 256)]");
+  DALM_REQUIRE(reinterpret_cast<uintptr_t>(hidden) % 16 == 0 && reinterpret_cast<uintptr_t>(weight_chunk) % 16 == 0 &&
+               reinterpret_cast<uintptr_t>(dl) % 4 == 0, DALM_E_ALIGN, "hidden / weight must be 16-byte aligned");
+  const uint64_t bytesH = static_cast<uint64_t>(R + 256) * K * 2, bytesW = static_cast<uint64_t>(Vc + 256) * K * 2;
+  DALM_REQUIRE(bytesH < 0xffffff00ull && bytesW < 0xffffff00ull, DALM_E_SHAPE, "operands above 4 GB: use smaller chunks");
+  Lm8Params q;
+  q.H = hidden; q.W = weight_chunk; q.labels = labels; q.K = static_cast<int>(K);
+  lm8_geometry(q, R, Vc);
+  q.bytesH = static_cast<unsigned>(static_cast<uint64_t>(R) * K * 2);
+  q.bytesW = static_cast<unsigned>(static_cast<uint64_t>(Vc) * K * 2);
+  q.pitchH = q.pitchW = static_cast<unsigned>(K * 2);
+  q.row_lse = row_lse; q.coef = coef; q.col_base = static_cast<int>(col_base);
+  q.out = dl; q.out_pitch = pitch; q.out_cols = static_cast<int>(pitch); q.accumulate = 0;
+  DALM_REQUIRE(static_cast<int64_t>(q.MT) * q.NT <= 0x7fffffffll, DALM_E_SHAPE, "too many tiles for one launch");
+  hipLaunchKernelGGL((lm_head_lse4w_kernel<8, 8, 0, 0, 0, false, false, EPI_DLOGITS>), dim3(static_cast<unsigned>(q.MT) * q.NT),
+                     dim3(256), 0, as_stream(stream), q);
+  return check_launch(__func__);
+}
+
+extern "C" int dalm_lm_head_dhidden(const void* dl, const void* wt, int64_t R, int64_t Vp, int64_t K, float* dh, int accumulate,
+                                    dalm_stream_t stream) {
+  DALM_REQUIRE(dl && wt && dh, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(R > 0 && Vp > 0 && K > 0 && Vp % 64 == 0, DALM_E_SHAPE, "need R, K > 0 and a chunk width that is a multiple of 64");
+  DALM_REQUIRE(reinterpret_cast<uintptr_t>(dl) % 16 == 0 && reinterpret_cast<uintptr_t>(wt) % 16 == 0, DALM_E_ALIGN,
+               "dl / wt must be 16-byte aligned");
+  const uint64_t bytesH = static_cast<uint64_t>(R + 256) * Vp * 2, bytesW = static_cast<uint64_t>(K + 256) * Vp * 2;
+  DALM_REQUIRE(bytesH < 0xffffff00ull && bytesW < 0xffffff00ull, DALM_E_SHAPE, "operands above 4 GB: use smaller chunks");
+  Lm8Params q;
+  q.H = dl; q.W = wt; q.labels = nullptr; q.K = static_cast<int>(Vp);          // the contraction runs over the chunk's vocabulary
+  lm8_geometry(q, R, K);
+  q.bytesH = static_cast<unsigned>(static_cast<uint64_t>(R) * Vp * 2);
+  q.bytesW = static_cast<unsigned>(static_cast<uint64_t>(K) * Vp * 2);
+  q.pitchH = q.pitchW = static_cast<unsigned>(Vp * 2);
+  q.row_lse = nullptr; q.coef = nullptr; q.col_base = 0;
+  q.out = dh; q.out_pitch = K; q.out_cols = static_cast<int>(K); q.accumulate = accumulate;
+  DALM_REQUIRE(static_cast<int64_t>(q.MT) * q.NT <= 0x7fffffffll, DALM_E_SHAPE, "too many tiles for one launch");
+  hipLaunchKernelGGL((lm_head_lse4w_kernel<8, 8, 0, 0, 0, false, false, EPI_CSTORE>), dim3(static_cast<unsigned>(q.MT) * q.NT),
+                     dim3(256), 0, as_stream(stream), q);
+  return check_launch(__func__);
+}
+
+extern "C" int dalm_transpose_bf16(const void* src, int64_t rows, int64_t cols, int64_t ld_src, void* dst, int64_t ld_dst,
+                                   dalm_stream_t stream) {
+  DALM_REQUIRE(src && dst, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= rows && rows <= 0x7fffffffll && cols <= 0x7fffffffll,
+               DALM_E_SHAPE, "need rows, cols > 0, ld_src >= cols, ld_dst >= rows");
+  const dim3 grid(static_cast<unsigned>((cols + 63) / 64), static_cast<unsigned>((ld_dst + 63) / 64));
+  DALM_REQUIRE(grid.y <= 65535, DALM_E_SHAPE, "too many rows for one launch");
+  hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, as_stream(stream), static_cast<const unsigned short*>(src),
+                     static_cast<int>(rows), static_cast<int>(cols), ld_src, static_cast<unsigned short*>(dst), ld_dst);
+  return check_launch(__func__);
+}
+
+extern "C" int dalm_f32_to_bf16(const float* src, void* dst, int64_t n, dalm_stream_t stream) {
+  DALM_REQUIRE(src && dst, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(n > 0 && n % 8 == 0, DALM_E_SHAPE, "need a positive multiple of 8 elements");
+  DALM_REQUIRE(reinterpret_cast<uintptr_t>(src) % 16 == 0 && reinterpret_cast<uintptr_t>(dst) % 16 == 0, DALM_E_ALIGN,
+               "src / dst must be 16-byte aligned");
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(static_cast<unsigned>((n / 8 + 255) / 256)), dim3(256), 0, as_stream(stream), src,
+                     static_cast<unsigned short*>(dst), n / 8);
   return check_launch(__func__);
 }

@@ -495,6 +495,53 @@ def _lm_head_nll_kernel(ops, h, w, ids, mask, live_rows):
     return out.index_copy_(0, torch.where(valid, rows, torch.full_like(rows, R)), nll_c)[:R]
 
 
+def _use_lm_head_train_kernel(ops, h, H, w, need_dw: bool) -> bool:
+    """TRAINING through the library's own bf16 MFMA kernels end to end (round 5): forward `dalm_lm_head_lse_fwd`,
+    backward `HipOps.lm_head_backward` (logits recomputed per vocabulary chunk; nothing of size [rows, V] is ever allocated -
+    the workspace is two chunk-sized staging buffers, <= 160 MB).  Taken when the head is frozen (LoRA: every BASELINE
+    configuration with a 7B generator) and bf16; a trainable head keeps the chunked library path below (it needs dW as well).
+    DALM_LM_HEAD_TRAIN_KERNEL=0 keeps the library path, =1 insists (raises when the shapes do not fit)."""
+    import os
+
+    env = os.environ.get("DALM_LM_HEAD_TRAIN_KERNEL")
+    ok = (h.is_cuda and h.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and H % 64 == 0 and not need_dw
+          and hasattr(ops, "lm_head_backward"))
+    if env == "1" and not ok:
+        raise RuntimeError("DALM_LM_HEAD_TRAIN_KERNEL=1 needs bf16 hidden states, a frozen bf16 head and a hidden width that is a "
+                           "multiple of 64")
+    return ok and env != "0"
+
+
+def _lm_head_train_kernel(ops, h, w, ids, mask, stats, live_rows):
+    """(d hidden [B, Tg, H], row_nll [B*Tg]) through the hand-written kernels; rows = the live ones when `live_rows` is given."""
+    B, Tg, H = h.shape
+    R = B * Tg
+    nxt_ids = torch.cat((ids[:, 1:], ids[:, :1]), dim=1).reshape(-1)
+    nxt_mask = torch.cat((mask[:, 1:], torch.zeros_like(mask[:, :1])), dim=1).reshape(-1)
+    coef_all = nxt_mask.to(torch.float32) / stats[0]                         # m_bt / M  (SURVEY 8a)
+    labels_all = torch.where(nxt_mask != 0, nxt_ids, torch.full_like(nxt_ids, -1))
+    if live_rows is None:
+        hc, labels, coef = h.reshape(R, H), labels_all, coef_all
+    else:
+        valid = live_rows >= 0
+        rows = live_rows.clamp_min(0)
+        hc = h.reshape(R, H).index_select(0, rows)
+        labels = torch.where(valid, labels_all.index_select(0, rows), torch.full_like(rows, -1))
+        coef = coef_all.index_select(0, rows) * valid.to(torch.float32)
+    _lse, nll_c = ops.lm_head_lse(hc, w, labels)
+    dh_c = ops.lm_head_backward(hc, w, labels, _lse, coef)
+    nll_c = nll_c * (coef != 0).to(nll_c.dtype)
+    if live_rows is None:
+        return dh_c.view(B, Tg, H), nll_c
+    Rp = live_rows.numel()
+    inv = torch.full((R + 1,), Rp, device=h.device, dtype=torch.int64)
+    dst = torch.where(valid, rows, torch.full_like(rows, R))
+    inv.scatter_(0, dst, torch.arange(Rp, device=h.device, dtype=torch.int64))
+    dh_pad = torch.cat((dh_c, dh_c.new_zeros((1, H))), dim=0)
+    nll_pad = torch.cat((nll_c, nll_c.new_zeros((1,))), dim=0)
+    return dh_pad.index_select(0, inv[:R]).view(B, Tg, H), nll_pad.index_select(0, inv[:R])
+
+
 class _LMHeadRagE2E(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, p, hidden, weight, ids, mask, qlen, scale, ops, comm, chunk, q_gather, p_gather, aux, live_rows=None):
@@ -513,6 +560,8 @@ class _LMHeadRagE2E(torch.autograd.Function):
         need_grad = need_dw or any(ctx.needs_input_grad[:3])
         if not need_grad and _use_lm_head_kernel(ops, h, H, w):
             dh, row_nll = None, _lm_head_nll_kernel(ops, h, w, ids, mask, live_rows)
+        elif need_grad and _use_lm_head_train_kernel(ops, h, H, w, need_dw):
+            dh, row_nll = _lm_head_train_kernel(ops, h, w, ids, mask, stats, live_rows)
         elif live_rows is None:
             dh = torch.empty_like(h) if need_grad else None
             row_nll = torch.empty((B * Tg,), device=h.device, dtype=torch.float32)

@@ -21,6 +21,22 @@ import torch
 from . import hip
 
 
+def lm_head_chunk_cols(R: int, V: int, K: int, budget_bytes: int = 160 << 20, cus: int = 256) -> int:
+    """Vocabulary columns per chunk of `HipOps.lm_head_backward`: the chunk's two staging buffers (dlogits [R, c] and the transposed
+    weight chunk [K, c], bf16) stay under `budget_bytes` (default 160 MB: they live in the 256 MB Infinity Cache between the three
+    kernels that touch them), and the logits-recompute launch - ceil(R / 256) x (c / 256) tiles of 256 x 256 - fills whole rounds
+    of the chip's 256 CUs as nearly as the budget allows."""
+    mt = -(-R // 256)
+    cap = max(256, (budget_bytes // (2 * (R + K))) // 256 * 256)
+    best, best_eff = 256, 0.0
+    for nt in range(1, cap // 256 + 1):
+        tiles = mt * nt
+        eff = tiles / (-(-tiles // cus) * cus)
+        if eff >= best_eff - 1e-9:                      # the widest chunk among the best-filling ones
+            best, best_eff = nt * 256, eff
+    return min(best, -(-V // 256) * 256)
+
+
 class HipOps:
     name = "hip"
 
@@ -285,6 +301,37 @@ class HipOps:
         hip.call("dalm_lm_head_lse_fwd", hip.ptr(hidden), hip.ptr(weight), hip.ptr(labels), R, V, K, hip.ptr(row_lse),
                  hip.ptr(row_nll), hip.ptr(ws), ws_bytes, hip.stream())
         return row_lse, row_nll
+
+    def lm_head_backward(self, hidden: torch.Tensor, weight: torch.Tensor, labels: torch.Tensor, row_lse: torch.Tensor,
+                         coef: torch.Tensor, chunk_cols: Optional[int] = None) -> torch.Tensor:
+        """d(hidden) [R, K] (bf16) of sum_r -coef_r log softmax(hidden_r W^T)[label_r], given row_lse from `lm_head_lse`: the
+        logits are recomputed per vocabulary chunk (`dalm_lm_head_dlogits`), staged as bf16 in a chunk-sized workspace and
+        contracted with the transposed chunk of W (`dalm_transpose_bf16`, `dalm_lm_head_dhidden`).  Workspace: about
+        (R + K) * chunk_cols * 2 bytes + R * K * 4; the [R, V] logits never exist."""
+        dev = hip.require_gpu(hidden, weight, labels, row_lse, coef)
+        if hidden.dtype != torch.bfloat16 or weight.dtype != torch.bfloat16:
+            raise TypeError("lm_head_backward needs bf16 hidden states and weights")
+        hidden, weight = hidden.contiguous(), weight.contiguous()
+        labels, row_lse, coef = hip.as_i64(labels).contiguous(), hip.as_f32c(row_lse), hip.as_f32c(coef)
+        R, K = hidden.shape
+        V = weight.shape[0]
+        if chunk_cols is None:
+            chunk_cols = lm_head_chunk_cols(R, V, K)
+        dh32 = torch.empty((R, K), device=dev, dtype=torch.float32)
+        st = hip.stream()
+        for c0 in range(0, V, chunk_cols):
+            vc = min(chunk_cols, V - c0)
+            pitch = -(-vc // 256) * 256
+            dl = torch.empty((R, pitch), device=dev, dtype=torch.bfloat16)
+            wt = torch.empty((K, pitch), device=dev, dtype=torch.bfloat16)
+            wc = weight[c0:c0 + vc]
+            hip.call("dalm_lm_head_dlogits", hip.ptr(hidden), hip.ptr(wc), hip.ptr(labels), hip.ptr(row_lse), hip.ptr(coef),
+                     R, vc, K, c0, hip.ptr(dl), pitch, st)
+            hip.call("dalm_transpose_bf16", hip.ptr(wc), vc, K, K, hip.ptr(wt), pitch, st)
+            hip.call("dalm_lm_head_dhidden", hip.ptr(dl), hip.ptr(wt), R, pitch, K, hip.ptr(dh32), int(c0 > 0), st)
+        dh = torch.empty((R, K), device=dev, dtype=torch.bfloat16)
+        hip.call("dalm_f32_to_bf16", hip.ptr(dh32), hip.ptr(dh), R * K, st)
+        return dh
 
     def contrastive_finalize(self, row_lse, col_lse, diag, n_global: int):
         dev = hip.require_gpu(row_lse, col_lse, diag)

@@ -494,6 +494,27 @@ int dalm_lora2_colacc(const void* x0, const void* x1, const float* z0, const flo
                       float* out0, float* out1, int64_t R, int64_t C, int rank, float scale, int mode, void* ws,
                       size_t ws_bytes, uint32_t* tickets, dalm_stream_t stream);
 
+/* ---- round 5: backward of the fused lm_head + marginalised CE ---------------------------------------
+ * Replaces, for a FROZEN bias-free head,   logits = lm_head(hidden); loss(logits).backward()
+ *   (dalm/models/rag_e2e_base_model.py:104-106 -> dalm/training/utils/train_utils.py:113-138)
+ * without the [R, V] logits or their gradient ever existing: with row_lse from dalm_lm_head_lse_fwd, per vocabulary chunk
+ *   dalm_lm_head_dlogits :  dl[r][c] = bf16( coef[r] * (exp(hidden[r] . W[col_base + c] - row_lse[r]) - [labels[r] == col_base + c]) )
+ *                           for c < Vc, zero for Vc <= c < pitch  (the logits tile is recomputed on the bf16 matrix cores)
+ *   dalm_transpose_bf16  :  wt[k][c] = W[col_base + c][k]   (zero for c >= Vc)        [K][pitch]
+ *   dalm_lm_head_dhidden :  dh[r][k] (+)= sum_c dl[r][c] * wt[k][c]                    f32 [R][K]
+ * hidden [R, K] and weight_chunk (= W + col_base * K, Vc rows) bf16 row-major, K % 64 == 0; labels: global vocabulary ids
+ * (anything outside [0, V) never matches); coef[r] = d loss / d log p(label_r) magnitude (mask_r / M; 0 for rows without
+ * loss); pitch: a multiple of 64 in [Vc, round_up(Vc, 256)].  dalm_f32_to_bf16 rounds the finished f32 gradient.
+ * Fixed summation order (chunks in call order, K tiles in order inside a launch): bit-reproducible. */
+int dalm_lm_head_dlogits(const void* hidden, const void* weight_chunk, const int64_t* labels, const float* row_lse,
+                         const float* coef, int64_t R, int64_t Vc, int64_t K, int64_t col_base, void* dl, int64_t pitch,
+                         dalm_stream_t stream);
+int dalm_lm_head_dhidden(const void* dl, const void* wt, int64_t R, int64_t Vp, int64_t K, float* dh, int accumulate,
+                         dalm_stream_t stream);
+int dalm_transpose_bf16(const void* src, int64_t rows, int64_t cols, int64_t ld_src, void* dst, int64_t ld_dst,
+                        dalm_stream_t stream);
+int dalm_f32_to_bf16(const float* src, void* dst, int64_t n, dalm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
