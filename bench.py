@@ -507,7 +507,7 @@ def main():
         # WORLD_SIZE / MASTER_ADDR=127.0.0.1), rank 0 prints the JSON line; fewer than N visible GPUs -> exit 2
         raise SystemExit(spawn_ranks([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], args.gpus))
     if args.graph_collectives:
-        os.environ["DALM_NATIVE_COMM"] = "1"       # (the default since round 4; a capture needs it, so insist)
+        os.environ["DALM_NATIVE_COMM"] = "1"       # a capture needs the collectives on the capturing stream: insist
     args.hw_queues = dalm_amd.configure_hw_queues(args.gpus)   # before the HIP runtime starts
 
     from dalm_amd import hip

@@ -1,7 +1,8 @@
 """`NativeRcclComm`: the communicator interface of dalm_amd.fused (all_gather_rows / all_reduce_sum_) on the
 library's own RCCL binding (`dalm_comm_*` in include/dalm_hip.h) instead of torch.distributed.
 
-The W > 1 default since round 4 (`dalm_amd.sharded.init_distributed`; `DALM_NATIVE_COMM=0` selects torch.distributed).
+Opt-in at W > 1 (`DALM_NATIVE_COMM=1` / `=auto`, see `dalm_amd.sharded.init_distributed`): torch.distributed(nccl) is the default until
+a run with two or more real ranks has been recorded.
 Bootstrap without a torch.distributed process group: rank 0 asks RCCL for the 128-byte unique id and publishes it
   * through the launcher's file when `DALM_COMM_ID_FILE` is set (`dalm_amd.launch` sets a path unique to the launch), else
   * through a `torch.distributed.TCPStore` on MASTER_ADDR:MASTER_PORT - the store torchrun's agent already hosts

@@ -16,6 +16,27 @@ import torch
 import torch.nn.functional as F
 
 
+_warned = set()
+
+
+def _warn_once(key: str, msg: str) -> None:
+    if key not in _warned:
+        _warned.add(key)
+        import warnings
+
+        warnings.warn("dalm_amd.fastpath: " + msg)
+
+
+def _close(a: torch.Tensor, b: torch.Tensor, ulps: float = 1.0) -> bool:
+    """Equal up to `ulps` units in the last place of the tensors' dtype, relative to the largest magnitude (the patches round
+    where transformers' chains round; what is left is the summation order of a mean or one fused multiply-add)."""
+    if a.shape != b.shape or a.dtype != b.dtype:
+        return False
+    eps = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}.get(a.dtype, 2.0 ** -20)
+    scale = max(float(b.float().abs().max()), 1e-6)
+    return float((a.float() - b.float()).abs().max()) <= ulps * eps * scale
+
+
 def _native_forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
     return F.rms_norm(hidden_states, (hidden_states.shape[-1],), self.weight, self._dalm_eps)
 
@@ -35,9 +56,28 @@ def use_native_rms_norm(model: torch.nn.Module) -> int:
         if "Gemma" in type(mod).__name__:  # (1 + w) parameterisation: not the same formula
             continue
         mod._dalm_eps = float(eps)
+        if not _norm_matches(mod):
+            _warn_once("norm:" + type(mod).__name__, f"{type(mod).__name__}.forward is not w * x * rsqrt(mean(x^2) + eps) here: "
+                       "transformers' own code stays in place")
+            continue
         mod.forward = types.MethodType(_native_forward, mod)
         n += 1
     return n
+
+
+def _norm_matches(mod: torch.nn.Module) -> bool:
+    """Run-time guard: the module's OWN forward against the fused formula on a small random tensor, once per
+    class, dtype and device type."""
+    w = mod.weight
+    key = ("norm", type(mod), w.dtype, w.device.type)
+    if key not in _checked:
+        x = torch.randn(4, 3, w.shape[0], generator=torch.Generator().manual_seed(0)).to(device=w.device, dtype=w.dtype)
+        with torch.no_grad():
+            _checked[key] = _close(_native_forward(mod, x), type(mod).forward(mod, x), 2.0)
+    return _checked[key]
+
+
+_checked: dict = {}
 
 
 # ---------------------------------------------------------------------------
@@ -85,8 +125,43 @@ def use_roll_rope(model: torch.nn.Module) -> bool:
         return False
     if getattr(mod.apply_rotary_pos_emb, "__name__", "") not in ("_rope_roll", "_rope_hip"):
         mod._dalm_orig_apply_rotary_pos_emb = mod.apply_rotary_pos_emb
+    # Run-time guard: the function being replaced must BE the formula the kernel implements.  The swap is
+    # PROCESS-WIDE (transformers resolves apply_rotary_pos_emb through the modeling file's globals; there is no per-model
+    # hook), so every model of this modeling file in the process takes the replacement.
+    dev = next((p.device for p in model.parameters()), torch.device("cpu"))
+    if not _rope_matches(mod._dalm_orig_apply_rotary_pos_emb, fn, dev):
+        _warn_once("rope:" + mod_name, f"{mod_name}.apply_rotary_pos_emb is not x * cos + rotate_half(x) * sin here: "
+                   "transformers' own code stays in place")
+        mod.apply_rotary_pos_emb = mod._dalm_orig_apply_rotary_pos_emb
+        return False
     mod.apply_rotary_pos_emb = fn
     return True
+
+
+def _rope_matches(orig, repl, dev: torch.device) -> bool:
+    """orig(q, k, cos, sin) against the replacement on small random tensors: on the CPU against the roll form in float32 (the
+    same formula, one fused multiply-add apart), on a GPU additionally against the HIP kernel in bfloat16 - there the values
+    must be EQUAL (tests/test_tower_ops_gpu.py asserts the same)."""
+    key = ("rope", orig, repl, dev.type)
+    if key in _checked:
+        return _checked[key]
+    g = torch.Generator().manual_seed(0)
+    q, k = torch.randn(2, 4, 5, 16, generator=g), torch.randn(2, 2, 5, 16, generator=g)
+    ang = torch.rand(2, 5, 8, generator=g) * 6.28
+    cos, sin = torch.cat((ang.cos(), ang.cos()), -1), torch.cat((ang.sin(), ang.sin()), -1)
+    ok = True
+    try:
+        with torch.no_grad():
+            want = orig(q, k, cos, sin)
+            got = _rope_roll(q, k, cos, sin)
+            ok = all(_close(a, b, 8.0) for a, b in zip(got, want))
+            if ok and dev.type == "cuda" and repl is _rope_hip:
+                args = [t.to(dev, torch.bfloat16) for t in (q, k, cos, sin)]
+                ok = all(torch.equal(a, b) for a, b in zip(_rope_hip(*args), orig(*args)))
+    except Exception:
+        ok = False
+    _checked[key] = ok
+    return ok
 
 
 # ---------------------------------------------------------------------------
@@ -117,9 +192,30 @@ def use_swiglu_kernel(model: torch.nn.Module) -> int:
             continue
         if not (isinstance(act, torch.nn.SiLU) or type(act).__name__ in ("SiLUActivation", "SiLU")):
             continue
+        if not _mlp_matches(mod):
+            _warn_once("mlp:" + type(mod).__name__, f"{type(mod).__name__}.forward is not down(silu(gate(x)) * up(x)) here: "
+                       "transformers' own code stays in place")
+            continue
         mod.forward = types.MethodType(_swiglu_mlp_forward, mod)
         n += 1
     return n
+
+
+def _mlp_matches(mod: torch.nn.Module) -> bool:
+    """Run-time guard: the class's own forward against the patched one on a small random input, once per
+    class, dtype and device type (on a GPU the patched forward runs the HIP kernel: <= 1 ulp of the output dtype)."""
+    w = getattr(mod.gate_proj, "weight", None)
+    if w is None:
+        return False
+    key = ("mlp", type(mod), w.dtype, w.device.type)
+    if key not in _checked:
+        x = torch.randn(2, 3, mod.gate_proj.in_features, generator=torch.Generator().manual_seed(0)).to(device=w.device, dtype=w.dtype)
+        try:
+            with torch.no_grad():
+                _checked[key] = _close(_swiglu_mlp_forward(mod, x), type(mod).forward(mod, x), 2.0)
+        except Exception:
+            _checked[key] = False
+    return _checked[key]
 
 
 # ---------------------------------------------------------------------------

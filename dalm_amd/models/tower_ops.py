@@ -104,8 +104,10 @@ def swiglu(gate, up):
 def rms_norm_supported(x: torch.Tensor, w: torch.Tensor) -> bool:
     D = x.shape[-1]
     vec = 4 if x.dtype == torch.float32 else 8
+    # w.dtype == x.dtype: eager LlamaRMSNorm with an f32 weight and bf16 activations promotes the product to f32 - another
+    # output dtype and rounding than the kernel's: those modules keep transformers' code
     return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and w.dim() == 1 and w.shape[0] == D
-            and D % vec == 0 and D <= 64 * vec * 16)
+            and w.dtype == x.dtype and D % vec == 0 and D <= 64 * vec * 16)
 
 
 def _norm_fwd(x2, delta2, w, eps):
@@ -127,7 +129,9 @@ def _norm_bwd(dy2, h2, w, rstd, dres2):
 
 
 def _weight_grad(dy2, h2, rstd):
-    return (dy2.float() * (h2.float() * rstd.unsqueeze(1))).sum(0)
+    # the normalised value rounded to the activation dtype first, as the eager chain does before its weight multiply
+    xh = (h2.float() * rstd.unsqueeze(1)).to(h2.dtype)
+    return (dy2.float() * xh.float()).sum(0)
 
 
 def _as_rows(t, D, dtype):

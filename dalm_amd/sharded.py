@@ -36,12 +36,16 @@ def init_distributed(backend: Optional[str] = None):
     import torch.distributed as dist
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # W > 1 on GPUs: the library's OWN RCCL binding (dalm_comm_* behind the C ABI, collectives on the caller's stream) is the
-    # default since round 4 - it ties torch.distributed on one rank (188.1 vs 188.9 ms per step, profiles/r03_comm_modes.txt)
-    # and is what north_star asks for.  DALM_NATIVE_COMM=0 selects torch.distributed(nccl); =1 insists on the native
-    # binding (errors propagate); unset: native, verified by a self-test collective, and torch.distributed if that raises.
-    native = os.environ.get("DALM_NATIVE_COMM")
-    if torch.cuda.is_available() and backend in (None, "nccl") and native != "0":
+    # W > 1 on GPUs: torch.distributed(nccl) - RCCL through torch - is the default.  The library's OWN RCCL binding (dalm_comm_*
+    # behind the C ABI, collectives on the caller's stream; it ties torch.distributed with one rank: 188.1 vs 188.9 ms per step,
+    # profiles/r03_comm_modes.txt) is OPT-IN until a run with two or more real ranks has been recorded (no multi-GPU box was
+    # available in rounds 1-5): a rank whose ncclCommInitRank stalls instead of raising would leave the others
+    # blocked inside the bring-up collective, and the agreement step below only covers failures that raise.
+    #   DALM_NATIVE_COMM=1     the native binding, errors propagate
+    #   DALM_NATIVE_COMM=auto  the native binding, self-tested; every rank falls back to torch.distributed if any rank raised
+    #   unset / 0              torch.distributed(nccl)
+    native = os.environ.get("DALM_NATIVE_COMM", "0")
+    if torch.cuda.is_available() and backend in (None, "nccl") and native in ("1", "auto"):
         dev = torch.device("cuda", local_rank)
         torch.cuda.set_device(dev)
         comm = native_comm_or_none(int(os.environ.get("RANK", "0")), world, insist=(native == "1"))

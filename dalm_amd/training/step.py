@@ -125,8 +125,11 @@ class RagE2EStep(_StepBase):
                  lm_head_chunk: Optional[int] = None, graph_towers: bool = False, graph_after: int = 2, **kw):
         super().__init__(*a, **kw)
         self.inplace_grad = inplace_grad
-        # run the decoder without its lm_head and let the loss consume the
-        # hidden states chunk by chunk - the [B,Tg,V] logits and their gradient never exist
+        # run the decoder without its lm_head and let the loss consume the hidden states chunk by chunk -
+        # the [B,Tg,V] logits and their gradient never exist (frozen bf16 head: the library's own MFMA kernels end to end,
+        # fused._lm_head_train_kernel).  True / False, or "auto": fused whenever the materialised logits of a batch would exceed
+        # DALM_LOGITS_BUDGET_MB (default 1024 MB; resolved on the first batch - the BASELINE batches stay below it, where the
+        # materialised path measures ~1 ms per step faster: profiles/r05_lm_head_train_kernels_vs_library.txt)
         self.fuse_lm_head = fuse_lm_head
         self.lm_head_chunk = lm_head_chunk
         # W > 1: graph the towers (fwd + bwd), keep collectives / loss / optimizer eager (GraphedTowers)
@@ -194,10 +197,22 @@ class RagE2EStep(_StepBase):
         return gm.base_model(input_ids=batch["generator_input_input_ids"],
                              attention_mask=batch["generator_input_attention_mask"], use_cache=False)[0]
 
+    def _resolve_fuse(self, batch) -> None:
+        if self.fuse_lm_head != "auto":
+            return
+        import os
+
+        head = self.model.generator_model.get_output_embeddings()
+        ids = batch["generator_input_input_ids"]
+        el = 2 if self.autocast_dtype in (torch.bfloat16, torch.float16) or head.weight.dtype != torch.float32 else 4
+        mb = ids.shape[0] * ids.shape[1] * head.weight.shape[0] * el / 2 ** 20
+        self.fuse_lm_head = bool(mb > float(os.environ.get("DALM_LOGITS_BUDGET_MB", "1024")) and getattr(head, "bias", None) is None)
+
     def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         m = self.model
         self.calls += 1
         self.graph_after = getattr(self, "graph_after", 2)
+        self._resolve_fuse(batch)
         self._maybe_build_towers(batch)
         _advance_dropout(batch)
         with self._autocast():

@@ -1,0 +1,81 @@
+"""Run-time guards of the tower patches: a patch goes in only where transformers' own function IS the formula
+the replacement implements - checked numerically at patch time, on the CPU here (on a GPU the same guards compare against the
+HIP kernels).  The reference reaches these functions through `self.generator_model(...)`
+(dalm/models/rag_e2e_base_model.py:104-106)."""
+import warnings
+
+import pytest
+import torch
+
+
+@pytest.fixture()
+def llama():
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    torch.manual_seed(0)
+    cfg = LlamaConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                      vocab_size=100)
+    return LlamaForCausalLM(cfg)
+
+
+@pytest.fixture()
+def clean():
+    """Undo the process-wide rope swap and the guard cache around a test."""
+    import transformers.models.llama.modeling_llama as ml
+
+    from dalm_amd.models import fastpath
+
+    saved = getattr(ml, "_dalm_orig_apply_rotary_pos_emb", ml.apply_rotary_pos_emb)
+    fastpath._checked.clear()
+    fastpath._warned.clear()
+    yield ml, fastpath, saved
+    ml.apply_rotary_pos_emb = saved
+    ml._dalm_orig_apply_rotary_pos_emb = saved
+    fastpath._checked.clear()
+
+
+def test_patches_go_in_on_the_stock_functions_and_keep_the_values(llama, clean):
+    ml, fastpath, saved = clean
+    ml.apply_rotary_pos_emb = saved
+    x = torch.randint(0, 100, (2, 9))
+    with torch.no_grad():
+        want = llama(x).logits
+    assert fastpath.use_native_rms_norm(llama) == 5 and fastpath.use_swiglu_kernel(llama) == 2 and fastpath.use_roll_rope(llama)
+    assert ml.apply_rotary_pos_emb.__name__ in ("_rope_hip", "_rope_roll")
+    with torch.no_grad():
+        got = llama(x).logits
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+
+
+def test_a_different_rotary_function_is_refused(llama, clean):
+    ml, fastpath, saved = clean
+
+    def other(q, k, cos, sin, position_ids=None, unsqueeze_dim=1):      # another model's convention: interleaved pairs
+        a, b = saved(q, k, cos, sin)
+        return a * 1.01, b
+
+    ml.apply_rotary_pos_emb = other
+    ml._dalm_orig_apply_rotary_pos_emb = other
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert fastpath.use_roll_rope(llama) is False
+    assert ml.apply_rotary_pos_emb is other                              # transformers' code stays in place
+    assert any("apply_rotary_pos_emb is not" in str(m.message) for m in w)
+
+
+def test_a_different_mlp_or_norm_formula_is_refused(llama, clean):
+    ml, fastpath, saved = clean
+    mlp_cls = type(llama.model.layers[0].mlp)
+    norm_cls = type(llama.model.norm)
+    orig_mlp, orig_norm = mlp_cls.forward, norm_cls.forward
+    try:
+        mlp_cls.forward = lambda self, x: self.down_proj(torch.nn.functional.gelu(self.gate_proj(x)) * self.up_proj(x))
+        norm_cls.forward = lambda self, x: self.weight * x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1.0)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            assert fastpath.use_swiglu_kernel(llama) == 0
+            assert fastpath.use_native_rms_norm(llama) == 0
+        assert sum("transformers' own code stays in place" in str(m.message) for m in w) == 2
+        assert "forward" not in llama.model.layers[0].mlp.__dict__ and "forward" not in llama.model.norm.__dict__
+    finally:
+        mlp_cls.forward, norm_cls.forward = orig_mlp, orig_norm

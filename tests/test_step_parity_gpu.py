@@ -116,12 +116,13 @@ def test_train_e2e_end_to_end_on_csv(tmp_path):
     assert [s for s, _ in more] == [7, 8, 9]  # epochs 0-1 are skipped, one more epoch of 3 steps runs
 
 
-@pytest.mark.parametrize("which", ["native-default", "torch-distributed"])
+@pytest.mark.parametrize("which", ["native-opt-in", "torch-distributed"])
 def test_multi_gpu_code_path_on_one_rank_matches_reference(monkeypatch, which):
     """The W > 1 step (RCCL all-gathers on a side stream, stats exchange, flat gradient all-reduce, graphed
     towers) run through a real one-rank RCCL communicator: collectives are identities, so the trajectory
-    must still be the reference's.  Round 4: `init_distributed` hands out the library's own RCCL binding by default
-    (rendezvous over a TCPStore, self-test collective); DALM_NATIVE_COMM=0 selects torch.distributed(nccl)."""
+    must still be the reference's.  `init_distributed` hands out torch.distributed(nccl) by default; DALM_NATIVE_COMM=auto /
+    =1 opts into the library's own RCCL binding (rendezvous over a TCPStore, self-test collective) - opt-in since round 5:
+    it has never run with two real ranks."""
     import torch.distributed as dist
     from transformers import get_scheduler
 
@@ -139,9 +140,9 @@ def test_multi_gpu_code_path_on_one_rank_matches_reference(monkeypatch, which):
     monkeypatch.setenv("LOCAL_RANK", "0")
     monkeypatch.delenv("DALM_COMM_ID_FILE", raising=False)
     if which == "torch-distributed":
-        monkeypatch.setenv("DALM_NATIVE_COMM", "0")
+        monkeypatch.delenv("DALM_NATIVE_COMM", raising=False)          # the default
     else:
-        monkeypatch.delenv("DALM_NATIVE_COMM", raising=False)
+        monkeypatch.setenv("DALM_NATIVE_COMM", "auto")
     comm, dev = init_distributed()
     try:
         if which == "torch-distributed":
