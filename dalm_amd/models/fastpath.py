@@ -170,7 +170,9 @@ def _rope_matches(orig, repl, dev: torch.device) -> bool:
 def _swiglu_mlp_forward(self, x):
     from . import tower_ops
 
-    gate, up = self.gate_proj(x), self.up_proj(x)
+    from . import frozen_linear
+
+    gate, up = frozen_linear.pair_forward(x, self.gate_proj, self.up_proj)   # frozen: one node, the two dx GEMMs accumulate
     if tower_ops.swiglu_supported(gate, up):
         return self.down_proj(tower_ops.swiglu(gate, up))
     return self.down_proj(self.act_fn(gate) * up)

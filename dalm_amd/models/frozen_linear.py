@@ -1,0 +1,160 @@
+"""Frozen projections with a transposed copy of the weight for the backward GEMM.
+
+Under LoRA (the reference's configuration for 7B generators: dalm/models/rag_e2e_base_model.py:61-80) every base projection is
+frozen: its backward is one GEMM, dx = g W with W [N, K] as stored - the library's "NN" layout.  hipBLASLt runs that layout
+slower than the forward's ("TN"): measured at the cfg3 shapes with the tuned solution table (profiles/r05_gemm_layout_probe.txt)
+    q/k/v/o   162.5 us (NN)  ->  148.6 us through a transposed copy (TN), 135.6 us when it accumulates into an existing dx
+    down_proj 376.1 us       ->  327.3 us        gate/up_proj 349.6 us -> 334.7 us
+A frozen weight never changes, so the copy W^T [K, N] is made once (lazily, on the weight's device; +1x the frozen weights'
+bytes - 13.5 GB for Llama-2-7b in bf16, on a 288 GB GPU) and the backward becomes F.linear(g, W^T).  Same values as autograd's
+own backward up to the summation order inside the library's kernel.  DALM_DGRAD_T=0 disables (no copies are made).
+
+Nothing in transformers is patched: frozen `nn.Linear` modules get the subclass below by class swap (same parameters, same
+state_dict keys); trainable weights, CPU tensors and inference keep `nn.Linear.forward`.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+_ENABLED = os.environ.get("DALM_DGRAD_T", "1") != "0"
+
+
+def enabled() -> bool:
+    return _ENABLED
+
+
+def dgrad_weight(w: torch.Tensor, dtype: Optional[torch.dtype] = None) -> Optional[torch.Tensor]:
+    """W^T [K, N], contiguous, in `dtype` (default: w's own) - cached on the parameter object; None when disabled, when w is
+    trainable or not on a GPU.  The cache is keyed by the weight's storage, version, device and dtype: a reloaded or moved weight
+    gets a fresh copy."""
+    if not _ENABLED or w.requires_grad or not w.is_cuda or w.dim() != 2:
+        return None
+    dtype = dtype or w.dtype
+    key = (w.data_ptr(), w._version, w.device, dtype, tuple(w.shape))
+    cached = getattr(w, "_dalm_wt", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    with torch.no_grad():
+        wt = w.detach().to(dtype).t().contiguous()
+    try:
+        w._dalm_wt = (key, wt)
+    except Exception:       # an object that takes no attributes: recompute next time
+        pass
+    return wt
+
+
+def _compute_dtype(x: torch.Tensor) -> torch.dtype:
+    return torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
+
+
+class _FrozenLinearFn(torch.autograd.Function):
+    """y = x W^T + b with W, b frozen: the backward is dx = F.linear(g, W^T copy)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        y = F.linear(x, w, b)                              # under autocast this casts exactly as nn.Linear.forward does
+        ctx.w = w
+        ctx.cdt = y.dtype
+        ctx.xshape, ctx.xdtype = x.shape, x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        w = ctx.w
+        wt = dgrad_weight(w, ctx.cdt)
+        g2 = g.reshape(-1, w.shape[0])
+        if g2.dtype != ctx.cdt:
+            g2 = g2.to(ctx.cdt)
+        dx = F.linear(g2, wt) if wt is not None else torch.mm(g2, w.to(ctx.cdt))
+        dx = dx.view(ctx.xshape)
+        return (dx if dx.dtype == ctx.xdtype else dx.to(ctx.xdtype)), None, None
+
+
+class _FrozenPairFn(torch.autograd.Function):
+    """(x W0^T, x W1^T) for two frozen bias-free projections of ONE input (gate_proj / up_proj): the two backward GEMMs
+    accumulate into one dx - no separate add of two [rows, K] tensors."""
+
+    @staticmethod
+    def forward(ctx, x, w0, w1):
+        y0, y1 = F.linear(x, w0), F.linear(x, w1)
+        ctx.w = (w0, w1)
+        ctx.cdt = y0.dtype
+        ctx.xshape, ctx.xdtype = x.shape, x.dtype
+        ctx.set_materialize_grads(False)
+        return y0, y1
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        dx = None
+        for g, w in zip((g0, g1), ctx.w):
+            if g is None:
+                continue
+            g2 = g.reshape(-1, w.shape[0])
+            if g2.dtype != ctx.cdt:
+                g2 = g2.to(ctx.cdt)
+            wt = dgrad_weight(w, ctx.cdt)
+            if dx is None:
+                dx = F.linear(g2, wt) if wt is not None else torch.mm(g2, w.to(ctx.cdt))
+            elif wt is not None:
+                dx.addmm_(g2, wt.t())
+            else:
+                dx.addmm_(g2, w.to(ctx.cdt))
+        if dx is None:
+            return None, None, None
+        dx = dx.view(ctx.xshape)
+        return (dx if dx.dtype == ctx.xdtype else dx.to(ctx.xdtype)), None, None
+
+
+def _eligible(x: torch.Tensor, *mods) -> bool:
+    if not (_ENABLED and x.is_cuda and torch.is_grad_enabled() and x.requires_grad):
+        return False
+    cdt = _compute_dtype(x)
+    if cdt not in (torch.bfloat16, torch.float16, torch.float32):
+        return False
+    for m in mods:
+        if m.weight.requires_grad or (m.bias is not None and m.bias.requires_grad) or not m.weight.is_cuda:
+            return False
+    return True
+
+
+class FrozenLinearT(torch.nn.Linear):
+    """nn.Linear whose backward uses the transposed copy while the layer is frozen."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if _eligible(x, self):
+            return _FrozenLinearFn.apply(x, self.weight, self.bias)
+        return super().forward(x)
+
+
+def pair_forward(x: torch.Tensor, m0: torch.nn.Linear, m1: torch.nn.Linear):
+    """(m0(x), m1(x)); one autograd node with an accumulating backward when both are frozen and bias-free."""
+    plain = (torch.nn.Linear, FrozenLinearT)
+    if m0.bias is None and m1.bias is None and type(m0) in plain and type(m1) in plain and _eligible(x, m0, m1):
+        return _FrozenPairFn.apply(x, m0.weight, m1.weight)
+    return m0(x), m1(x)
+
+
+def _is_plain_linear(m: torch.nn.Module) -> bool:
+    # nn.Linear itself, or Falcon's FalconLinear (y = x W^T + b spelled as a matmul: the same function)
+    return type(m) is torch.nn.Linear or (isinstance(m, torch.nn.Linear) and type(m).__name__ == "FalconLinear")
+
+
+def use_transposed_dgrad(model: torch.nn.Module) -> int:
+    """Class-swap the FROZEN plain `nn.Linear` modules of `model` to FrozenLinearT (a model that is fine-tuned in full is left
+    alone; the forward still checks per call that the layer is frozen); returns how many were swapped.  LoRA-wrapped projections
+    and their siblings keep their own modules: the LoRA group node (models/lora_ops.py) asks `dgrad_weight` itself."""
+    if not _ENABLED:
+        return 0
+    n = 0
+    for name, m in model.named_modules():
+        if not _is_plain_linear(m) or name.endswith("base_layer"):              # LoRALinear.base_layer: the group node's business
+            continue
+        if m.weight.requires_grad or (m.bias is not None and m.bias.requires_grad):
+            continue
+        m.__class__ = FrozenLinearT
+        n += 1
+    return n

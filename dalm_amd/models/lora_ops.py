@@ -342,6 +342,7 @@ class _LoRAGroupFn(torch.autograd.Function):
                 for i in grp:
                     rankupd2_([outs[i]], [zs[i]], [Bts[i]], None, rank, meta[i][0], 1)
         ctx.meta, ctx.lora, ctx.n, ctx.rank = meta, lora, n, rank
+        ctx.w_params = Ws
         ctx.xshape, ctx.xdtype = x.shape, x.dtype
         ctx.set_materialize_grads(False)          # an output nobody differentiated arrives as None, not as a zero tensor
         ctx.save_for_backward(x2, *wc, *[As[i] for i in lora], *[Bts[i] for i in lora], *[zs[i] for i in lora],
@@ -396,11 +397,18 @@ class _LoRAGroupFn(torch.autograd.Function):
                     dA[i] = colacc2([x2], [dz[i]], [bits[i]] if bits[i] is not None else None, rank, 1.0 / (1.0 - pi), 1)[0]
         dx = None
         if ctx.needs_input_grad[0]:
+            from . import frozen_linear
+
             for i in range(n):                             # the base GEMMs accumulate into one dx
                 if g2[i] is None:
                     continue
+                # frozen weights: through the transposed copy (the forward's GEMM layout: frozen_linear.py); ctx.w_params holds
+                # the PARAMETERS (the cache lives on them), wc the compute-dtype tensors the forward used
+                wt = frozen_linear.dgrad_weight(ctx.w_params[i], x2.dtype)
                 if dx is None:
-                    dx = torch.mm(g2[i], wc[i])
+                    dx = torch.nn.functional.linear(g2[i], wt) if wt is not None else torch.mm(g2[i], wc[i])
+                elif wt is not None:
+                    dx.addmm_(g2[i], wt.t())
                 else:
                     dx.addmm_(g2[i], wc[i])
             if dx is None:

@@ -125,6 +125,12 @@ class AutoModelForRagE2E(torch.nn.Module):
                 lora.inject_lora(self.retriever_model, targets)
             if get_peft in (Mode.GENERATOR, Mode.BOTH):
                 lora.inject_lora(self.generator_model, ["q_proj", "v_proj"])
+        # frozen projections: the backward GEMM through a transposed weight copy (models/frozen_linear.py; after the adapters
+        # are in, so that LoRA-wrapped projections and the plain Linears grouped with them keep their own modules)
+        from .frozen_linear import use_transposed_dgrad
+
+        use_transposed_dgrad(self.generator_model)
+        use_transposed_dgrad(self.retriever_model)
 
     # ---- retrieval tower ---------------------------------------------------------------
     def retrieval_hidden(self, input_ids: torch.Tensor, attention_mask: torch.Tensor):

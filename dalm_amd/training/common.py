@@ -535,6 +535,16 @@ def load_training_state(path: str, optimizer, scheduler) -> Dict[str, Any]:
         st["optimizer"] = merge_optimizer_shards(shards_)
     lr_devices = [g["lr"].device if torch.is_tensor(g["lr"]) else None for g in optimizer.param_groups]
     optimizer.load_state_dict(st["optimizer"])
+    # per-parameter state follows the parameter's memory layout (the fused Adam kernel requires it): lora_B lives in
+    # transposed-dense memory (models/lora.py), checkpoints hold plain contiguous tensors
+    for g in optimizer.param_groups:
+        for p in g["params"]:
+            ps = optimizer.state.get(p)
+            if not ps:
+                continue
+            for k, v in list(ps.items()):
+                if torch.is_tensor(v) and v.shape == p.shape and v.dim() > 1 and v.stride() != p.stride():
+                    ps[k] = torch.empty_like(p, dtype=v.dtype).copy_(v)
     for g, dev in zip(optimizer.param_groups, lr_devices):  # a tensor lr (capturable Adam) must stay on its device
         if dev is not None:
             g["lr"] = torch.as_tensor(g["lr"], dtype=torch.float32).to(dev)

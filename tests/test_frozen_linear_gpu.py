@@ -1,0 +1,81 @@
+"""Frozen projections whose backward GEMM runs through a transposed weight copy (dalm_amd/models/frozen_linear.py): the same
+function as `nn.Linear` forward and backward (the towers the reference runs through `self.generator_model(...)`,
+dalm/models/rag_e2e_base_model.py:104-106, under its LoRA configuration :61-80 where every base projection is frozen)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f32-autocast", "f32"])
+@pytest.mark.parametrize("bias", [False, True])
+def test_forward_equal_and_backward_close_to_nn_linear(dev, mode, bias):
+    from dalm_amd.models import frozen_linear as FL
+
+    torch.manual_seed(0)
+    wdt = torch.bfloat16 if mode == "bf16" else torch.float32
+    ref = torch.nn.Linear(512, 384, bias=bias).to(dev, wdt).requires_grad_(False)
+    seq = torch.nn.Sequential(torch.nn.Linear(512, 384, bias=bias).to(dev, wdt).requires_grad_(False))
+    seq[0].load_state_dict(ref.state_dict())
+    assert FL.use_transposed_dgrad(seq) == 1 and type(seq[0]) is FL.FrozenLinearT
+    x = torch.randn(6, 50, 512, device=dev, dtype=torch.float32 if mode != "bf16" else torch.bfloat16)
+    up = torch.randn(6, 50, 384, device=dev)
+    outs = []
+    for m in (ref, seq[0]):
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode == "f32-autocast"):
+            y = m(xi)
+        (y.float() * up).sum().backward()
+        outs.append((y.detach(), xi.grad))
+    assert torch.equal(outs[0][0], outs[1][0])                       # the forward is the same library call
+    tol = 1e-6 if mode == "f32" else 3e-3                            # another GEMM kernel: summation order only
+    assert outs[0][1].dtype == outs[1][1].dtype and _rel(outs[1][1], outs[0][1]) < tol
+    wt = FL.dgrad_weight(seq[0].weight, torch.bfloat16 if mode != "f32" else torch.float32)
+    assert wt.shape == (512, 384) and wt.is_contiguous() and torch.equal(wt.t(), seq[0].weight.to(wt.dtype))
+    # the copy follows the weight
+    with torch.no_grad():
+        seq[0].weight.mul_(2.0)
+    wt2 = FL.dgrad_weight(seq[0].weight, wt.dtype)
+    assert torch.equal(wt2.t(), seq[0].weight.to(wt.dtype)) and not torch.equal(wt2, wt)
+
+
+def test_pair_node_accumulates_one_dx_and_trainable_layers_keep_autograd(dev):
+    from dalm_amd.models import frozen_linear as FL
+
+    torch.manual_seed(1)
+    m0 = torch.nn.Linear(256, 320, bias=False).to(dev, torch.bfloat16).requires_grad_(False)
+    m1 = torch.nn.Linear(256, 320, bias=False).to(dev, torch.bfloat16).requires_grad_(False)
+    x = torch.randn(40, 256, device=dev, dtype=torch.bfloat16)
+    u0, u1 = torch.randn(40, 320, device=dev), torch.randn(40, 320, device=dev)
+    xa = x.clone().requires_grad_(True)
+    ((m0(xa).float() * u0).sum() + (m1(xa).float() * u1).sum()).backward()
+    xb = x.clone().requires_grad_(True)
+    y0, y1 = FL.pair_forward(xb, m0, m1)
+    assert y0.grad_fn is y1.grad_fn and "FrozenPair" in type(y0.grad_fn).__name__
+    ((y0.float() * u0).sum() + (y1.float() * u1).sum()).backward()
+    assert _rel(xb.grad, xa.grad) < 4e-3
+    # only one of the two outputs used: the other arrives as None
+    xc = x.clone().requires_grad_(True)
+    y0, y1 = FL.pair_forward(xc, m0, m1)
+    (y1.float() * u1).sum().backward()
+    xd = x.clone().requires_grad_(True)
+    (m1(xd).float() * u1).sum().backward()
+    assert _rel(xc.grad, xd.grad) < 4e-3
+    # a trainable layer: plain nn.Linear semantics, weight gradient included
+    m1.requires_grad_(True)
+    xe = x.clone().requires_grad_(True)
+    y0, y1 = FL.pair_forward(xe, m0, m1)
+    assert y0.grad_fn is not y1.grad_fn
+    (y0.float().sum() + y1.float().sum()).backward()
+    assert m1.weight.grad is not None

@@ -833,3 +833,33 @@ def test_lora_linear_path_selection_and_seed_word():
     import inspect
 
     assert "generator=g" in inspect.getsource(lora_ops.dropout_seed)
+
+
+def test_resumed_optimizer_state_follows_the_transposed_lora_b_layout(tmp_path):
+    """lora_B.weight lives in [r, N]-major memory (models/lora.py); a checkpoint holds plain contiguous moments.  After
+    `load_training_state` every per-parameter tensor has the parameter's strides again - the fused Adam kernel refuses mixed
+    layouts (reference resume path: dalm/training/rag_e2e/train_rage2e.py:486-524 through accelerate.load_state)."""
+    from dalm_amd.models import lora
+    from dalm_amd.training import common
+
+    torch.manual_seed(0)
+    m = lora.LoRALinear(torch.nn.Linear(16, 24))
+    params = [p for p in m.parameters() if p.requires_grad]
+    assert m.lora_B["default"].weight.stride() == (1, 24)
+    opt = torch.optim.Adam(params, lr=1e-2)
+    m(torch.randn(5, 16)).sum().backward()
+    opt.step()
+    sd = opt.state_dict()
+    for st in sd["state"].values():                      # what a checkpoint file holds: contiguous host tensors
+        for k, v in list(st.items()):
+            if torch.is_tensor(v) and v.dim() > 1:
+                st[k] = v.contiguous()
+    torch.save({"optimizer": sd, "scheduler": None, "extra": {"completed_steps": 1}}, tmp_path / "trainer_state.pt")
+    opt2 = torch.optim.Adam(params, lr=1e-2)
+    extra = common.load_training_state(str(tmp_path), opt2, None)
+    assert extra["completed_steps"] == 1
+    for p in params:
+        for k, v in opt2.state[p].items():
+            if torch.is_tensor(v) and v.dim() > 1:
+                assert v.stride() == p.stride(), (k, v.stride(), p.stride())
+                assert torch.equal(v, opt.state[p][k])
