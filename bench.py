@@ -82,7 +82,13 @@ def _tower_kernels(model) -> dict:
 
     rope = getattr(getattr(importlib.import_module(type(getattr(gen, "base_model", gen)).__module__), "apply_rotary_pos_emb", None),
                    "__name__", None)
-    return {"lora_branch": "dalm_lora_* (fused node / in-place branch)" if lora_mod._FUSED and "LoRALinear" in names else "eager",
+    from dalm_amd.models import frozen_linear
+
+    grouped = any(getattr(m, "_group", None) is not None and m._group.enabled for m in gen.modules() if isinstance(m, lora_mod.LoRALinear))
+    return {"lora_branch": ("dalm_lora2_* (q / k / v of a block as ONE autograd node, mask bits)" if grouped and lora_mod._GROUPS
+                            else "dalm_lora2_* / dalm_lora_* (one node per projection)") if lora_mod._FUSED and "LoRALinear" in names else "eager",
+            "frozen_dgrad": "transposed weight copies (F.linear(g, W^T))" if frozen_linear.enabled() and "FrozenLinearT" in names
+                            else "autograd (torch.mm(g, W))",
             "rotary": {"_rope_hip": "dalm_rope_qk", "_rope_roll": "roll + addcmul (torch)"}.get(rope, "transformers"),
             "swiglu": "dalm_swiglu_*" if "_swiglu_mlp_forward" in fwd("LlamaMLP") else "transformers",
             "residual_norm": "dalm_rms_norm_*" if "_llama_layer_forward" in fwd("LlamaDecoderLayer") else "transformers / torch",
@@ -196,13 +202,64 @@ def ce_back_to_back_probe(dev, batch, dtype, V, launches=20):
     return us, nbytes / (us * 1e-6) / 1e9
 
 
+class _ReferenceLossCode:
+    """The REFERENCE'S OWN loss functions ("run the reference code itself") behind the two entry points the CPU
+    baselines call: dalm/training/utils/train_utils.py:76-138 and AutoModelForRagE2E.mean_pooling
+    (dalm/models/rag_e2e_base_model.py:108-111), composed as train_rage2e.py:431-467 composes them.  Importable only where
+    /root/reference exists (the build container; the GPU box has no copy of the reference): there `kind` = "reference"."""
+
+    kind = "reference"
+
+    def __init__(self, root):
+        import types
+
+        import transformers  # noqa: F401  (resolve it before the stub goes in, as oracle/make_golden.py does)
+
+        stub = types.ModuleType("peft")        # the image has no peft; the reference only needs the four names to import
+        for name in ("LoraConfig", "PeftModel", "TaskType", "get_peft_model"):
+            setattr(stub, name, type(name, (), {}))
+        sys.modules["peft"] = stub
+        sys.path.insert(0, str(root))
+        try:
+            import dalm.models.rag_e2e_base_model as m_rag
+            import dalm.training.utils.train_utils as tu
+        finally:
+            sys.modules.pop("peft", None)
+            sys.path.remove(str(root))
+        self.tu, self.m_rag = tu, m_rag
+
+    def ref_retrieval_embed(self, token_states, mask):
+        e = self.m_rag.AutoModelForRagE2E.mean_pooling(None, token_states, mask)
+        return torch.nn.functional.normalize(e, p=2, dim=1)
+
+    def ref_step_loss(self, q, p, logits, ids, mask, qlen, scale):
+        tu = self.tu
+        S = tu.get_cosine_sim(q, p, scale)
+        con = (tu.get_nt_xent_loss(S) + tu.get_nt_xent_loss(S.t())) / 2.0
+        gen = tu.compute_marginalized_loss_from_logits(logits, ids, mask, S, qlen)
+        return {"loss": con + gen, "contrastive": con, "generator": gen}
+
+
+def _cpu_loss_code():
+    """(implementation, kind): the reference's own functions when /root/reference is present, else the oracle restatement
+    ("port": oracle/dalm_oracle.py ref_*, pinned to the reference by tests/test_oracle_golden.py)."""
+    root = Path(os.environ.get("DALM_REFERENCE_ROOT", "/root/reference"))
+    if (root / "dalm" / "training" / "utils" / "train_utils.py").exists():
+        try:
+            return _ReferenceLossCode(root), "reference"
+        except Exception:
+            pass
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import dalm_oracle as O
+
+    return O, "port"
+
+
 def cpu_loss_path_baseline(batch_cpu, V):
     """SURVEY 8d level (i), the like-for-like number for what this repo replaces: the reference's LOSS PATH op sequence
     (oracle ref_*: mean-pool + normalise x2, get_cosine_sim, get_nt_xent_loss x2, compute_marginalized_loss_from_logits),
     forward + backward in fp32 at the step's full shapes on the host cores - beside `roofline.loss_path_us`."""
-    sys.path.insert(0, str(ROOT / "oracle"))
-    import dalm_oracle as O
-
+    O, kind = _cpu_loss_code()
     threads = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(threads)
     B, Tq, Tp, Tg, D = CFG["B"], CFG["Tq"], CFG["Tp"], CFG["Tg"], CFG["D"]
@@ -223,9 +280,69 @@ def cpu_loss_path_baseline(batch_cpu, V):
         dt = time.time() - t0
         if it > 0:                       # first pass warms the thread pool / allocator
             best = dt if best is None else min(best, dt)
-    return {"ms": 1e3 * best, "cores": threads, "kind": "port",
-            "what": f"reference loss-path op sequence (oracle ref_*), fwd+bwd, fp32, [B={B},Tg={Tg},V={V}] logits + pooling of "
+    return {"ms": 1e3 * best, "cores": threads, "kind": kind,
+            "what": f"reference loss-path op sequence ({'the reference package itself' if kind == 'reference' else 'oracle ref_*'}), fwd+bwd, fp32, [B={B},Tg={Tg},V={V}] logits + pooling of "
                     f"[{B},{Tq}|{Tp},{D}] token states; min of 2 after a warm-up"}
+
+
+def f1_head_paths(dev, batch, model, iters=6):
+    """lm_head + marginalised CE + d(hidden) of THIS batch's generator rows through (a) the library's own bf16
+    MFMA kernels end to end (`fused._lm_head_train_kernel`: forward lse, logits recomputed per vocabulary chunk for the
+    backward - nothing [rows, V]-sized is allocated) and (b) the chunked library path (torch.mm + the fused CE kernel), both
+    over the live rows; run alone after the timed region, HIP events around `iters` eager calls each.  The timed step itself
+    uses whichever path its flags select (default: materialised logits + the fused CE kernel)."""
+    from dalm_amd.fused import gemm_wave_rows, live_row_index, rag_e2e_loss_from_hidden
+
+    head = model.generator_model.get_output_embeddings()
+    W = head.weight.detach()
+    if W.dtype != torch.bfloat16 or W.requires_grad or getattr(head, "bias", None) is not None:
+        return None
+    V, H = W.shape
+    ids, mask, qlen = batch["generator_input_input_ids"], batch["generator_input_attention_mask"], batch["query_passage_input_len"]
+    B, Tg = ids.shape
+    g = torch.Generator(device=dev).manual_seed(0)
+    h = torch.randn(B, Tg, H, device=dev, dtype=torch.bfloat16, generator=g)
+    q = torch.nn.functional.normalize(torch.randn(B, 1024, device=dev, generator=g), dim=1)
+    p = torch.nn.functional.normalize(torch.randn(B, 1024, device=dev, generator=g), dim=1)
+    live = live_row_index(mask, multiple=gemm_wave_rows(V))
+    live = live.to(dev) if live is not None else None
+    res = {}
+    saved = os.environ.get("DALM_LM_HEAD_TRAIN_KERNEL")
+    try:
+        for name, env in (("kernels", "1"), ("library", "0")):
+            os.environ["DALM_LM_HEAD_TRAIN_KERNEL"] = env
+
+            def call():
+                hh = h.clone().requires_grad_(True)
+                loss = rag_e2e_loss_from_hidden(q, p, hh, W, ids, mask, qlen, CFG["logit_scale"], live_rows=live)
+                loss.backward()
+                return loss.detach(), hh.grad
+
+            for _ in range(2):
+                loss, dh = call()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                loss, dh = call()
+            e1.record()
+            torch.cuda.synchronize()
+            res[name] = (e0.elapsed_time(e1) / iters, float(loss), dh.float())
+    finally:
+        if saved is None:
+            os.environ.pop("DALM_LM_HEAD_TRAIN_KERNEL", None)
+        else:
+            os.environ["DALM_LM_HEAD_TRAIN_KERNEL"] = saved
+    k, l = res["kernels"], res["library"]
+    return {"rows": int(live.numel()) if live is not None else B * Tg, "V": V, "H": H,
+            "kernels_ms": k[0], "library_ms": l[0], "kernels_over_library": k[0] / l[0],
+            "loss_rel_diff": abs(k[1] - l[1]) / max(abs(l[1]), 1e-30),
+            "dhidden_rel_diff": float((k[2] - l[2]).norm() / l[2].norm()),
+            "note": "lm_head + marginalised CE + d(hidden) over the live rows, eager launches (HIP events over "
+                    f"{iters} calls): `kernels` = dalm_lm_head_lse_fwd + dalm_lm_head_dlogits / dalm_transpose_bf16 / "
+                    "dalm_lm_head_dhidden (three contractions, the logits recomputed; workspace <= 160 MB), `library` = torch.mm "
+                    "x2 + the fused CE kernel in row chunks.  RagE2EStep(fuse_lm_head='auto') takes the fused path when a batch's "
+                    "logits would exceed DALM_LOGITS_BUDGET_MB (1024)"}
 
 
 def gpu_loss_path_probe(dev, batch, dtype, V, iters=20):
@@ -374,10 +491,10 @@ def cpu_reference_baseline(max_seconds=90.0, parity_dev=None):
     depth 2 instead of 24 / 32 layers, median of 3 steps each; the per-layer increment is extrapolated to full
     depth.  Threads: min(host cores, 16) - measured on the 256-core GPU-box host, 16 threads is the
     fastest setting for this eager-torch workload (16: 4.9 s, 32: 5.5 s, 64: 6.8 s, 256: 80 s per
-    depth-1 step), so this is the CPU path at its best, and `cores` reports the threads used."""
-    sys.path.insert(0, str(ROOT / "oracle"))
-    import dalm_oracle as O
-
+    depth-1 step), so this is the CPU path at its best, and `cores` reports the threads used.
+    Loss code: the reference package itself where /root/reference exists (`kind` "reference"), the oracle restatement
+    otherwise (`kind` "port": the GPU box has no copy of the reference)."""
+    O, kind = _cpu_loss_code()
     threads = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(threads)
     dev = torch.device("cpu")
@@ -428,7 +545,8 @@ def cpu_reference_baseline(max_seconds=90.0, parity_dev=None):
         # split the increment by layer FLOPs (Llama layer 202 M params x 4608 tokens vs BERT layer
         # 12.6 M x 3204 tokens -> 95.8 % / 4.2 %) and scale each share to its true depth (32 / 24)
         full = fixed + delta * (0.958 * 32 + 0.042 * 24)
-        note = (f"reference-equivalent CPU step (oracle loss code at full cfg3 shapes + HF towers, LoRA, fp32, "
+        code = "the reference's own loss functions" if kind == "reference" else "oracle loss code"
+        note = (f"reference-equivalent CPU step ({code} at full cfg3 shapes + HF towers, LoRA, fp32, "
                 f"{threads} threads): median of 3 steps per depth after a warm-up step - depth 1 = {times[1]:.2f} s "
                 f"(min {spread[1][0]:.2f}, max {spread[1][1]:.2f}), depth 2 = {times[2]:.2f} s (min {spread[2][0]:.2f}, max "
                 f"{spread[2][1]:.2f}); per-layer increment extrapolated to 24 BERT / 32 Llama layers -> {full:.1f} s per "
@@ -437,7 +555,7 @@ def cpu_reference_baseline(max_seconds=90.0, parity_dev=None):
         full = times[1] * 30.0
         note = (f"depth-1 towers only (median of 3: {times[1]:.2f} s/step, min {spread[1][0]:.2f}, max {spread[1][1]:.2f}, "
                 f"{threads} threads) x30 (time bound hit before depth 2)")
-    return {"value": CFG["B"] / full, "unit": "training pairs/s", "cores": threads, "kind": "port", "sample": note}, parity
+    return {"value": CFG["B"] / full, "unit": "training pairs/s", "cores": threads, "kind": kind, "sample": note}, parity
 
 
 def main():
@@ -711,6 +829,11 @@ def main():
                                  "side); the all-ones-mask roofline point is in profiles/ (tools/kernel_bench.py)",
                          "timing": probe_note},
         }
+        if args.gpus == 1 and args.dtype == "bf16" and not args.no_pmc and batches:
+            try:
+                out["f1_lm_head_paths"] = f1_head_paths(dev, batches[0], model)
+            except Exception as e:
+                out["f1_lm_head_paths"] = {"error": repr(e)}
         if args.gpus == 1 and not args.no_cpu_baseline and args.workload == "cfg3":
             try:
                 out["cpu_baseline"], parity = cpu_reference_baseline(parity_dev=dev)

@@ -109,10 +109,17 @@ def bench_sim(m, n, D):
     # comparable with earlier rounds) report the GPU time of the call inside a hipGraph - how the training step runs it
     graphed = 256 * 256 <= m * n <= 4096 * 4096
     med, best = time_fn(lambda: ops.sim_rowstats(A, Bm, 100.0, 0), iters=10, warmup=3)
-    out["rowstats"] = {"s": med, "TFLOPs": 2.0 * m * n * D / med / 1e12, "frac": 2.0 * m * n * D / med / MFMA_F32_PEAK}
+    # the default entry point routes m, n >= 3072 to the bf16x3 form (6 x the flops on the bf16 pipe): its roofline fraction is
+    # the flops ACTUALLY ISSUED over the bf16 peak - never an f32-equivalent rate over the f32 peak (that read 1.19 / 1.40 in
+    # profiles/r04_kernel_bench.txt)
+    on_bf16 = m >= 3072 and n >= 3072 and D % 64 == 0
+    flops = (12.0 if on_bf16 else 2.0) * m * n * D
+    peak = 2.5e15 if on_bf16 else MFMA_F32_PEAK
+    out["rowstats"] = {"s": med, "TFLOPs_f32_equivalent": 2.0 * m * n * D / med / 1e12, "pipe": "bf16 x3" if on_bf16 else "f32",
+                       "TFLOPs_issued": flops / med / 1e12, "frac": flops / med / peak}
     if graphed:
         gm, _ = time_graph(lambda: ops.sim_rowstats(A, Bm, 100.0, 0), reps=10, replays=7)
-        out["rowstats"].update({"graph_s": gm, "graph_frac": 2.0 * m * n * D / gm / MFMA_F32_PEAK})
+        out["rowstats"].update({"graph_s": gm, "graph_frac": flops / gm / peak})
     if m >= 1024 and n >= 1024:
         # round 4: the same statistics on the bf16 matrix cores (three bf16 thirds per operand, 6 D deep); "TFLOPs" stays the
         # f32-EQUIVALENT rate 2 m n D / t (the kernel executes 6 x that on the bf16 pipe); sim_rowstats itself routes
