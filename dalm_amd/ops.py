@@ -170,11 +170,13 @@ class HipOps:
     _tickets: dict = {}
 
     def _small_tickets(self, dev: torch.device, words: int) -> torch.Tensor:
-        """Arrival tickets of the one-launch forward: zeroed ONCE here, left zero by every call.  One buffer per device,
-        allocated on first use (an eager warm-up step, i.e. outside any hipGraph pool) and kept for the life of the process:
-        calls that share it must be stream-ordered - every caller in this package issues the contrastive forward of a step
-        from one stream, and a captured step replays in that order."""
-        key = dev.index
+        """Arrival tickets of the one-launch forward / backward: zeroed ONCE here, left zero by every call (the last arriver of
+        a tile resets its ticket).  One buffer per (device, STREAM) (a buffer shared across streams would make the
+        hand-off depend on every caller using one stream): calls that share a buffer are ordered by that stream.  Allocated on
+        first use and kept for the life of the process.  The hand-off itself (write-through agent-scope payload stores, drained
+        with s_waitcnt vmcnt(0), one agent-scope ticket, agent-scope payload loads) is the form the MI355X guide documents as
+        valid on gfx950 ("inter-workgroup visibility"); tools/handoff_stress.py exercises it under uneven load."""
+        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
         buf = HipOps._tickets.get(key)
         if buf is None or buf.numel() < words:
             # 64 Ki words cover every shape of the small path at D <= 8192 (forward: <= ~1.5 k tiles; sliced backward:
