@@ -228,10 +228,15 @@ struct Lm8Params {
   int64_t out_pitch;         // elements
   int out_cols;              // columns that exist in `out` (EPI_DLOGITS: zero-filled from V up to here)
   int accumulate;            // EPI_CSTORE: add to what `out` holds
+  // EPI_DS3 (round 5: the similarity backward on the bf16 pipe); row statistics ride in row_lse / coef above
+  const float* col_lse;      // [V] column log-sum-exp (global column = col_base + local)
+  const float* col_coef;     // [V]
+  int64_t diag_offset;       // the positive of row i is global column diag_offset + i
+  int64_t out_third;         // elements between the hi / mid / lo images inside a row of `out`
 };
 
 constexpr int L8_BUF = 65536;
-constexpr int EPI_LSE = 0, EPI_DLOGITS = 2, EPI_CSTORE = 3;
+constexpr int EPI_LSE = 0, EPI_DLOGITS = 2, EPI_CSTORE = 3, EPI_DS3 = 4;
 
 // Tile order.  The ordered tile list walks the output in bands of gh row tiles - within a band vocabulary tile by vocabulary
 // tile, the band's row tiles innermost - and every XCD (workgroup L runs on XCD L % 8, own 4 MB L2) works through ONE
@@ -479,6 +484,78 @@ __device__ __forceinline__ void lm_tile_epilogue_dlogits(const Lm8Params& p, f32
   }
 }
 
+// EPI_DS3: the similarity backward's dS tile (reference: the autograd of get_nt_xent_loss(S) + get_nt_xent_loss(S.t()) +
+// the doc term, dalm/training/utils/train_utils.py:76-88,121-124; closed form SURVEY 8a):
+//   dS[i][j] = rc_i e^{S_ij - rl_i} + cc_j e^{S_ij - cl_j} - [j == diag_offset + i] (rc_i + cc_j)
+// from the f32 accumulator tile of S, split into bf16 hi / mid / lo thirds (24 significand bits) and written as three images
+// side by side in a row of `out` - the A operand of the dA = dS . B contraction, which runs through this same kernel
+// (SPLIT3 + EPI_CSTORE).
+__device__ __forceinline__ void lm_tile_epilogue_ds3(const Lm8Params& p, f32x16 (&acc)[4][4], unsigned char* lds, int r0, int c0,
+                                                     int wr, int wc, int tid) {
+  const int lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+  float* nrl_s = reinterpret_cast<float*>(lds);               // [256] -row_lse * log2(e)
+  float* rc_s = nrl_s + 256;                                   // [256] row_coef
+  float* ncl_s = nrl_s + 512;                                  // [256] -col_lse * log2(e)
+  float* cc_s = nrl_s + 768;                                   // [256] col_coef
+  {
+    const int r = r0 + tid, c = c0 + tid;
+    float a = 0.f, b = 0.f, cl = 0.f, cc = 0.f;
+    if (r < p.R) { a = -p.row_lse[r] * kLog2e; b = p.coef[r]; }
+    if (c < p.V) { cl = -p.col_lse[p.col_base + c] * kLog2e; cc = p.col_coef[p.col_base + c]; }
+    nrl_s[tid] = a; rc_s[tid] = b; ncl_s[tid] = cl; cc_s[tid] = cc;
+  }
+  __syncthreads();
+  const int colw = wc * 128 + l31;
+  const bool odd = (lane & 1) != 0;
+  unsigned short* outp = static_cast<unsigned short*>(p.out);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = colw + 32 * j;                             // relative to c0
+    const bool live = c0 + col < p.V;
+    const float ncl = ncl_s[col], ccj = cc_s[col];
+    const int64_t gcol = static_cast<int64_t>(p.col_base) + c0 + col;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int rl4 = wr * 128 + i * 32 + 8 * g + 4 * lhi;
+        const float4 l4 = *reinterpret_cast<const float4*>(nrl_s + rl4);
+        const float4 c4 = *reinterpret_cast<const float4*>(rc_s + rl4);
+        const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, cs[4] = {c4.x, c4.y, c4.z, c4.w};
+        float v[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const float t = acc[i][j][4 * g + rr] * kLog2e;
+          float d = cs[rr] * __builtin_amdgcn_exp2f(t + ls[rr]) + ccj * __builtin_amdgcn_exp2f(t + ncl);
+          const int row = r0 + rl4 + rr;
+          if (gcol == p.diag_offset + row) d -= cs[rr] + ccj;
+          v[rr] = (live && row < p.R) ? d : 0.f;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float mine_a = v[2 * h], mine_b = v[2 * h + 1];
+          const float send = odd ? mine_a : mine_b;
+          const float got = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(send), 0xB1, 0xf, 0xf, false));
+          const float x0 = odd ? got : mine_a, x1 = odd ? mine_b : got;      // columns (even, odd) of this lane's row
+          const int row = r0 + rl4 + 2 * h + (odd ? 1 : 0);
+          const int ce = c0 + (col & ~1);
+          if (row < p.R && ce < p.out_cols) {
+            // thirds of both columns: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid); every difference is exact
+            const unsigned int hi = pack_bf16x2(x0, x1);
+            const float r0a = x0 - __uint_as_float(hi << 16), r0b = x1 - __uint_as_float(hi & 0xffff0000u);
+            const unsigned int mid = pack_bf16x2(r0a, r0b);
+            const unsigned int lo = pack_bf16x2(r0a - __uint_as_float(mid << 16), r0b - __uint_as_float(mid & 0xffff0000u));
+            unsigned short* dst = outp + static_cast<int64_t>(row) * p.out_pitch + ce;
+            *reinterpret_cast<unsigned int*>(dst) = hi;
+            *reinterpret_cast<unsigned int*>(dst + p.out_third) = mid;
+            *reinterpret_cast<unsigned int*>(dst + 2 * p.out_third) = lo;
+          }
+        }
+      }
+    }
+  }
+}
+
 // EPI_CSTORE: the 256 x 256 tile is stored (or added) as f32 into out[row][c0 + column]: d(hidden) += dlogits_chunk . W_chunk
 __device__ __forceinline__ void lm_tile_epilogue_cstore(const Lm8Params& p, f32x16 (&acc)[4][4], int r0, int c0, int wr, int wc,
                                                         int tid) {
@@ -641,7 +718,8 @@ __global__ __launch_bounds__(256, 1) void lm_head_lse4w_kernel(const Lm8Params p
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // tail re-reads still target the LDS about to be reused
   __builtin_amdgcn_s_barrier();
 
-  if constexpr (EPI == EPI_DLOGITS) lm_tile_epilogue_dlogits(p, acc, lds, r0, c0, wr, wc, tid);
+  if constexpr (EPI == EPI_DS3) lm_tile_epilogue_ds3(p, acc, lds, r0, c0, wr, wc, tid);
+  else if constexpr (EPI == EPI_DLOGITS) lm_tile_epilogue_dlogits(p, acc, lds, r0, c0, wr, wc, tid);
   else if constexpr (EPI == EPI_CSTORE) lm_tile_epilogue_cstore(p, acc, r0, c0, wr, wc, tid);
   else if constexpr (GMAX) lm_tile_epilogue_gmax(p, acc, r0, c0, wr, wc, tid);
   else lm_tile_epilogue<ABL>(p, acc, lds, r0, c0, nt, wr, wc, tid);
@@ -752,6 +830,35 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const unsigned shor
   for (int k = 0; k < 16; ++k) {
     const int c_out = blockIdx.x * 64 + ty + 4 * k;           // destination row = source column
     if (c_out < cols && r_out < ld_dst) dst[static_cast<int64_t>(c_out) * ld_dst + r_out] = tile[tx][ty + 4 * k];
+  }
+}
+
+// out[d][third * ncp + j] = third(scale * B[j0 + j][d]) for j < nc, zero for nc <= j < ncp: the K-contiguous (j-contiguous)
+// bf16x3 image of a block of rows of B, transposed - the B operand of dA = dS . B.  64 x 64 tiles through LDS.
+__global__ __launch_bounds__(256) void split3_transpose_kernel(const float* __restrict__ Bm, int64_t j0, int nc, int D, float scale,
+                                                               unsigned short* __restrict__ out, int ncp) {
+  __shared__ float tile[64][65];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int d_in = blockIdx.y * 64 + tx;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int j = blockIdx.x * 64 + ty + 4 * k;
+    tile[ty + 4 * k][tx] = (j < nc && d_in < D) ? __fmul_rn(Bm[(j0 + j) * static_cast<int64_t>(D) + d_in], scale) : 0.f;
+  }
+  __syncthreads();
+  const int j_out = blockIdx.x * 64 + tx;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int d_out = blockIdx.y * 64 + ty + 4 * k;
+    if (d_out >= D || j_out >= ncp) continue;
+    const float v = tile[tx][ty + 4 * k];
+    const float h = bf16_to_f32(f32_to_bf16(v));
+    const float r1 = v - h;
+    const float m = bf16_to_f32(f32_to_bf16(r1));
+    unsigned short* o = out + static_cast<int64_t>(d_out) * (3 * static_cast<int64_t>(ncp)) + j_out;
+    o[0] = f32_to_bf16(v);
+    o[ncp] = f32_to_bf16(r1);
+    o[2 * static_cast<int64_t>(ncp)] = f32_to_bf16(r1 - m);
   }
 }
 
@@ -1057,5 +1164,113 @@ extern "C" int dalm_f32_to_bf16(const float* src, void* dst, int64_t n, dalm_str
                "src / dst must be 16-byte aligned");
   hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(static_cast<unsigned>((n / 8 + 255) / 256)), dim3(256), 0, as_stream(stream), src,
                      static_cast<unsigned short*>(dst), n / 8);
+  return check_launch(__func__);
+}
+
+
+// ---- round 5: the similarity BACKWARD on the bf16 pipe ---------------------------------------------------
+//   reference: the autograd of get_cosine_sim + get_nt_xent_loss (x2) + the doc term, dalm/training/utils/train_utils.py:76-88
+// dA = scale * dS . B with dS rebuilt from S = scale * A . B^T: both contractions as bf16x3 (six significant products, f32
+// accumulation) through the lm_head core - per block of `nc` columns of S: (1) S tile -> dS thirds image (EPI_DS3), (2) the
+// transposed thirds image of the block's rows of B, (3) dA (+)= dS_blk . B_blk (SPLIT3 + EPI_CSTORE).  24 m n D bf16 flops
+// instead of 6 m n D on the f32 pipe (1/16 of the rate).
+namespace {
+// Columns of S per block (a multiple of 256); the dS image is m x 3 x block x 2 bytes.  Larger blocks = fewer, fuller launches
+// (16384^2, profiles/r05_sim_grad_x3.txt: block 2048 163 TF f32-equivalent, 4096 179, 8192 188): as large as a 1 GiB dS image
+// allows, between 2048 and 8192.  DALM_X3_GRAD_BLOCK overrides (measurement).
+inline int64_t x3_grad_block(int64_t m) {
+  static const int64_t forced = [] { const char* e = getenv("DALM_X3_GRAD_BLOCK"); return e ? atoll(e) : 0ll; }();
+  int64_t b = forced > 0 ? forced : (int64_t(1) << 30) / (6 * (m > 0 ? m : 1));
+  if (forced <= 0) { if (b > 8192) b = 8192; if (b < 2048) b = 2048; }
+  if (b < 256) b = 256;
+  return b / 256 * 256;
+}
+struct X3GradLayout { size_t a3, b3, ds3, bt3, total; int64_t ncp; };
+inline X3GradLayout x3_grad_layout(int64_t m, int64_t n, int64_t D) {
+  X3GradLayout L{};
+  const int64_t blk = x3_grad_block(m);
+  L.ncp = n < blk ? (n + 255) / 256 * 256 : blk;
+  size_t o = 256;
+  L.a3 = o; o += up256(static_cast<size_t>(m) * 3 * D * 2);
+  L.b3 = o; o += up256(static_cast<size_t>(n) * 3 * D * 2);
+  L.ds3 = o; o += up256(static_cast<size_t>(m) * 3 * L.ncp * 2);
+  L.bt3 = o; o += up256(static_cast<size_t>(D) * 3 * L.ncp * 2);
+  L.total = o;
+  return L;
+}
+}  // namespace
+
+extern "C" int dalm_sim_grad_bf16x3_supported(int64_t m, int64_t n, int64_t D) {
+  if (!dalm_sim_rowstats_bf16x3_supported(m, n, D)) return 0;
+  const int64_t blk = x3_grad_block(m);
+  const int64_t ncp = n < blk ? (n + 255) / 256 * 256 : blk;
+  if (static_cast<uint64_t>(m + 256) * 3 * ncp * 2 >= 0xffffff00ull) return 0;       // 32-bit buffer offsets of the dS image
+  if (static_cast<uint64_t>(D + 256) * 3 * ncp * 2 >= 0xffffff00ull) return 0;
+  return 1;
+}
+
+extern "C" size_t dalm_sim_grad_bf16x3_workspace_bytes(int64_t m, int64_t n, int64_t D) {
+  if (!dalm_sim_grad_bf16x3_supported(m, n, D)) return 0;
+  return x3_grad_layout(m, n, D).total;
+}
+
+extern "C" int dalm_sim_grad_bf16x3(const float* A, const float* Bm, int64_t m, int64_t n, int64_t D, float scale,
+                                    int64_t diag_offset, const float* row_coef, const float* row_lse, const float* col_coef,
+                                    const float* col_lse, float* dA, void* ws, size_t ws_bytes, dalm_stream_t stream) {
+  DALM_REQUIRE(A && Bm && row_coef && row_lse && col_coef && col_lse && dA && ws, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(dalm_sim_grad_bf16x3_supported(m, n, D), DALM_E_SHAPE,
+               "bf16x3 similarity backward needs D % 64 == 0 and operand images below 4 GB (dalm_sim_grad_bf16x3_supported)");
+  DALM_REQUIRE(diag_offset >= 0 && diag_offset + m <= n, DALM_E_SHAPE, "diag_offset + m must be <= n");
+  DALM_REQUIRE(reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(Bm) % 16 == 0, DALM_E_ALIGN,
+               "A / B must be 16-byte aligned");
+  const X3GradLayout L = x3_grad_layout(m, n, D);
+  DALM_REQUIRE(ws_bytes >= L.total, DALM_E_WORKSPACE, "workspace too small");
+  hipStream_t s = as_stream(stream);
+  unsigned char* base = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(ws) + 255) / 256 * 256) - 256;
+  auto* a3 = reinterpret_cast<unsigned short*>(base + L.a3);
+  auto* b3 = reinterpret_cast<unsigned short*>(base + L.b3);
+  auto* ds3 = reinterpret_cast<unsigned short*>(base + L.ds3);
+  auto* bt3 = reinterpret_cast<unsigned short*>(base + L.bt3);
+  const int per_row = static_cast<int>(D / 8);
+  hipLaunchKernelGGL(split3_bf16_kernel, dim3(static_cast<unsigned>((m * per_row + 255) / 256)), dim3(256), 0, s, A,
+                     static_cast<int>(m), static_cast<int>(D), scale, a3, static_cast<int64_t*>(nullptr), static_cast<int64_t>(0));
+  hipLaunchKernelGGL(split3_bf16_kernel, dim3(static_cast<unsigned>((n * per_row + 255) / 256)), dim3(256), 0, s, Bm,
+                     static_cast<int>(n), static_cast<int>(D), 1.0f, b3, static_cast<int64_t*>(nullptr), static_cast<int64_t>(0));
+  for (int64_t j0 = 0; j0 < n; j0 += L.ncp) {
+    const int64_t nc = n - j0 < L.ncp ? n - j0 : L.ncp;
+    {  // (1) S tile -> dS thirds
+      Lm8Params q;
+      q.H = a3; q.W = b3 + j0 * 3 * D; q.labels = nullptr; q.K = static_cast<int>(6 * D);
+      lm8_geometry(q, m, nc);
+      q.pitchH = q.pitchW = static_cast<unsigned>(3 * D * 2);
+      q.bytesH = static_cast<unsigned>(static_cast<uint64_t>(m) * 3 * D * 2);
+      q.bytesW = static_cast<unsigned>(static_cast<uint64_t>(nc) * 3 * D * 2);
+      q.tpd = static_cast<int>(D / 64);
+      q.tpd_inv = static_cast<unsigned>(((1u << 24) + q.tpd - 1) / q.tpd);
+      q.seg_bytes = static_cast<unsigned>(D * 2);
+      q.row_lse = row_lse; q.coef = row_coef; q.col_lse = col_lse; q.col_coef = col_coef;
+      q.col_base = static_cast<int>(j0); q.diag_offset = diag_offset;
+      q.out = ds3; q.out_pitch = 3 * L.ncp; q.out_third = L.ncp; q.out_cols = static_cast<int>(L.ncp); q.accumulate = 0;
+      hipLaunchKernelGGL((lm_head_lse4w_kernel<8, 8, 0, 0, 0, true, false, EPI_DS3>), dim3(static_cast<unsigned>(q.MT) * q.NT),
+                         dim3(256), 0, s, q);
+    }
+    hipLaunchKernelGGL(split3_transpose_kernel, dim3(static_cast<unsigned>(L.ncp / 64), static_cast<unsigned>((D + 63) / 64)),
+                       dim3(256), 0, s, Bm, j0, static_cast<int>(nc), static_cast<int>(D), scale, bt3, static_cast<int>(L.ncp));
+    {  // (3) dA (+)= dS_blk . B_blk
+      Lm8Params q;
+      q.H = ds3; q.W = bt3; q.labels = nullptr; q.K = static_cast<int>(6 * L.ncp);
+      lm8_geometry(q, m, D);
+      q.pitchH = q.pitchW = static_cast<unsigned>(3 * L.ncp * 2);
+      q.bytesH = static_cast<unsigned>(static_cast<uint64_t>(m) * 3 * L.ncp * 2);
+      q.bytesW = static_cast<unsigned>(static_cast<uint64_t>(D) * 3 * L.ncp * 2);
+      q.tpd = static_cast<int>(L.ncp / 64);
+      q.tpd_inv = static_cast<unsigned>(((1u << 24) + q.tpd - 1) / q.tpd);
+      q.seg_bytes = static_cast<unsigned>(L.ncp * 2);
+      q.row_lse = nullptr; q.coef = nullptr; q.col_base = 0;
+      q.out = dA; q.out_pitch = D; q.out_cols = static_cast<int>(D); q.accumulate = j0 > 0;
+      hipLaunchKernelGGL((lm_head_lse4w_kernel<8, 8, 0, 0, 0, true, false, EPI_CSTORE>), dim3(static_cast<unsigned>(q.MT) * q.NT),
+                         dim3(256), 0, s, q);
+    }
+  }
   return check_launch(__func__);
 }

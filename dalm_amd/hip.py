@@ -101,6 +101,9 @@ SIGNATURES = {
     "dalm_lora2_rankupd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _f32, _int, _vp]),
     "dalm_lora2_colacc_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
     "dalm_lora2_colacc_ticket_words": (_sz, [_i64, _int]),
+    "dalm_sim_grad_bf16x3_supported": (_int, [_i64, _i64, _i64]),
+    "dalm_sim_grad_bf16x3_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "dalm_sim_grad_bf16x3": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dalm_lm_head_dlogits": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp]),
     "dalm_lm_head_dhidden": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _int, _vp]),
     "dalm_transpose_bf16": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp]),

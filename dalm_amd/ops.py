@@ -152,12 +152,36 @@ class HipOps:
         m, D = A.shape
         n = Bm.shape[0]
         lib = hip.load()
+        # large global batches: both contractions on the bf16 pipe at f32 accuracy (bf16x3).  From m, n >= 8192 it is the faster
+        # form (profiles/r05_sim_grad_x3.txt: 16384^2 9.2 -> 7.1 ms; at 4096^2 its launches of 64-128 tiles do not fill the chip
+        # and the f32-pipe flash kernel wins); DALM_SIM_GRAD_X3 = 0 keeps the flash kernel, = 1 forces x3
+        x3 = os.environ.get("DALM_SIM_GRAD_X3")
+        if x3 != "0" and lib.dalm_sim_grad_bf16x3_supported(m, n, D) and (x3 == "1" or (m >= 8192 and n >= 8192)):
+            return self.sim_grad_bf16x3(A, Bm, scale, diag_offset, row_coef, row_lse, col_coef, col_lse)
         ws_bytes = lib.dalm_sim_grad_workspace_bytes(m, n, D)
         ws = torch.empty((max(ws_bytes, 4) // 4,), device=dev, dtype=torch.float32)
         dA = torch.empty((m, D), device=dev, dtype=torch.float32)
         hip.call("dalm_sim_grad", hip.ptr(A), hip.ptr(Bm), m, n, D, float(scale), int(diag_offset),
                  hip.ptr(row_coef), hip.ptr(row_lse), hip.ptr(col_coef), hip.ptr(col_lse), hip.ptr(dA),
                  hip.ptr(ws), ws_bytes, hip.stream())
+        return dA
+
+    def sim_grad_bf16x3(self, A, Bm, scale: float, diag_offset: int, row_coef, row_lse, col_coef, col_lse):
+        """`sim_grad` through `dalm_sim_grad_bf16x3` (S recomputed and dS . B contracted as bf16x3 on the lm_head core)."""
+        dev = hip.require_gpu(A, Bm, row_coef, row_lse, col_coef, col_lse)
+        A, Bm = hip.as_f32c(A), hip.as_f32c(Bm)
+        row_coef, row_lse = hip.as_f32c(row_coef), hip.as_f32c(row_lse)
+        col_coef, col_lse = hip.as_f32c(col_coef), hip.as_f32c(col_lse)
+        m, D = A.shape
+        n = Bm.shape[0]
+        lib = hip.load()
+        if not lib.dalm_sim_grad_bf16x3_supported(m, n, D):
+            raise ValueError(f"bf16x3 similarity backward does not support m={m}, n={n}, D={D}")
+        ws_bytes = lib.dalm_sim_grad_bf16x3_workspace_bytes(m, n, D)
+        ws = torch.empty((ws_bytes,), device=dev, dtype=torch.uint8)
+        dA = torch.empty((m, D), device=dev, dtype=torch.float32)
+        hip.call("dalm_sim_grad_bf16x3", hip.ptr(A), hip.ptr(Bm), m, n, D, float(scale), int(diag_offset), hip.ptr(row_coef),
+                 hip.ptr(row_lse), hip.ptr(col_coef), hip.ptr(col_lse), hip.ptr(dA), hip.ptr(ws), ws_bytes, hip.stream())
         return dA
 
     # ---- K2-K4, small-batch form: S once, 2 launches forward / 1 launch backward ----------------

@@ -515,6 +515,18 @@ int dalm_transpose_bf16(const void* src, int64_t rows, int64_t cols, int64_t ld_
                         dalm_stream_t stream);
 int dalm_f32_to_bf16(const float* src, void* dst, int64_t n, dalm_stream_t stream);
 
+/* ---- round 5: the similarity BACKWARD on the bf16 matrix cores at f32 accuracy --------------------------------------------------
+ * Same result as dalm_sim_grad (dA = scale * dS . B, dS rebuilt from S = scale * A . B^T and the row / column statistics; the
+ * autograd of dalm/training/utils/train_utils.py:76-88 + the doc term :121-124), computed as two bf16x3 contractions (three bf16
+ * thirds per operand, six significant products, f32 accumulation) through the lm_head core instead of the f32 MFMA pipe:
+ * dA within ~2e-6 of fp64 relative to its largest entry.  D % 64 == 0, operand images below 4 GB
+ * (dalm_sim_grad_bf16x3_supported); workspace: dalm_sim_grad_bf16x3_workspace_bytes.  Fixed summation order. */
+int dalm_sim_grad_bf16x3_supported(int64_t m, int64_t n, int64_t D);
+size_t dalm_sim_grad_bf16x3_workspace_bytes(int64_t m, int64_t n, int64_t D);
+int dalm_sim_grad_bf16x3(const float* A, const float* Bm, int64_t m, int64_t n, int64_t D, float scale, int64_t diag_offset,
+                         const float* row_coef, const float* row_lse, const float* col_coef, const float* col_lse, float* dA,
+                         void* ws, size_t ws_bytes, dalm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

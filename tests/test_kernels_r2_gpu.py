@@ -6,6 +6,8 @@ configurations compared with the oracle itself (not just properties).
 Tolerances as in test_hip_parity.py: fp32 loss rel <= 1e-4, gradient norm-rel <= 1e-4 (north-star 1e-3);
 bf16 gradient outputs norm-rel <= 4e-3.
 """
+import os
+
 import pytest
 import torch
 
@@ -809,3 +811,48 @@ def test_large_rowstats_route_to_bf16x3_and_keep_the_loss(dev):
         got = 0.5 * ((r1.double().cpu() - d1.double().cpu()).mean() + (c1.double().cpu() - d1.double().cpu()).mean())
         tol = 1e-6 * abs(float(ref)) + 2e-6 * float(S.abs().max()) * (1.0 if kind == "trained" else 0.0)
         assert abs(float(got) - float(ref)) <= tol + 1e-7, (kind, float(got), float(ref))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 5: the similarity BACKWARD on the bf16 matrix cores (dalm_sim_grad_bf16x3)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n,D,off", [(256, 256, 64, 0), (300, 517, 128, 100), (37, 1000, 384, 500), (1024, 1536, 1024, 256),
+                                       (4096, 4096, 1024, 0), (513, 4352, 1024, 1111), (700, 5000, 256, 2049)])
+def test_bf16x3_sim_grad_vs_fp64(dev, m, n, D, off):
+    """dA = scale * dS . B on the `_problem` generator (peaked softmax: the diagonal term is a cancellation) against fp64:
+    within 2e-6 of the largest |dA| entry-wise, no worse than the f32-pipe flash kernel; ragged rows and
+    columns, several 2048-column blocks (accumulation across blocks), sharded diagonal offsets; deterministic."""
+    from dalm_amd.ops import default_ops
+
+    ops = default_ops()
+    A, Bm, scale, S, rc, rl, cc, cl, dS = _problem(m, n, D, off)
+    ref = scale * (dS @ Bm.double())
+    args = (A.to(dev), Bm.to(dev), scale, off, rc.to(dev), rl.float().to(dev), cc.to(dev), cl.float().to(dev))
+    got = ops.sim_grad_bf16x3(*args)
+    # the row / column statistics enter in f32 (rl, cl rounded): the same inputs the f32 kernel gets - compare both to fp64
+    err = float((got.cpu().double() - ref).abs().max())
+    big = float(ref.abs().max())
+    monkey = os.environ.get("DALM_SIM_GRAD_X3")
+    os.environ["DALM_SIM_GRAD_X3"] = "0"
+    try:
+        f32 = ops.sim_grad(*args)
+    finally:
+        if monkey is None:
+            os.environ.pop("DALM_SIM_GRAD_X3", None)
+        else:
+            os.environ["DALM_SIM_GRAD_X3"] = monkey
+    err_f = float((f32.cpu().double() - ref).abs().max())
+    assert err <= max(2.0 * err_f, 2e-6 * big), (err, err_f, big)
+    assert_grad_close(got, ref, 5e-4, "dA")
+    assert torch.equal(ops.sim_grad_bf16x3(*args), got)
+
+
+def test_large_sim_grad_routes_to_bf16x3(dev):
+    from dalm_amd.ops import default_ops
+
+    ops = default_ops()
+    m = n = 8192
+    A, Bm, scale, S, rc, rl, cc, cl, dS = _problem(m, n, 1024, 0, seed=9)
+    args = (A.to(dev), Bm.to(dev), scale, 0, rc.to(dev), rl.float().to(dev), cc.to(dev), cl.float().to(dev))
+    assert torch.equal(ops.sim_grad(*args), ops.sim_grad_bf16x3(*args))
+    assert_grad_close(ops.sim_grad(*args), scale * (dS @ Bm.double()), 5e-4, "dA")
