@@ -307,6 +307,61 @@ __global__ __launch_bounds__(256) void rms_norm_bwd_kernel(const T* __restrict__
   }
 }
 
+// Second form (bf16; the default since round 5, DALM_RMS_BWD_V2=0 selects the first): the three streams of a row (dy, h, and
+// the residual-path gradient) are requested as raw 16-byte chunks BEFORE the wave reduction - 3 NCH loads in flight per lane
+// instead of 2 NCH, then NCH after the reduction - and decoded twice (raw data in registers instead of f32 copies).
+// [4608, 4096] bf16, 151 MB: 26.2 -> 23.4 us (profiles/r05_tower_attempts.txt).
+template <int NCH, bool ADD>
+__global__ __launch_bounds__(256) void rms_norm_bwd_v2_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ h,
+                                                              const bf16_t* __restrict__ w, const float* __restrict__ rstd_in,
+                                                              const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx, int R, int D) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const int64_t base = static_cast<int64_t>(row) * D;
+  uint4 rg[NCH], rh[NCH], rr[NCH], rw[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int d = (c * 64 + lane) * 8;
+    const bool ok = d < D;
+    rg[c] = ok ? *reinterpret_cast<const uint4*>(dy + base + d) : make_uint4(0u, 0u, 0u, 0u);
+    rh[c] = ok ? *reinterpret_cast<const uint4*>(h + base + d) : make_uint4(0u, 0u, 0u, 0u);
+    if constexpr (ADD) rr[c] = ok ? *reinterpret_cast<const uint4*>(dres + base + d) : make_uint4(0u, 0u, 0u, 0u);
+    rw[c] = ok ? *reinterpret_cast<const uint4*>(w + d) : make_uint4(0u, 0u, 0u, 0u);
+  }
+  const float rstd = rstd_in[row];
+  auto dec = [](const uint4& v, float (&x)[8]) {
+    const unsigned int q[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { x[2 * i] = __uint_as_float(q[i] << 16); x[2 * i + 1] = __uint_as_float(q[i] & 0xffff0000u); }
+  };
+  float dot = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    float g[8], xh[8], wv[8];
+    dec(rg[c], g); dec(rh[c], xh); dec(rw[c], wv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dot = fmaf(g[e] * wv[e], xh[e] * rstd, dot);
+  }
+  dot = wave_sum(dot) / static_cast<float>(D);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int d = (c * 64 + lane) * 8;
+    if (d >= D) continue;
+    float g[8], xh[8], wv[8], o[8];
+    dec(rg[c], g); dec(rh[c], xh); dec(rw[c], wv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = rstd * (g[e] * wv[e] - (xh[e] * rstd) * dot);
+    if constexpr (ADD) {
+      float r[8];
+      dec(rr[c], r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += r[e];
+    }
+    *reinterpret_cast<uint4*>(dx + base + d) = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]),
+                                                           pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+  }
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -353,6 +408,8 @@ extern "C" int dalm_rope_qk(const void* q, const void* k, void* q_out, void* k_o
 }
 
 namespace {
+// tiles of 256 * VEC elements per workgroup: 8 / 12 sixteen-byte loads in flight per lane (forward / backward).  8 tiles
+// measured SLOWER at [4608, 11008] bf16 (forward 70.3 -> 76.2 us, backward 110.7 -> 123.7 us: profiles/r05_tower_attempts.txt)
 constexpr int kSwigluSteps = 4;
 inline int64_t swiglu_blocks(int64_t n, int vec) {
   const int64_t per = static_cast<int64_t>(kSwigluSteps) * 256 * vec;
@@ -449,6 +506,16 @@ extern "C" int dalm_rms_norm_bwd(const void* dy, const void* h, const void* w, c
                                 static_cast<const float*>(w), rstd, static_cast<const float*>(dres), static_cast<float*>(dx), Ri, Di);
     else DALM_RMS_DISPATCH(rms_norm_bwd_kernel, float, false, static_cast<const float*>(dy), static_cast<const float*>(h),
                            static_cast<const float*>(w), rstd, static_cast<const float*>(nullptr), static_cast<float*>(dx), Ri, Di);
+  } else if (static const bool v2 = [] { const char* e = getenv("DALM_RMS_BWD_V2"); return !e || atoi(e) != 0; }(); v2 && nch <= 8) {
+#define DALM_RMS_V2(ADDV, DRES)                                                                                           \
+    do {                                                                                                                  \
+      if (nch <= 1) hipLaunchKernelGGL((rms_norm_bwd_v2_kernel<1, ADDV>), grid, dim3(256), 0, as_stream(stream), static_cast<const bf16_t*>(dy), static_cast<const bf16_t*>(h), static_cast<const bf16_t*>(w), rstd, DRES, static_cast<bf16_t*>(dx), Ri, Di); \
+      else if (nch <= 2) hipLaunchKernelGGL((rms_norm_bwd_v2_kernel<2, ADDV>), grid, dim3(256), 0, as_stream(stream), static_cast<const bf16_t*>(dy), static_cast<const bf16_t*>(h), static_cast<const bf16_t*>(w), rstd, DRES, static_cast<bf16_t*>(dx), Ri, Di); \
+      else if (nch <= 4) hipLaunchKernelGGL((rms_norm_bwd_v2_kernel<4, ADDV>), grid, dim3(256), 0, as_stream(stream), static_cast<const bf16_t*>(dy), static_cast<const bf16_t*>(h), static_cast<const bf16_t*>(w), rstd, DRES, static_cast<bf16_t*>(dx), Ri, Di); \
+      else hipLaunchKernelGGL((rms_norm_bwd_v2_kernel<8, ADDV>), grid, dim3(256), 0, as_stream(stream), static_cast<const bf16_t*>(dy), static_cast<const bf16_t*>(h), static_cast<const bf16_t*>(w), rstd, DRES, static_cast<bf16_t*>(dx), Ri, Di); \
+    } while (0)
+    if (dres) DALM_RMS_V2(true, static_cast<const bf16_t*>(dres)); else DALM_RMS_V2(false, static_cast<const bf16_t*>(nullptr));
+#undef DALM_RMS_V2
   } else {
     if (dres) DALM_RMS_DISPATCH(rms_norm_bwd_kernel, bf16_t, true, static_cast<const bf16_t*>(dy), static_cast<const bf16_t*>(h),
                                 static_cast<const bf16_t*>(w), rstd, static_cast<const bf16_t*>(dres), static_cast<bf16_t*>(dx), Ri, Di);
