@@ -231,6 +231,12 @@ def _split_heads_sliced(self, fused_qkv: torch.Tensor):
     b, t, _ = fused_qkv.shape
     x = fused_qkv.view(b, t, self.num_heads + 2, self.head_dim)
     n = self.num_heads
+    if getattr(self, "_dalm_expand_kv", False):
+        # one shared key / value head BROADCAST to the query heads (views; FalconAttention.forward's reshape materialises them):
+        # scaled_dot_product_attention then sees equal head counts and takes its fused kernel.  With [B, 1, T, hd] keys it
+        # falls back to the unfused "math" path - f32 scores, softmax, masks: ~1.5 ms per layer at cfg5, 48 ms of a 230 ms
+        # step (profiles/r05cfg5_step_by_stream_before.txt)
+        return x[..., :n, :], x[..., n:n + 1, :].expand(b, t, n, self.head_dim), x[..., n + 1:, :].expand(b, t, n, self.head_dim)
     return x[..., :n, :], x[..., n:n + 1, :], x[..., n + 1:, :]
 
 
@@ -243,8 +249,36 @@ def use_capturable_falcon_heads(model: torch.nn.Module) -> int:
         if getattr(mod, "new_decoder_architecture", False) or not getattr(mod, "multi_query", False):
             continue
         mod._split_heads = types.MethodType(_split_heads_sliced, mod)
+        # multi-query + SDPA: hand the attention equal head counts (see _split_heads_sliced).  forward() reshapes the key / value
+        # to `self.num_kv_heads` heads - the attribute follows.  DALM_FALCON_EXPAND_KV=0 keeps the [B, 1, T, hd] form.
+        if (os.environ.get("DALM_FALCON_EXPAND_KV", "1") != "0" and getattr(mod, "num_kv_heads", None) == 1
+                and getattr(getattr(mod, "config", None), "_attn_implementation", None) == "sdpa"
+                and _falcon_forward_reshapes_by_num_kv_heads(type(mod))):
+            mod._dalm_expand_kv = True
+            mod.num_kv_heads = mod.num_heads
         n += 1
     return n
+
+
+def _falcon_forward_reshapes_by_num_kv_heads(cls) -> bool:
+    """Run-time guard: the expansion relies on FalconAttention.forward reshaping key / value by `self.num_kv_heads` and on nothing
+    else reading that attribute in the forward (checked on the source of the installed transformers, once per class)."""
+    key = ("falcon-kv", cls)
+    if key not in _checked:
+        try:
+            import inspect
+
+            src = inspect.getsource(cls.forward)
+            _checked[key] = (src.count("num_kv_heads") == 4 and "self._split_heads(fused_qkv)" in src
+                             and "num_kv_heads = self.num_heads if self.new_decoder_architecture else self.num_kv_heads" in src
+                             and "key_layer.transpose(1, 2).reshape(batch_size, num_kv_heads" in src
+                             and "value_layer.transpose(1, 2).reshape(batch_size, num_kv_heads" in src)
+        except Exception:
+            _checked[key] = False
+        if not _checked[key]:
+            _warn_once("falcon-kv", "FalconAttention.forward does not handle key / value heads the way this patch expects: "
+                       "the multi-query attention keeps transformers' broadcast form")
+    return _checked[key]
 
 
 # ---------------------------------------------------------------------------

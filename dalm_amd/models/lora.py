@@ -172,7 +172,7 @@ class LoRAGroup:
             return None
         for m in self.members:               # the plain-Linear path of a member must be exactly F.linear
             base = m.base_layer if isinstance(m, LoRALinear) else m
-            if type(base) not in (nn.Linear, GroupedLinear):
+            if type(base) not in (nn.Linear, GroupedLinear) and type(base).__name__ != "FalconLinear":
                 return None
         args = [self._member_args(m) for m in self.members]
         if not lora_ops.group_supported(x, args):

@@ -77,8 +77,13 @@ def _colacc_b(g2, z, rank, scale, b):
 
 def supported(x: torch.Tensor, base, a: torch.Tensor, b: torch.Tensor) -> bool:
     """Base GEMM and branch as one autograd node: plain nn.Linear bases only (a subclass may override forward)."""
-    return (branch_supported(x, a, b) and type(base) is torch.nn.Linear
+    return (branch_supported(x, a, b) and _is_plain_linear(base)
             and base.weight.dtype in (torch.float32, torch.bfloat16))
+
+
+def _is_plain_linear(m) -> bool:
+    # nn.Linear itself, or Falcon's FalconLinear (y = x W^T + b spelled as a matmul: the same function; BASELINE config 5)
+    return type(m) is torch.nn.Linear or (isinstance(m, torch.nn.Linear) and type(m).__name__ == "FalconLinear")
 
 
 def _rowdot(x2, w, kmajor, rank, scale, p, seed, salt):

@@ -79,3 +79,30 @@ def test_a_different_mlp_or_norm_formula_is_refused(llama, clean):
         assert "forward" not in llama.model.layers[0].mlp.__dict__ and "forward" not in llama.model.norm.__dict__
     finally:
         mlp_cls.forward, norm_cls.forward = orig_mlp, orig_norm
+
+
+def test_falcon_shared_kv_head_is_broadcast_for_sdpa_and_keeps_the_values():
+    """Falcon-7B's multi-query attention (one key / value head): the patch hands scaled_dot_product_attention equal head counts
+    (it otherwise runs its unfused math path) - same logits and gradients as transformers' broadcast form."""
+    from transformers import FalconConfig, FalconForCausalLM
+
+    from dalm_amd.models import fastpath
+
+    torch.manual_seed(0)
+    cfg = FalconConfig(num_hidden_layers=2, hidden_size=128, num_attention_heads=4, vocab_size=100)
+    ref = FalconForCausalLM(cfg).train()
+    new = FalconForCausalLM(cfg).train()
+    new.load_state_dict(ref.state_dict())
+    x = torch.randint(0, 100, (2, 9))
+    am = torch.ones(2, 9, dtype=torch.long)
+    am[0, :3] = 0                                                   # left padding
+    assert fastpath.use_capturable_falcon_heads(new) == 2
+    att = new.transformer.h[0].self_attention
+    assert att._dalm_expand_kv and att.num_kv_heads == att.num_heads == 4
+    outs = []
+    for m in (ref, new):
+        logits = m(input_ids=x, attention_mask=am).logits
+        logits.square().sum().backward()
+        outs.append((logits.detach(), m.transformer.h[0].self_attention.query_key_value.weight.grad.clone()))
+    torch.testing.assert_close(outs[1][0], outs[0][0], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(outs[1][1], outs[0][1], rtol=1e-4, atol=1e-5)
