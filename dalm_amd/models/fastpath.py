@@ -282,6 +282,124 @@ def _falcon_forward_reshapes_by_num_kv_heads(cls) -> bool:
 
 
 # ---------------------------------------------------------------------------
+# Falcon decoder layer (7B flavour: parallel attention, one LayerNorm, no dropout): LayerNorm, GELU and the residual adds
+# ---------------------------------------------------------------------------
+_FALCON_LAYER_PARAMS = ["self", "hidden_states", "alibi", "attention_mask", "position_ids", "layer_past", "use_cache",
+                        "output_attentions", "position_embeddings", "kwargs"]
+
+
+def _falcon_mlp_forward(self, x):
+    from . import tower_ops
+
+    h = self.dense_h_to_4h(x)
+    if tower_ops.flat_bf16_supported(h):
+        return self.dense_4h_to_h(tower_ops.gelu(h))
+    return self.dense_4h_to_h(self.act(h))
+
+
+def _falcon_layer_forward(self, hidden_states, alibi, attention_mask, position_ids=None, layer_past=None, use_cache=False,
+                          output_attentions=False, position_embeddings=None, **kwargs):
+    """transformers' FalconDecoderLayer.forward for `parallel_attn` without the new decoder architecture and without dropout:
+        ln = input_layernorm(x);  out = x + (mlp(ln) + attention(ln))
+    with the LayerNorm on `dalm_layer_norm_{fwd,bwd}` (under bf16 autocast the eager form is two up-casts, an f32 LayerNorm and
+    two down-casts forward, and the same again backward) and the two adds on `dalm_add3`.  The backward kernel of the norm also
+    adds the gradient that reaches x through the residual path."""
+    from . import tower_ops
+
+    ln = self.input_layernorm
+    if not tower_ops.layer_norm_supported(hidden_states, ln.weight, ln.bias):
+        return self._dalm_orig_forward(hidden_states, alibi, attention_mask, position_ids=position_ids, layer_past=layer_past,
+                                       use_cache=use_cache, output_attentions=output_attentions,
+                                       position_embeddings=position_embeddings, **kwargs)
+    residual, normed = tower_ops.layer_norm_res(hidden_states, ln.weight, ln.bias, ln.eps)
+    attn_out, attn_weights = self.self_attention(normed, layer_past=layer_past, attention_mask=attention_mask,
+                                                 position_ids=position_ids, alibi=alibi, use_cache=use_cache,
+                                                 output_attentions=output_attentions, position_embeddings=position_embeddings)
+    mlp_out = self.mlp(normed)
+    if tower_ops.flat_bf16_supported(mlp_out, attn_out, residual):
+        return tower_ops.add3(mlp_out, attn_out, residual), attn_weights
+    mlp_out = mlp_out + attn_out
+    return residual + mlp_out, attn_weights
+
+
+def use_falcon_layer_kernels(model: torch.nn.Module) -> int:
+    """Patch FalconDecoderLayer / FalconMLP modules of the 7B flavour whose code is the one this file was written against
+    (signature and source checked once per class).  DALM_FALCON_KERNELS=0 disables.  Returns how many layers were patched."""
+    if os.environ.get("DALM_FALCON_KERNELS", "1") == "0":
+        return 0
+    n = 0
+    for mod in model.modules():
+        if type(mod).__name__ != "FalconDecoderLayer":
+            continue
+        cfg = getattr(mod, "config", None)
+        if cfg is None or getattr(cfg, "new_decoder_architecture", True) or not getattr(cfg, "parallel_attn", False):
+            continue
+        if float(getattr(cfg, "hidden_dropout", 1.0)) != 0.0 or float(getattr(cfg, "attention_dropout", 1.0)) != 0.0:
+            continue            # dropout_add with p > 0 draws from torch's generator: transformers' code stays
+        ln = getattr(mod, "input_layernorm", None)
+        if not isinstance(ln, torch.nn.LayerNorm) or ln.weight is None or not hasattr(mod, "self_attention") \
+                or not hasattr(mod, "mlp"):
+            continue
+        if not _falcon_layer_matches(type(mod)):
+            continue
+        mod._dalm_orig_forward = mod.forward
+        mod.forward = types.MethodType(_falcon_layer_forward, mod)
+        mlp = mod.mlp
+        if type(mlp).__name__ == "FalconMLP" and _is_erf_gelu(getattr(mlp, "act", None)) and _falcon_mlp_matches(type(mlp)):
+            mlp.forward = types.MethodType(_falcon_mlp_forward, mlp)
+        n += 1
+    return n
+
+
+def _is_erf_gelu(act) -> bool:
+    """torch's exact GELU: nn.GELU() or transformers' GELUActivation around nn.functional.gelu (config.activation = "gelu")."""
+    if isinstance(act, torch.nn.GELU):
+        return getattr(act, "approximate", "none") == "none"
+    return type(act).__name__ == "GELUActivation" and getattr(act, "act", None) is torch.nn.functional.gelu
+
+
+def _falcon_layer_matches(cls) -> bool:
+    """Run-time guard: the class's forward must have the signature and the statements `_falcon_layer_forward` restates."""
+    key = ("falcon-layer", cls)
+    if key not in _checked:
+        try:
+            import inspect
+
+            params = list(inspect.signature(cls.forward).parameters)
+            src = inspect.getsource(cls.forward)
+            _checked[key] = (params == _FALCON_LAYER_PARAMS
+                             and "attention_layernorm_out = self.input_layernorm(hidden_states)" in src
+                             and "mlp_layernorm_out = attention_layernorm_out" in src
+                             and "mlp_output = self.mlp(mlp_layernorm_out)" in src
+                             and "mlp_output += attention_output" in src
+                             and "output = dropout_add(mlp_output, residual, self.config.hidden_dropout, training=self.training)" in src
+                             and "return output, attn_weights" in src)
+        except Exception:
+            _checked[key] = False
+        if not _checked[key]:
+            _warn_once("falcon-layer", "FalconDecoderLayer.forward is not the code this patch restates: transformers' own "
+                       "code stays in place")
+    return _checked[key]
+
+
+def _falcon_mlp_matches(cls) -> bool:
+    key = ("falcon-mlp", cls)
+    if key not in _checked:
+        try:
+            import inspect
+
+            src = inspect.getsource(cls.forward)
+            _checked[key] = ("x = self.act(self.dense_h_to_4h(x))" in src and "x = self.dense_4h_to_h(x)" in src
+                             and src.count("self.") == 3)
+        except Exception:
+            _checked[key] = False
+        if not _checked[key]:
+            _warn_once("falcon-mlp", "FalconMLP.forward is not dense_4h_to_h(act(dense_h_to_4h(x))) here: transformers' own "
+                       "code stays in place")
+    return _checked[key]
+
+
+# ---------------------------------------------------------------------------
 # decoder layer: residual add + RMSNorm in one launch each way
 # ---------------------------------------------------------------------------
 _LLAMA_LAYER_PARAMS = ["self", "hidden_states", "attention_mask", "position_ids", "past_key_values", "use_cache",

@@ -172,3 +172,103 @@ def add_rms_norm(x, delta, w, eps):
     """x + delta and its RMSNorm in one launch (one more in the backward, which also folds in the residual-path gradient).
     delta = None: (x itself, rmsnorm(x) * w)."""
     return _AddRmsNorm.apply(x, delta, w, eps)
+
+
+# ---------------------------------------------------------------------------
+# Falcon decoder layer: LayerNorm, erf-GELU and the three-way residual add (dalm_amd/csrc/falcon.hip), bf16 activations
+# ---------------------------------------------------------------------------
+def layer_norm_supported(x: torch.Tensor, w: torch.Tensor, b) -> bool:
+    D = x.shape[-1]
+    return (x.is_cuda and x.dtype == torch.bfloat16 and w.dim() == 1 and w.shape[0] == D and w.dtype == torch.bfloat16
+            and (b is None or (b.dtype == torch.bfloat16 and b.shape == w.shape)) and D % 8 == 0 and D <= 8192)
+
+
+class _LayerNormRes(torch.autograd.Function):
+    """(x, y) = (x, LayerNorm(x) in the activation dtype); x is handed back so that the gradient reaching it through the
+    residual path is added INSIDE the norm's backward kernel (as `_AddRmsNorm` with delta None)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        D = x.shape[-1]
+        x2 = _as_rows(x, D, x.dtype)
+        R = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean = torch.empty(R, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(R, device=x.device, dtype=torch.float32)
+        hip.call("dalm_layer_norm_fwd", hip.ptr(x2), hip.ptr(w), hip.ptr(b), R, D, float(eps), hip.ptr(y), hip.ptr(mean),
+                 hip.ptr(rstd), hip.stream())
+        ctx.save_for_backward(x2, w, mean, rstd)
+        ctx.shape, ctx.has_bias = x.shape, b is not None
+        return x, y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dres, dy):
+        x2, w, mean, rstd = ctx.saved_tensors
+        R, D = x2.shape
+        if dy is None:
+            return dres, None, None, None
+        dy2 = _as_rows(dy, D, x2.dtype)
+        dres2 = _as_rows(dres, D, x2.dtype) if dres is not None else None
+        dx = torch.empty_like(x2)
+        hip.call("dalm_layer_norm_bwd", hip.ptr(dy2), hip.ptr(x2), hip.ptr(w), hip.ptr(mean), hip.ptr(rstd), hip.ptr(dres2), R, D,
+                 hip.ptr(dx), hip.stream())
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            xh = (x2.float() - mean.unsqueeze(1)) * rstd.unsqueeze(1)
+            dw = (dy2.float() * xh).sum(0).to(w.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy2.float().sum(0).to(w.dtype)
+        return dx.view(ctx.shape), dw, db, None
+
+
+def layer_norm_res(x, w, b, eps):
+    """(x, LayerNorm(x)): one launch forward, one backward (which also folds in the residual-path gradient)."""
+    return _LayerNormRes.apply(x, w, b, eps)
+
+
+def flat_bf16_supported(*ts) -> bool:
+    t0 = ts[0]
+    return all(t.is_cuda and t.dtype == torch.bfloat16 and t.shape == t0.shape for t in ts) and t0.numel() % 8 == 0
+
+
+class _Gelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        hip.require_gpu(x)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        hip.call("dalm_gelu_fwd", hip.ptr(x), hip.ptr(y), x.numel(), hip.stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        hip.call("dalm_gelu_bwd", hip.ptr(dy), hip.ptr(x), hip.ptr(dx), x.numel(), hip.stream())
+        return dx
+
+
+def gelu(x):
+    """0.5 x (1 + erf(x / sqrt 2)), bf16 in and out, f32 arithmetic."""
+    return _Gelu.apply(x)
+
+
+class _Add3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, c):
+        hip.require_gpu(a, b, c)
+        a, b, c = a.contiguous(), b.contiguous(), c.contiguous()
+        out = torch.empty_like(a)
+        hip.call("dalm_add3", hip.ptr(a), hip.ptr(b), hip.ptr(c), hip.ptr(out), a.numel(), hip.stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g, g
+
+
+def add3(a, b, c):
+    """c + (a + b), the inner sum rounded to bf16 first (what `a += b; c + a` leaves)."""
+    return _Add3.apply(a, b, c)

@@ -438,6 +438,24 @@ int dalm_rms_norm_fwd(const void* x, const void* delta, const void* w, int dtype
 int dalm_rms_norm_bwd(const void* dy, const void* h, const void* w, const float* rstd, const void* dres, int dtype, int64_t R,
                       int64_t D, void* dx, dalm_stream_t stream);
 
+/* Elementwise chains of a Falcon-7B decoder layer (transformers modeling_falcon.py FalconDecoderLayer.forward /
+ * FalconMLP.forward / dropout_add, reached by the reference through self.generator_model(...),
+ * dalm/models/rag_e2e_base_model.py:104-106; BASELINE.json config 5).  bf16 tensors, 16-byte aligned.
+ *   layer_norm fwd: y = bf16((x - mean) * rstd * w + b) with f32 statistics of the bf16 row - torch's autocast LayerNorm (f32)
+ *        followed by its consumers' casts to bf16; b may be NULL; mean / rstd [R] f32 are kept for the backward.
+ *        [R, D] row-major, D a multiple of 8, at most 8192.
+ *   layer_norm bwd: dx = rstd * (g - mean(g) - xh * mean(g * xh)) (+ dres), g = dy * w, xh = (x - mean) * rstd.  Weight / bias
+ *        gradients are not produced (LoRA freezes them).
+ *   gelu: exact erf form, f32 arithmetic, one rounding (torch.nn.GELU() on bf16); bwd: dy * (Phi(x) + x phi(x)).
+ *   add3: out = bf16(c + bf16(a + b))  (mlp_output += attention_output; then residual + that).  n a multiple of 8. */
+int dalm_layer_norm_fwd(const void* x, const void* w, const void* b, int64_t R, int64_t D, float eps, void* y, float* mean,
+                        float* rstd, dalm_stream_t stream);
+int dalm_layer_norm_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd, const void* dres,
+                        int64_t R, int64_t D, void* dx, dalm_stream_t stream);
+int dalm_gelu_fwd(const void* x, void* y, int64_t n, dalm_stream_t stream);
+int dalm_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, dalm_stream_t stream);
+int dalm_add3(const void* a, const void* b, const void* c, void* out, int64_t n, dalm_stream_t stream);
+
 /* ---- the low-rank branch of a LoRA-wrapped Linear ----------------------------------------------------------------
  * The reference wraps q_proj / v_proj (key / query / value for BERT retrievers) in peft LoRA adapters, r = 8, alpha = 16,
  * dropout 0.05 (dalm/models/rag_e2e_base_model.py:145-160, retriever_only_base_model.py:92-107); peft evaluates

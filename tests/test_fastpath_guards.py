@@ -106,3 +106,52 @@ def test_falcon_shared_kv_head_is_broadcast_for_sdpa_and_keeps_the_values():
         outs.append((logits.detach(), m.transformer.h[0].self_attention.query_key_value.weight.grad.clone()))
     torch.testing.assert_close(outs[1][0], outs[0][0], rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(outs[1][1], outs[0][1], rtol=1e-4, atol=1e-5)
+
+
+def test_falcon_layer_patch_goes_in_on_the_stock_code_and_is_refused_on_other_code():
+    """FalconDecoderLayer / FalconMLP (7B flavour): the patch restates transformers' statements and checks them on the class's
+    source.  On CPU tensors the patched layer hands over to transformers' forward (the kernels take GPU bf16 only): same values."""
+    from transformers import FalconConfig, FalconForCausalLM
+
+    from dalm_amd.models import fastpath
+
+    fastpath._checked.clear()
+    torch.manual_seed(0)
+    cfg = FalconConfig(num_hidden_layers=2, hidden_size=128, num_attention_heads=4, vocab_size=100)
+    m = FalconForCausalLM(cfg).eval()
+    x = torch.randint(0, 100, (2, 9))
+    with torch.no_grad():
+        want = m(input_ids=x).logits
+    assert fastpath.use_falcon_layer_kernels(m) == 2
+    layer = m.transformer.h[0]
+    assert layer.forward.__func__ is fastpath._falcon_layer_forward and layer.mlp.forward.__func__ is fastpath._falcon_mlp_forward
+    with torch.no_grad():
+        got = m(input_ids=x).logits
+    torch.testing.assert_close(got, want, rtol=0, atol=0)
+
+    # dropout in the residual adds, or the new decoder architecture: transformers' code stays
+    for kw in ({"hidden_dropout": 0.1}, {"new_decoder_architecture": True, "num_kv_heads": 2}, {"parallel_attn": False}):
+        other = FalconForCausalLM(FalconConfig(num_hidden_layers=1, hidden_size=128, num_attention_heads=4, vocab_size=100, **kw))
+        assert fastpath.use_falcon_layer_kernels(other) == 0
+        assert "forward" not in other.transformer.h[0].__dict__
+
+    # another forward on the class: refused with a warning
+    cls = type(layer)
+    orig = cls.forward
+    fastpath._checked.clear()
+    fastpath._warned.clear()
+    try:
+        def forward(self, hidden_states, alibi, attention_mask, position_ids=None, layer_past=None, use_cache=False,
+                    output_attentions=False, position_embeddings=None, **kwargs):
+            return orig(self, hidden_states, alibi, attention_mask, position_ids, layer_past, use_cache, output_attentions,
+                        position_embeddings, **kwargs)
+
+        cls.forward = forward
+        fresh = FalconForCausalLM(cfg)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            assert fastpath.use_falcon_layer_kernels(fresh) == 0
+        assert any("FalconDecoderLayer.forward is not the code this patch restates" in str(m_.message) for m_ in w)
+    finally:
+        cls.forward = orig
+        fastpath._checked.clear()

@@ -29,7 +29,7 @@ OUT = Path(__file__).resolve().parent.parent / "gpurun_out"
 TOL_KERNELS_OFF = {"loss": 2.5e-4, "grad": 8e-4}     # (A) vs (B): both bf16 autocast; the kernels round where the eager chains round
 TOL_HOST_FP32 = {"loss": 4e-4, "grad": 7e-3}         # (A) vs (C): bf16 activations against float32 activations
 
-KERNEL_ENVS = ("DALM_FAST_ROPE", "DALM_ROPE_KERNEL", "DALM_SWIGLU_KERNEL", "DALM_NORM_KERNEL")
+KERNEL_ENVS = ("DALM_FAST_ROPE", "DALM_ROPE_KERNEL", "DALM_SWIGLU_KERNEL", "DALM_NORM_KERNEL", "DALM_FALCON_KERNELS")
 
 
 def _rel(a, b):
@@ -120,6 +120,9 @@ def test_headline_configuration_at_real_width(case):
     if case == "cfg3":          # the Llama layer patches and the LoRA group node really ran / really did not
         assert "_llama_layer_forward" in on["patched_forwards"] and "_swiglu_mlp_forward" in on["patched_forwards"]
         assert "_llama_layer_forward" not in off["patched_forwards"] and "_swiglu_mlp_forward" not in off["patched_forwards"]
+    else:                       # the Falcon layer patches (LayerNorm, GELU, residual adds)
+        assert "_falcon_layer_forward" in on["patched_forwards"] and "_falcon_mlp_forward" in on["patched_forwards"]
+        assert "_falcon_layer_forward" not in off["patched_forwards"] and "_falcon_mlp_forward" not in off["patched_forwards"]
 
     old_threads = torch.get_num_threads()
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
