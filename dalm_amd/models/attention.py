@@ -1,0 +1,191 @@
+"""Scaled-dot-product attention of the generator tower with a hand-written HIP BACKWARD (`dalm_attn_bwd`,
+dalm_amd/csrc/attn.hip), registered with transformers as the attention implementation "dalm_sdpa".
+
+transformers evaluates a decoder layer's attention through `sdpa_attention_forward`
+(transformers/integrations/sdpa_attention.py) -> torch.nn.functional.scaled_dot_product_attention; the reference reaches it through
+`self.generator_model(...)` (dalm/models/rag_e2e_base_model.py:104-106) and differentiates it in `loss.backward()`
+(dalm/training/rag_e2e/train_rage2e.py:466).  With HF's boolean mask (causal + left padding) torch runs its memory-efficient
+kernels: 60 us forward, 440 us backward per layer at cfg3 (2.7 % of the MFMA peak).  Here
+
+  forward   torch's own memory-efficient kernel, called as the aten op so that its log-sum-exp comes back
+            (`aten::_scaled_dot_product_efficient_attention`; same values as F.scaled_dot_product_attention, bit for bit);
+  backward  `dalm_attn_bwd`: the mask read as packed bits (packed once per mask tensor - every layer passes the same one),
+            dead 32 x 32 tiles skipped, two launches.
+
+Everything the kernels do not take (CPU tensors, other head widths, dropout, float masks, a KV cache, no gradient wanted) goes
+to transformers' own `sdpa_attention_forward`, unchanged.  DALM_ATTN_KERNEL=0 keeps the model on "sdpa".
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+from .. import hip
+
+NAME = "dalm_sdpa"
+_HEAD_DIM = 128
+
+
+class _MaskPack:
+    """What the kernels read of one mask tensor: bias (for torch's forward), row / column bit words, live tiles."""
+
+    __slots__ = ("mask", "key", "bias", "rows", "cols", "live")
+
+
+_last: list = [None]          # the pack of the mask seen last: one forward pass hands the same tensor object to every layer
+
+
+def _pack(mask: Optional[torch.Tensor], B: int, H: int, T: int, causal: bool, dtype, device) -> _MaskPack:
+    key = (None if mask is None else (mask.data_ptr(), mask._version, tuple(mask.shape), tuple(mask.stride())), B, T, causal,
+           dtype, device, torch.cuda.current_stream(device).cuda_stream)
+    cur = _last[0]
+    if cur is not None and cur.mask is mask and cur.key == key:
+        return cur
+    pk = _MaskPack()
+    pk.mask, pk.key = mask, key
+    W = (T + 31) // 32
+    pk.rows = torch.empty(B * 32 * W * W, dtype=torch.int32, device=device)
+    pk.cols = torch.empty_like(pk.rows)
+    pk.live = torch.empty(B * W * W, dtype=torch.uint8, device=device)
+    if mask is None:
+        pk.bias = None
+        hip.call("dalm_attn_mask_bits", None, B, T, 0, 0, 1, hip.ptr(pk.rows), hip.ptr(pk.cols), hip.ptr(pk.live), hip.stream())
+    else:
+        m = mask if mask.stride(-1) == 1 else mask.contiguous()
+        # torch's own conversion of a boolean mask (aten convert_boolean_attn_mask): 0 where attended, -inf elsewhere; the last
+        # dimension's allocation padded to a multiple of 8 elements as the memory-efficient kernel wants its bias aligned
+        Ta = (T + 7) // 8 * 8
+        bias = torch.zeros(B, 1, T, Ta, dtype=dtype, device=device)[..., :T]
+        bias.masked_fill_(m.logical_not(), float("-inf"))
+        pk.bias = bias.expand(B, H, T, T)
+        hip.call("dalm_attn_mask_bits", hip.ptr(m), B, T, m.stride(0), m.stride(2), int(causal), hip.ptr(pk.rows), hip.ptr(pk.cols),
+                 hip.ptr(pk.live), hip.stream())
+    _last[0] = pk
+    return pk
+
+
+def _strides3(t: torch.Tensor):
+    return [t.stride(0), t.stride(1), t.stride(2)]
+
+
+def _dense_like(t: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(t)                       # preserve_format: the [B, T, H, hd] memory of the projections' views
+    if out.stride(-1) != 1:
+        out = torch.empty(t.shape, dtype=t.dtype, device=t.device)
+    return out
+
+
+class _SdpaHipBackward(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, mask, scale, causal):
+        B, H, T, hd = q.shape
+        pk = _pack(mask, B, H, T, causal, q.dtype, q.device)
+        out, lse, _, _ = torch.ops.aten._scaled_dot_product_efficient_attention(q, k, v, pk.bias, True, 0.0, causal, scale=scale)
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.pack, ctx.scale = pk, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        q, k, v, out, lse = ctx.saved_tensors
+        pk = ctx.pack
+        B, H, T, hd = q.shape
+        if d_out.stride(-1) != 1 or any(s % 8 for s in d_out.stride()[:3]):
+            d_out = d_out.contiguous()
+        lse = lse if (lse.is_contiguous() and lse.shape[-1] == T) else lse[..., :T].contiguous()
+        dq, dk, dv = _dense_like(q), _dense_like(k), _dense_like(v)
+        delta = torch.empty(B, H, T, dtype=torch.float32, device=q.device)
+        flat = []
+        for t in (q, k, v, out, d_out, dq, dk, dv):
+            flat += _strides3(t)
+        strides = (C.c_int64 * 24)(*flat)
+        hip.call("dalm_attn_bwd", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(out), hip.ptr(d_out), hip.ptr(lse), hip.ptr(pk.rows),
+                 hip.ptr(pk.cols), hip.ptr(pk.live), B, H, T, hd, float(ctx.scale), strides, hip.ptr(dq), hip.ptr(dk), hip.ptr(dv),
+                 hip.ptr(delta), hip.stream())
+        return dq, dk, dv, None, None, None
+
+
+def _views_ok(*ts) -> bool:
+    return all(t.stride(-1) == 1 and all(s % 8 == 0 for s in t.stride()[:3]) and t.data_ptr() % 16 == 0 for t in ts)
+
+
+def supported(query, key, value, mask, dropout, causal, kwargs) -> bool:
+    if not (query.is_cuda and query.dtype == torch.bfloat16 and key.dtype == query.dtype and value.dtype == query.dtype):
+        return False
+    if query.dim() != 4 or query.shape[-1] != _HEAD_DIM or key.shape != query.shape or value.shape != query.shape:
+        return False                                 # a KV cache (kv length != q length) or grouped heads left unexpanded
+    if query.shape[2] < 2 or dropout != 0.0 or kwargs.get("position_bias") is not None:
+        return False
+    if not (torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad)):
+        return False                                 # nothing to differentiate: torch's fused forward alone is the best path
+    B, _, T, _ = query.shape
+    if mask is None:
+        if not causal:
+            return False
+    elif not (mask.dtype == torch.bool and mask.dim() == 4 and tuple(mask.shape) == (B, 1, T, T) and mask.is_cuda and not causal):
+        return False
+    return _views_ok(query, key, value)
+
+
+def dalm_sdpa_attention_forward(module, query, key, value, attention_mask, dropout: float = 0.0, scaling: Optional[float] = None,
+                                is_causal: Optional[bool] = None, **kwargs):
+    """Same contract as transformers' `sdpa_attention_forward`: ([B, T, H, hd] output, None)."""
+    from transformers.integrations.sdpa_attention import repeat_kv, sdpa_attention_forward
+
+    groups = getattr(module, "num_key_value_groups", 1)
+    causal = bool(query.shape[2] > 1 and attention_mask is None
+                  and (is_causal if is_causal is not None else getattr(module, "is_causal", True)))
+    k2, v2 = (repeat_kv(key, groups), repeat_kv(value, groups)) if (groups > 1 and key.shape[1] != query.shape[1]) else (key, value)
+    if os.environ.get("DALM_ATTN_KERNEL", "1") == "0" or not supported(query, k2, v2, attention_mask, dropout, causal, kwargs):
+        return sdpa_attention_forward(module, query, key, value, attention_mask, dropout=dropout, scaling=scaling,
+                                      is_causal=is_causal, **kwargs)
+    scale = float(scaling) if scaling is not None else float(query.shape[-1]) ** -0.5
+    out = _SdpaHipBackward.apply(query, k2, v2, attention_mask, scale, causal)
+    return out.transpose(1, 2).contiguous(), None
+
+
+_registered = [False]
+
+
+def register() -> bool:
+    """Register "dalm_sdpa" with transformers (attention function + the SDPA mask builder).  False when this transformers has
+    no such registry or its `sdpa_attention_forward` is not the code the replacement restates."""
+    if _registered[0]:
+        return True
+    try:
+        import inspect
+
+        from transformers import AttentionInterface
+        from transformers.integrations import sdpa_attention
+        from transformers.masking_utils import AttentionMaskInterface, sdpa_mask
+
+        src = inspect.getsource(sdpa_attention.sdpa_attention_forward)
+        if not ("torch.nn.functional.scaled_dot_product_attention(" in src and "attn_output.transpose(1, 2).contiguous()" in src
+                and "is_causal = q_length > 1 and attention_mask is None and is_causal" in src
+                and "return attn_output, None" in src):
+            return False
+        AttentionInterface.register(NAME, dalm_sdpa_attention_forward)
+        AttentionMaskInterface.register(NAME, sdpa_mask)
+    except Exception:
+        return False
+    _registered[0] = True
+    return True
+
+
+def use_hip_attention_backward(model: torch.nn.Module) -> bool:
+    """Switch a Llama-family model (head width 128) from "sdpa" to "dalm_sdpa".  DALM_ATTN_KERNEL=0 disables."""
+    if os.environ.get("DALM_ATTN_KERNEL", "1") == "0":
+        return False
+    cfg = getattr(model, "config", None)
+    if cfg is None or getattr(cfg, "_attn_implementation", None) != "sdpa":
+        return False
+    if getattr(cfg, "model_type", "") not in ("llama", "mistral", "qwen2"):
+        return False
+    hd = getattr(cfg, "head_dim", None) or (cfg.hidden_size // cfg.num_attention_heads)
+    if hd != _HEAD_DIM or not register():
+        return False
+    cfg._attn_implementation = NAME
+    return True

@@ -456,6 +456,24 @@ int dalm_gelu_fwd(const void* x, void* y, int64_t n, dalm_stream_t stream);
 int dalm_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, dalm_stream_t stream);
 int dalm_add3(const void* a, const void* b, const void* c, void* out, int64_t n, dalm_stream_t stream);
 
+/* Backward of scaled-dot-product attention, bf16, head width 128, boolean mask (dalm_amd/csrc/attn.hip).  Stands in for the
+ * backward of torch.nn.functional.scaled_dot_product_attention as transformers' sdpa_attention_forward calls it inside
+ * self.generator_model(...) (dalm/models/rag_e2e_base_model.py:104-106; loss.backward(), train_rage2e.py:466).
+ *   dalm_attn_mask_bits: mask [B, 1, T, T] bytes (non-zero = attend; element strides mask_stride_b / mask_stride_row, last
+ *        dimension contiguous; NULL = no mask) AND the causal flag -> bits_rows, bits_cols [B][32 W][W] u32 (W = ceil(T / 32);
+ *        bit c of word w of row i = mask[i][32 w + c]; columns likewise over rows) and live [B][W][W] bytes (32 x 32 tile not
+ *        empty).  Once per mask: every layer and head reads the same words.
+ *   dalm_attn_bwd: q, k, v, o (the forward's output), d_o, and lse [B, H, T] f32 (natural log of the row sums, what torch's
+ *        memory-efficient forward returns) -> dq, dk, dv.  strides: 8 x (batch, head, row) ELEMENT strides of
+ *        q, k, v, o, d_o, dq, dk, dv (last dimension contiguous, multiples of 8); delta: [B, H, T] f32 scratch
+ *        (D = rowsum(dO o O)).  P and dS are rounded to bf16 for their products, sums in f32. */
+int dalm_attn_mask_bits(const void* mask, int64_t B, int64_t T, int64_t mask_stride_b, int64_t mask_stride_row, int causal,
+                        uint32_t* bits_rows, uint32_t* bits_cols, uint8_t* live, dalm_stream_t stream);
+int dalm_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                  const uint32_t* bits_rows, const uint32_t* bits_cols, const uint8_t* live, int64_t B, int64_t H, int64_t T,
+                  int64_t hd, float scale, const int64_t* strides, void* dq, void* dk, void* dv, float* delta,
+                  dalm_stream_t stream);
+
 /* ---- the low-rank branch of a LoRA-wrapped Linear ----------------------------------------------------------------
  * The reference wraps q_proj / v_proj (key / query / value for BERT retrievers) in peft LoRA adapters, r = 8, alpha = 16,
  * dropout 0.05 (dalm/models/rag_e2e_base_model.py:145-160, retriever_only_base_model.py:92-107); peft evaluates

@@ -1,0 +1,182 @@
+"""`dalm_attn_bwd` / `dalm_attn_mask_bits` (dalm_amd/csrc/attn.hip) behind the "dalm_sdpa" attention implementation
+(dalm_amd/models/attention.py) against torch.nn.functional.scaled_dot_product_attention as transformers'
+sdpa_attention_forward calls it (the reference reaches it through self.generator_model(...),
+dalm/models/rag_e2e_base_model.py:104-106, and differentiates it in loss.backward(), train_rage2e.py:466):
+
+* forward: EQUAL to F.scaled_dot_product_attention (it is torch's own kernel);
+* backward: dq, dk, dv against a float64 evaluation of the same masked softmax attention, no further from it than
+  torch's own bf16 backward is (x 1.5 + 1e-3), for HF's causal + left-padding masks, ragged lengths, rows with no live
+  key, the pure causal case without a mask, arbitrary boolean masks, transposed ([B, T, H, hd] memory) and contiguous views;
+* the mask bit words against a numpy packing;
+* a Llama layer on "dalm_sdpa" against the same layer on "sdpa": logits and LoRA-free parameter gradients."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _hf_mask(B, T, starts, dev):
+    col = torch.arange(T, device=dev)
+    st = torch.tensor(starts, device=dev)
+    return ((col[None, None, :] <= col[None, :, None]) & (col[None, None, :] >= st[:, None, None]))[:, None]
+
+
+def _ref64(q, k, v, mask, causal, scale, go):
+    q, k, v = [t.detach().double().requires_grad_(True) for t in (q, k, v)]
+    s = (q @ k.transpose(-1, -2)) * scale
+    T = s.shape[-1]
+    live = torch.ones(T, T, dtype=torch.bool, device=s.device).tril() if causal else torch.ones(T, T, dtype=torch.bool, device=s.device)
+    live = live[None, None] if mask is None else (mask & live)
+    s = s.masked_fill(~live, float("-inf"))
+    p = torch.softmax(s, -1)
+    p = torch.nan_to_num(p, nan=0.0)                       # rows without a live key: zero output, zero gradient
+    o = p @ v
+    o.backward(go.double())
+    return o, q.grad, k.grad, v.grad
+
+
+def _run(fn, q, k, v, go):
+    q, k, v = [t.detach().clone().requires_grad_(True) for t in (q, k, v)]
+    o = fn(q, k, v)
+    o.backward(go)
+    return o.detach(), q.grad, k.grad, v.grad
+
+
+CASES = [
+    # B, H, T, starts (left padding per batch row; None = no mask, is_causal), layout
+    (2, 3, 256, [0, 37], "bthd"),
+    (3, 2, 256, [0, 255, 128], "bhtd"),
+    (2, 2, 200, [5, 150], "bthd"),
+    (1, 4, 96, [0], "bthd"),
+    (2, 2, 40, [3, 0], "bhtd"),
+    (2, 3, 256, None, "bthd"),
+    (1, 2, 333 // 8 * 8, None, "bthd"),
+    (2, 2, 512, [100, 0], "bthd"),
+]
+
+
+@pytest.mark.parametrize("B,H,T,starts,layout", CASES)
+def test_backward_vs_fp64_and_torch(dev, B, H, T, starts, layout):
+    from dalm_amd.models import attention
+
+    hd = 128
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    def mk():
+        if layout == "bthd":
+            return (torch.randn(B, T, H, hd, generator=g) * 1.2).bfloat16().to(dev).transpose(1, 2)
+        return (torch.randn(B, H, T, hd, generator=g) * 1.2).bfloat16().to(dev)
+    q, k, v, go = mk(), mk(), mk(), mk()
+    mask = None if starts is None else _hf_mask(B, T, starts, dev)
+    causal = starts is None
+    scale = hd ** -0.5
+    assert attention.supported(q.requires_grad_(True), k, v, mask, 0.0, causal, {})
+
+    ours = _run(lambda a, b, c: attention._SdpaHipBackward.apply(a, b, c, mask, scale, causal), q, k, v, go)
+    theirs = _run(lambda a, b, c: torch.nn.functional.scaled_dot_product_attention(a, b, c, attn_mask=mask, is_causal=causal,
+                                                                                    scale=scale), q, k, v, go)
+    ref = _ref64(q, k, v, mask, causal, scale, go)
+    assert torch.equal(ours[0], theirs[0])
+    for name, a, b, r in zip(("dq", "dk", "dv"), ours[1:], theirs[1:], ref[1:]):
+        assert torch.isfinite(a).all(), name
+        e_a, e_b = _rel(a, r), _rel(b, r)
+        assert e_a <= 1.5 * e_b + 1e-3, (name, e_a, e_b)
+        assert a.stride() == b.stride() or a.is_contiguous()
+    if starts is not None:                                   # query rows in the padding have no live key: exactly zero dq
+        for b_, st in enumerate(starts):
+            if st > 0:
+                assert float(ours[1][b_, :, :st].abs().max()) == 0.0
+                assert float(ours[2][b_, :, :st].abs().max()) == 0.0 and float(ours[3][b_, :, :st].abs().max()) == 0.0
+
+
+def test_arbitrary_boolean_mask(dev):
+    from dalm_amd.models import attention
+
+    B, H, T, hd = 2, 2, 128, 128
+    g = torch.Generator().manual_seed(7)
+    q, k, v, go = [(torch.randn(B, T, H, hd, generator=g)).bfloat16().to(dev).transpose(1, 2) for _ in range(4)]
+    mask = (torch.rand(B, 1, T, T, generator=g) < 0.3).to(dev)
+    mask[:, :, :, 0] = True                                  # every row keeps a key
+    mask[0, 0, 64:96, :] = False
+    mask[0, 0, 64:96, 5] = True                              # a block of rows with one live key, 32 x 32 tiles entirely dead
+    scale = 0.11
+    ours = _run(lambda a, b, c: attention._SdpaHipBackward.apply(a, b, c, mask, scale, False), q, k, v, go)
+    theirs = _run(lambda a, b, c: torch.nn.functional.scaled_dot_product_attention(a, b, c, attn_mask=mask, scale=scale), q, k, v, go)
+    ref = _ref64(q, k, v, mask, False, scale, go)
+    assert torch.equal(ours[0], theirs[0])
+    for a, b, r in zip(ours[1:], theirs[1:], ref[1:]):
+        assert _rel(a, r) <= 1.5 * _rel(b, r) + 1e-3
+
+
+def test_mask_bit_words(dev):
+    from dalm_amd import hip
+
+    B, T = 3, 100
+    W = (T + 31) // 32
+    g = torch.Generator().manual_seed(1)
+    mask = (torch.rand(B, 1, T, T, generator=g) < 0.5)
+    mask[1] = False
+    for causal in (0, 1):
+        rows = torch.empty(B * 32 * W * W, dtype=torch.int32, device=dev)
+        cols = torch.empty_like(rows)
+        live = torch.empty(B * W * W, dtype=torch.uint8, device=dev)
+        m = mask.to(dev)
+        hip.call("dalm_attn_mask_bits", hip.ptr(m), B, T, m.stride(0), m.stride(2), causal, hip.ptr(rows), hip.ptr(cols), hip.ptr(live),
+                 hip.stream())
+        mm = mask[:, 0].numpy().copy()
+        if causal:
+            mm &= np.tril(np.ones((T, T), dtype=bool))[None]
+        pad = np.zeros((B, 32 * W, 32 * W), dtype=bool)
+        pad[:, :T, :T] = mm
+        weights = (1 << np.arange(32, dtype=np.uint64))
+        want_rows = (pad.reshape(B, 32 * W, W, 32).astype(np.uint64) * weights).sum(-1).astype(np.uint32)
+        want_cols = (pad.transpose(0, 2, 1).reshape(B, 32 * W, W, 32).astype(np.uint64) * weights).sum(-1).astype(np.uint32)
+        want_live = pad.reshape(B, W, 32, W, 32).any(axis=(2, 4)).astype(np.uint8)
+        assert np.array_equal(rows.cpu().numpy().view(np.uint32).reshape(B, 32 * W, W), want_rows)
+        assert np.array_equal(cols.cpu().numpy().view(np.uint32).reshape(B, 32 * W, W), want_cols)
+        assert np.array_equal(live.cpu().numpy().reshape(B, W, W), want_live)
+
+
+def test_llama_layer_on_dalm_sdpa_matches_sdpa(dev):
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    from dalm_amd.models import attention
+
+    torch.manual_seed(0)
+    cfg = LlamaConfig(hidden_size=512, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4,
+                      vocab_size=300)
+    ref = LlamaForCausalLM(cfg).to(dev).to(torch.bfloat16).train()
+    new = copy.deepcopy(ref)
+    assert attention.use_hip_attention_backward(new) and new.config._attn_implementation == "dalm_sdpa"
+    assert ref.config._attn_implementation == "sdpa"
+    B, T = 3, 64
+    ids = torch.randint(0, 300, (B, T), device=dev)
+    am = torch.ones(B, T, dtype=torch.long, device=dev)
+    am[0, :20] = 0
+    am[2, :63] = 0
+    outs = []
+    for m in (ref, new):
+        logits = m(input_ids=ids, attention_mask=am).logits
+        (logits.float() * am[..., None]).square().sum().backward()
+        outs.append((logits.detach(), [p.grad.detach().clone() for p in m.parameters()]))
+    live = am.bool()
+    assert torch.equal(outs[0][0][live], outs[1][0][live])
+    for a, b in zip(outs[1][1], outs[0][1]):
+        assert _rel(a, b) < 2e-2
+    # no gradient wanted: transformers' own path (and the same values)
+    with torch.no_grad():
+        assert torch.equal(new(input_ids=ids, attention_mask=am).logits[live], outs[0][0][live])
