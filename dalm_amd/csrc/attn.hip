@@ -64,16 +64,17 @@ __device__ __forceinline__ float dot8(const uint4& a, const uint4& b) {
   return s;
 }
 
-// one 64-row block of a [rows][128] bf16 tensor -> LDS, row-major (`rm`) and, when `tr` is given, transposed ([d][row]).
-// lane <-> row (the transposed 2-byte stores of a wave are then one contiguous 128-byte run), wave w takes 16-byte chunks 4 w .. 4 w + 3
-__device__ __forceinline__ void stage_block(const unsigned short* base, int64_t row_stride, int row0, int T, unsigned char* rm,
-                                            unsigned char* tr, int w, int l) {
+// one 64-row block of a [rows][128] bf16 tensor -> registers (lane <-> row, wave w takes the 16-byte chunks 4 w .. 4 w + 3) ...
+__device__ __forceinline__ void block_load(const unsigned short* base, int64_t row_stride, int row0, int T, int w, int l, uint4 (&v)[4]) {
   const int row = row0 + l;
   const bool ok = row < T;
   const unsigned short* src = base + static_cast<int64_t>(row) * row_stride;
-  uint4 v[4];
 #pragma unroll
   for (int n = 0; n < 4; ++n) v[n] = ok ? ld16(src + 8 * (4 * w + n)) : make_uint4(0u, 0u, 0u, 0u);
+}
+// ... -> LDS, row-major (`rm`) and, when `tr` is given, transposed ([d][row]: the 2-byte stores of a wave are one contiguous
+// 128-byte run)
+__device__ __forceinline__ void block_store(const uint4 (&v)[4], unsigned char* rm, unsigned char* tr, int w, int l) {
 #pragma unroll
   for (int n = 0; n < 4; ++n) {
     const int c = 4 * w + n;
@@ -89,6 +90,26 @@ __device__ __forceinline__ void stage_block(const unsigned short* base, int64_t 
   }
 }
 
+// the workgroup's own 128 rows, coalesced (16 lanes per 256-byte row): thread t holds chunk t & 15 of rows (t >> 4) + 16 n
+template <int N>
+__device__ __forceinline__ void rows_load(const unsigned short* base, int64_t row_stride, int row0, int T, int t, uint4 (&v)[N]) {
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    const int row = row0 + (t >> 4) + 16 * n;
+    v[n] = row < T ? ld16(base + static_cast<int64_t>(row) * row_stride + 8 * (t & 15)) : make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+template <int N>
+__device__ __forceinline__ void rows_store(const uint4 (&v)[N], unsigned char* rm, int t) {
+#pragma unroll
+  for (int n = 0; n < N; ++n) *reinterpret_cast<uint4*>(rm + ((t >> 4) + 16 * n) * kLRow + 16 * (t & 15)) = v[n];
+}
+// the wave's 32 rows as B operands: lane <-> row, 8 k-steps of 16
+__device__ __forceinline__ void rows_frags(const unsigned char* rm, int tile, int l31, int hi, bf16x8 (&f)[8]) {
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) f[kk] = *reinterpret_cast<const bf16x8*>(rm + (32 * tile + l31) * kLRow + 32 * kk + 16 * hi);
+}
+
 // A operand of a product whose contraction index runs over the ROWS of a 32 x 32 C tile held as the B operand:
 // k-step s, lane half h: rows 16 s + 4 h + {0..3}, then 16 s + 8 + 4 h + {0..3}
 __device__ __forceinline__ bf16x8 ld_tr_frag(const unsigned char* tr, int drow, int r0, int s, int hi) {
@@ -99,25 +120,53 @@ __device__ __forceinline__ bf16x8 ld_tr_frag(const unsigned char* tr, int drow, 
 
 // a wave's [32 rows][128] accumulators held transposed (acc[dblk]: row d = 32 dblk + .., column = lane & 31 <-> the wave's row)
 // -> LDS [128 rows][kLRow] as bf16
-__device__ __forceinline__ void spill_transposed(const f32x16 (&acc)[4], float mul, unsigned char* out, int w, int l31, int hi) {
+template <int ND>
+__device__ __forceinline__ void spill_transposed(const f32x16 (&acc)[ND], int d0, float mul, unsigned char* out, int tile, int l31, int hi) {
 #pragma unroll
-  for (int dblk = 0; dblk < 4; ++dblk)
+  for (int dblk = 0; dblk < ND; ++dblk)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       uint2 pk;
       pk.x = pack_bf16x2(acc[dblk][4 * q] * mul, acc[dblk][4 * q + 1] * mul);
       pk.y = pack_bf16x2(acc[dblk][4 * q + 2] * mul, acc[dblk][4 * q + 3] * mul);
-      *reinterpret_cast<uint2*>(out + (32 * w + l31) * kLRow + 2 * (32 * dblk + 8 * q + 4 * hi)) = pk;
+      *reinterpret_cast<uint2*>(out + (32 * tile + l31) * kLRow + 2 * (32 * (d0 + dblk) + 8 * q + 4 * hi)) = pk;
     }
 }
+template <int N>
 __device__ __forceinline__ void store_rows(const unsigned char* out, unsigned short* dst, int64_t row_stride, int row0, int T, int t) {
 #pragma unroll
-  for (int n = 0; n < 8; ++n) {
-    const int idx = t + 256 * n, row = idx >> 4, c = idx & 15;
+  for (int n = 0; n < N; ++n) {
+    const int row = (t >> 4) + 16 * n, c = t & 15;
     if (row0 + row < T)
       *reinterpret_cast<uint4*>(dst + static_cast<int64_t>(row0 + row) * row_stride + 8 * c) =
-          *reinterpret_cast<const uint4*>(out + row * kLRow + 16 * c);
+          out ? *reinterpret_cast<const uint4*>(out + row * kLRow + 16 * c) : make_uint4(0u, 0u, 0u, 0u);
   }
+}
+
+// launch index -> (row block, head, batch): the row blocks of one (batch, head) - which re-read the same K / V (or Q / dO) - go to
+// the same XCD (launch index mod 8) and sit 8 apart in launch order, so the second one finds the first one's lines in that L2
+__device__ __forceinline__ bool block_coords(const AttnBwdParams& p, int nblk, int& blk, int& h, int& b) {
+  const int n = blockIdx.x, x = n & 7, a = n / (8 * nblk);
+  blk = (n >> 3) % nblk;
+  const int pair = 8 * a + x;
+  if (pair >= p.B * p.H) return false;
+  h = pair % p.H;
+  b = pair / p.H;
+  return true;
+}
+
+// which 32-wide sub-blocks of the other axis have a live tile against this workgroup's NT 32-row tiles: bit jj (T <= 2048)
+template <int NT>
+__device__ __forceinline__ unsigned long long need_mask(const AttnBwdParams& p, int b, int own32, bool own_is_row, int l) {
+  unsigned int v = 0u;
+  if (l < p.W) {
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+      if (own32 + a < p.W)
+        v |= own_is_row ? p.live[(static_cast<int64_t>(b) * p.W + own32 + a) * p.W + l]
+                        : p.live[(static_cast<int64_t>(b) * p.W + l) * p.W + own32 + a];
+  }
+  return __builtin_amdgcn_ballot_w64(v != 0u);
 }
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams p) {
@@ -125,31 +174,52 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams
   unsigned char* Ks = lds;
   unsigned char* Vs = lds + kTile;
   unsigned char* KT = lds + 2 * kTile;
+  float* dl_s = reinterpret_cast<float*>(lds + 128 * kLRow);          // prologue only: [128] D of the workgroup's rows
   const int t = threadIdx.x, w = t >> 6, l = t & 63, l31 = l & 31, hi = l >> 5;
-  const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * 128;
+  int blk, h, b;
+  if (!block_coords(p, (p.T + 127) >> 7, blk, h, b)) return;
+  const int i0 = blk * 128;
   const int i = i0 + 32 * w + l31;
-  const bool iok = i < p.T;
   const int64_t bh = static_cast<int64_t>(b) * p.H + h;
-  const unsigned short* qrow = p.q + b * p.s[0][0] + h * p.s[0][1] + static_cast<int64_t>(i) * p.s[0][2];
-  const unsigned short* orow = p.o + b * p.s[3][0] + h * p.s[3][1] + static_cast<int64_t>(i) * p.s[3][2];
-  const unsigned short* grow = p.d_o + b * p.s[4][0] + h * p.s[4][1] + static_cast<int64_t>(i) * p.s[4][2];
+  unsigned short* dq_base = p.dq + b * p.s[5][0] + h * p.s[5][1];
+  const unsigned long long need = need_mask<4>(p, b, i0 >> 5, true, l);
+  if (need == 0ull) {                                            // padding rows only: zero gradient, nothing to read
+    store_rows<8>(nullptr, dq_base, p.s[5][2], i0, p.T, t);
+    return;
+  }
   const unsigned short* kbase = p.k + b * p.s[1][0] + h * p.s[1][1];
   const unsigned short* vbase = p.v + b * p.s[2][0] + h * p.s[2][1];
 
   bf16x8 Qb[8], Gb[8];
-  float Dl = 0.f;
+  float Dl;
+  {
+    uint4 qv[8], gv[8], ov[8];
+    rows_load(p.q + b * p.s[0][0] + h * p.s[0][1], p.s[0][2], i0, p.T, t, qv);
+    rows_load(p.d_o + b * p.s[4][0] + h * p.s[4][1], p.s[4][2], i0, p.T, t, gv);
+    rows_load(p.o + b * p.s[3][0] + h * p.s[3][1], p.s[3][2], i0, p.T, t, ov);
+    rows_store(qv, lds, t);
 #pragma unroll
-  for (int kk = 0; kk < 8; ++kk) {
-    const int off = 16 * kk + 8 * hi;
-    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-    const uint4 a = iok ? ld16(qrow + off) : z, g = iok ? ld16(grow + off) : z, o = iok ? ld16(orow + off) : z;
-    Qb[kk] = __builtin_bit_cast(bf16x8, a);
-    Gb[kk] = __builtin_bit_cast(bf16x8, g);
-    Dl += dot8(g, o);
+    for (int n = 0; n < 8; ++n) {                                // D = rowsum(dO o O): 16 lanes hold one row
+      float d = dot8(gv[n], ov[n]);
+      d += __shfl_xor(d, 1, 64);
+      d += __shfl_xor(d, 2, 64);
+      d += __shfl_xor(d, 4, 64);
+      d += __shfl_xor(d, 8, 64);
+      const int row = (t >> 4) + 16 * n;
+      if ((t & 15) == 0) {
+        dl_s[row] = d;
+        if (i0 + row < p.T) p.delta[bh * p.T + i0 + row] = d;
+      }
+    }
+    __syncthreads();
+    rows_frags(lds, w, l31, hi, Qb);
+    Dl = dl_s[32 * w + l31];
+    __syncthreads();
+    rows_store(gv, lds, t);
+    __syncthreads();
+    rows_frags(lds, w, l31, hi, Gb);
   }
-  Dl += __shfl_xor(Dl, 32, 64);
-  const float nl = iok ? -p.lse[bh * p.T + i] * kLog2e : 0.f;
-  if (iok && hi == 0) p.delta[bh * p.T + i] = Dl;
+  const float nl = i < p.T ? -p.lse[bh * p.T + i] * kLog2e : 0.f;
   const float c1 = p.scale * kLog2e;
   const int Tp = 32 * p.W;
 
@@ -159,23 +229,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
 
-  const int nJ = (p.T + 63) >> 6, ib32 = i0 >> 5;
-  for (int jb = 0; jb < nJ; ++jb) {
-    int any = 0;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-        if (ib32 + a < p.W && 2 * jb + c < p.W) any |= p.live[(static_cast<int64_t>(b) * p.W + ib32 + a) * p.W + 2 * jb + c];
-    if (!any) continue;                                        // uniform over the workgroup
-    uint32_t word[2];
+  // the live 64-row blocks, one ahead: block n + 1's rows are in flight (registers) while block n is multiplied
+  const int nJ = (p.T + 63) >> 6;
+  unsigned int blocks = 0u;                                    // bit jb: K / V block jb has a live tile (T <= 2048: 32 blocks)
+  for (int jb = 0; jb < nJ; ++jb) blocks |= (((need >> (2 * jb)) & 3ull) != 0ull ? 1u : 0u) << jb;
+  uint32_t nword[2];
+  uint4 kv[4], vv[4];
+  auto fetch = [&](int jb) {
 #pragma unroll
     for (int c = 0; c < 2; ++c)
-      word[c] = (i < Tp && 2 * jb + c < p.W) ? p.bits_rows[(static_cast<int64_t>(b) * Tp + i) * p.W + 2 * jb + c] : 0u;
+      nword[c] = (i < Tp && 2 * jb + c < p.W) ? p.bits_rows[(static_cast<int64_t>(b) * Tp + i) * p.W + 2 * jb + c] : 0u;
+    block_load(kbase, p.s[1][2], 64 * jb, p.T, w, l, kv);
+    block_load(vbase, p.s[2][2], 64 * jb, p.T, w, l, vv);
+  };
+  fetch(__builtin_ctz(blocks));
+  while (blocks) {
+    const int jb = __builtin_ctz(blocks);
+    blocks &= blocks - 1u;
+    uint32_t word[2] = {nword[0], nword[1]};
     __syncthreads();                                           // the previous block's fragments have been read
-    stage_block(kbase, p.s[1][2], 64 * jb, p.T, Ks, KT, w, l);
-    stage_block(vbase, p.s[2][2], 64 * jb, p.T, Vs, nullptr, w, l);
+    block_store(kv, Ks, KT, w, l);
+    block_store(vv, Vs, nullptr, w, l);
     __syncthreads();
+    if (blocks) fetch(__builtin_ctz(blocks));
+    (void)jb;
 #pragma unroll
     for (int js = 0; js < 2; ++js) {
       if (__builtin_amdgcn_ballot_w64(word[js] != 0u) == 0ull) continue;
@@ -211,14 +288,147 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams
     }
   }
   __syncthreads();
-  spill_transposed(acc, p.scale, lds, w, l31, hi);
+  spill_transposed<4>(acc, 0, p.scale, lds, w, l31, hi);
   __syncthreads();
-  store_rows(lds, p.dq + b * p.s[5][0] + h * p.s[5][1], p.s[5][2], i0, p.T, t);
+  store_rows<8>(lds, dq_base, p.s[5][2], i0, p.T, t);
+}
+
+// Forward: O = softmax(scale Q K^T + mask) V and the rows' log-sum-exp (natural log), the dq kernel's structure with the
+// roles turned: S^T tiles [key row (regs), query row (lane)] put a query row's scores into the registers of ONE lane pair
+// (lanes l and l ^ 32), so the running maximum / sum of the online softmax are per-lane scalars and one cross-half exchange per
+// tile; P^T rounded to bf16 is the B operand of O^T[d, i] += V^T[d, j] P^T[j, i] (V^T from a transposed LDS copy).
+// torch's memory-efficient forward takes 115 - 123 us at cfg3 (B 18, H 32, T 256; profiles/r05_step_by_stream.txt).
+// Algorithmic bytes: q, k, v read + o written = 4 B H T hd el (151 MB at cfg3).
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnBwdParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[128 * kLRow];
+  unsigned char* Ks = lds;                                     // [64 key rows][kLRow]
+  unsigned char* VT = lds + kTile;                             // [128 d][kTRow]: V transposed
+  const int t = threadIdx.x, w = t >> 6, l = t & 63, l31 = l & 31, hi = l >> 5;
+  int blk, h, b;
+  if (!block_coords(p, (p.T + 127) >> 7, blk, h, b)) return;
+  const int i0 = blk * 128;
+  const int i = i0 + 32 * w + l31;
+  const int64_t bh = static_cast<int64_t>(b) * p.H + h;
+  unsigned short* o_base = p.dq + b * p.s[5][0] + h * p.s[5][1];          // the output travels in the dq slot
+  float* lse_out = p.delta;                                                // and the log-sum-exp in the delta slot
+  const unsigned long long need = need_mask<4>(p, b, i0 >> 5, true, l);
+  if (need == 0ull) {                                          // rows without a live key: zero output (as torch returns)
+    store_rows<8>(nullptr, o_base, p.s[5][2], i0, p.T, t);
+    if (t < 128 && i0 + t < p.T) lse_out[bh * p.T + i0 + t] = 0.f;
+    return;
+  }
+  const unsigned short* kbase = p.k + b * p.s[1][0] + h * p.s[1][1];
+  const unsigned short* vbase = p.v + b * p.s[2][0] + h * p.s[2][1];
+  const int Tp = 32 * p.W;
+  const int nJ = (p.T + 63) >> 6;
+  unsigned int blocks = 0u;
+  for (int jb = 0; jb < nJ; ++jb) blocks |= (((need >> (2 * jb)) & 3ull) != 0ull ? 1u : 0u) << jb;
+  uint32_t nword[2];
+  uint4 kv[4], vv[4];
+  auto fetch = [&](int jb) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      nword[c] = (i < Tp && 2 * jb + c < p.W) ? p.bits_rows[(static_cast<int64_t>(b) * Tp + i) * p.W + 2 * jb + c] : 0u;
+    block_load(kbase, p.s[1][2], 64 * jb, p.T, w, l, kv);
+    block_load(vbase, p.s[2][2], 64 * jb, p.T, w, l, vv);
+  };
+  fetch(__builtin_ctz(blocks));
+
+  bf16x8 Qb[8];
+  {
+    uint4 qv[8];
+    rows_load<8>(p.q + b * p.s[0][0] + h * p.s[0][1], p.s[0][2], i0, p.T, t, qv);
+    rows_store<8>(qv, lds, t);
+    __syncthreads();
+    rows_frags(lds, w, l31, hi, Qb);
+  }
+  const float c1 = p.scale * kLog2e;
+  f32x16 acc[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+  float m = -INFINITY, lsum = 0.f;                              // running maximum (log2 domain) of the row; this lane's share of the sum
+
+  while (blocks) {
+    blocks &= blocks - 1u;
+    uint32_t word[2] = {nword[0], nword[1]};
+    __syncthreads();                                           // the previous block's (or Q's) fragments have been read
+    block_store(kv, Ks, nullptr, w, l);
+    {                                                          // V: transposed copy only
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const int c = 4 * w + n;
+        const unsigned int q[4] = {vv[n].x, vv[n].y, vv[n].z, vv[n].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          *reinterpret_cast<unsigned short*>(VT + (8 * c + 2 * e) * kTRow + 2 * l) = static_cast<unsigned short>(q[e] & 0xffffu);
+          *reinterpret_cast<unsigned short*>(VT + (8 * c + 2 * e + 1) * kTRow + 2 * l) = static_cast<unsigned short>(q[e] >> 16);
+        }
+      }
+    }
+    __syncthreads();
+    if (blocks) fetch(__builtin_ctz(blocks));
+#pragma unroll
+    for (int js = 0; js < 2; ++js) {
+      if (__builtin_amdgcn_ballot_w64(word[js] != 0u) == 0ull) continue;
+      f32x16 St;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) St[r] = 0.f;
+      const unsigned char* ka = Ks + (32 * js + l31) * kLRow + 16 * hi;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk)
+        St = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(ka + 32 * kk), Qb[kk], St, 0, 0, 0);
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int jl = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        St[r] = ((word[js] >> jl) & 1u) ? St[r] * c1 : -INFINITY;
+        mx = fmaxf(mx, St[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m, mx);
+      const float base = mn == -INFINITY ? 0.f : mn;             // a row with nothing live so far: every p below is exp2(-inf) = 0
+      const float alpha = __builtin_amdgcn_exp2f(m - base);      // m = -inf: 0
+      m = mn;
+      float ps = 0.f;
+      unsigned int pk[8];
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(St[r] - base), p1 = __builtin_amdgcn_exp2f(St[r + 1] - base);
+        ps += p0 + p1;
+        pk[r >> 1] = pack_bf16x2(p0, p1);
+      }
+      lsum = fmaf(lsum, alpha, ps);
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[d][r] *= alpha;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 pb = __builtin_bit_cast(bf16x8, make_uint4(pk[4 * s], pk[4 * s + 1], pk[4 * s + 2], pk[4 * s + 3]));
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+          acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_tr_frag(VT, 32 * d + l31, 32 * js, s, hi), pb, acc[d], 0, 0, 0);
+      }
+    }
+  }
+  const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+  const float inv = ltot > 0.f ? 1.0f / ltot : 0.f;
+  if (hi == 0 && i < p.T) lse_out[bh * p.T + i] = ltot > 0.f ? (m + __builtin_amdgcn_logf(ltot)) * kLn2 : 0.f;
+  __syncthreads();
+  spill_transposed<4>(acc, 0, inv, lds, w, l31, hi);
+  __syncthreads();
+  store_rows<8>(lds, o_base, p.s[5][2], i0, p.T, t);
 }
 
 constexpr int kDkdvLds = 4 * kTile + 2 * 64 * 4;
 
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnBwdParams p) {
+// 64 key rows per workgroup; wave (jt, dh) = (w >> 1, w & 1) computes the S and dP tiles of key tile jt (both waves of a tile
+// do: 16 of the 24 MFMAs per tile and wave) and accumulates dV^T / dK^T for the 64 columns d of half dh only - 64 accumulator
+// registers instead of 128, which is what lets TWO workgroups share a CU (the one-wave-per-SIMD form spent its time waiting:
+// 113 us against 97 us, tools/attn_bench.py)
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dlds[];
   unsigned char* Qs = dlds;
   unsigned char* Gs = dlds + kTile;
@@ -226,53 +436,62 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnBwdPara
   unsigned char* GT = dlds + 3 * kTile;
   float* nl_s = reinterpret_cast<float*>(dlds + 4 * kTile);
   float* dl_s = nl_s + 64;
-  const int t = threadIdx.x, w = t >> 6, l = t & 63, l31 = l & 31, hi = l >> 5;
-  const int b = blockIdx.z, h = blockIdx.y, j0 = blockIdx.x * 128;
-  const int j = j0 + 32 * w + l31;
-  const bool jok = j < p.T;
+  const int t = threadIdx.x, w = t >> 6, l = t & 63, l31 = l & 31, hi = l >> 5, jt = w >> 1, dh = w & 1;
+  int blk, h, b;
+  if (!block_coords(p, (p.T + 63) >> 6, blk, h, b)) return;
+  const int j0 = blk * 64;
+  const int j = j0 + 32 * jt + l31;
   const int64_t bh = static_cast<int64_t>(b) * p.H + h;
-  const unsigned short* krow = p.k + b * p.s[1][0] + h * p.s[1][1] + static_cast<int64_t>(j) * p.s[1][2];
-  const unsigned short* vrow = p.v + b * p.s[2][0] + h * p.s[2][1] + static_cast<int64_t>(j) * p.s[2][2];
+  unsigned short* dk_base = p.dk + b * p.s[6][0] + h * p.s[6][1];
+  unsigned short* dv_base = p.dv + b * p.s[7][0] + h * p.s[7][1];
+  const unsigned long long need = need_mask<2>(p, b, j0 >> 5, false, l);
+  if (need == 0ull) {
+    store_rows<4>(nullptr, dk_base, p.s[6][2], j0, p.T, t);
+    store_rows<4>(nullptr, dv_base, p.s[7][2], j0, p.T, t);
+    return;
+  }
   const unsigned short* qbase = p.q + b * p.s[0][0] + h * p.s[0][1];
   const unsigned short* gbase = p.d_o + b * p.s[4][0] + h * p.s[4][1];
 
   bf16x8 Kb[8], Vb[8];
-#pragma unroll
-  for (int kk = 0; kk < 8; ++kk) {
-    const int off = 16 * kk + 8 * hi;
-    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-    Kb[kk] = __builtin_bit_cast(bf16x8, jok ? ld16(krow + off) : z);
-    Vb[kk] = __builtin_bit_cast(bf16x8, jok ? ld16(vrow + off) : z);
+  {
+    uint4 kv[4], vv[4];
+    rows_load<4>(p.k + b * p.s[1][0] + h * p.s[1][1], p.s[1][2], j0, p.T, t, kv);
+    rows_load<4>(p.v + b * p.s[2][0] + h * p.s[2][1], p.s[2][2], j0, p.T, t, vv);
+    rows_store<4>(kv, dlds, t);
+    rows_store<4>(vv, dlds + kTile, t);
+    __syncthreads();
+    rows_frags(dlds, jt, l31, hi, Kb);
+    rows_frags(dlds + kTile, jt, l31, hi, Vb);
   }
   const float c1 = p.scale * kLog2e;
   const int Tp = 32 * p.W;
-  f32x16 dVt[4], dKt[4];
+  f32x16 dVt[2], dKt[2];
 #pragma unroll
-  for (int d = 0; d < 4; ++d)
+  for (int d = 0; d < 2; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dVt[d][r] = 0.f; dKt[d][r] = 0.f; }
 
-  const int nI = (p.T + 63) >> 6, jb32 = j0 >> 5;
+  // (fetching block n + 1 while block n is multiplied, as the dq kernel does, costs this kernel 23 spilled registers: 91 -> 124 us)
+  const int nI = (p.T + 63) >> 6;
   for (int ib = 0; ib < nI; ++ib) {
-    int any = 0;
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-        if (2 * ib + c < p.W && jb32 + a < p.W) any |= p.live[(static_cast<int64_t>(b) * p.W + 2 * ib + c) * p.W + jb32 + a];
-    if (!any) continue;
+    if (((need >> (2 * ib)) & 3ull) == 0ull) continue;
     uint32_t word[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
       word[c] = (j < Tp && 2 * ib + c < p.W) ? p.bits_cols[(static_cast<int64_t>(b) * Tp + j) * p.W + 2 * ib + c] : 0u;
-    __syncthreads();
-    stage_block(qbase, p.s[0][2], 64 * ib, p.T, Qs, QT, w, l);
-    stage_block(gbase, p.s[4][2], 64 * ib, p.T, Gs, GT, w, l);
-    if (t < 64) {
-      const int i = 64 * ib + t;
-      nl_s[t] = i < p.T ? -p.lse[bh * p.T + i] * kLog2e : 0.f;
-      dl_s[t] = i < p.T ? p.delta[bh * p.T + i] : 0.f;
+    uint4 qv[4], gv[4];
+    block_load(qbase, p.s[0][2], 64 * ib, p.T, w, l, qv);
+    block_load(gbase, p.s[4][2], 64 * ib, p.T, w, l, gv);
+    float nlv = 0.f, dlv = 0.f;
+    if (t < 64 && 64 * ib + t < p.T) {
+      nlv = -p.lse[bh * p.T + 64 * ib + t] * kLog2e;
+      dlv = p.delta[bh * p.T + 64 * ib + t];
     }
+    __syncthreads();
+    block_store(qv, Qs, QT, w, l);
+    block_store(gv, Gs, GT, w, l);
+    if (t < 64) { nl_s[t] = nlv; dl_s[t] = dlv; }
     __syncthreads();
 #pragma unroll
     for (int is = 0; is < 2; ++is) {
@@ -310,21 +529,20 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnBwdPara
         const bf16x8 pb = __builtin_bit_cast(bf16x8, make_uint4(ppk[4 * s], ppk[4 * s + 1], ppk[4 * s + 2], ppk[4 * s + 3]));
         const bf16x8 db = __builtin_bit_cast(bf16x8, make_uint4(dpk[4 * s], dpk[4 * s + 1], dpk[4 * s + 2], dpk[4 * s + 3]));
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          dVt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_tr_frag(GT, 32 * d + l31, 32 * is, s, hi), pb, dVt[d], 0, 0, 0);
-          dKt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_tr_frag(QT, 32 * d + l31, 32 * is, s, hi), db, dKt[d], 0, 0, 0);
+        for (int d = 0; d < 2; ++d) {
+          const int drow = 32 * (2 * dh + d) + l31;
+          dVt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_tr_frag(GT, drow, 32 * is, s, hi), pb, dVt[d], 0, 0, 0);
+          dKt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_tr_frag(QT, drow, 32 * is, s, hi), db, dKt[d], 0, 0, 0);
         }
       }
     }
   }
   __syncthreads();
-  spill_transposed(dKt, p.scale, dlds, w, l31, hi);
+  spill_transposed<2>(dKt, 2 * dh, p.scale, dlds, jt, l31, hi);
+  spill_transposed<2>(dVt, 2 * dh, 1.0f, dlds + kTile, jt, l31, hi);
   __syncthreads();
-  store_rows(dlds, p.dk + b * p.s[6][0] + h * p.s[6][1], p.s[6][2], j0, p.T, t);
-  __syncthreads();
-  spill_transposed(dVt, 1.0f, dlds, w, l31, hi);
-  __syncthreads();
-  store_rows(dlds, p.dv + b * p.s[7][0] + h * p.s[7][1], p.s[7][2], j0, p.T, t);
+  store_rows<4>(dlds, dk_base, p.s[6][2], j0, p.T, t);
+  store_rows<4>(dlds + kTile, dv_base, p.s[7][2], j0, p.T, t);
 }
 
 // mask [B, 1, T, T] bytes (non-zero = attend; NULL = all) and / or causal -> row words, column words, live 32 x 32 tiles
@@ -380,7 +598,7 @@ extern "C" int dalm_attn_bwd(const void* q, const void* k, const void* v, const 
   DALM_REQUIRE(q && k && v && o && d_o && lse && bits_rows && bits_cols && live && strides && dq && dk && dv && delta, DALM_E_NULL,
                "null pointer argument");
   DALM_REQUIRE(hd == kHd, DALM_E_SHAPE, "head width must be 128");
-  DALM_REQUIRE(B > 0 && H > 0 && T > 0 && T <= 32768 && B <= 65535 && H <= 65535, DALM_E_SHAPE, "need 0 < T <= 32768, 0 < B, H <= 65535");
+  DALM_REQUIRE(B > 0 && H > 0 && T > 0 && T <= 2048 && B * H <= (1ll << 24), DALM_E_SHAPE, "need 0 < T <= 2048 and B H <= 2^24");
   const void* ptrs[8] = {q, k, v, o, d_o, dq, dk, dv};
   for (int i = 0; i < 8; ++i) {
     DALM_REQUIRE(al16(ptrs[i]), DALM_E_ALIGN, "tensors must be 16-byte aligned");
@@ -405,9 +623,38 @@ extern "C" int dalm_attn_bwd(const void* q, const void* k, const void* v, const 
       return fail(static_cast<int>(e), __func__, "could not raise the dynamic LDS limit of the dk / dv kernel");
     lds_set = true;
   }
-  const dim3 grid(static_cast<unsigned>((T + 127) / 128), static_cast<unsigned>(H), static_cast<unsigned>(B));
+  const int64_t pairs8 = (B * H + 7) / 8 * 8;
+  const dim3 grid_dq(static_cast<unsigned>(pairs8 * ((T + 127) / 128))), grid_dkdv(static_cast<unsigned>(pairs8 * ((T + 63) / 64)));
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, p);
-  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), kDkdvLds, s, p);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid_dq, dim3(256), 0, s, p);
+  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid_dkdv, dim3(256), kDkdvLds, s, p);
+  return check_launch(__func__);
+}
+
+extern "C" int dalm_attn_fwd(const void* q, const void* k, const void* v, const uint32_t* bits_rows, const uint8_t* live, int64_t B,
+                             int64_t H, int64_t T, int64_t hd, float scale, const int64_t* strides, void* o, float* lse,
+                             dalm_stream_t stream) {
+  DALM_REQUIRE(q && k && v && bits_rows && live && strides && o && lse, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(hd == kHd, DALM_E_SHAPE, "head width must be 128");
+  DALM_REQUIRE(B > 0 && H > 0 && T > 0 && T <= 2048 && B * H <= (1ll << 24), DALM_E_SHAPE, "need 0 < T <= 2048 and B H <= 2^24");
+  const void* ptrs[4] = {q, k, v, o};
+  for (int i = 0; i < 4; ++i) {
+    DALM_REQUIRE(al16(ptrs[i]), DALM_E_ALIGN, "tensors must be 16-byte aligned");
+    for (int a = 0; a < 3; ++a)
+      DALM_REQUIRE(strides[3 * i + a] >= 0 && strides[3 * i + a] % 8 == 0, DALM_E_ALIGN, "strides must be non-negative multiples of 8 elements");
+  }
+  AttnBwdParams p = {};
+  p.q = static_cast<const unsigned short*>(q); p.k = static_cast<const unsigned short*>(k);
+  p.v = static_cast<const unsigned short*>(v);
+  p.bits_rows = bits_rows; p.live = live;
+  p.dq = static_cast<unsigned short*>(o);
+  p.delta = lse;
+  p.B = static_cast<int>(B); p.H = static_cast<int>(H); p.T = static_cast<int>(T); p.W = static_cast<int>((T + 31) / 32);
+  p.scale = scale;
+  for (int a = 0; a < 3; ++a) {
+    p.s[0][a] = strides[a]; p.s[1][a] = strides[3 + a]; p.s[2][a] = strides[6 + a]; p.s[5][a] = strides[9 + a];
+  }
+  const int64_t pairs8 = (B * H + 7) / 8 * 8;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(static_cast<unsigned>(pairs8 * ((T + 127) / 128))), dim3(256), 0, as_stream(stream), p);
   return check_launch(__func__);
 }

@@ -7,10 +7,11 @@ transformers evaluates a decoder layer's attention through `sdpa_attention_forwa
 (dalm/training/rag_e2e/train_rage2e.py:466).  With HF's boolean mask (causal + left padding) torch runs its memory-efficient
 kernels: 60 us forward, 440 us backward per layer at cfg3 (2.7 % of the MFMA peak).  Here
 
-  forward   torch's own memory-efficient kernel, called as the aten op so that its log-sum-exp comes back
-            (`aten::_scaled_dot_product_efficient_attention`; same values as F.scaled_dot_product_attention, bit for bit);
-  backward  `dalm_attn_bwd`: the mask read as packed bits (packed once per mask tensor - every layer passes the same one),
-            dead 32 x 32 tiles skipped, two launches.
+  forward   `dalm_attn_fwd` (one launch, online softmax, writes the rows' log-sum-exp);  DALM_ATTN_FWD_KERNEL=0: torch's own
+            memory-efficient kernel called as the aten op so that its log-sum-exp comes back
+            (`aten::_scaled_dot_product_efficient_attention`, the values of F.scaled_dot_product_attention bit for bit);
+  backward  `dalm_attn_bwd`: two launches.
+Both read the mask as packed bits (packed once per mask tensor - every layer passes the same one) and skip dead 32 x 32 tiles.
 
 Everything the kernels do not take (CPU tensors, other head widths, dropout, float masks, a KV cache, no gradient wanted) goes
 to transformers' own `sdpa_attention_forward`, unchanged.  DALM_ATTN_KERNEL=0 keeps the model on "sdpa".
@@ -50,21 +51,29 @@ def _pack(mask: Optional[torch.Tensor], B: int, H: int, T: int, causal: bool, dt
     pk.rows = torch.empty(B * 32 * W * W, dtype=torch.int32, device=device)
     pk.cols = torch.empty_like(pk.rows)
     pk.live = torch.empty(B * W * W, dtype=torch.uint8, device=device)
+    pk.bias = None
     if mask is None:
-        pk.bias = None
         hip.call("dalm_attn_mask_bits", None, B, T, 0, 0, 1, hip.ptr(pk.rows), hip.ptr(pk.cols), hip.ptr(pk.live), hip.stream())
     else:
         m = mask if mask.stride(-1) == 1 else mask.contiguous()
-        # torch's own conversion of a boolean mask (aten convert_boolean_attn_mask): 0 where attended, -inf elsewhere; the last
-        # dimension's allocation padded to a multiple of 8 elements as the memory-efficient kernel wants its bias aligned
-        Ta = (T + 7) // 8 * 8
-        bias = torch.zeros(B, 1, T, Ta, dtype=dtype, device=device)[..., :T]
-        bias.masked_fill_(m.logical_not(), float("-inf"))
-        pk.bias = bias.expand(B, H, T, T)
         hip.call("dalm_attn_mask_bits", hip.ptr(m), B, T, m.stride(0), m.stride(2), int(causal), hip.ptr(pk.rows), hip.ptr(pk.cols),
                  hip.ptr(pk.live), hip.stream())
     _last[0] = pk
     return pk
+
+
+def _torch_bias(pk: _MaskPack, B: int, H: int, T: int, dtype, device):
+    """torch's own conversion of a boolean mask (aten convert_boolean_attn_mask): 0 where attended, -inf elsewhere; the last
+    dimension's allocation padded to a multiple of 8 elements as its memory-efficient kernel wants the bias aligned."""
+    if pk.mask is None:
+        return None
+    if pk.bias is None:
+        m = pk.mask
+        Ta = (T + 7) // 8 * 8
+        bias = torch.zeros(B, 1, T, Ta, dtype=dtype, device=device)[..., :T]
+        bias.masked_fill_(m.logical_not(), float("-inf"))
+        pk.bias = bias.expand(B, H, T, T)
+    return pk.bias
 
 
 def _strides3(t: torch.Tensor):
@@ -83,7 +92,17 @@ class _SdpaHipBackward(torch.autograd.Function):
     def forward(ctx, q, k, v, mask, scale, causal):
         B, H, T, hd = q.shape
         pk = _pack(mask, B, H, T, causal, q.dtype, q.device)
-        out, lse, _, _ = torch.ops.aten._scaled_dot_product_efficient_attention(q, k, v, pk.bias, True, 0.0, causal, scale=scale)
+        if os.environ.get("DALM_ATTN_FWD_KERNEL", "1") == "0":         # torch's memory-efficient forward + its log-sum-exp
+            out, lse, _, _ = torch.ops.aten._scaled_dot_product_efficient_attention(
+                q, k, v, _torch_bias(pk, B, H, T, q.dtype, q.device), True, 0.0, causal, scale=scale)
+        else:
+            out = torch.empty(B, T, H, hd, dtype=q.dtype, device=q.device).transpose(1, 2)   # torch's layout: the caller's
+            lse = torch.empty(B, H, T, dtype=torch.float32, device=q.device)                  # transpose(1, 2).contiguous() is free
+            flat = []
+            for t in (q, k, v, out):
+                flat += _strides3(t)
+            hip.call("dalm_attn_fwd", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(pk.rows), hip.ptr(pk.live), B, H, T, hd, float(scale),
+                     (C.c_int64 * 12)(*flat), hip.ptr(out), hip.ptr(lse), hip.stream())
         ctx.save_for_backward(q, k, v, out, lse)
         ctx.pack, ctx.scale = pk, scale
         return out
@@ -117,7 +136,7 @@ def supported(query, key, value, mask, dropout, causal, kwargs) -> bool:
         return False
     if query.dim() != 4 or query.shape[-1] != _HEAD_DIM or key.shape != query.shape or value.shape != query.shape:
         return False                                 # a KV cache (kv length != q length) or grouped heads left unexpanded
-    if query.shape[2] < 2 or dropout != 0.0 or kwargs.get("position_bias") is not None:
+    if query.shape[2] < 2 or query.shape[2] > 2048 or dropout != 0.0 or kwargs.get("position_bias") is not None:
         return False
     if not (torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad)):
         return False                                 # nothing to differentiate: torch's fused forward alone is the best path

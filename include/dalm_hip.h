@@ -467,6 +467,10 @@ int dalm_add3(const void* a, const void* b, const void* c, void* out, int64_t n,
  *        memory-efficient forward returns) -> dq, dk, dv.  strides: 8 x (batch, head, row) ELEMENT strides of
  *        q, k, v, o, d_o, dq, dk, dv (last dimension contiguous, multiples of 8); delta: [B, H, T] f32 scratch
  *        (D = rowsum(dO o O)).  P and dS are rounded to bf16 for their products, sums in f32. */
+/*   dalm_attn_fwd: o = softmax(scale q k^T + mask) v and lse [B, H, T] f32 (natural log; 0 for rows without a live key, whose
+ *        output is 0).  strides: 4 x (batch, head, row) element strides of q, k, v, o. */
+int dalm_attn_fwd(const void* q, const void* k, const void* v, const uint32_t* bits_rows, const uint8_t* live, int64_t B, int64_t H,
+                  int64_t T, int64_t hd, float scale, const int64_t* strides, void* o, float* lse, dalm_stream_t stream);
 int dalm_attn_mask_bits(const void* mask, int64_t B, int64_t T, int64_t mask_stride_b, int64_t mask_stride_row, int causal,
                         uint32_t* bits_rows, uint32_t* bits_cols, uint8_t* live, dalm_stream_t stream);
 int dalm_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,

@@ -3,13 +3,15 @@
 sdpa_attention_forward calls it (the reference reaches it through self.generator_model(...),
 dalm/models/rag_e2e_base_model.py:104-106, and differentiates it in loss.backward(), train_rage2e.py:466):
 
-* forward: EQUAL to F.scaled_dot_product_attention (it is torch's own kernel);
+* forward (`dalm_attn_fwd`): against a float64 evaluation, no further from it than torch's kernel is (x 1.5 + 1e-3); with
+  DALM_ATTN_FWD_KERNEL=0 (torch's kernel called for its log-sum-exp) EQUAL to F.scaled_dot_product_attention;
 * backward: dq, dk, dv against a float64 evaluation of the same masked softmax attention, no further from it than
   torch's own bf16 backward is (x 1.5 + 1e-3), for HF's causal + left-padding masks, ragged lengths, rows with no live
   key, the pure causal case without a mask, arbitrary boolean masks, transposed ([B, T, H, hd] memory) and contiguous views;
 * the mask bit words against a numpy packing;
 * a Llama layer on "dalm_sdpa" against the same layer on "sdpa": logits and LoRA-free parameter gradients."""
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -90,7 +92,17 @@ def test_backward_vs_fp64_and_torch(dev, B, H, T, starts, layout):
     theirs = _run(lambda a, b, c: torch.nn.functional.scaled_dot_product_attention(a, b, c, attn_mask=mask, is_causal=causal,
                                                                                     scale=scale), q, k, v, go)
     ref = _ref64(q, k, v, mask, causal, scale, go)
-    assert torch.equal(ours[0], theirs[0])
+    assert torch.isfinite(ours[0]).all()
+    assert _rel(ours[0], ref[0]) <= 1.5 * _rel(theirs[0], ref[0]) + 1e-3
+    assert ours[0].stride() == theirs[0].stride()
+    os.environ["DALM_ATTN_FWD_KERNEL"] = "0"
+    try:
+        lib = _run(lambda a, b, c: attention._SdpaHipBackward.apply(a, b, c, mask, scale, causal), q, k, v, go)
+    finally:
+        os.environ.pop("DALM_ATTN_FWD_KERNEL", None)
+    assert torch.equal(lib[0], theirs[0])
+    for a, r in zip(lib[1:], ref[1:]):
+        assert _rel(a, r) < 2e-2
     for name, a, b, r in zip(("dq", "dk", "dv"), ours[1:], theirs[1:], ref[1:]):
         assert torch.isfinite(a).all(), name
         e_a, e_b = _rel(a, r), _rel(b, r)
@@ -99,6 +111,7 @@ def test_backward_vs_fp64_and_torch(dev, B, H, T, starts, layout):
     if starts is not None:                                   # query rows in the padding have no live key: exactly zero dq
         for b_, st in enumerate(starts):
             if st > 0:
+                assert float(ours[0][b_, :, :st].abs().max()) == 0.0
                 assert float(ours[1][b_, :, :st].abs().max()) == 0.0
                 assert float(ours[2][b_, :, :st].abs().max()) == 0.0 and float(ours[3][b_, :, :st].abs().max()) == 0.0
 
@@ -117,8 +130,7 @@ def test_arbitrary_boolean_mask(dev):
     ours = _run(lambda a, b, c: attention._SdpaHipBackward.apply(a, b, c, mask, scale, False), q, k, v, go)
     theirs = _run(lambda a, b, c: torch.nn.functional.scaled_dot_product_attention(a, b, c, attn_mask=mask, scale=scale), q, k, v, go)
     ref = _ref64(q, k, v, mask, False, scale, go)
-    assert torch.equal(ours[0], theirs[0])
-    for a, b, r in zip(ours[1:], theirs[1:], ref[1:]):
+    for a, b, r in zip(ours, theirs, ref):
         assert _rel(a, r) <= 1.5 * _rel(b, r) + 1e-3
 
 
@@ -174,9 +186,9 @@ def test_llama_layer_on_dalm_sdpa_matches_sdpa(dev):
         (logits.float() * am[..., None]).square().sum().backward()
         outs.append((logits.detach(), [p.grad.detach().clone() for p in m.parameters()]))
     live = am.bool()
-    assert torch.equal(outs[0][0][live], outs[1][0][live])
+    assert _rel(outs[1][0][live], outs[0][0][live]) < 1e-2
     for a, b in zip(outs[1][1], outs[0][1]):
         assert _rel(a, b) < 2e-2
-    # no gradient wanted: transformers' own path (and the same values)
+    # no gradient wanted: transformers' own path, torch's kernel, the same values as the "sdpa" model
     with torch.no_grad():
-        assert torch.equal(new(input_ids=ids, attention_mask=am).logits[live], outs[0][0][live])
+        assert torch.equal(new(input_ids=ids, attention_mask=am).logits[live], ref(input_ids=ids, attention_mask=am).logits[live])
