@@ -35,10 +35,20 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kHd = 128;
-constexpr int kLRow = 2 * kHd + 16;      // bytes of a [row][128] LDS row (16 bytes of padding: conflict-free 16-byte reads)
 constexpr int kTRow = 2 * 64 + 8;        // bytes of a [d][64 rows] transposed LDS row (8-byte reads stay aligned and spread)
-constexpr int kTile = 64 * kLRow;        // 17408 = 128 * kTRow as well
+template <int HD>
+struct AT {                              // head width 128 (Llama-2-7b) or 64 (Falcon-7b)
+  static constexpr int LROW = 2 * HD + 16;   // bytes of a [row][HD] LDS row (16 bytes of padding: conflict-free 16-byte reads)
+  static constexpr int KK = HD / 16;         // k-steps of a contraction over d
+  static constexpr int ND = HD / 32;         // 32-column blocks of d
+  static constexpr int CH = HD / 8;          // 16-byte chunks per row
+  static constexpr int NCW = CH / 4;         // chunks a wave stages per row of a 64-row block
+  static constexpr int RM = 64 * LROW;       // a 64-row block, row-major
+  static constexpr int TR = HD * kTRow;      // the same block transposed
+  static constexpr int N128 = CH / 2;        // 16-byte pieces a thread holds of the workgroup's own 128 rows ...
+  static constexpr int N64 = CH / 4;         // ... of its own 64 rows
+  static constexpr int OCC = HD == 128 ? 2 : 3;
+};
 
 struct AttnBwdParams {
   const unsigned short *q, *k, *v, *o, *d_o;
@@ -65,20 +75,23 @@ __device__ __forceinline__ float dot8(const uint4& a, const uint4& b) {
 }
 
 // one 64-row block of a [rows][128] bf16 tensor -> registers (lane <-> row, wave w takes the 16-byte chunks 4 w .. 4 w + 3) ...
-__device__ __forceinline__ void block_load(const unsigned short* base, int64_t row_stride, int row0, int T, int w, int l, uint4 (&v)[4]) {
+template <int HD>
+__device__ __forceinline__ void block_load(const unsigned short* base, int64_t row_stride, int row0, int T, int w, int l,
+                                           uint4 (&v)[AT<HD>::NCW]) {
   const int row = row0 + l;
   const bool ok = row < T;
   const unsigned short* src = base + static_cast<int64_t>(row) * row_stride;
 #pragma unroll
-  for (int n = 0; n < 4; ++n) v[n] = ok ? ld16(src + 8 * (4 * w + n)) : make_uint4(0u, 0u, 0u, 0u);
+  for (int n = 0; n < AT<HD>::NCW; ++n) v[n] = ok ? ld16(src + 8 * (AT<HD>::NCW * w + n)) : make_uint4(0u, 0u, 0u, 0u);
 }
 // ... -> LDS, row-major (`rm`) and, when `tr` is given, transposed ([d][row]: the 2-byte stores of a wave are one contiguous
 // 128-byte run)
-__device__ __forceinline__ void block_store(const uint4 (&v)[4], unsigned char* rm, unsigned char* tr, int w, int l) {
+template <int HD>
+__device__ __forceinline__ void block_store(const uint4 (&v)[AT<HD>::NCW], unsigned char* rm, unsigned char* tr, int w, int l) {
 #pragma unroll
-  for (int n = 0; n < 4; ++n) {
-    const int c = 4 * w + n;
-    *reinterpret_cast<uint4*>(rm + l * kLRow + 16 * c) = v[n];
+  for (int n = 0; n < AT<HD>::NCW; ++n) {
+    const int c = AT<HD>::NCW * w + n;
+    if (rm) *reinterpret_cast<uint4*>(rm + l * AT<HD>::LROW + 16 * c) = v[n];
     if (tr) {
       const unsigned int q[4] = {v[n].x, v[n].y, v[n].z, v[n].w};
 #pragma unroll
@@ -90,24 +103,28 @@ __device__ __forceinline__ void block_store(const uint4 (&v)[4], unsigned char* 
   }
 }
 
-// the workgroup's own 128 rows, coalesced (16 lanes per 256-byte row): thread t holds chunk t & 15 of rows (t >> 4) + 16 n
-template <int N>
+// the workgroup's own rows, coalesced (HD / 8 lanes per row): thread t holds chunk t % CH of rows t / CH + (256 / CH) n
+template <int HD, int N>
 __device__ __forceinline__ void rows_load(const unsigned short* base, int64_t row_stride, int row0, int T, int t, uint4 (&v)[N]) {
+  constexpr int CH = AT<HD>::CH;
 #pragma unroll
   for (int n = 0; n < N; ++n) {
-    const int row = row0 + (t >> 4) + 16 * n;
-    v[n] = row < T ? ld16(base + static_cast<int64_t>(row) * row_stride + 8 * (t & 15)) : make_uint4(0u, 0u, 0u, 0u);
+    const int row = row0 + t / CH + (256 / CH) * n;
+    v[n] = row < T ? ld16(base + static_cast<int64_t>(row) * row_stride + 8 * (t % CH)) : make_uint4(0u, 0u, 0u, 0u);
   }
 }
-template <int N>
+template <int HD, int N>
 __device__ __forceinline__ void rows_store(const uint4 (&v)[N], unsigned char* rm, int t) {
+  constexpr int CH = AT<HD>::CH;
 #pragma unroll
-  for (int n = 0; n < N; ++n) *reinterpret_cast<uint4*>(rm + ((t >> 4) + 16 * n) * kLRow + 16 * (t & 15)) = v[n];
+  for (int n = 0; n < N; ++n) *reinterpret_cast<uint4*>(rm + (t / CH + (256 / CH) * n) * AT<HD>::LROW + 16 * (t % CH)) = v[n];
 }
-// the wave's 32 rows as B operands: lane <-> row, 8 k-steps of 16
-__device__ __forceinline__ void rows_frags(const unsigned char* rm, int tile, int l31, int hi, bf16x8 (&f)[8]) {
+// the wave's 32 rows as B operands: lane <-> row, HD / 16 k-steps of 16
+template <int HD>
+__device__ __forceinline__ void rows_frags(const unsigned char* rm, int tile, int l31, int hi, bf16x8 (&f)[AT<HD>::KK]) {
 #pragma unroll
-  for (int kk = 0; kk < 8; ++kk) f[kk] = *reinterpret_cast<const bf16x8*>(rm + (32 * tile + l31) * kLRow + 32 * kk + 16 * hi);
+  for (int kk = 0; kk < AT<HD>::KK; ++kk)
+    f[kk] = *reinterpret_cast<const bf16x8*>(rm + (32 * tile + l31) * AT<HD>::LROW + 32 * kk + 16 * hi);
 }
 
 // A operand of a product whose contraction index runs over the ROWS of a 32 x 32 C tile held as the B operand:
@@ -119,8 +136,8 @@ __device__ __forceinline__ bf16x8 ld_tr_frag(const unsigned char* tr, int drow, 
 }
 
 // a wave's [32 rows][128] accumulators held transposed (acc[dblk]: row d = 32 dblk + .., column = lane & 31 <-> the wave's row)
-// -> LDS [128 rows][kLRow] as bf16
-template <int ND>
+// -> LDS [rows][LROW] as bf16
+template <int HD, int ND>
 __device__ __forceinline__ void spill_transposed(const f32x16 (&acc)[ND], int d0, float mul, unsigned char* out, int tile, int l31, int hi) {
 #pragma unroll
   for (int dblk = 0; dblk < ND; ++dblk)
@@ -129,17 +146,18 @@ __device__ __forceinline__ void spill_transposed(const f32x16 (&acc)[ND], int d0
       uint2 pk;
       pk.x = pack_bf16x2(acc[dblk][4 * q] * mul, acc[dblk][4 * q + 1] * mul);
       pk.y = pack_bf16x2(acc[dblk][4 * q + 2] * mul, acc[dblk][4 * q + 3] * mul);
-      *reinterpret_cast<uint2*>(out + (32 * tile + l31) * kLRow + 2 * (32 * (d0 + dblk) + 8 * q + 4 * hi)) = pk;
+      *reinterpret_cast<uint2*>(out + (32 * tile + l31) * AT<HD>::LROW + 2 * (32 * (d0 + dblk) + 8 * q + 4 * hi)) = pk;
     }
 }
-template <int N>
+template <int HD, int N>
 __device__ __forceinline__ void store_rows(const unsigned char* out, unsigned short* dst, int64_t row_stride, int row0, int T, int t) {
+  constexpr int CH = AT<HD>::CH;
 #pragma unroll
   for (int n = 0; n < N; ++n) {
-    const int row = (t >> 4) + 16 * n, c = t & 15;
+    const int row = t / CH + (256 / CH) * n, c = t % CH;
     if (row0 + row < T)
       *reinterpret_cast<uint4*>(dst + static_cast<int64_t>(row0 + row) * row_stride + 8 * c) =
-          out ? *reinterpret_cast<const uint4*>(out + row * kLRow + 16 * c) : make_uint4(0u, 0u, 0u, 0u);
+          out ? *reinterpret_cast<const uint4*>(out + row * AT<HD>::LROW + 16 * c) : make_uint4(0u, 0u, 0u, 0u);
   }
 }
 
@@ -169,12 +187,15 @@ __device__ __forceinline__ unsigned long long need_mask(const AttnBwdParams& p, 
   return __builtin_amdgcn_ballot_w64(v != 0u);
 }
 
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[3 * kTile];
+template <int HD>
+__global__ __launch_bounds__(256, AT<HD>::OCC) void attn_bwd_dq_kernel(const AttnBwdParams p) {
+  using A = AT<HD>;
+  constexpr int LDS = (2 * A::RM + A::TR) > (128 * A::LROW + 512) ? (2 * A::RM + A::TR) : (128 * A::LROW + 512);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS];
   unsigned char* Ks = lds;
-  unsigned char* Vs = lds + kTile;
-  unsigned char* KT = lds + 2 * kTile;
-  float* dl_s = reinterpret_cast<float*>(lds + 128 * kLRow);          // prologue only: [128] D of the workgroup's rows
+  unsigned char* Vs = lds + A::RM;
+  unsigned char* KT = lds + 2 * A::RM;
+  float* dl_s = reinterpret_cast<float*>(lds + 128 * A::LROW);          // prologue only: [128] D of the workgroup's rows
   const int t = threadIdx.x, w = t >> 6, l = t & 63, l31 = l & 31, hi = l >> 5;
   int blk, h, b;
   if (!block_coords(p, (p.T + 127) >> 7, blk, h, b)) return;
@@ -184,48 +205,46 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams
   unsigned short* dq_base = p.dq + b * p.s[5][0] + h * p.s[5][1];
   const unsigned long long need = need_mask<4>(p, b, i0 >> 5, true, l);
   if (need == 0ull) {                                            // padding rows only: zero gradient, nothing to read
-    store_rows<8>(nullptr, dq_base, p.s[5][2], i0, p.T, t);
+    store_rows<HD, A::N128>(nullptr, dq_base, p.s[5][2], i0, p.T, t);
     return;
   }
   const unsigned short* kbase = p.k + b * p.s[1][0] + h * p.s[1][1];
   const unsigned short* vbase = p.v + b * p.s[2][0] + h * p.s[2][1];
 
-  bf16x8 Qb[8], Gb[8];
+  bf16x8 Qb[A::KK], Gb[A::KK];
   float Dl;
   {
-    uint4 qv[8], gv[8], ov[8];
-    rows_load(p.q + b * p.s[0][0] + h * p.s[0][1], p.s[0][2], i0, p.T, t, qv);
-    rows_load(p.d_o + b * p.s[4][0] + h * p.s[4][1], p.s[4][2], i0, p.T, t, gv);
-    rows_load(p.o + b * p.s[3][0] + h * p.s[3][1], p.s[3][2], i0, p.T, t, ov);
-    rows_store(qv, lds, t);
+    uint4 qv[A::N128], gv[A::N128], ov[A::N128];
+    rows_load<HD, A::N128>(p.q + b * p.s[0][0] + h * p.s[0][1], p.s[0][2], i0, p.T, t, qv);
+    rows_load<HD, A::N128>(p.d_o + b * p.s[4][0] + h * p.s[4][1], p.s[4][2], i0, p.T, t, gv);
+    rows_load<HD, A::N128>(p.o + b * p.s[3][0] + h * p.s[3][1], p.s[3][2], i0, p.T, t, ov);
+    rows_store<HD, A::N128>(qv, lds, t);
 #pragma unroll
-    for (int n = 0; n < 8; ++n) {                                // D = rowsum(dO o O): 16 lanes hold one row
+    for (int n = 0; n < A::N128; ++n) {                          // D = rowsum(dO o O): HD / 8 consecutive lanes hold one row
       float d = dot8(gv[n], ov[n]);
-      d += __shfl_xor(d, 1, 64);
-      d += __shfl_xor(d, 2, 64);
-      d += __shfl_xor(d, 4, 64);
-      d += __shfl_xor(d, 8, 64);
-      const int row = (t >> 4) + 16 * n;
-      if ((t & 15) == 0) {
+#pragma unroll
+      for (int off = 1; off < A::CH; off <<= 1) d += __shfl_xor(d, off, 64);
+      const int row = t / A::CH + (256 / A::CH) * n;
+      if (t % A::CH == 0) {
         dl_s[row] = d;
         if (i0 + row < p.T) p.delta[bh * p.T + i0 + row] = d;
       }
     }
     __syncthreads();
-    rows_frags(lds, w, l31, hi, Qb);
+    rows_frags<HD>(lds, w, l31, hi, Qb);
     Dl = dl_s[32 * w + l31];
     __syncthreads();
-    rows_store(gv, lds, t);
+    rows_store<HD, A::N128>(gv, lds, t);
     __syncthreads();
-    rows_frags(lds, w, l31, hi, Gb);
+    rows_frags<HD>(lds, w, l31, hi, Gb);
   }
   const float nl = i < p.T ? -p.lse[bh * p.T + i] * kLog2e : 0.f;
   const float c1 = p.scale * kLog2e;
   const int Tp = 32 * p.W;
 
-  f32x16 acc[4];
+  f32x16 acc[A::ND];
 #pragma unroll
-  for (int d = 0; d < 4; ++d)
+  for (int d = 0; d < A::ND; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
 
@@ -234,35 +253,33 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams
   unsigned int blocks = 0u;                                    // bit jb: K / V block jb has a live tile (T <= 2048: 32 blocks)
   for (int jb = 0; jb < nJ; ++jb) blocks |= (((need >> (2 * jb)) & 3ull) != 0ull ? 1u : 0u) << jb;
   uint32_t nword[2];
-  uint4 kv[4], vv[4];
+  uint4 kv[A::NCW], vv[A::NCW];
   auto fetch = [&](int jb) {
 #pragma unroll
     for (int c = 0; c < 2; ++c)
       nword[c] = (i < Tp && 2 * jb + c < p.W) ? p.bits_rows[(static_cast<int64_t>(b) * Tp + i) * p.W + 2 * jb + c] : 0u;
-    block_load(kbase, p.s[1][2], 64 * jb, p.T, w, l, kv);
-    block_load(vbase, p.s[2][2], 64 * jb, p.T, w, l, vv);
+    block_load<HD>(kbase, p.s[1][2], 64 * jb, p.T, w, l, kv);
+    block_load<HD>(vbase, p.s[2][2], 64 * jb, p.T, w, l, vv);
   };
   fetch(__builtin_ctz(blocks));
   while (blocks) {
-    const int jb = __builtin_ctz(blocks);
     blocks &= blocks - 1u;
     uint32_t word[2] = {nword[0], nword[1]};
     __syncthreads();                                           // the previous block's fragments have been read
-    block_store(kv, Ks, KT, w, l);
-    block_store(vv, Vs, nullptr, w, l);
+    block_store<HD>(kv, Ks, KT, w, l);
+    block_store<HD>(vv, Vs, nullptr, w, l);
     __syncthreads();
     if (blocks) fetch(__builtin_ctz(blocks));
-    (void)jb;
 #pragma unroll
     for (int js = 0; js < 2; ++js) {
       if (__builtin_amdgcn_ballot_w64(word[js] != 0u) == 0ull) continue;
       f32x16 St, Pt;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { St[r] = 0.f; Pt[r] = 0.f; }
-      const unsigned char* ka = Ks + (32 * js + l31) * kLRow + 16 * hi;
-      const unsigned char* va = Vs + (32 * js + l31) * kLRow + 16 * hi;
+      const unsigned char* ka = Ks + (32 * js + l31) * A::LROW + 16 * hi;
+      const unsigned char* va = Vs + (32 * js + l31) * A::LROW + 16 * hi;
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
+      for (int kk = 0; kk < A::KK; ++kk) {
         St = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(ka + 32 * kk), Qb[kk], St, 0, 0, 0);
         Pt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(va + 32 * kk), Gb[kk], Pt, 0, 0, 0);
       }
@@ -282,15 +299,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams
       for (int s = 0; s < 2; ++s) {
         const bf16x8 dsb = __builtin_bit_cast(bf16x8, make_uint4(pk[4 * s], pk[4 * s + 1], pk[4 * s + 2], pk[4 * s + 3]));
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
+        for (int d = 0; d < A::ND; ++d)
           acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_tr_frag(KT, 32 * d + l31, 32 * js, s, hi), dsb, acc[d], 0, 0, 0);
       }
     }
   }
   __syncthreads();
-  spill_transposed<4>(acc, 0, p.scale, lds, w, l31, hi);
+  spill_transposed<HD, A::ND>(acc, 0, p.scale, lds, w, l31, hi);
   __syncthreads();
-  store_rows<8>(lds, dq_base, p.s[5][2], i0, p.T, t);
+  store_rows<HD, A::N128>(lds, dq_base, p.s[5][2], i0, p.T, t);
 }
 
 // Forward: O = softmax(scale Q K^T + mask) V and the rows' log-sum-exp (natural log), the dq kernel's structure with the
@@ -299,10 +316,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams
 // tile; P^T rounded to bf16 is the B operand of O^T[d, i] += V^T[d, j] P^T[j, i] (V^T from a transposed LDS copy).
 // torch's memory-efficient forward takes 115 - 123 us at cfg3 (B 18, H 32, T 256; profiles/r05_step_by_stream.txt).
 // Algorithmic bytes: q, k, v read + o written = 4 B H T hd el (151 MB at cfg3).
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnBwdParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[128 * kLRow];
-  unsigned char* Ks = lds;                                     // [64 key rows][kLRow]
-  unsigned char* VT = lds + kTile;                             // [128 d][kTRow]: V transposed
+template <int HD>
+__global__ __launch_bounds__(256, AT<HD>::OCC) void attn_fwd_kernel(const AttnBwdParams p) {
+  using A = AT<HD>;
+  constexpr int LDS = (A::RM + A::TR) > 128 * A::LROW ? (A::RM + A::TR) : 128 * A::LROW;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS];
+  unsigned char* Ks = lds;                                     // [64 key rows][LROW]
+  unsigned char* VT = lds + A::RM;                             // [HD][kTRow]: V transposed
   const int t = threadIdx.x, w = t >> 6, l = t & 63, l31 = l & 31, hi = l >> 5;
   int blk, h, b;
   if (!block_coords(p, (p.T + 127) >> 7, blk, h, b)) return;
@@ -313,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnBwdParams p)
   float* lse_out = p.delta;                                                // and the log-sum-exp in the delta slot
   const unsigned long long need = need_mask<4>(p, b, i0 >> 5, true, l);
   if (need == 0ull) {                                          // rows without a live key: zero output (as torch returns)
-    store_rows<8>(nullptr, o_base, p.s[5][2], i0, p.T, t);
+    store_rows<HD, A::N128>(nullptr, o_base, p.s[5][2], i0, p.T, t);
     if (t < 128 && i0 + t < p.T) lse_out[bh * p.T + i0 + t] = 0.f;
     return;
   }
@@ -324,28 +344,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnBwdParams p)
   unsigned int blocks = 0u;
   for (int jb = 0; jb < nJ; ++jb) blocks |= (((need >> (2 * jb)) & 3ull) != 0ull ? 1u : 0u) << jb;
   uint32_t nword[2];
-  uint4 kv[4], vv[4];
+  uint4 kv[A::NCW], vv[A::NCW];
   auto fetch = [&](int jb) {
 #pragma unroll
     for (int c = 0; c < 2; ++c)
       nword[c] = (i < Tp && 2 * jb + c < p.W) ? p.bits_rows[(static_cast<int64_t>(b) * Tp + i) * p.W + 2 * jb + c] : 0u;
-    block_load(kbase, p.s[1][2], 64 * jb, p.T, w, l, kv);
-    block_load(vbase, p.s[2][2], 64 * jb, p.T, w, l, vv);
+    block_load<HD>(kbase, p.s[1][2], 64 * jb, p.T, w, l, kv);
+    block_load<HD>(vbase, p.s[2][2], 64 * jb, p.T, w, l, vv);
   };
   fetch(__builtin_ctz(blocks));
 
-  bf16x8 Qb[8];
+  bf16x8 Qb[A::KK];
   {
-    uint4 qv[8];
-    rows_load<8>(p.q + b * p.s[0][0] + h * p.s[0][1], p.s[0][2], i0, p.T, t, qv);
-    rows_store<8>(qv, lds, t);
+    uint4 qv[A::N128];
+    rows_load<HD, A::N128>(p.q + b * p.s[0][0] + h * p.s[0][1], p.s[0][2], i0, p.T, t, qv);
+    rows_store<HD, A::N128>(qv, lds, t);
     __syncthreads();
-    rows_frags(lds, w, l31, hi, Qb);
+    rows_frags<HD>(lds, w, l31, hi, Qb);
   }
   const float c1 = p.scale * kLog2e;
-  f32x16 acc[4];
+  f32x16 acc[A::ND];
 #pragma unroll
-  for (int d = 0; d < 4; ++d)
+  for (int d = 0; d < A::ND; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
   float m = -INFINITY, lsum = 0.f;                              // running maximum (log2 domain) of the row; this lane's share of the sum
@@ -354,19 +374,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnBwdParams p)
     blocks &= blocks - 1u;
     uint32_t word[2] = {nword[0], nword[1]};
     __syncthreads();                                           // the previous block's (or Q's) fragments have been read
-    block_store(kv, Ks, nullptr, w, l);
-    {                                                          // V: transposed copy only
-#pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        const int c = 4 * w + n;
-        const unsigned int q[4] = {vv[n].x, vv[n].y, vv[n].z, vv[n].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          *reinterpret_cast<unsigned short*>(VT + (8 * c + 2 * e) * kTRow + 2 * l) = static_cast<unsigned short>(q[e] & 0xffffu);
-          *reinterpret_cast<unsigned short*>(VT + (8 * c + 2 * e + 1) * kTRow + 2 * l) = static_cast<unsigned short>(q[e] >> 16);
-        }
-      }
-    }
+    block_store<HD>(kv, Ks, nullptr, w, l);
+    block_store<HD>(vv, nullptr, VT, w, l);                    // V: transposed copy only
     __syncthreads();
     if (blocks) fetch(__builtin_ctz(blocks));
 #pragma unroll
@@ -375,9 +384,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnBwdParams p)
       f32x16 St;
 #pragma unroll
       for (int r = 0; r < 16; ++r) St[r] = 0.f;
-      const unsigned char* ka = Ks + (32 * js + l31) * kLRow + 16 * hi;
+      const unsigned char* ka = Ks + (32 * js + l31) * A::LROW + 16 * hi;
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk)
+      for (int kk = 0; kk < A::KK; ++kk)
         St = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(ka + 32 * kk), Qb[kk], St, 0, 0, 0);
       float mx = -INFINITY;
 #pragma unroll
@@ -401,14 +410,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnBwdParams p)
       }
       lsum = fmaf(lsum, alpha, ps);
 #pragma unroll
-      for (int d = 0; d < 4; ++d)
+      for (int d = 0; d < A::ND; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[d][r] *= alpha;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const bf16x8 pb = __builtin_bit_cast(bf16x8, make_uint4(pk[4 * s], pk[4 * s + 1], pk[4 * s + 2], pk[4 * s + 3]));
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
+        for (int d = 0; d < A::ND; ++d)
           acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_tr_frag(VT, 32 * d + l31, 32 * js, s, hi), pb, acc[d], 0, 0, 0);
       }
     }
@@ -417,24 +426,29 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnBwdParams p)
   const float inv = ltot > 0.f ? 1.0f / ltot : 0.f;
   if (hi == 0 && i < p.T) lse_out[bh * p.T + i] = ltot > 0.f ? (m + __builtin_amdgcn_logf(ltot)) * kLn2 : 0.f;
   __syncthreads();
-  spill_transposed<4>(acc, 0, inv, lds, w, l31, hi);
+  spill_transposed<HD, A::ND>(acc, 0, inv, lds, w, l31, hi);
   __syncthreads();
-  store_rows<8>(lds, o_base, p.s[5][2], i0, p.T, t);
+  store_rows<HD, A::N128>(lds, o_base, p.s[5][2], i0, p.T, t);
 }
 
-constexpr int kDkdvLds = 4 * kTile + 2 * 64 * 4;
+template <int HD>
+constexpr int dkdv_lds() { return 2 * AT<HD>::RM + 2 * AT<HD>::TR + 2 * 64 * 4; }
 
 // 64 key rows per workgroup; wave (jt, dh) = (w >> 1, w & 1) computes the S and dP tiles of key tile jt (both waves of a tile
-// do: 16 of the 24 MFMAs per tile and wave) and accumulates dV^T / dK^T for the 64 columns d of half dh only - 64 accumulator
-// registers instead of 128, which is what lets TWO workgroups share a CU (the one-wave-per-SIMD form spent its time waiting:
-// 113 us against 97 us, tools/attn_bench.py)
+// do: 16 of the 24 MFMAs per tile and wave at HD = 128) and accumulates dV^T / dK^T for the HD / 2 columns d of half dh only -
+// half the accumulator registers, which is what lets TWO workgroups share a CU (the one-wave-per-SIMD form spent its time
+// waiting: 113 us against 97 us, tools/attn_bench.py).
+// (Fetching block n + 1 while block n is multiplied, as the dq kernel does, costs this kernel 23 spilled registers: 91 -> 124 us.)
+template <int HD>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdParams p) {
+  using A = AT<HD>;
+  constexpr int NDH = A::ND / 2;                               // d blocks of this wave's half
   extern __shared__ __attribute__((aligned(16))) unsigned char dlds[];
   unsigned char* Qs = dlds;
-  unsigned char* Gs = dlds + kTile;
-  unsigned char* QT = dlds + 2 * kTile;
-  unsigned char* GT = dlds + 3 * kTile;
-  float* nl_s = reinterpret_cast<float*>(dlds + 4 * kTile);
+  unsigned char* Gs = dlds + A::RM;
+  unsigned char* QT = dlds + 2 * A::RM;
+  unsigned char* GT = dlds + 2 * A::RM + A::TR;
+  float* nl_s = reinterpret_cast<float*>(dlds + 2 * A::RM + 2 * A::TR);
   float* dl_s = nl_s + 64;
   const int t = threadIdx.x, w = t >> 6, l = t & 63, l31 = l & 31, hi = l >> 5, jt = w >> 1, dh = w & 1;
   int blk, h, b;
@@ -446,33 +460,32 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdPara
   unsigned short* dv_base = p.dv + b * p.s[7][0] + h * p.s[7][1];
   const unsigned long long need = need_mask<2>(p, b, j0 >> 5, false, l);
   if (need == 0ull) {
-    store_rows<4>(nullptr, dk_base, p.s[6][2], j0, p.T, t);
-    store_rows<4>(nullptr, dv_base, p.s[7][2], j0, p.T, t);
+    store_rows<HD, A::N64>(nullptr, dk_base, p.s[6][2], j0, p.T, t);
+    store_rows<HD, A::N64>(nullptr, dv_base, p.s[7][2], j0, p.T, t);
     return;
   }
   const unsigned short* qbase = p.q + b * p.s[0][0] + h * p.s[0][1];
   const unsigned short* gbase = p.d_o + b * p.s[4][0] + h * p.s[4][1];
 
-  bf16x8 Kb[8], Vb[8];
+  bf16x8 Kb[A::KK], Vb[A::KK];
   {
-    uint4 kv[4], vv[4];
-    rows_load<4>(p.k + b * p.s[1][0] + h * p.s[1][1], p.s[1][2], j0, p.T, t, kv);
-    rows_load<4>(p.v + b * p.s[2][0] + h * p.s[2][1], p.s[2][2], j0, p.T, t, vv);
-    rows_store<4>(kv, dlds, t);
-    rows_store<4>(vv, dlds + kTile, t);
+    uint4 kv[A::N64], vv[A::N64];
+    rows_load<HD, A::N64>(p.k + b * p.s[1][0] + h * p.s[1][1], p.s[1][2], j0, p.T, t, kv);
+    rows_load<HD, A::N64>(p.v + b * p.s[2][0] + h * p.s[2][1], p.s[2][2], j0, p.T, t, vv);
+    rows_store<HD, A::N64>(kv, dlds, t);
+    rows_store<HD, A::N64>(vv, dlds + A::RM, t);
     __syncthreads();
-    rows_frags(dlds, jt, l31, hi, Kb);
-    rows_frags(dlds + kTile, jt, l31, hi, Vb);
+    rows_frags<HD>(dlds, jt, l31, hi, Kb);
+    rows_frags<HD>(dlds + A::RM, jt, l31, hi, Vb);
   }
   const float c1 = p.scale * kLog2e;
   const int Tp = 32 * p.W;
-  f32x16 dVt[2], dKt[2];
+  f32x16 dVt[NDH], dKt[NDH];
 #pragma unroll
-  for (int d = 0; d < 2; ++d)
+  for (int d = 0; d < NDH; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dVt[d][r] = 0.f; dKt[d][r] = 0.f; }
 
-  // (fetching block n + 1 while block n is multiplied, as the dq kernel does, costs this kernel 23 spilled registers: 91 -> 124 us)
   const int nI = (p.T + 63) >> 6;
   for (int ib = 0; ib < nI; ++ib) {
     if (((need >> (2 * ib)) & 3ull) == 0ull) continue;
@@ -480,17 +493,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdPara
 #pragma unroll
     for (int c = 0; c < 2; ++c)
       word[c] = (j < Tp && 2 * ib + c < p.W) ? p.bits_cols[(static_cast<int64_t>(b) * Tp + j) * p.W + 2 * ib + c] : 0u;
-    uint4 qv[4], gv[4];
-    block_load(qbase, p.s[0][2], 64 * ib, p.T, w, l, qv);
-    block_load(gbase, p.s[4][2], 64 * ib, p.T, w, l, gv);
+    uint4 qv[A::NCW], gv[A::NCW];
+    block_load<HD>(qbase, p.s[0][2], 64 * ib, p.T, w, l, qv);
+    block_load<HD>(gbase, p.s[4][2], 64 * ib, p.T, w, l, gv);
     float nlv = 0.f, dlv = 0.f;
     if (t < 64 && 64 * ib + t < p.T) {
       nlv = -p.lse[bh * p.T + 64 * ib + t] * kLog2e;
       dlv = p.delta[bh * p.T + 64 * ib + t];
     }
     __syncthreads();
-    block_store(qv, Qs, QT, w, l);
-    block_store(gv, Gs, GT, w, l);
+    block_store<HD>(qv, Qs, QT, w, l);
+    block_store<HD>(gv, Gs, GT, w, l);
     if (t < 64) { nl_s[t] = nlv; dl_s[t] = dlv; }
     __syncthreads();
 #pragma unroll
@@ -499,10 +512,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdPara
       f32x16 S, dP;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
-      const unsigned char* qa = Qs + (32 * is + l31) * kLRow + 16 * hi;
-      const unsigned char* ga = Gs + (32 * is + l31) * kLRow + 16 * hi;
+      const unsigned char* qa = Qs + (32 * is + l31) * A::LROW + 16 * hi;
+      const unsigned char* ga = Gs + (32 * is + l31) * A::LROW + 16 * hi;
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
+      for (int kk = 0; kk < A::KK; ++kk) {
         S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(qa + 32 * kk), Kb[kk], S, 0, 0, 0);
         dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(ga + 32 * kk), Vb[kk], dP, 0, 0, 0);
       }
@@ -529,8 +542,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdPara
         const bf16x8 pb = __builtin_bit_cast(bf16x8, make_uint4(ppk[4 * s], ppk[4 * s + 1], ppk[4 * s + 2], ppk[4 * s + 3]));
         const bf16x8 db = __builtin_bit_cast(bf16x8, make_uint4(dpk[4 * s], dpk[4 * s + 1], dpk[4 * s + 2], dpk[4 * s + 3]));
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          const int drow = 32 * (2 * dh + d) + l31;
+        for (int d = 0; d < NDH; ++d) {
+          const int drow = 32 * (NDH * dh + d) + l31;
           dVt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_tr_frag(GT, drow, 32 * is, s, hi), pb, dVt[d], 0, 0, 0);
           dKt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_tr_frag(QT, drow, 32 * is, s, hi), db, dKt[d], 0, 0, 0);
         }
@@ -538,11 +551,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdPara
     }
   }
   __syncthreads();
-  spill_transposed<2>(dKt, 2 * dh, p.scale, dlds, jt, l31, hi);
-  spill_transposed<2>(dVt, 2 * dh, 1.0f, dlds + kTile, jt, l31, hi);
+  spill_transposed<HD, NDH>(dKt, NDH * dh, p.scale, dlds, jt, l31, hi);
+  spill_transposed<HD, NDH>(dVt, NDH * dh, 1.0f, dlds + A::RM, jt, l31, hi);
   __syncthreads();
-  store_rows<4>(dlds, dk_base, p.s[6][2], j0, p.T, t);
-  store_rows<4>(dlds + kTile, dv_base, p.s[7][2], j0, p.T, t);
+  store_rows<HD, A::N64>(dlds, dk_base, p.s[6][2], j0, p.T, t);
+  store_rows<HD, A::N64>(dlds + A::RM, dv_base, p.s[7][2], j0, p.T, t);
 }
 
 // mask [B, 1, T, T] bytes (non-zero = attend; NULL = all) and / or causal -> row words, column words, live 32 x 32 tiles
@@ -597,7 +610,7 @@ extern "C" int dalm_attn_bwd(const void* q, const void* k, const void* v, const 
                              dalm_stream_t stream) {
   DALM_REQUIRE(q && k && v && o && d_o && lse && bits_rows && bits_cols && live && strides && dq && dk && dv && delta, DALM_E_NULL,
                "null pointer argument");
-  DALM_REQUIRE(hd == kHd, DALM_E_SHAPE, "head width must be 128");
+  DALM_REQUIRE(hd == 128 || hd == 64, DALM_E_SHAPE, "head width must be 64 or 128");
   DALM_REQUIRE(B > 0 && H > 0 && T > 0 && T <= 2048 && B * H <= (1ll << 24), DALM_E_SHAPE, "need 0 < T <= 2048 and B H <= 2^24");
   const void* ptrs[8] = {q, k, v, o, d_o, dq, dk, dv};
   for (int i = 0; i < 8; ++i) {
@@ -618,7 +631,8 @@ extern "C" int dalm_attn_bwd(const void* q, const void* k, const void* v, const 
     for (int a = 0; a < 3; ++a) p.s[i][a] = strides[3 * i + a];
   static bool lds_set = false;
   if (!lds_set) {
-    if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDkdvLds);
+    if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel<128>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, dkdv_lds<128>());
         e != hipSuccess)
       return fail(static_cast<int>(e), __func__, "could not raise the dynamic LDS limit of the dk / dv kernel");
     lds_set = true;
@@ -626,8 +640,13 @@ extern "C" int dalm_attn_bwd(const void* q, const void* k, const void* v, const 
   const int64_t pairs8 = (B * H + 7) / 8 * 8;
   const dim3 grid_dq(static_cast<unsigned>(pairs8 * ((T + 127) / 128))), grid_dkdv(static_cast<unsigned>(pairs8 * ((T + 63) / 64)));
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid_dq, dim3(256), 0, s, p);
-  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid_dkdv, dim3(256), kDkdvLds, s, p);
+  if (hd == 128) {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, grid_dq, dim3(256), 0, s, p);
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<128>, grid_dkdv, dim3(256), dkdv_lds<128>(), s, p);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid_dq, dim3(256), 0, s, p);
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<64>, grid_dkdv, dim3(256), dkdv_lds<64>(), s, p);
+  }
   return check_launch(__func__);
 }
 
@@ -635,7 +654,7 @@ extern "C" int dalm_attn_fwd(const void* q, const void* k, const void* v, const 
                              int64_t H, int64_t T, int64_t hd, float scale, const int64_t* strides, void* o, float* lse,
                              dalm_stream_t stream) {
   DALM_REQUIRE(q && k && v && bits_rows && live && strides && o && lse, DALM_E_NULL, "null pointer argument");
-  DALM_REQUIRE(hd == kHd, DALM_E_SHAPE, "head width must be 128");
+  DALM_REQUIRE(hd == 128 || hd == 64, DALM_E_SHAPE, "head width must be 64 or 128");
   DALM_REQUIRE(B > 0 && H > 0 && T > 0 && T <= 2048 && B * H <= (1ll << 24), DALM_E_SHAPE, "need 0 < T <= 2048 and B H <= 2^24");
   const void* ptrs[4] = {q, k, v, o};
   for (int i = 0; i < 4; ++i) {
@@ -655,6 +674,8 @@ extern "C" int dalm_attn_fwd(const void* q, const void* k, const void* v, const 
     p.s[0][a] = strides[a]; p.s[1][a] = strides[3 + a]; p.s[2][a] = strides[6 + a]; p.s[5][a] = strides[9 + a];
   }
   const int64_t pairs8 = (B * H + 7) / 8 * 8;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(static_cast<unsigned>(pairs8 * ((T + 127) / 128))), dim3(256), 0, as_stream(stream), p);
+  const dim3 grid(static_cast<unsigned>(pairs8 * ((T + 127) / 128)));
+  if (hd == 128) hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(256), 0, as_stream(stream), p);
+  else hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, as_stream(stream), p);
   return check_launch(__func__);
 }

@@ -4,7 +4,7 @@ dalm_amd/csrc/attn.hip), registered with transformers as the attention implement
 transformers evaluates a decoder layer's attention through `sdpa_attention_forward`
 (transformers/integrations/sdpa_attention.py) -> torch.nn.functional.scaled_dot_product_attention; the reference reaches it through
 `self.generator_model(...)` (dalm/models/rag_e2e_base_model.py:104-106) and differentiates it in `loss.backward()`
-(dalm/training/rag_e2e/train_rage2e.py:466).  With HF's boolean mask (causal + left padding) torch runs its memory-efficient
+(dalm/training/rag_e2e/train_rage2e.py:466).  Head widths 128 (Llama-2-7b) and 64 (Falcon-7b, through fastpath's FalconAttention patch).  With HF's boolean mask (causal + left padding) torch runs its memory-efficient
 kernels: 60 us forward, 440 us backward per layer at cfg3 (2.7 % of the MFMA peak).  Here
 
   forward   `dalm_attn_fwd` (one launch, online softmax, writes the rows' log-sum-exp);  DALM_ATTN_FWD_KERNEL=0: torch's own
@@ -27,7 +27,7 @@ import torch
 from .. import hip
 
 NAME = "dalm_sdpa"
-_HEAD_DIM = 128
+_HEAD_DIMS = (64, 128)
 
 
 class _MaskPack:
@@ -134,7 +134,7 @@ def _views_ok(*ts) -> bool:
 def supported(query, key, value, mask, dropout, causal, kwargs) -> bool:
     if not (query.is_cuda and query.dtype == torch.bfloat16 and key.dtype == query.dtype and value.dtype == query.dtype):
         return False
-    if query.dim() != 4 or query.shape[-1] != _HEAD_DIM or key.shape != query.shape or value.shape != query.shape:
+    if query.dim() != 4 or query.shape[-1] not in _HEAD_DIMS or key.shape != query.shape or value.shape != query.shape:
         return False                                 # a KV cache (kv length != q length) or grouped heads left unexpanded
     if query.shape[2] < 2 or query.shape[2] > 2048 or dropout != 0.0 or kwargs.get("position_bias") is not None:
         return False
@@ -194,8 +194,13 @@ def register() -> bool:
     return True
 
 
+def sdpa(query, key, value, mask, scale: float, causal: bool):
+    """F.scaled_dot_product_attention(query, key, value, attn_mask=mask, is_causal=causal, scale=scale) for what `supported` accepts."""
+    return _SdpaHipBackward.apply(query, key, value, mask, scale, causal)
+
+
 def use_hip_attention_backward(model: torch.nn.Module) -> bool:
-    """Switch a Llama-family model (head width 128) from "sdpa" to "dalm_sdpa".  DALM_ATTN_KERNEL=0 disables."""
+    """Switch a Llama-family model (head width 64 or 128) from "sdpa" to "dalm_sdpa".  DALM_ATTN_KERNEL=0 disables."""
     if os.environ.get("DALM_ATTN_KERNEL", "1") == "0":
         return False
     cfg = getattr(model, "config", None)
@@ -204,7 +209,7 @@ def use_hip_attention_backward(model: torch.nn.Module) -> bool:
     if getattr(cfg, "model_type", "") not in ("llama", "mistral", "qwen2"):
         return False
     hd = getattr(cfg, "head_dim", None) or (cfg.hidden_size // cfg.num_attention_heads)
-    if hd != _HEAD_DIM or not register():
+    if hd not in _HEAD_DIMS or not register():
         return False
     cfg._attn_implementation = NAME
     return True

@@ -400,6 +400,93 @@ def _falcon_mlp_matches(cls) -> bool:
 
 
 # ---------------------------------------------------------------------------
+# Falcon attention (7B flavour, rotary, sdpa): the attention itself on dalm_attn_fwd / dalm_attn_bwd
+# ---------------------------------------------------------------------------
+_FALCON_ATTN_PARAMS = ["self", "hidden_states", "alibi", "attention_mask", "position_ids", "layer_past", "use_cache",
+                       "output_attentions", "position_embeddings", "kwargs"]
+
+
+def _falcon_attention_forward(self, hidden_states, alibi, attention_mask, position_ids=None, layer_past=None, use_cache=False,
+                              output_attentions=False, position_embeddings=None, **kwargs):
+    """transformers' FalconAttention.forward for the training call (rotary positions, no KV cache, "sdpa"): the same statements
+    with F.scaled_dot_product_attention replaced by `attention.sdpa` (dalm_amd/csrc/attn.hip).  Every other call goes to
+    transformers' own forward."""
+    import importlib
+
+    from . import attention
+
+    orig = self._dalm_orig_attn_forward
+    if (alibi is not None or layer_past is not None or output_attentions or position_embeddings is None
+            or getattr(self.config, "_attn_implementation", None) != "sdpa" or os.environ.get("DALM_ATTN_KERNEL", "1") == "0"):
+        return orig(hidden_states, alibi, attention_mask, position_ids=position_ids, layer_past=layer_past, use_cache=use_cache,
+                    output_attentions=output_attentions, position_embeddings=position_embeddings, **kwargs)
+    fused_qkv = self.query_key_value(hidden_states)
+    num_kv_heads = self.num_heads if self.new_decoder_architecture else self.num_kv_heads
+    query_layer, key_layer, value_layer = self._split_heads(fused_qkv)
+    batch_size, query_length, _, _ = query_layer.shape
+    query_layer = query_layer.transpose(1, 2).reshape(batch_size, self.num_heads, query_length, self.head_dim)
+    key_layer = key_layer.transpose(1, 2).reshape(batch_size, num_kv_heads, query_length, self.head_dim)
+    value_layer = value_layer.transpose(1, 2).reshape(batch_size, num_kv_heads, query_length, self.head_dim)
+    cos, sin = position_embeddings
+    rope = importlib.import_module(type(self).__module__).apply_rotary_pos_emb        # the modeling file's own (maybe swapped) one
+    query_layer, key_layer = rope(query_layer, key_layer, cos, sin)
+    is_causal = bool(self.is_causal and attention_mask is None and query_length > 1)
+    if not attention.supported(query_layer, key_layer, value_layer, attention_mask, 0.0, is_causal, {}):
+        attn_output = torch.nn.functional.scaled_dot_product_attention(query_layer, key_layer, value_layer, attn_mask=attention_mask,
+                                                                       dropout_p=0.0, is_causal=is_causal)
+    else:
+        attn_output = attention.sdpa(query_layer, key_layer, value_layer, attention_mask, float(self.head_dim) ** -0.5, is_causal)
+    attn_output = attn_output.view(batch_size, self.num_heads, query_length, self.head_dim)
+    attn_output = attn_output.permute(0, 2, 1, 3)
+    attn_output = attn_output.reshape(batch_size, query_length, self.num_heads * self.head_dim)
+    return self.dense(attn_output), None
+
+
+def use_falcon_attention_kernels(model: torch.nn.Module) -> int:
+    """Patch FalconAttention modules (head width 64 or 128, no alibi) whose forward is the code `_falcon_attention_forward`
+    restates (signature and statements checked once per class).  DALM_ATTN_KERNEL=0 disables.  Returns the count."""
+    if os.environ.get("DALM_ATTN_KERNEL", "1") == "0":
+        return 0
+    n = 0
+    for mod in model.modules():
+        if type(mod).__name__ != "FalconAttention" or getattr(mod, "head_dim", None) not in (64, 128):
+            continue
+        if getattr(getattr(mod, "config", None), "alibi", True) or float(getattr(mod.config, "attention_dropout", 1.0)) != 0.0:
+            continue
+        if not _falcon_attention_matches(type(mod)):
+            continue
+        mod._dalm_orig_attn_forward = mod.forward
+        mod.forward = types.MethodType(_falcon_attention_forward, mod)
+        n += 1
+    return n
+
+
+def _falcon_attention_matches(cls) -> bool:
+    key = ("falcon-attn", cls)
+    if key not in _checked:
+        try:
+            import inspect
+
+            params = list(inspect.signature(cls.forward).parameters)
+            src = inspect.getsource(cls.forward)
+            _checked[key] = (params == _FALCON_ATTN_PARAMS
+                             and "fused_qkv = self.query_key_value(hidden_states)" in src
+                             and "(query_layer, key_layer, value_layer) = self._split_heads(fused_qkv)" in src
+                             and "query_layer, key_layer = apply_rotary_pos_emb(query_layer, key_layer, cos, sin)" in src
+                             and "is_causal = self.is_causal and attention_mask is None and query_length > 1" in src
+                             and "attn_output = attn_output.view(batch_size, self.num_heads, query_length, self.head_dim)" in src
+                             and "attn_output = attn_output.permute(0, 2, 1, 3)" in src
+                             and "attn_output = self.dense(attn_output)" in src
+                             and "return attn_output, attention_scores" in src)
+        except Exception:
+            _checked[key] = False
+        if not _checked[key]:
+            _warn_once("falcon-attn", "FalconAttention.forward is not the code this patch restates: transformers' own code "
+                       "stays in place")
+    return _checked[key]
+
+
+# ---------------------------------------------------------------------------
 # decoder layer: residual add + RMSNorm in one launch each way
 # ---------------------------------------------------------------------------
 _LLAMA_LAYER_PARAMS = ["self", "hidden_states", "attention_mask", "position_ids", "past_key_values", "use_cache",

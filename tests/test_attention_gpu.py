@@ -60,23 +60,27 @@ def _run(fn, q, k, v, go):
 
 
 CASES = [
-    # B, H, T, starts (left padding per batch row; None = no mask, is_causal), layout
-    (2, 3, 256, [0, 37], "bthd"),
-    (3, 2, 256, [0, 255, 128], "bhtd"),
-    (2, 2, 200, [5, 150], "bthd"),
-    (1, 4, 96, [0], "bthd"),
-    (2, 2, 40, [3, 0], "bhtd"),
-    (2, 3, 256, None, "bthd"),
-    (1, 2, 333 // 8 * 8, None, "bthd"),
-    (2, 2, 512, [100, 0], "bthd"),
+    # B, H, T, starts (left padding per batch row; None = no mask, is_causal), layout, head width
+    (2, 3, 256, [0, 37], "bthd", 128),
+    (3, 2, 256, [0, 255, 128], "bhtd", 128),
+    (2, 2, 200, [5, 150], "bthd", 128),
+    (1, 4, 96, [0], "bthd", 128),
+    (2, 2, 40, [3, 0], "bhtd", 128),
+    (2, 3, 256, None, "bthd", 128),
+    (1, 2, 333 // 8 * 8, None, "bthd", 128),
+    (2, 2, 512, [100, 0], "bthd", 128),
+    (2, 5, 256, [0, 37], "bhtd", 64),           # Falcon-7b's head width
+    (3, 2, 256, [0, 255, 128], "bthd", 64),
+    (2, 3, 200, [5, 150], "bhtd", 64),
+    (2, 2, 40, [3, 0], "bthd", 64),
+    (2, 3, 320, None, "bhtd", 64),
 ]
 
 
-@pytest.mark.parametrize("B,H,T,starts,layout", CASES)
-def test_backward_vs_fp64_and_torch(dev, B, H, T, starts, layout):
+@pytest.mark.parametrize("B,H,T,starts,layout,hd", CASES)
+def test_backward_vs_fp64_and_torch(dev, B, H, T, starts, layout, hd):
     from dalm_amd.models import attention
 
-    hd = 128
     g = torch.Generator().manual_seed(B * 1000 + T)
     def mk():
         if layout == "bthd":
@@ -94,7 +98,7 @@ def test_backward_vs_fp64_and_torch(dev, B, H, T, starts, layout):
     ref = _ref64(q, k, v, mask, causal, scale, go)
     assert torch.isfinite(ours[0]).all()
     assert _rel(ours[0], ref[0]) <= 1.5 * _rel(theirs[0], ref[0]) + 1e-3
-    assert ours[0].stride() == theirs[0].stride()
+    assert ours[0].transpose(1, 2).is_contiguous()           # [B, T, H, hd] memory: the caller's transpose(1, 2).contiguous() is free
     os.environ["DALM_ATTN_FWD_KERNEL"] = "0"
     try:
         lib = _run(lambda a, b, c: attention._SdpaHipBackward.apply(a, b, c, mask, scale, causal), q, k, v, go)
@@ -192,3 +196,37 @@ def test_llama_layer_on_dalm_sdpa_matches_sdpa(dev):
     # no gradient wanted: transformers' own path, torch's kernel, the same values as the "sdpa" model
     with torch.no_grad():
         assert torch.equal(new(input_ids=ids, attention_mask=am).logits[live], ref(input_ids=ids, attention_mask=am).logits[live])
+
+
+def test_falcon_attention_patch_matches_transformers(dev):
+    """FalconAttention (multi-query, rotary, head width 64) with `attention.sdpa` in place of F.scaled_dot_product_attention:
+    hidden states and the gradient reaching the embeddings against transformers' own forward."""
+    from transformers import FalconConfig
+    from transformers.models.falcon.modeling_falcon import FalconModel
+
+    from dalm_amd.models import fastpath
+
+    cfg = FalconConfig(vocab_size=300, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, multi_query=True,
+                       parallel_attn=True, new_decoder_architecture=False, bias=False, alibi=False, hidden_dropout=0.0,
+                       attention_dropout=0.0)
+    cfg._attn_implementation = "sdpa"
+    torch.manual_seed(1)
+    ref = FalconModel(cfg).to(dev).to(torch.bfloat16).train()
+    new = copy.deepcopy(ref)
+    assert fastpath.use_capturable_falcon_heads(new) == 2 and fastpath.use_falcon_attention_kernels(new) == 2
+    assert new.h[0].self_attention.forward.__func__ is fastpath._falcon_attention_forward
+    B, T = 3, 96
+    ids = torch.randint(0, 300, (B, T), device=dev)
+    am = torch.ones(B, T, dtype=torch.long, device=dev)
+    am[1, :30] = 0
+    outs = []
+    for m in (ref, new):
+        for p in m.parameters():
+            p.requires_grad_(False)
+        e = m.word_embeddings(ids).detach().requires_grad_(True)
+        h = m(inputs_embeds=e, attention_mask=am).last_hidden_state
+        (h.float() * am[..., None] * torch.linspace(-1, 1, h.shape[-1], device=dev)).sum().backward()
+        outs.append((h.detach(), e.grad.detach()))
+    live = am.bool()
+    assert _rel(outs[1][0][live], outs[0][0][live]) < 1e-2
+    assert _rel(outs[1][1][live], outs[0][1][live]) < 2e-2
