@@ -92,6 +92,11 @@ def _tower_kernels(model) -> dict:
             "rotary": {"_rope_hip": "dalm_rope_qk", "_rope_roll": "roll + addcmul (torch)"}.get(rope, "transformers"),
             "swiglu": "dalm_swiglu_*" if "_swiglu_mlp_forward" in fwd("LlamaMLP") else "transformers",
             "residual_norm": "dalm_rms_norm_*" if "_llama_layer_forward" in fwd("LlamaDecoderLayer") else "transformers / torch",
+            "attention": ("dalm_attn_fwd / dalm_attn_bwd (bit-packed mask)"
+                          if (getattr(gen.config, "_attn_implementation", None) == "dalm_sdpa"
+                              or "_falcon_attention_forward" in fwd("FalconAttention")) else "torch SDPA"),
+            "falcon_layer": ("dalm_layer_norm_* / dalm_gelu_* / dalm_add3" if "_falcon_layer_forward" in fwd("FalconDecoderLayer")
+                             else None),
             "use_cache": False}
 
 

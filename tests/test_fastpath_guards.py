@@ -155,3 +155,79 @@ def test_falcon_layer_patch_goes_in_on_the_stock_code_and_is_refused_on_other_co
     finally:
         cls.forward = orig
         fastpath._checked.clear()
+
+
+def test_dalm_sdpa_registration_and_cpu_delegation():
+    """"dalm_sdpa" is a registered transformers attention implementation (models/attention.py).  On CPU tensors (and for anything
+    else the HIP kernels do not take) it IS transformers' sdpa_attention_forward: same logits, same gradients.
+    DALM_ATTN_KERNEL=0 leaves the model on "sdpa"."""
+    import os
+
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    from dalm_amd.models import attention
+
+    torch.manual_seed(0)
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2,
+                      vocab_size=100)
+    ref = LlamaForCausalLM(cfg)
+    new = LlamaForCausalLM(cfg)
+    new.load_state_dict(ref.state_dict())
+    os.environ["DALM_ATTN_KERNEL"] = "0"
+    try:
+        assert attention.use_hip_attention_backward(new) is False and new.config._attn_implementation == "sdpa"
+    finally:
+        os.environ.pop("DALM_ATTN_KERNEL", None)
+    assert attention.use_hip_attention_backward(new) is True and new.config._attn_implementation == "dalm_sdpa"
+    x = torch.randint(0, 100, (2, 9))
+    am = torch.ones(2, 9, dtype=torch.long)
+    am[0, :3] = 0
+    outs = []
+    for m in (ref, new):
+        logits = m(input_ids=x, attention_mask=am).logits
+        logits.square().sum().backward()
+        outs.append((logits.detach(), m.model.layers[0].self_attn.q_proj.weight.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # head widths the kernels do not take: the model stays on "sdpa"
+    other = LlamaForCausalLM(LlamaConfig(hidden_size=96, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2,
+                                         num_key_value_heads=2, vocab_size=50))
+    assert attention.use_hip_attention_backward(other) is False and other.config._attn_implementation == "sdpa"
+    # nothing the kernels take on the CPU
+    q = torch.randn(1, 2, 8, 128, dtype=torch.bfloat16, requires_grad=True)
+    assert attention.supported(q, q, q, None, 0.0, True, {}) is False
+
+
+def test_falcon_attention_patch_is_refused_on_other_code():
+    from transformers import FalconConfig, FalconForCausalLM
+
+    from dalm_amd.models import fastpath
+
+    fastpath._checked.clear()
+    fastpath._warned.clear()
+    cfg = FalconConfig(num_hidden_layers=1, hidden_size=128, num_attention_heads=2, vocab_size=100)
+    m = FalconForCausalLM(cfg)
+    assert fastpath.use_falcon_attention_kernels(m) == 1
+    att = m.transformer.h[0].self_attention
+    assert att.forward.__func__ is fastpath._falcon_attention_forward
+    # alibi positions, attention dropout, other head widths: transformers' code stays
+    for kw in ({"alibi": True}, {"attention_dropout": 0.1}, {"num_attention_heads": 4}):
+        kw = {"num_attention_heads": 2, **kw}
+        other = FalconForCausalLM(FalconConfig(num_hidden_layers=1, hidden_size=128, vocab_size=100, **kw))
+        assert fastpath.use_falcon_attention_kernels(other) == 0
+    cls = type(att)
+    orig = cls.forward
+    fastpath._checked.clear()
+    try:
+        def forward(self, hidden_states, alibi, attention_mask, position_ids=None, layer_past=None, use_cache=False,
+                    output_attentions=False, position_embeddings=None, **kwargs):
+            return orig(self, hidden_states, alibi, attention_mask, position_ids, layer_past, use_cache, output_attentions,
+                        position_embeddings, **kwargs)
+
+        cls.forward = forward
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            assert fastpath.use_falcon_attention_kernels(FalconForCausalLM(cfg)) == 0
+        assert any("FalconAttention.forward is not the code this patch restates" in str(m_.message) for m_ in w)
+    finally:
+        cls.forward = orig
+        fastpath._checked.clear()
