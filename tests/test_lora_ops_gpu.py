@@ -102,6 +102,21 @@ def test_dropout_mask_is_the_same_in_all_three_kernels(dev, R, K, rank, dtype):
     assert not torch.equal(moved, cnt) or K < 64
 
 
+def _record_measured(key, values):
+    """Measured errors -> gpurun_out/measured_tolerances.json (the bounds in this file are stated from them)."""
+    import json
+    from pathlib import Path
+
+    try:
+        path = Path(__file__).resolve().parent.parent / "gpurun_out" / "measured_tolerances.json"
+        path.parent.mkdir(exist_ok=True)
+        cur = json.loads(path.read_text()) if path.exists() else {}
+        cur[key] = values
+        path.write_text(json.dumps(cur, indent=1))
+    except OSError:
+        pass
+
+
 class _LinearSubclass(torch.nn.Linear):
     """Not `type(...) is nn.Linear`: LoRALinear must run it as its own module and add only the low-rank branch (the route nf4
     bases take as well)."""
@@ -145,9 +160,13 @@ def test_fused_lora_linear_matches_the_eager_branch(dev, mode):
                         m.lora_B["default"].weight.grad.float()))
         finally:
             lora_mod._FUSED = True
-    tol = 3e-6 if mode == "fp32" else 1.5e-2
-    for name, a, b in zip(("out", "dx", "dA", "dB"), res[1], res[0]):
-        assert _rel(a, b) < tol, f"{name}: {_rel(a, b):.2e}"
+    # measured on the MI355X (profiles/r05_measured_tolerances.json): fp32 <= 3.5e-7, bf16 autocast <= 2.85e-3 (the kernels keep
+    # z = A x in f32 where the eager branch rounds it to bf16); bounds = 5 x measured
+    tol = 1.8e-6 if mode == "fp32" else 1.4e-2
+    got = {name: _rel(a, b) for name, a, b in zip(("out", "dx", "dA", "dB"), res[1], res[0])}
+    _record_measured("lora_linear:" + mode, got)
+    for name, e in got.items():
+        assert e < tol, f"{name}: {e:.2e}"
     assert res[1][0].dtype == res[0][0].dtype
 
 

@@ -148,6 +148,20 @@ def test_rms_norm_kernels_vs_llama_rms_norm(dev, R, D, dtype, with_add):
         assert rel(d1.grad, d64.grad) < tol
 
 
+def _record_measured(key, values):
+    import json
+    from pathlib import Path
+
+    try:
+        path = Path(__file__).resolve().parent.parent / "gpurun_out" / "measured_tolerances.json"
+        path.parent.mkdir(exist_ok=True)
+        cur = json.loads(path.read_text()) if path.exists() else {}
+        cur[key] = values
+        path.write_text(json.dumps(cur, indent=1))
+    except OSError:
+        pass
+
+
 def test_patched_llama_layer_matches_transformers(dev):
     """A 2-layer Llama (head_dim 128) with the rotary and SwiGLU kernels patched in against the unpatched module: logits and
     every parameter gradient, bf16 autocast and fp32."""
@@ -181,12 +195,18 @@ def test_patched_llama_layer_matches_transformers(dev):
             logits.float().square().mean().backward()
             outs.append((logits.detach().float(), {n: p.grad.detach().float() for n, p in model.named_parameters()}))
         (l0, g0), (l1, g1) = outs
+        worst = max(float((g1[n] - g0[n]).norm()) / (float(g0[n].norm()) + 1e-12) for n in g0)
+        _record_measured("llama_layer:" + ("bf16-autocast" if autocast else "fp32"),
+                         {"logits_rel": float((l1 - l0).norm() / l0.norm()), "logits_max_abs": float((l1 - l0).abs().max()),
+                          "logits_max": float(l0.abs().max()), "worst_grad_rel": worst})
+        # measured on the MI355X (profiles/r05_measured_tolerances.json): bf16 autocast - logits IDENTICAL, worst gradient 7.6e-8
+        # (the kernels round where the eager chains round); fp32 - logits 8.3e-7 absolute, worst gradient 9.4e-7 (summation
+        # order of mean(x^2)).  Bounds = 5 x measured (one bf16 ulp of the largest logit where 0 was measured).
         if autocast:
-            # rotary is bit-identical; SwiGLU may move single bf16 roundings: a loose bound that a wrong formula cannot meet
-            torch.testing.assert_close(l1, l0, rtol=2e-2, atol=2e-3)
+            assert float((l1 - l0).abs().max()) <= 2.0 ** -8 * float(l0.abs().max())
         else:
-            torch.testing.assert_close(l1, l0, rtol=1e-5, atol=1e-6)
+            torch.testing.assert_close(l1, l0, rtol=0, atol=4.2e-6)
         for n in g0:
             num = float((g1[n] - g0[n]).norm())
             den = float(g0[n].norm()) + 1e-12
-            assert num / den < (2e-2 if autocast else 2e-5), f"{n}: relative gradient error {num / den:.2e}"
+            assert num / den < (4e-7 if autocast else 4.7e-6), f"{n}: relative gradient error {num / den:.2e}"
