@@ -60,6 +60,8 @@ struct AttnBwdParams {
   int B, H, T, W;                        // W = ceil(T / 32) mask words per row
   float scale;
   int64_t s[8][3];                       // element strides (batch, head, row) of q, k, v, o, dO, dq, dk, dv
+  const unsigned short *cos, *sin;       // backward only, may be NULL: q and k are ROTATED tensors (rotary embedding applied by
+  int64_t cs_b, cs_t;                    // dalm_rope_qk); dq and dk leave as gradients of the UN-rotated ones.  [B or 1, T, hd]
 };
 
 __device__ __forceinline__ uint4 ld16(const unsigned short* p) { return *reinterpret_cast<const uint4*>(p); }
@@ -158,6 +160,45 @@ __device__ __forceinline__ void store_rows(const unsigned char* out, unsigned sh
     if (row0 + row < T)
       *reinterpret_cast<uint4*>(dst + static_cast<int64_t>(row0 + row) * row_stride + 8 * c) =
           out ? *reinterpret_cast<const uint4*>(out + row * AT<HD>::LROW + 16 * c) : make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+
+// store_rows for a gradient of a ROTATED tensor: what leaves is the gradient of the tensor BEFORE dalm_rope_qk, i.e. that kernel's
+// backward (csrc/tower.hip rope_qk_kernel, transformers' apply_rotary_pos_emb differentiated op by op) applied to the bf16 rows
+// of the LDS tile, with its rounding points: lower half  o1 = rb(rb(g1 c1) + rb(g2 s2)),  upper half  o2 = rb(rb(g2 c2) - rb(g1 s1)).
+template <int HD, int N>
+__device__ __forceinline__ void store_rows_unrope(const unsigned char* out, unsigned short* dst, int64_t row_stride, int row0, int T,
+                                                  int t, const unsigned short* cosb, const unsigned short* sinb, int64_t cs_t) {
+#pragma clang fp contract(off)   // separate multiplies and add, as the eager chain's kernels
+  constexpr int CH = AT<HD>::CH;
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    const int row = t / CH + (256 / CH) * n, c = t % CH, pc = c ^ (CH / 2);
+    if (row0 + row >= T) continue;
+    const uint4 own = *reinterpret_cast<const uint4*>(out + row * AT<HD>::LROW + 16 * c);
+    const uint4 oth = *reinterpret_cast<const uint4*>(out + row * AT<HD>::LROW + 16 * pc);
+    const uint4 cv = ld16(cosb + static_cast<int64_t>(row0 + row) * cs_t + 8 * c);
+    const uint4 sv = ld16(sinb + static_cast<int64_t>(row0 + row) * cs_t + 8 * pc);
+    const unsigned int g[4] = {own.x, own.y, own.z, own.w}, o[4] = {oth.x, oth.y, oth.z, oth.w};
+    const unsigned int cc[4] = {cv.x, cv.y, cv.z, cv.w}, ss[4] = {sv.x, sv.y, sv.z, sv.w};
+    const float sgn = c < CH / 2 ? 1.0f : -1.0f;
+    unsigned int r[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float gx = u ? __uint_as_float(g[e] & 0xffff0000u) : __uint_as_float(g[e] << 16);
+        const float ox = u ? __uint_as_float(o[e] & 0xffff0000u) : __uint_as_float(o[e] << 16);
+        const float cx = u ? __uint_as_float(cc[e] & 0xffff0000u) : __uint_as_float(cc[e] << 16);
+        const float sx = u ? __uint_as_float(ss[e] & 0xffff0000u) : __uint_as_float(ss[e] << 16);
+        const float a = bf16_to_f32(f32_to_bf16(gx * cx));
+        const float bterm = bf16_to_f32(f32_to_bf16(ox * sx));
+        v[u] = a + sgn * bterm;
+      }
+      r[e] = pack_bf16x2(v[0], v[1]);
+    }
+    *reinterpret_cast<uint4*>(dst + static_cast<int64_t>(row0 + row) * row_stride + 8 * c) = make_uint4(r[0], r[1], r[2], r[3]);
   }
 }
 
@@ -307,7 +348,8 @@ __global__ __launch_bounds__(256, AT<HD>::OCC) void attn_bwd_dq_kernel(const Att
   __syncthreads();
   spill_transposed<HD, A::ND>(acc, 0, p.scale, lds, w, l31, hi);
   __syncthreads();
-  store_rows<HD, A::N128>(lds, dq_base, p.s[5][2], i0, p.T, t);
+  if (p.cos) store_rows_unrope<HD, A::N128>(lds, dq_base, p.s[5][2], i0, p.T, t, p.cos + b * p.cs_b, p.sin + b * p.cs_b, p.cs_t);
+  else store_rows<HD, A::N128>(lds, dq_base, p.s[5][2], i0, p.T, t);
 }
 
 // Forward: O = softmax(scale Q K^T + mask) V and the rows' log-sum-exp (natural log), the dq kernel's structure with the
@@ -554,7 +596,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdPara
   spill_transposed<HD, NDH>(dKt, NDH * dh, p.scale, dlds, jt, l31, hi);
   spill_transposed<HD, NDH>(dVt, NDH * dh, 1.0f, dlds + A::RM, jt, l31, hi);
   __syncthreads();
-  store_rows<HD, A::N64>(dlds, dk_base, p.s[6][2], j0, p.T, t);
+  if (p.cos) store_rows_unrope<HD, A::N64>(dlds, dk_base, p.s[6][2], j0, p.T, t, p.cos + b * p.cs_b, p.sin + b * p.cs_b, p.cs_t);
+  else store_rows<HD, A::N64>(dlds, dk_base, p.s[6][2], j0, p.T, t);
   store_rows<HD, A::N64>(dlds + A::RM, dv_base, p.s[7][2], j0, p.T, t);
 }
 
@@ -606,7 +649,8 @@ extern "C" int dalm_attn_mask_bits(const void* mask, int64_t B, int64_t T, int64
 
 extern "C" int dalm_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
                              const uint32_t* bits_rows, const uint32_t* bits_cols, const uint8_t* live, int64_t B, int64_t H,
-                             int64_t T, int64_t hd, float scale, const int64_t* strides, void* dq, void* dk, void* dv, float* delta,
+                             int64_t T, int64_t hd, float scale, const int64_t* strides, const void* cos, const void* sin,
+                             int64_t cs_stride_b, int64_t cs_stride_t, void* dq, void* dk, void* dv, float* delta,
                              dalm_stream_t stream) {
   DALM_REQUIRE(q && k && v && o && d_o && lse && bits_rows && bits_cols && live && strides && dq && dk && dv && delta, DALM_E_NULL,
                "null pointer argument");
@@ -618,7 +662,12 @@ extern "C" int dalm_attn_bwd(const void* q, const void* k, const void* v, const 
     for (int a = 0; a < 3; ++a)
       DALM_REQUIRE(strides[3 * i + a] >= 0 && strides[3 * i + a] % 8 == 0, DALM_E_ALIGN, "strides must be non-negative multiples of 8 elements");
   }
+  DALM_REQUIRE((cos == nullptr) == (sin == nullptr), DALM_E_NULL, "cos and sin come together");
+  DALM_REQUIRE(!cos || (al16(cos) && al16(sin) && cs_stride_b >= 0 && cs_stride_b % 8 == 0 && cs_stride_t >= hd && cs_stride_t % 8 == 0),
+               DALM_E_ALIGN, "cos / sin: 16-byte aligned rows of hd elements");
   AttnBwdParams p;
+  p.cos = static_cast<const unsigned short*>(cos); p.sin = static_cast<const unsigned short*>(sin);
+  p.cs_b = cs_stride_b; p.cs_t = cs_stride_t;
   p.q = static_cast<const unsigned short*>(q); p.k = static_cast<const unsigned short*>(k);
   p.v = static_cast<const unsigned short*>(v); p.o = static_cast<const unsigned short*>(o);
   p.d_o = static_cast<const unsigned short*>(d_o); p.lse = lse;

@@ -87,22 +87,45 @@ def _dense_like(t: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def _attn_forward(q, k, v, pk, scale, causal):
+    B, H, T, hd = q.shape
+    if os.environ.get("DALM_ATTN_FWD_KERNEL", "1") == "0":         # torch's memory-efficient forward + its log-sum-exp
+        out, lse, _, _ = torch.ops.aten._scaled_dot_product_efficient_attention(
+            q, k, v, _torch_bias(pk, B, H, T, q.dtype, q.device), True, 0.0, causal, scale=scale)
+        return out, lse
+    out = torch.empty(B, T, H, hd, dtype=q.dtype, device=q.device).transpose(1, 2)   # torch's layout: the caller's
+    lse = torch.empty(B, H, T, dtype=torch.float32, device=q.device)                  # transpose(1, 2).contiguous() is free
+    flat = []
+    for t in (q, k, v, out):
+        flat += _strides3(t)
+    hip.call("dalm_attn_fwd", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(pk.rows), hip.ptr(pk.live), B, H, T, hd, float(scale),
+             (C.c_int64 * 12)(*flat), hip.ptr(out), hip.ptr(lse), hip.stream())
+    return out, lse
+
+
+def _attn_backward(q, k, v, out, lse, d_out, pk, scale, cos=None, sin=None):
+    B, H, T, hd = q.shape
+    if d_out.stride(-1) != 1 or any(s % 8 for s in d_out.stride()[:3]):
+        d_out = d_out.contiguous()
+    lse = lse if (lse.is_contiguous() and lse.shape[-1] == T) else lse[..., :T].contiguous()
+    dq, dk, dv = _dense_like(q), _dense_like(k), _dense_like(v)
+    delta = torch.empty(B, H, T, dtype=torch.float32, device=q.device)
+    flat = []
+    for t in (q, k, v, out, d_out, dq, dk, dv):
+        flat += _strides3(t)
+    cs_b = 0 if (cos is None or cos.shape[0] == 1) else cos.stride(0)
+    hip.call("dalm_attn_bwd", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(out), hip.ptr(d_out), hip.ptr(lse), hip.ptr(pk.rows),
+             hip.ptr(pk.cols), hip.ptr(pk.live), B, H, T, hd, float(scale), (C.c_int64 * 24)(*flat), hip.ptr(cos), hip.ptr(sin),
+             cs_b, 0 if cos is None else cos.stride(1), hip.ptr(dq), hip.ptr(dk), hip.ptr(dv), hip.ptr(delta), hip.stream())
+    return dq, dk, dv
+
+
 class _SdpaHipBackward(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, mask, scale, causal):
         B, H, T, hd = q.shape
         pk = _pack(mask, B, H, T, causal, q.dtype, q.device)
-        if os.environ.get("DALM_ATTN_FWD_KERNEL", "1") == "0":         # torch's memory-efficient forward + its log-sum-exp
-            out, lse, _, _ = torch.ops.aten._scaled_dot_product_efficient_attention(
-                q, k, v, _torch_bias(pk, B, H, T, q.dtype, q.device), True, 0.0, causal, scale=scale)
-        else:
-            out = torch.empty(B, T, H, hd, dtype=q.dtype, device=q.device).transpose(1, 2)   # torch's layout: the caller's
-            lse = torch.empty(B, H, T, dtype=torch.float32, device=q.device)                  # transpose(1, 2).contiguous() is free
-            flat = []
-            for t in (q, k, v, out):
-                flat += _strides3(t)
-            hip.call("dalm_attn_fwd", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(pk.rows), hip.ptr(pk.live), B, H, T, hd, float(scale),
-                     (C.c_int64 * 12)(*flat), hip.ptr(out), hip.ptr(lse), hip.stream())
+        out, lse = _attn_forward(q, k, v, pk, scale, causal)
         ctx.save_for_backward(q, k, v, out, lse)
         ctx.pack, ctx.scale = pk, scale
         return out
@@ -110,21 +133,45 @@ class _SdpaHipBackward(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_out):
         q, k, v, out, lse = ctx.saved_tensors
-        pk = ctx.pack
-        B, H, T, hd = q.shape
-        if d_out.stride(-1) != 1 or any(s % 8 for s in d_out.stride()[:3]):
-            d_out = d_out.contiguous()
-        lse = lse if (lse.is_contiguous() and lse.shape[-1] == T) else lse[..., :T].contiguous()
-        dq, dk, dv = _dense_like(q), _dense_like(k), _dense_like(v)
-        delta = torch.empty(B, H, T, dtype=torch.float32, device=q.device)
-        flat = []
-        for t in (q, k, v, out, d_out, dq, dk, dv):
-            flat += _strides3(t)
-        strides = (C.c_int64 * 24)(*flat)
-        hip.call("dalm_attn_bwd", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(out), hip.ptr(d_out), hip.ptr(lse), hip.ptr(pk.rows),
-                 hip.ptr(pk.cols), hip.ptr(pk.live), B, H, T, hd, float(ctx.scale), strides, hip.ptr(dq), hip.ptr(dk), hip.ptr(dv),
-                 hip.ptr(delta), hip.stream())
+        dq, dk, dv = _attn_backward(q, k, v, out, lse, d_out, ctx.pack, ctx.scale)
         return dq, dk, dv, None, None, None
+
+
+class _RopeSdpaHip(torch.autograd.Function):
+    """rotary embedding of q and k (`dalm_rope_qk`, one launch) + the attention; the backward of the rotation happens in the
+    epilogues of `dalm_attn_bwd` (no launch of its own, the rotated gradients never reach memory)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, cos, sin, mask, scale, causal):
+        from . import tower_ops
+
+        B, H, T, hd = q.shape
+        q2, k2 = tower_ops._rope_launch(q, k, cos, sin, False)
+        pk = _pack(mask, B, H, T, causal, q.dtype, q.device)
+        out, lse = _attn_forward(q2, k2, v, pk, scale, causal)
+        ctx.save_for_backward(q2, k2, v, out, lse, cos, sin)
+        ctx.pack, ctx.scale = pk, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        q2, k2, v, out, lse, cos, sin = ctx.saved_tensors
+        dq, dk, dv = _attn_backward(q2, k2, v, out, lse, d_out, ctx.pack, ctx.scale, cos, sin)
+        return dq, dk, dv, None, None, None, None, None
+
+
+def rope_fusable(q, k, cos, sin) -> bool:
+    """cos / sin tables `dalm_attn_bwd` reads in its epilogues: what `tower_ops.rope_supported` takes, bf16, 16-byte rows."""
+    from . import tower_ops
+
+    return (tower_ops.rope_supported(q, k, cos, sin) and cos.dtype == torch.bfloat16 and cos.shape[-1] == q.shape[-1]
+            and cos.stride(1) % 8 == 0 and (cos.shape[0] == 1 or cos.stride(0) % 8 == 0)
+            and cos.data_ptr() % 16 == 0 and sin.data_ptr() % 16 == 0 and k.shape == q.shape)
+
+
+def rope_sdpa(query, key, value, cos, sin, mask, scale: float, causal: bool):
+    """sdpa(apply_rotary_pos_emb(query, key, cos, sin), value, ...) for what `supported` and `rope_fusable` accept."""
+    return _RopeSdpaHip.apply(query, key, value, cos, sin, mask, scale, causal)
 
 
 def _views_ok(*ts) -> bool:

@@ -428,9 +428,18 @@ def _falcon_attention_forward(self, hidden_states, alibi, attention_mask, positi
     key_layer = key_layer.transpose(1, 2).reshape(batch_size, num_kv_heads, query_length, self.head_dim)
     value_layer = value_layer.transpose(1, 2).reshape(batch_size, num_kv_heads, query_length, self.head_dim)
     cos, sin = position_embeddings
+    is_causal = bool(self.is_causal and attention_mask is None and query_length > 1)
+    if (attention.supported(query_layer, key_layer, value_layer, attention_mask, 0.0, is_causal, {})
+            and attention.rope_fusable(query_layer, key_layer, cos, sin) and os.environ.get("DALM_ROPE_KERNEL", "1") != "0"
+            and os.environ.get("DALM_FAST_ROPE", "1") != "0"):
+        attn_output = attention.rope_sdpa(query_layer, key_layer, value_layer, cos, sin, attention_mask,
+                                          float(self.head_dim) ** -0.5, is_causal)     # the rotation's backward: in dalm_attn_bwd
+        attn_output = attn_output.view(batch_size, self.num_heads, query_length, self.head_dim)
+        attn_output = attn_output.permute(0, 2, 1, 3)
+        attn_output = attn_output.reshape(batch_size, query_length, self.num_heads * self.head_dim)
+        return self.dense(attn_output), None
     rope = importlib.import_module(type(self).__module__).apply_rotary_pos_emb        # the modeling file's own (maybe swapped) one
     query_layer, key_layer = rope(query_layer, key_layer, cos, sin)
-    is_causal = bool(self.is_causal and attention_mask is None and query_length > 1)
     if not attention.supported(query_layer, key_layer, value_layer, attention_mask, 0.0, is_causal, {}):
         attn_output = torch.nn.functional.scaled_dot_product_attention(query_layer, key_layer, value_layer, attn_mask=attention_mask,
                                                                        dropout_p=0.0, is_causal=is_causal)
@@ -483,6 +492,93 @@ def _falcon_attention_matches(cls) -> bool:
         if not _checked[key]:
             _warn_once("falcon-attn", "FalconAttention.forward is not the code this patch restates: transformers' own code "
                        "stays in place")
+    return _checked[key]
+
+
+# ---------------------------------------------------------------------------
+# Llama attention: rotary embedding + attention as ONE autograd node (the rotation's backward rides in dalm_attn_bwd's epilogues)
+# ---------------------------------------------------------------------------
+_LLAMA_ATTN_PARAMS = ["self", "hidden_states", "position_embeddings", "attention_mask", "past_key_values", "kwargs"]
+
+
+def _llama_attention_forward(self, hidden_states, position_embeddings=None, attention_mask=None, past_key_values=None, **kwargs):
+    """transformers' LlamaAttention.forward for the training call ("dalm_sdpa", no KV cache, no dropout): the same statements with
+    apply_rotary_pos_emb + the attention call as `attention.rope_sdpa`.  Every other call goes to transformers' own forward."""
+    from . import attention
+
+    cfg = self.config
+    if (past_key_values is not None or position_embeddings is None or getattr(cfg, "_attn_implementation", None) != attention.NAME
+            or (self.training and float(getattr(self, "attention_dropout", 0.0)) != 0.0)
+            or os.environ.get("DALM_ROPE_KERNEL", "1") == "0" or os.environ.get("DALM_FAST_ROPE", "1") == "0"
+            or os.environ.get("DALM_ATTN_KERNEL", "1") == "0" or kwargs.get("output_attentions")):
+        return self._dalm_orig_attn_forward(hidden_states, position_embeddings=position_embeddings, attention_mask=attention_mask,
+                                            past_key_values=past_key_values, **kwargs)
+    input_shape = hidden_states.shape[:-1]
+    hidden_shape = (*input_shape, -1, self.head_dim)
+    query_states = self.q_proj(hidden_states).view(hidden_shape).transpose(1, 2)
+    key_states = self.k_proj(hidden_states).view(hidden_shape).transpose(1, 2)
+    value_states = self.v_proj(hidden_states).view(hidden_shape).transpose(1, 2)
+    cos, sin = position_embeddings
+    causal = bool(query_states.shape[2] > 1 and attention_mask is None and getattr(self, "is_causal", True))
+    if (key_states.shape == query_states.shape
+            and attention.supported(query_states, key_states, value_states, attention_mask, 0.0, causal, {})
+            and attention.rope_fusable(query_states, key_states, cos, sin)):
+        attn_output = attention.rope_sdpa(query_states, key_states, value_states, cos, sin, attention_mask, float(self.scaling), causal)
+        attn_output = attn_output.transpose(1, 2)
+    else:                                            # grouped heads, CPU tensors, ...: transformers' own sequence from here on
+        import importlib
+
+        from transformers.modeling_utils import ALL_ATTENTION_FUNCTIONS
+
+        rope = importlib.import_module(type(self).__module__).apply_rotary_pos_emb
+        query_states, key_states = rope(query_states, key_states, cos, sin)
+        attn_output, _ = ALL_ATTENTION_FUNCTIONS[cfg._attn_implementation](
+            self, query_states, key_states, value_states, attention_mask, dropout=0.0, scaling=self.scaling, **kwargs)
+    attn_output = attn_output.reshape(*input_shape, -1).contiguous()
+    return self.o_proj(attn_output), None
+
+
+def use_llama_attention_node(model: torch.nn.Module) -> int:
+    """Patch LlamaAttention modules of a model that runs on "dalm_sdpa" (models/attention.py) and whose forward is the code
+    `_llama_attention_forward` restates.  Returns the count."""
+    from . import attention
+
+    if getattr(getattr(model, "config", None), "_attn_implementation", None) != attention.NAME:
+        return 0
+    n = 0
+    for mod in model.modules():
+        if type(mod).__name__ != "LlamaAttention" or not all(hasattr(mod, a) for a in ("q_proj", "k_proj", "v_proj", "o_proj", "scaling")):
+            continue
+        if not _llama_attention_matches(type(mod)):
+            continue
+        mod._dalm_orig_attn_forward = mod.forward
+        mod.forward = types.MethodType(_llama_attention_forward, mod)
+        n += 1
+    return n
+
+
+def _llama_attention_matches(cls) -> bool:
+    key = ("llama-attn", cls)
+    if key not in _checked:
+        try:
+            import inspect
+
+            params = list(inspect.signature(cls.forward).parameters)
+            src = inspect.getsource(cls.forward)
+            _checked[key] = (params == _LLAMA_ATTN_PARAMS
+                             and "query_states = self.q_proj(hidden_states).view(hidden_shape).transpose(1, 2)" in src
+                             and "key_states = self.k_proj(hidden_states).view(hidden_shape).transpose(1, 2)" in src
+                             and "value_states = self.v_proj(hidden_states).view(hidden_shape).transpose(1, 2)" in src
+                             and "query_states, key_states = apply_rotary_pos_emb(query_states, key_states, cos, sin)" in src
+                             and "dropout=0.0 if not self.training else self.attention_dropout" in src
+                             and "scaling=self.scaling" in src
+                             and "attn_output = attn_output.reshape(*input_shape, -1).contiguous()" in src
+                             and "attn_output = self.o_proj(attn_output)" in src)
+        except Exception:
+            _checked[key] = False
+        if not _checked[key]:
+            _warn_once("llama-attn", "LlamaAttention.forward is not the code this patch restates: transformers' own code stays "
+                       "in place")
     return _checked[key]
 
 

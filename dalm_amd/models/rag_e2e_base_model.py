@@ -16,7 +16,7 @@ from ..utils import eos_mask
 from . import lora
 from .attention import use_hip_attention_backward
 from .fastpath import (use_capturable_falcon_heads, use_falcon_attention_kernels, use_falcon_layer_kernels,
-                       use_fused_residual_norm, use_native_rms_norm, use_roll_rope, use_swiglu_kernel)
+                       use_fused_residual_norm, use_llama_attention_node, use_native_rms_norm, use_roll_rope, use_swiglu_kernel)
 
 
 class Mode(Enum):
@@ -120,6 +120,7 @@ class AutoModelForRagE2E(torch.nn.Module):
         use_falcon_layer_kernels(self.generator_model)
         use_falcon_attention_kernels(self.generator_model)
         use_hip_attention_backward(self.generator_model)
+        use_llama_attention_node(self.generator_model)
         if autoregressive:
             use_native_rms_norm(self.retriever_model)
         if get_peft is not None:

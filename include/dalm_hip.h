@@ -466,7 +466,10 @@ int dalm_add3(const void* a, const void* b, const void* c, void* out, int64_t n,
  *   dalm_attn_bwd: q, k, v, o (the forward's output), d_o, and lse [B, H, T] f32 (natural log of the row sums, what torch's
  *        memory-efficient forward returns) -> dq, dk, dv.  strides: 8 x (batch, head, row) ELEMENT strides of
  *        q, k, v, o, d_o, dq, dk, dv (last dimension contiguous, multiples of 8); delta: [B, H, T] f32 scratch
- *        (D = rowsum(dO o O)).  P and dS are rounded to bf16 for their products, sums in f32. */
+ *        (D = rowsum(dO o O)).  P and dS are rounded to bf16 for their products, sums in f32.
+ *        cos / sin (NULL, or [B or 1, T, hd] bf16 with element strides cs_stride_b (0 for one table) / cs_stride_t): q and k
+ *        are the outputs of dalm_rope_qk and dq / dk leave as the gradients of its INPUTS - that kernel's backward applied
+ *        in the epilogue, same rounding points. */
 /*   dalm_attn_fwd: o = softmax(scale q k^T + mask) v and lse [B, H, T] f32 (natural log; 0 for rows without a live key, whose
  *        output is 0).  strides: 4 x (batch, head, row) element strides of q, k, v, o. */
 int dalm_attn_fwd(const void* q, const void* k, const void* v, const uint32_t* bits_rows, const uint8_t* live, int64_t B, int64_t H,
@@ -475,8 +478,8 @@ int dalm_attn_mask_bits(const void* mask, int64_t B, int64_t T, int64_t mask_str
                         uint32_t* bits_rows, uint32_t* bits_cols, uint8_t* live, dalm_stream_t stream);
 int dalm_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
                   const uint32_t* bits_rows, const uint32_t* bits_cols, const uint8_t* live, int64_t B, int64_t H, int64_t T,
-                  int64_t hd, float scale, const int64_t* strides, void* dq, void* dk, void* dv, float* delta,
-                  dalm_stream_t stream);
+                  int64_t hd, float scale, const int64_t* strides, const void* cos, const void* sin, int64_t cs_stride_b,
+                  int64_t cs_stride_t, void* dq, void* dk, void* dv, float* delta, dalm_stream_t stream);
 
 /* ---- the low-rank branch of a LoRA-wrapped Linear ----------------------------------------------------------------
  * The reference wraps q_proj / v_proj (key / query / value for BERT retrievers) in peft LoRA adapters, r = 8, alpha = 16,

@@ -230,3 +230,67 @@ def test_falcon_attention_patch_matches_transformers(dev):
     live = am.bool()
     assert _rel(outs[1][0][live], outs[0][0][live]) < 1e-2
     assert _rel(outs[1][1][live], outs[0][1][live]) < 2e-2
+
+
+@pytest.mark.parametrize("hd,H,T,batch_tables", [(128, 3, 256, False), (64, 5, 200, False), (128, 2, 96, True)])
+def test_rotation_backward_in_the_attention_epilogues_equals_the_two_node_form(dev, hd, H, T, batch_tables):
+    """`rope_sdpa` (rotary embedding + attention as one autograd node; the rotation's backward applied in dalm_attn_bwd's
+    epilogues) against `tower_ops.rope_qk` followed by `attention.sdpa` (two nodes, `dalm_rope_qk` launched for the backward):
+    the same output and the SAME dq, dk, dv - the epilogue keeps that kernel's rounding points."""
+    from dalm_amd.models import attention, tower_ops
+
+    B = 2
+    g = torch.Generator().manual_seed(hd + T)
+    q, k, v, go = [(torch.randn(B, T, H, hd, generator=g)).bfloat16().to(dev).transpose(1, 2) for _ in range(4)]
+    pos = torch.arange(T).float()[None, :, None] + (torch.tensor([0.0, 7.0])[:, None, None] if batch_tables else 0.0)
+    inv = 1.0 / (10000 ** (torch.arange(0, hd, 2).float() / hd))
+    ang = torch.cat((pos * inv, pos * inv), -1)                       # [1 or B, T, hd], halves duplicated as transformers builds them
+    cos, sin = ang.cos().bfloat16().to(dev), ang.sin().bfloat16().to(dev)
+    mask = _hf_mask(B, T, [0, T // 3], dev)
+    scale = hd ** -0.5
+    assert attention.rope_fusable(q, k, cos, sin)
+
+    def two_nodes(a, b, c):
+        a2, b2 = tower_ops.rope_qk(a, b, cos, sin)
+        return attention.sdpa(a2, b2, c, mask, scale, False)
+
+    one = _run(lambda a, b, c: attention.rope_sdpa(a, b, c, cos, sin, mask, scale, False), q, k, v, go)
+    two = _run(two_nodes, q, k, v, go)
+    for name, a, b in zip(("out", "dq", "dk", "dv"), one, two):
+        assert torch.equal(a, b), (name, float((a.float() - b.float()).abs().max()))
+    # and against transformers' own rotary function differentiated by autograd, around torch's attention
+    import transformers.models.llama.modeling_llama as ml
+
+    rope = getattr(ml, "_dalm_orig_apply_rotary_pos_emb", ml.apply_rotary_pos_emb)
+    eager = _run(lambda a, b, c: torch.nn.functional.scaled_dot_product_attention(*rope(a, b, cos, sin), c, attn_mask=mask, scale=scale),
+                 q, k, v, go)
+    for a, b in zip(one, eager):
+        assert _rel(a, b) < 1.5e-2
+
+
+def test_llama_attention_node_matches_the_unpatched_dalm_sdpa_model(dev):
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    from dalm_amd.models import attention, fastpath
+
+    torch.manual_seed(0)
+    cfg = LlamaConfig(hidden_size=512, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4,
+                      vocab_size=300)
+    a = LlamaForCausalLM(cfg).to(dev).to(torch.bfloat16).train()
+    b = copy.deepcopy(a)
+    for m in (a, b):
+        assert attention.use_hip_attention_backward(m) and fastpath.use_roll_rope(m)
+    assert fastpath.use_llama_attention_node(b) == 2
+    assert b.model.layers[0].self_attn.forward.__func__ is fastpath._llama_attention_forward
+    B, T = 3, 64
+    ids = torch.randint(0, 300, (B, T), device=dev)
+    am = torch.ones(B, T, dtype=torch.long, device=dev)
+    am[0, :20] = 0
+    outs = []
+    for m in (a, b):
+        logits = m(input_ids=ids, attention_mask=am).logits
+        (logits.float() * am[..., None]).square().sum().backward()
+        outs.append((logits.detach(), [p.grad.detach().clone() for p in m.parameters()]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for x, y in zip(outs[1][1], outs[0][1]):
+        assert torch.equal(x, y)
