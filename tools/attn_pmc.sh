@@ -12,9 +12,10 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/atp/*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "attn_bwd" not in k and "bwd_kernel" not in k:
+        if "attn_" not in k and "bwd_kernel" not in k:
             continue
-        agg[k.split("(")[0][-40:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        name = next((n for n in ("attn_bwd_dq", "attn_bwd_dkdv", "attn_fwd_kernel", "attn_mask_bits") if n in k), k.split("(")[0][-40:])
+        agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in agg.items():
     print(k)
     for c, v in sorted(cs.items()):

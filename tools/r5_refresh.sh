@@ -42,6 +42,7 @@ if [ "$PART" = prof ] || [ "$PART" = all ]; then
     --source "profiles/r05_bench_pmc_loss_kernels.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of bench.py, real masks; FETCH doubled per the gfx950 guide)" > /dev/null
   bash tools/step_streams.sh r05 > /dev/null 2>&1; cp gpurun_out/r05_step_by_stream.txt $P/r05_step_by_stream.txt
   bash tools/step_streams.sh r05cfg2 "--workload cfg2" "small_grad_kernel|sim_small|small_" > /dev/null 2>&1; cp gpurun_out/r05cfg2_step_by_stream.txt $P/r05cfg2_step_by_stream.txt 2>/dev/null
+  bash tools/step_streams.sh r05cfg5 "--workload cfg5" > /dev/null 2>&1; cp gpurun_out/r05cfg5_step_by_stream.txt $P/r05cfg5_step_by_stream.txt 2>/dev/null
 fi
 if [ "$PART" = kernels ] || [ "$PART" = all ]; then
   python tools/kernel_bench.py > $P/r05_kernel_bench.txt 2>/dev/null
@@ -49,6 +50,11 @@ if [ "$PART" = kernels ] || [ "$PART" = all ]; then
   python tools/lora_bench.py --rows 19200 --cols 1024 > $P/r05_lora_bench_19200x1024.txt 2>/dev/null
   python tools/lm_head_train_bench.py --json $P/r05_lm_head_train_bench.json > $P/r05_lm_head_train_kernels_vs_library.txt 2>/dev/null
   python tools/lm_head_train_bench.py --tuned > $P/r05_lm_head_train_kernels_vs_library_tuned_table.txt 2>/dev/null
+  python tools/attn_bench.py > $P/r05_attn_bench.txt 2>/dev/null
+  python tools/attn_bench.py --lens full >> $P/r05_attn_bench.txt 2>/dev/null
+  bash tools/attn_prof.sh > /dev/null 2>&1; cp gpurun_out/attn_kernels.txt $P/r05_attn_kernels_per_launch.txt
+  bash tools/attn_pmc.sh > /dev/null 2>&1; cp gpurun_out/attn_pmc.txt $P/r05_attn_pmc.txt
+  python tools/sim_grad_x3_bench.py > $P/r05_sim_grad_x3.txt 2>/dev/null
   rm -rf $P/lt; (cd /tmp; rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$P/lt -- python $GRAFT_REPO_ROOT/tools/lora_bench.py --iters 10 > /dev/null 2>&1)
   python tools/summarize_trace.py "$(find $P/lt -name '*kernel_trace.csv' | head -1)" "lora" 40 > $P/r05_lora_kernels_per_shape.txt; rm -rf $P/lt
 fi
