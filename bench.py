@@ -834,11 +834,23 @@ def main():
                                  "side); the all-ones-mask roofline point is in profiles/ (tools/kernel_bench.py)",
                          "timing": probe_note},
         }
-        if args.gpus == 1 and args.dtype == "bf16" and not args.no_pmc and batches:
+        if args.gpus == 1 and args.dtype == "bf16" and batches and (not args.no_pmc or args.fuse_lm_head):
             try:
                 out["f1_lm_head_paths"] = f1_head_paths(dev, batches[0], model)
             except Exception as e:
                 out["f1_lm_head_paths"] = {"error": repr(e)}
+        f1 = out.get("f1_lm_head_paths") or {}
+        if args.fuse_lm_head and os.environ.get("DALM_LM_HEAD_TRAIN_KERNEL", "1") != "0" and f1.get("kernels_ms"):
+            # the fused CE kernel does not run on this path: the loss path's dominant kernels are the three bf16 MFMA contractions
+            # of the logits-free lm_head + CE (forward lse, logits recomputed for d(logits), d(hidden)), timed live above
+            flop = 3 * 2.0 * f1["rows"] * f1["V"] * f1["H"]
+            tf = flop / (f1["kernels_ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "dalm_lm_head_lse_fwd + dalm_lm_head_dlogits + dalm_lm_head_dhidden (bf16 MFMA, "
+                                                          "logits never materialised; incl. the transposes and the merge launches)",
+                               "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0, "traffic": None,
+                               "algorithmic_flop": flop, "avg_launch_us": f1["kernels_ms"] * 1e3,
+                               "note": "3 contractions of [rows, H] x [V, H] over the live rows (HIP events around eager calls, "
+                                       "f1_lm_head_paths.kernels_ms); the library path of the same rows takes f1_lm_head_paths.library_ms"}
         if args.gpus == 1 and not args.no_cpu_baseline and args.workload == "cfg3":
             try:
                 out["cpu_baseline"], parity = cpu_reference_baseline(parity_dev=dev)

@@ -60,6 +60,9 @@ struct AttnBwdParams {
   int B, H, T, W;                        // W = ceil(T / 32) mask words per row
   float scale;
   int64_t s[8][3];                       // element strides (batch, head, row) of q, k, v, o, dO, dq, dk, dv
+  const unsigned long long* seed;        // attention dropout (BERT's attention_probs_dropout_prob): device seed word, NULL = off
+  unsigned int salt, thresh;             // per-call salt; keep an element when its 16-bit field >= thresh = round(p 65536)
+  float keep_scale;                      // 1 / (1 - p)
   const unsigned short *cos, *sin;       // backward only, may be NULL: q and k are ROTATED tensors (rotary embedding applied by
   int64_t cs_b, cs_t;                    // dalm_rope_qk); dq and dk leave as gradients of the UN-rotated ones.  [B or 1, T, hd]
 };
@@ -202,6 +205,26 @@ __device__ __forceinline__ void store_rows_unrope(const unsigned char* out, unsi
   }
 }
 
+// Attention dropout: P o M / (1 - p) in front of the P V product (torch applies it there), M regenerated by every kernel from
+// (device seed word, per-call salt, element index) - never stored.  One 32-bit hash serves the PAIR of elements (i, j), (i, j + 1),
+// j even (T even): 16-bit fields compared with round(p 65536).  oracle/attn_dropout.py restates it; tests pin every bit.
+struct AttnDrop { unsigned int a, b, thresh; float ks; };
+__device__ __forceinline__ unsigned int mix32(unsigned int x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ AttnDrop attn_drop(const AttnBwdParams& p) {
+  AttnDrop d;
+  d.thresh = p.seed ? p.thresh : 0u;
+  d.ks = p.seed ? p.keep_scale : 1.0f;
+  const unsigned long long s = p.seed ? *p.seed : 0ull;
+  d.a = mix32(static_cast<unsigned int>(s) ^ (p.salt * 0x9E3779B9u));
+  d.b = mix32(static_cast<unsigned int>(s >> 32) + p.salt + 0x85ebca6bu) | 1u;
+  return d;
+}
+// both fields of the pair that holds element index c (c even): low half = element c, high half = element c + 1
+__device__ __forceinline__ unsigned int drop_pair(const AttnDrop& d, unsigned int c) { return mix32(((c >> 1) ^ d.a) + d.b); }
+
 // launch index -> (row block, head, batch): the row blocks of one (batch, head) - which re-read the same K / V (or Q / dO) - go to
 // the same XCD (launch index mod 8) and sit 8 apart in launch order, so the second one finds the first one's lines in that L2
 __device__ __forceinline__ bool block_coords(const AttnBwdParams& p, int nblk, int& blk, int& h, int& b) {
@@ -228,8 +251,8 @@ __device__ __forceinline__ unsigned long long need_mask(const AttnBwdParams& p, 
   return __builtin_amdgcn_ballot_w64(v != 0u);
 }
 
-template <int HD>
-__global__ __launch_bounds__(256, AT<HD>::OCC) void attn_bwd_dq_kernel(const AttnBwdParams p) {
+template <int HD, bool DROP>
+__global__ __launch_bounds__(256, DROP ? 2 : AT<HD>::OCC) void attn_bwd_dq_kernel(const AttnBwdParams p) {
   using A = AT<HD>;
   constexpr int LDS = (2 * A::RM + A::TR) > (128 * A::LROW + 512) ? (2 * A::RM + A::TR) : (128 * A::LROW + 512);
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS];
@@ -303,7 +326,12 @@ __global__ __launch_bounds__(256, AT<HD>::OCC) void attn_bwd_dq_kernel(const Att
     block_load<HD>(vbase, p.s[2][2], 64 * jb, p.T, w, l, vv);
   };
   fetch(__builtin_ctz(blocks));
+  const AttnDrop drop = attn_drop(p);
+  const unsigned int cbase = (static_cast<unsigned int>(bh) * p.T + i) * p.T;      // element index of (row i, column 0)
+  (void)drop; (void)cbase;
   while (blocks) {
+    const int jb = __builtin_ctz(blocks);
+    (void)jb;
     blocks &= blocks - 1u;
     uint32_t word[2] = {nword[0], nword[1]};
     __syncthreads();                                           // the previous block's fragments have been read
@@ -328,11 +356,16 @@ __global__ __launch_bounds__(256, AT<HD>::OCC) void attn_bwd_dq_kernel(const Att
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         float ds[2];
+        const int jl0 = (r & 3) + 8 * (r >> 2) + 4 * hi;       // even: (jl0, jl0 + 1) share a hash
+        unsigned int hw = 0xffffffffu;
+        if constexpr (DROP) hw = drop_pair(drop, cbase + 64 * jb + 32 * js + jl0);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          const int jl = ((r + u) & 3) + 8 * ((r + u) >> 2) + 4 * hi;
+          const int jl = jl0 + u;
           const float pv = ((word[js] >> jl) & 1u) ? __builtin_amdgcn_exp2f(fmaf(St[r + u], c1, nl)) : 0.f;
-          ds[u] = pv * (Pt[r + u] - Dl);
+          float dpe = Pt[r + u];
+          if constexpr (DROP) dpe = ((u ? hw >> 16 : hw & 0xffffu) >= drop.thresh) ? dpe * drop.ks : 0.f;
+          ds[u] = pv * (dpe - Dl);
         }
         pk[r >> 1] = pack_bf16x2(ds[0], ds[1]);
       }
@@ -358,7 +391,7 @@ __global__ __launch_bounds__(256, AT<HD>::OCC) void attn_bwd_dq_kernel(const Att
 // tile; P^T rounded to bf16 is the B operand of O^T[d, i] += V^T[d, j] P^T[j, i] (V^T from a transposed LDS copy).
 // torch's memory-efficient forward takes 115 - 123 us at cfg3 (B 18, H 32, T 256; profiles/r05_step_by_stream.txt).
 // Algorithmic bytes: q, k, v read + o written = 4 B H T hd el (151 MB at cfg3).
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(256, AT<HD>::OCC) void attn_fwd_kernel(const AttnBwdParams p) {
   using A = AT<HD>;
   constexpr int LDS = (A::RM + A::TR) > 128 * A::LROW ? (A::RM + A::TR) : 128 * A::LROW;
@@ -412,7 +445,12 @@ __global__ __launch_bounds__(256, AT<HD>::OCC) void attn_fwd_kernel(const AttnBw
     for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
   float m = -INFINITY, lsum = 0.f;                              // running maximum (log2 domain) of the row; this lane's share of the sum
 
+  const AttnDrop drop = attn_drop(p);
+  const unsigned int cbase = (static_cast<unsigned int>(bh) * p.T + i) * p.T;
+  (void)drop; (void)cbase;
   while (blocks) {
+    const int jb = __builtin_ctz(blocks);
+    (void)jb;
     blocks &= blocks - 1u;
     uint32_t word[2] = {nword[0], nword[1]};
     __syncthreads();                                           // the previous block's (or Q's) fragments have been read
@@ -447,8 +485,13 @@ __global__ __launch_bounds__(256, AT<HD>::OCC) void attn_fwd_kernel(const AttnBw
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const float p0 = __builtin_amdgcn_exp2f(St[r] - base), p1 = __builtin_amdgcn_exp2f(St[r + 1] - base);
-        ps += p0 + p1;
-        pk[r >> 1] = pack_bf16x2(p0, p1);
+        ps += p0 + p1;                                           // the softmax denominator counts dropped elements too
+        if constexpr (DROP) {
+          const unsigned int hw = drop_pair(drop, cbase + 64 * jb + 32 * js + (r & 3) + 8 * (r >> 2) + 4 * hi);
+          pk[r >> 1] = pack_bf16x2((hw & 0xffffu) >= drop.thresh ? p0 * drop.ks : 0.f, (hw >> 16) >= drop.thresh ? p1 * drop.ks : 0.f);
+        } else {
+          pk[r >> 1] = pack_bf16x2(p0, p1);
+        }
       }
       lsum = fmaf(lsum, alpha, ps);
 #pragma unroll
@@ -481,7 +524,7 @@ constexpr int dkdv_lds() { return 2 * AT<HD>::RM + 2 * AT<HD>::TR + 2 * 64 * 4; 
 // half the accumulator registers, which is what lets TWO workgroups share a CU (the one-wave-per-SIMD form spent its time
 // waiting: 113 us against 97 us, tools/attn_bench.py).
 // (Fetching block n + 1 while block n is multiplied, as the dq kernel does, costs this kernel 23 spilled registers: 91 -> 124 us.)
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdParams p) {
   using A = AT<HD>;
   constexpr int NDH = A::ND / 2;                               // d blocks of this wave's half
@@ -528,6 +571,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdPara
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dVt[d][r] = 0.f; dKt[d][r] = 0.f; }
 
+  const AttnDrop drop = attn_drop(p);
+  (void)drop;
   const int nI = (p.T + 63) >> 6;
   for (int ib = 0; ib < nI; ++ib) {
     if (((need >> (2 * ib)) & 3ull) == 0ull) continue;
@@ -572,7 +617,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdPara
         for (int u = 0; u < 4; ++u) {
           const int il = 8 * q + 4 * hi + u;
           pv[u] = ((word[is] >> il) & 1u) ? __builtin_amdgcn_exp2f(fmaf(S[4 * q + u], c1, nl[u])) : 0.f;
-          ds[u] = pv[u] * (dP[4 * q + u] - dl[u]);
+          float dpe = dP[4 * q + u];
+          if constexpr (DROP) {
+            const unsigned int c = (static_cast<unsigned int>(bh) * p.T + 64 * ib + 32 * is + il) * p.T + j;
+            const unsigned int hw = drop_pair(drop, c & ~1u);
+            const bool keep = ((c & 1u) ? hw >> 16 : hw & 0xffffu) >= drop.thresh;
+            dpe = keep ? dpe * drop.ks : 0.f;
+            ds[u] = pv[u] * (dpe - dl[u]);
+            pv[u] = keep ? pv[u] * drop.ks : 0.f;                // what multiplies dO in dV = (P o M / (1 - p))^T dO
+          } else {
+            ds[u] = pv[u] * (dpe - dl[u]);
+          }
         }
         ppk[2 * q] = pack_bf16x2(pv[0], pv[1]);
         ppk[2 * q + 1] = pack_bf16x2(pv[2], pv[3]);
@@ -627,6 +682,13 @@ __global__ __launch_bounds__(256) void attn_mask_bits_kernel(const unsigned char
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline void set_dropout(AttnBwdParams& p, float dropout_p, const void* seed, uint32_t salt) {
+  const bool on = dropout_p > 0.f;
+  p.seed = on ? static_cast<const unsigned long long*>(seed) : nullptr;
+  p.salt = salt;
+  p.thresh = on ? static_cast<unsigned int>(dropout_p * 65536.0f + 0.5f) : 0u;
+  p.keep_scale = on ? 1.0f / (1.0f - dropout_p) : 1.0f;
+}
 
 }  // namespace
 }  // namespace dalm
@@ -637,7 +699,6 @@ extern "C" int dalm_attn_mask_bits(const void* mask, int64_t B, int64_t T, int64
                                    uint32_t* bits_rows, uint32_t* bits_cols, uint8_t* live, dalm_stream_t stream) {
   DALM_REQUIRE(bits_rows && bits_cols && live, DALM_E_NULL, "null pointer argument");
   DALM_REQUIRE(B > 0 && T > 0 && T <= 32768 && B <= 65535, DALM_E_SHAPE, "need 0 < T <= 32768 and 0 < B <= 65535");
-  DALM_REQUIRE(mask || causal, DALM_E_NULL, "neither a mask nor the causal flag: nothing to pack");
   const int64_t W = (T + 31) / 32, total = B * 32 * W * W;
   hipStream_t s = as_stream(stream);
   if (hipError_t e = hipMemsetAsync(live, 0, static_cast<size_t>(B * W * W), s); e != hipSuccess) return fail(static_cast<int>(e), __func__, hipGetErrorString(e));
@@ -650,8 +711,8 @@ extern "C" int dalm_attn_mask_bits(const void* mask, int64_t B, int64_t T, int64
 extern "C" int dalm_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
                              const uint32_t* bits_rows, const uint32_t* bits_cols, const uint8_t* live, int64_t B, int64_t H,
                              int64_t T, int64_t hd, float scale, const int64_t* strides, const void* cos, const void* sin,
-                             int64_t cs_stride_b, int64_t cs_stride_t, void* dq, void* dk, void* dv, float* delta,
-                             dalm_stream_t stream) {
+                             int64_t cs_stride_b, int64_t cs_stride_t, float dropout_p, const void* seed, uint32_t salt, void* dq,
+                             void* dk, void* dv, float* delta, dalm_stream_t stream) {
   DALM_REQUIRE(q && k && v && o && d_o && lse && bits_rows && bits_cols && live && strides && dq && dk && dv && delta, DALM_E_NULL,
                "null pointer argument");
   DALM_REQUIRE(hd == 128 || hd == 64, DALM_E_SHAPE, "head width must be 64 or 128");
@@ -665,7 +726,10 @@ extern "C" int dalm_attn_bwd(const void* q, const void* k, const void* v, const 
   DALM_REQUIRE((cos == nullptr) == (sin == nullptr), DALM_E_NULL, "cos and sin come together");
   DALM_REQUIRE(!cos || (al16(cos) && al16(sin) && cs_stride_b >= 0 && cs_stride_b % 8 == 0 && cs_stride_t >= hd && cs_stride_t % 8 == 0),
                DALM_E_ALIGN, "cos / sin: 16-byte aligned rows of hd elements");
+  DALM_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f && (dropout_p == 0.f || (seed && T % 2 == 0)), DALM_E_SHAPE,
+               "dropout needs 0 <= p < 1, a device seed word and an even T");
   AttnBwdParams p;
+  set_dropout(p, dropout_p, seed, salt);
   p.cos = static_cast<const unsigned short*>(cos); p.sin = static_cast<const unsigned short*>(sin);
   p.cs_b = cs_stride_b; p.cs_t = cs_stride_t;
   p.q = static_cast<const unsigned short*>(q); p.k = static_cast<const unsigned short*>(k);
@@ -680,28 +744,29 @@ extern "C" int dalm_attn_bwd(const void* q, const void* k, const void* v, const 
     for (int a = 0; a < 3; ++a) p.s[i][a] = strides[3 * i + a];
   static bool lds_set = false;
   if (!lds_set) {
-    if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel<128>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, dkdv_lds<128>());
-        e != hipSuccess)
-      return fail(static_cast<int>(e), __func__, "could not raise the dynamic LDS limit of the dk / dv kernel");
+    for (const void* fn : {reinterpret_cast<const void*>(attn_bwd_dkdv_kernel<128, false>),
+                           reinterpret_cast<const void*>(attn_bwd_dkdv_kernel<128, true>)})
+      if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, dkdv_lds<128>()); e != hipSuccess)
+        return fail(static_cast<int>(e), __func__, "could not raise the dynamic LDS limit of the dk / dv kernel");
     lds_set = true;
   }
   const int64_t pairs8 = (B * H + 7) / 8 * 8;
   const dim3 grid_dq(static_cast<unsigned>(pairs8 * ((T + 127) / 128))), grid_dkdv(static_cast<unsigned>(pairs8 * ((T + 63) / 64)));
   hipStream_t s = as_stream(stream);
-  if (hd == 128) {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, grid_dq, dim3(256), 0, s, p);
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<128>, grid_dkdv, dim3(256), dkdv_lds<128>(), s, p);
-  } else {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid_dq, dim3(256), 0, s, p);
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<64>, grid_dkdv, dim3(256), dkdv_lds<64>(), s, p);
-  }
+#define DALM_ATTN_BWD(HD, DROP)                                                                         \
+  do {                                                                                                 \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, DROP>), grid_dq, dim3(256), 0, s, p);                   \
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD, DROP>), grid_dkdv, dim3(256), dkdv_lds<HD>(), s, p);  \
+  } while (0)
+  if (hd == 128) { if (p.seed) DALM_ATTN_BWD(128, true); else DALM_ATTN_BWD(128, false); }
+  else { if (p.seed) DALM_ATTN_BWD(64, true); else DALM_ATTN_BWD(64, false); }
+#undef DALM_ATTN_BWD
   return check_launch(__func__);
 }
 
 extern "C" int dalm_attn_fwd(const void* q, const void* k, const void* v, const uint32_t* bits_rows, const uint8_t* live, int64_t B,
-                             int64_t H, int64_t T, int64_t hd, float scale, const int64_t* strides, void* o, float* lse,
-                             dalm_stream_t stream) {
+                             int64_t H, int64_t T, int64_t hd, float scale, const int64_t* strides, float dropout_p, const void* seed,
+                             uint32_t salt, void* o, float* lse, dalm_stream_t stream) {
   DALM_REQUIRE(q && k && v && bits_rows && live && strides && o && lse, DALM_E_NULL, "null pointer argument");
   DALM_REQUIRE(hd == 128 || hd == 64, DALM_E_SHAPE, "head width must be 64 or 128");
   DALM_REQUIRE(B > 0 && H > 0 && T > 0 && T <= 2048 && B * H <= (1ll << 24), DALM_E_SHAPE, "need 0 < T <= 2048 and B H <= 2^24");
@@ -711,7 +776,10 @@ extern "C" int dalm_attn_fwd(const void* q, const void* k, const void* v, const 
     for (int a = 0; a < 3; ++a)
       DALM_REQUIRE(strides[3 * i + a] >= 0 && strides[3 * i + a] % 8 == 0, DALM_E_ALIGN, "strides must be non-negative multiples of 8 elements");
   }
+  DALM_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f && (dropout_p == 0.f || (seed && T % 2 == 0)), DALM_E_SHAPE,
+               "dropout needs 0 <= p < 1, a device seed word and an even T");
   AttnBwdParams p = {};
+  set_dropout(p, dropout_p, seed, salt);
   p.q = static_cast<const unsigned short*>(q); p.k = static_cast<const unsigned short*>(k);
   p.v = static_cast<const unsigned short*>(v);
   p.bits_rows = bits_rows; p.live = live;
@@ -724,7 +792,13 @@ extern "C" int dalm_attn_fwd(const void* q, const void* k, const void* v, const 
   }
   const int64_t pairs8 = (B * H + 7) / 8 * 8;
   const dim3 grid(static_cast<unsigned>(pairs8 * ((T + 127) / 128)));
-  if (hd == 128) hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(256), 0, as_stream(stream), p);
-  else hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, as_stream(stream), p);
+  hipStream_t s = as_stream(stream);
+  if (hd == 128) {
+    if (p.seed) hipLaunchKernelGGL((attn_fwd_kernel<128, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<128, false>), grid, dim3(256), 0, s, p);
+  } else {
+    if (p.seed) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<64, false>), grid, dim3(256), 0, s, p);
+  }
   return check_launch(__func__);
 }

@@ -13,7 +13,10 @@ kernels: 60 us forward, 440 us backward per layer at cfg3 (2.7 % of the MFMA pea
   backward  `dalm_attn_bwd`: two launches.
 Both read the mask as packed bits (packed once per mask tensor - every layer passes the same one) and skip dead 32 x 32 tiles.
 
-Everything the kernels do not take (CPU tensors, other head widths, dropout, float masks, a KV cache, no gradient wanted) goes
+Attention dropout (BERT's attention_probs_dropout_prob in training mode) is applied inside the kernels, its keep mask regenerated
+from (a device seed word, a per-call salt, the element index) and never stored - this library's own generator
+(oracle/attn_dropout.py), not torch's philox stream.  DALM_ATTN_DROPOUT=0 sends dropout calls to torch.
+Everything the kernels do not take (CPU tensors, other head widths, odd T with dropout, float masks, a KV cache, no gradient wanted) goes
 to transformers' own `sdpa_attention_forward`, unchanged.  DALM_ATTN_KERNEL=0 keeps the model on "sdpa".
 """
 from __future__ import annotations
@@ -33,7 +36,7 @@ _HEAD_DIMS = (64, 128)
 class _MaskPack:
     """What the kernels read of one mask tensor: bias (for torch's forward), row / column bit words, live tiles."""
 
-    __slots__ = ("mask", "key", "bias", "rows", "cols", "live")
+    __slots__ = ("mask", "key", "bias", "rows", "cols", "live", "seed")
 
 
 _last: list = [None]          # the pack of the mask seen last: one forward pass hands the same tensor object to every layer
@@ -52,8 +55,9 @@ def _pack(mask: Optional[torch.Tensor], B: int, H: int, T: int, causal: bool, dt
     pk.cols = torch.empty_like(pk.rows)
     pk.live = torch.empty(B * W * W, dtype=torch.uint8, device=device)
     pk.bias = None
+    pk.seed = None
     if mask is None:
-        hip.call("dalm_attn_mask_bits", None, B, T, 0, 0, 1, hip.ptr(pk.rows), hip.ptr(pk.cols), hip.ptr(pk.live), hip.stream())
+        hip.call("dalm_attn_mask_bits", None, B, T, 0, 0, int(causal), hip.ptr(pk.rows), hip.ptr(pk.cols), hip.ptr(pk.live), hip.stream())
     else:
         m = mask if mask.stride(-1) == 1 else mask.contiguous()
         hip.call("dalm_attn_mask_bits", hip.ptr(m), B, T, m.stride(0), m.stride(2), int(causal), hip.ptr(pk.rows), hip.ptr(pk.cols),
@@ -87,9 +91,9 @@ def _dense_like(t: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def _attn_forward(q, k, v, pk, scale, causal):
+def _attn_forward(q, k, v, pk, scale, causal, drop=(0.0, None, 0)):
     B, H, T, hd = q.shape
-    if os.environ.get("DALM_ATTN_FWD_KERNEL", "1") == "0":         # torch's memory-efficient forward + its log-sum-exp
+    if os.environ.get("DALM_ATTN_FWD_KERNEL", "1") == "0" and drop[0] == 0.0:    # torch's memory-efficient forward + its log-sum-exp
         out, lse, _, _ = torch.ops.aten._scaled_dot_product_efficient_attention(
             q, k, v, _torch_bias(pk, B, H, T, q.dtype, q.device), True, 0.0, causal, scale=scale)
         return out, lse
@@ -99,11 +103,12 @@ def _attn_forward(q, k, v, pk, scale, causal):
     for t in (q, k, v, out):
         flat += _strides3(t)
     hip.call("dalm_attn_fwd", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(pk.rows), hip.ptr(pk.live), B, H, T, hd, float(scale),
-             (C.c_int64 * 12)(*flat), hip.ptr(out), hip.ptr(lse), hip.stream())
+             (C.c_int64 * 12)(*flat), float(drop[0]), hip.ptr(drop[1]), int(drop[2]) & 0xFFFFFFFF, hip.ptr(out), hip.ptr(lse),
+             hip.stream())
     return out, lse
 
 
-def _attn_backward(q, k, v, out, lse, d_out, pk, scale, cos=None, sin=None):
+def _attn_backward(q, k, v, out, lse, d_out, pk, scale, cos=None, sin=None, drop=(0.0, None, 0)):
     B, H, T, hd = q.shape
     if d_out.stride(-1) != 1 or any(s % 8 for s in d_out.stride()[:3]):
         d_out = d_out.contiguous()
@@ -116,25 +121,33 @@ def _attn_backward(q, k, v, out, lse, d_out, pk, scale, cos=None, sin=None):
     cs_b = 0 if (cos is None or cos.shape[0] == 1) else cos.stride(0)
     hip.call("dalm_attn_bwd", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(out), hip.ptr(d_out), hip.ptr(lse), hip.ptr(pk.rows),
              hip.ptr(pk.cols), hip.ptr(pk.live), B, H, T, hd, float(scale), (C.c_int64 * 24)(*flat), hip.ptr(cos), hip.ptr(sin),
-             cs_b, 0 if cos is None else cos.stride(1), hip.ptr(dq), hip.ptr(dk), hip.ptr(dv), hip.ptr(delta), hip.stream())
+             cs_b, 0 if cos is None else cos.stride(1), float(drop[0]), hip.ptr(drop[1]), int(drop[2]) & 0xFFFFFFFF, hip.ptr(dq),
+             hip.ptr(dk), hip.ptr(dv), hip.ptr(delta), hip.stream())
     return dq, dk, dv
 
 
 class _SdpaHipBackward(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, mask, scale, causal):
+    def forward(ctx, q, k, v, mask, scale, causal, dropout_p=0.0, salt=0):
         B, H, T, hd = q.shape
         pk = _pack(mask, B, H, T, causal, q.dtype, q.device)
-        out, lse = _attn_forward(q, k, v, pk, scale, causal)
+        drop = (0.0, None, 0)
+        if dropout_p > 0.0:
+            if pk.seed is None:         # this pass's copy of the device seed word (the step advances the word itself; a backward
+                from . import lora_ops  # that runs after the next advance must still see the forward's value)
+
+                pk.seed = lora_ops.dropout_seed(q.device).clone()
+            drop = (float(dropout_p), pk.seed, int(salt))
+        out, lse = _attn_forward(q, k, v, pk, scale, causal, drop)
         ctx.save_for_backward(q, k, v, out, lse)
-        ctx.pack, ctx.scale = pk, scale
+        ctx.pack, ctx.scale, ctx.drop = pk, scale, drop
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         q, k, v, out, lse = ctx.saved_tensors
-        dq, dk, dv = _attn_backward(q, k, v, out, lse, d_out, ctx.pack, ctx.scale)
-        return dq, dk, dv, None, None, None
+        dq, dk, dv = _attn_backward(q, k, v, out, lse, d_out, ctx.pack, ctx.scale, drop=ctx.drop)
+        return dq, dk, dv, None, None, None, None, None
 
 
 class _RopeSdpaHip(torch.autograd.Function):
@@ -183,14 +196,15 @@ def supported(query, key, value, mask, dropout, causal, kwargs) -> bool:
         return False
     if query.dim() != 4 or query.shape[-1] not in _HEAD_DIMS or key.shape != query.shape or value.shape != query.shape:
         return False                                 # a KV cache (kv length != q length) or grouped heads left unexpanded
-    if query.shape[2] < 2 or query.shape[2] > 2048 or dropout != 0.0 or kwargs.get("position_bias") is not None:
+    if query.shape[2] < 2 or query.shape[2] > 2048 or kwargs.get("position_bias") is not None:
         return False
+    if dropout != 0.0 and not (0.0 < dropout < 1.0 and query.shape[2] % 2 == 0 and os.environ.get("DALM_ATTN_DROPOUT", "1") != "0"):
+        return False                                 # the in-kernel mask pairs elements (i, j), (i, j + 1): even T
     if not (torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad)):
         return False                                 # nothing to differentiate: torch's fused forward alone is the best path
     B, _, T, _ = query.shape
     if mask is None:
-        if not causal:
-            return False
+        pass                                         # causal, or fully bidirectional (an encoder batch without padding)
     elif not (mask.dtype == torch.bool and mask.dim() == 4 and tuple(mask.shape) == (B, 1, T, T) and mask.is_cuda and not causal):
         return False
     return _views_ok(query, key, value)
@@ -209,7 +223,11 @@ def dalm_sdpa_attention_forward(module, query, key, value, attention_mask, dropo
         return sdpa_attention_forward(module, query, key, value, attention_mask, dropout=dropout, scaling=scaling,
                                       is_causal=is_causal, **kwargs)
     scale = float(scaling) if scaling is not None else float(query.shape[-1]) ** -0.5
-    out = _SdpaHipBackward.apply(query, k2, v2, attention_mask, scale, causal)
+    salt = 0
+    if dropout > 0.0:      # this module's id in the upper bits, a host call counter below (graph replays re-use the captured salt;
+        module._dalm_attn_calls = getattr(module, "_dalm_attn_calls", 0) + 1        # there the device seed word changes the masks)
+        salt = ((id(module) >> 4) << 12) ^ (module._dalm_attn_calls & 0xFFF)
+    out = _SdpaHipBackward.apply(query, k2, v2, attention_mask, scale, causal, float(dropout), salt)
     return out.transpose(1, 2).contiguous(), None
 
 
@@ -241,9 +259,10 @@ def register() -> bool:
     return True
 
 
-def sdpa(query, key, value, mask, scale: float, causal: bool):
-    """F.scaled_dot_product_attention(query, key, value, attn_mask=mask, is_causal=causal, scale=scale) for what `supported` accepts."""
-    return _SdpaHipBackward.apply(query, key, value, mask, scale, causal)
+def sdpa(query, key, value, mask, scale: float, causal: bool, dropout_p: float = 0.0, salt: int = 0):
+    """F.scaled_dot_product_attention(query, key, value, attn_mask=mask, is_causal=causal, scale=scale, dropout_p=dropout_p) for
+    what `supported` accepts (the dropout mask comes from this library's own generator, oracle/attn_dropout.py)."""
+    return _SdpaHipBackward.apply(query, key, value, mask, scale, causal, dropout_p, salt)
 
 
 def use_hip_attention_backward(model: torch.nn.Module) -> bool:
@@ -253,7 +272,7 @@ def use_hip_attention_backward(model: torch.nn.Module) -> bool:
     cfg = getattr(model, "config", None)
     if cfg is None or getattr(cfg, "_attn_implementation", None) != "sdpa":
         return False
-    if getattr(cfg, "model_type", "") not in ("llama", "mistral", "qwen2"):
+    if getattr(cfg, "model_type", "") not in ("llama", "mistral", "qwen2", "bert"):
         return False
     hd = getattr(cfg, "head_dim", None) or (cfg.hidden_size // cfg.num_attention_heads)
     if hd not in _HEAD_DIMS or not register():

@@ -121,6 +121,7 @@ class AutoModelForRagE2E(torch.nn.Module):
         use_falcon_attention_kernels(self.generator_model)
         use_hip_attention_backward(self.generator_model)
         use_llama_attention_node(self.generator_model)
+        use_hip_attention_backward(self.retriever_model)          # BERT: head width 64, attention dropout inside the kernels
         if autoregressive:
             use_native_rms_norm(self.retriever_model)
         if get_peft is not None:

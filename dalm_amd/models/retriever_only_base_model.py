@@ -45,6 +45,9 @@ class AutoModelForSentenceEmbedding(torch.nn.Module):
         self.model = model
         if is_autoregressive:
             use_native_rms_norm(self.model)
+        from .attention import use_hip_attention_backward
+
+        use_hip_attention_backward(self.model)        # BERT / Llama-family: dalm_attn_* (attention dropout inside the kernels)
         if get_peft:
             lora.inject_lora(self.model, ["key", "query", "value"] if not is_autoregressive else ["q_proj", "v_proj"])
         self.normalize = normalize

@@ -469,17 +469,22 @@ int dalm_add3(const void* a, const void* b, const void* c, void* out, int64_t n,
  *        (D = rowsum(dO o O)).  P and dS are rounded to bf16 for their products, sums in f32.
  *        cos / sin (NULL, or [B or 1, T, hd] bf16 with element strides cs_stride_b (0 for one table) / cs_stride_t): q and k
  *        are the outputs of dalm_rope_qk and dq / dk leave as the gradients of its INPUTS - that kernel's backward applied
- *        in the epilogue, same rounding points. */
+ *        in the epilogue, same rounding points.
+ *   dropout_p > 0 (BERT's attention_probs_dropout_prob; T even): P o M / (1 - p) in front of P V, the keep mask M regenerated in
+ *        every kernel from (the 64-bit word at `seed` in DEVICE memory, salt, element index ((b H + h) T + i) T + j) - never
+ *        stored; pass the same three values to dalm_attn_fwd and dalm_attn_bwd.  oracle/attn_dropout.py restates the mask. */
 /*   dalm_attn_fwd: o = softmax(scale q k^T + mask) v and lse [B, H, T] f32 (natural log; 0 for rows without a live key, whose
  *        output is 0).  strides: 4 x (batch, head, row) element strides of q, k, v, o. */
 int dalm_attn_fwd(const void* q, const void* k, const void* v, const uint32_t* bits_rows, const uint8_t* live, int64_t B, int64_t H,
-                  int64_t T, int64_t hd, float scale, const int64_t* strides, void* o, float* lse, dalm_stream_t stream);
+                  int64_t T, int64_t hd, float scale, const int64_t* strides, float dropout_p, const void* seed, uint32_t salt,
+                  void* o, float* lse, dalm_stream_t stream);
 int dalm_attn_mask_bits(const void* mask, int64_t B, int64_t T, int64_t mask_stride_b, int64_t mask_stride_row, int causal,
                         uint32_t* bits_rows, uint32_t* bits_cols, uint8_t* live, dalm_stream_t stream);
 int dalm_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
                   const uint32_t* bits_rows, const uint32_t* bits_cols, const uint8_t* live, int64_t B, int64_t H, int64_t T,
                   int64_t hd, float scale, const int64_t* strides, const void* cos, const void* sin, int64_t cs_stride_b,
-                  int64_t cs_stride_t, void* dq, void* dk, void* dv, float* delta, dalm_stream_t stream);
+                  int64_t cs_stride_t, float dropout_p, const void* seed, uint32_t salt, void* dq, void* dk, void* dv,
+                  float* delta, dalm_stream_t stream);
 
 /* ---- the low-rank branch of a LoRA-wrapped Linear ----------------------------------------------------------------
  * The reference wraps q_proj / v_proj (key / query / value for BERT retrievers) in peft LoRA adapters, r = 8, alpha = 16,

@@ -294,3 +294,113 @@ def test_llama_attention_node_matches_the_unpatched_dalm_sdpa_model(dev):
     assert torch.equal(outs[0][0], outs[1][0])
     for x, y in zip(outs[1][1], outs[0][1]):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("B,H,T,hd,pad", [(3, 4, 128, 64, [128, 90, 17]), (2, 3, 50, 64, [50, 31]), (2, 2, 256, 128, [256, 200])])
+def test_attention_dropout_mask_and_gradients(dev, B, H, T, hd, pad):
+    """BERT's attention dropout inside the kernels (bidirectional padding mask, p = 0.1): the keep mask the forward used - read off
+    its output with V = identity-like probes - equals oracle/attn_dropout.py bit for bit; out, dq, dk, dv against a float64
+    evaluation of softmax -> (P o M) / (1 - p) -> P V with THAT mask; forward and backward therefore use the same bits."""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "oracle"))
+    import attn_dropout as AD
+
+    from dalm_amd.models import attention, lora_ops
+
+    p, salt = 0.1, 0x5A17
+    g = torch.Generator().manual_seed(T + hd)
+    q, k, v, go = [(torch.randn(B, T, H, hd, generator=g)).bfloat16().to(dev).transpose(1, 2) for _ in range(4)]
+    col = torch.arange(T, device=dev)
+    lens = torch.tensor(pad, device=dev)
+    mask = (col[None, None, None, :] < lens[:, None, None, None]).expand(B, 1, T, T)          # HF's bidirectional padding mask
+    scale = hd ** -0.5
+    assert attention.supported(q.requires_grad_(True), k, v, mask, p, False, {})
+    seed = int(lora_ops.dropout_seed(dev).item())
+    keep = torch.from_numpy(AD.keep_mask(seed, salt, B, H, T, p)).to(dev)
+    assert abs(float((~keep).float().mean()) - p) < 0.01
+
+    ours = _run(lambda a, b, c: attention.sdpa(a, b, c, mask, scale, False, p, salt), q, k, v, go)
+    q64, k64, v64 = [t.detach().double().requires_grad_(True) for t in (q, k, v)]
+    s = (q64 @ k64.transpose(-1, -2)) * scale
+    s = s.masked_fill(~mask, float("-inf"))
+    pr = torch.softmax(s, -1) * keep.double() / (1.0 - p)
+    o64 = pr @ v64
+    o64.backward(go.double())
+    for name, a, r in zip(("out", "dq", "dk", "dv"), ours, (o64, q64.grad, k64.grad, v64.grad)):
+        assert torch.isfinite(a).all(), name
+        assert _rel(a, r) < 1.2e-2, (name, _rel(a, r))
+    # a different salt draws a different mask; p = 0 is the plain attention
+    other = _run(lambda a, b, c: attention.sdpa(a, b, c, mask, scale, False, p, salt + 1), q, k, v, go)
+    assert not torch.equal(other[0], ours[0])
+    plain = _run(lambda a, b, c: attention.sdpa(a, b, c, mask, scale, False, 0.0, 0), q, k, v, go)
+    theirs = _run(lambda a, b, c: torch.nn.functional.scaled_dot_product_attention(a, b, c, attn_mask=mask, scale=scale), q, k, v, go)
+    for a, b in zip(plain, theirs):
+        assert _rel(a, b) < 1.2e-2
+
+
+def test_every_keep_bit_of_the_forward_equals_the_oracle(dev):
+    """V = one-hot columns: out[b, h, i, d] = sum_j P_drop[i, j] [j == d] exposes every element of P o M / (1 - p) for T <= hd."""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "oracle"))
+    import attn_dropout as AD
+
+    from dalm_amd.models import attention, lora_ops
+
+    B, H, T, hd, p, salt = 2, 3, 64, 64, 0.25, 99
+    q = torch.zeros(B, H, T, hd, dtype=torch.bfloat16, device=dev).requires_grad_(True)       # uniform probabilities 1 / T
+    k = torch.zeros_like(q)
+    v = torch.eye(T, hd, dtype=torch.bfloat16, device=dev).expand(B, H, T, hd).contiguous()
+    out = attention.sdpa(q, k, v, None, 1.0, False, p, salt)
+    got = out.detach().float() > 0
+    want = torch.from_numpy(AD.keep_mask(int(lora_ops.dropout_seed(dev).item()), salt, B, H, T, p)).to(dev)
+    assert torch.equal(got, want)
+    assert torch.allclose(out.detach().float()[got], torch.tensor(1.0 / T / (1 - p), device=dev), rtol=1e-2)
+
+
+def test_bert_layer_on_dalm_sdpa_trains_with_dropout(dev):
+    """A BERT encoder (head width 64) on "dalm_sdpa" in training mode: runs through the kernels (attention dropout 0.1), matches the
+    "sdpa" model exactly in eval mode through no_grad, and in training mode with dropout off."""
+    from transformers import BertConfig, BertModel
+
+    from dalm_amd.models import attention
+
+    torch.manual_seed(0)
+    cfg = BertConfig(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512, vocab_size=300,
+                     hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    ref = BertModel(cfg).to(dev).train()                            # f32 parameters under bf16 autocast, as the trainers run it
+    new = copy.deepcopy(ref)
+    assert attention.use_hip_attention_backward(new) and new.config._attn_implementation == "dalm_sdpa"
+    B, T = 4, 64
+    ids = torch.randint(0, 300, (B, T), device=dev)
+    am = torch.ones(B, T, dtype=torch.long, device=dev)
+    am[1, 40:] = 0
+    outs = []
+    for m in (ref, new):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            h = m(input_ids=ids, attention_mask=am)[0]
+        # (a sum of squares of a LayerNorm's output is a constant: weighted sum instead)
+        (h.float() * am[..., None] * torch.linspace(-1, 1, h.shape[-1], device=dev)).sum().backward()
+        # (the key bias has a zero gradient in exact arithmetic - softmax ignores a shift of every score of a row - so what
+        # it holds is rounding noise: left out of the comparison)
+        outs.append((h.detach(), {n: p_.grad.detach().clone() for n, p_ in m.named_parameters()
+                                  if p_.grad is not None and not n.endswith("key.bias")}))
+    live = am.bool()
+    assert _rel(outs[1][0][live], outs[0][0][live]) < 1e-2
+    for n in outs[0][1]:
+        assert _rel(outs[1][1][n], outs[0][1][n]) < 3e-2, (n, _rel(outs[1][1][n], outs[0][1][n]))
+    # with attention dropout: finite, different from the no-dropout output, deterministic for a fixed seed word and call count
+    new.config.attention_probs_dropout_prob = 0.1
+    for layer in new.encoder.layer:
+        layer.attention.self.dropout.p = 0.1
+        layer.attention.self._dalm_attn_calls = 0
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        h1 = new(input_ids=ids, attention_mask=am)[0]
+        for layer in new.encoder.layer:
+            layer.attention.self._dalm_attn_calls = 0
+        h2 = new(input_ids=ids, attention_mask=am)[0]
+    assert torch.isfinite(h1).all() and torch.equal(h1, h2) and not torch.equal(h1[live], outs[1][0][live])
+    h1.float().sum().backward()
