@@ -169,3 +169,21 @@ def test_lora_mask_oracle_is_a_deterministic_well_mixed_function():
 
 
 KNOWN_LORA_MASK_BYTESUM = 888
+
+
+def test_attention_dropout_oracle_known_answers():
+    """oracle/attn_dropout.py (the numpy restatement the GPU tests pin the attention kernels' keep mask to): known answers of the
+    restatement itself, so that an edit of the oracle cannot silently move with an edit of the kernels; drop rate; salt and seed
+    both change the mask; one hash serves the pair (c even, c + 1)."""
+    import attn_dropout as A
+
+    m = A.keep_mask(0x0123456789ABCDEF, 0x5A17, 2, 3, 8, 0.1)
+    assert m.shape == (2, 3, 8, 8) and int(m.sum()) == 345
+    assert m.reshape(-1)[:40].astype(int).tolist() == [1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1, 1, 1,
+                                                       1, 1, 0, 1, 1, 0, 1, 1, 1, 1, 1, 1]
+    m2 = A.keep_mask(0x0123456789ABCDEF, 0x5A17, 1, 2, 64, 0.5)
+    assert int(m2.sum()) == 4157 and np.packbits(m2.reshape(-1)[:64]).tolist() == [240, 106, 249, 173, 59, 187, 238, 140]
+    big = A.keep_mask(7, 1, 4, 4, 128, 0.1)
+    assert abs(1.0 - big.mean() - 0.1) < 3e-3
+    assert not np.array_equal(big, A.keep_mask(7, 2, 4, 4, 128, 0.1)) and not np.array_equal(big, A.keep_mask(8, 1, 4, 4, 128, 0.1))
+    assert A.keep_mask(7, 1, 1, 1, 8, 0.0).all()
