@@ -73,16 +73,16 @@ def main():
     print(f"{'kernel':92s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>6s}")
     for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:a.top]:
         print(f"{k:92s} {c:7d} {t/1e6:10.3f} {t/c/1e3:10.2f} {100*t/total:6.2f}")
-    groups = {"hipBLASLt / rocBLAS GEMM": 0.0, "aten elementwise / reduce / copy": 0.0, "attention (SDPA)": 0.0,
+    groups = {"hipBLASLt / rocBLAS GEMM": 0.0, "aten elementwise / reduce / copy": 0.0, "attention (torch SDPA)": 0.0,
               "dalm_* (this library)": 0.0, "optimizer": 0.0, "other": 0.0}
     for k, (c, t) in agg.items():
         if k.startswith("hipBLASLt") or "Cijk" in k or "gemm" in k.lower() and "dalm" not in k and "mfma" not in k:
             groups["hipBLASLt / rocBLAS GEMM"] += t
         elif "multi_tensor_apply" in k:
             groups["optimizer"] += t
-        elif any(x in k for x in ("attention", "attn", "fmha", "flash_fwd", "flash_bwd", "sdpa", "bwd_kernel_dk_dv", "bwd_kernel_dq",
+        elif "dalm::" not in k and any(x in k for x in ("attention", "attn", "fmha", "flash_fwd", "flash_bwd", "sdpa", "bwd_kernel_dk_dv", "bwd_kernel_dq",
                                   "bwd_kernel_fuse", "bwd_preprocess")):
-            groups["attention (SDPA)"] += t
+            groups["attention (torch SDPA)"] += t
         elif "dalm::" in k or any(x in k for x in ("marg_ce", "pool_", "small_", "rag_loss", "ce_prep", "ce_finalize", "rms_norm", "nf4", "l2norm",
                                   "sim_", "scale_inplace", "contrastive")):
             groups["dalm_* (this library)"] += t
