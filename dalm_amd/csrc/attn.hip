@@ -1,32 +1,38 @@
-// Backward of scaled-dot-product attention for a decoder layer of the generator tower, bf16, head width 128 (Llama-2-7b:
-// BASELINE.json configs 3 / 4), arbitrary boolean mask (HF's causal + left-padding mask) - hand-written for gfx950.
+// Scaled-dot-product attention of the towers - forward and backward, bf16, head width 128 (Llama-2-7b: BASELINE.json configs 3 / 4)
+// or 64 (Falcon-7b, config 5; bge-large / BERT, every config), arbitrary boolean mask (HF's causal + left-padding mask, BERT's
+// padding mask), optional attention dropout - hand-written for gfx950.
 // transformers reaches torch.nn.functional.scaled_dot_product_attention through sdpa_attention_forward
-// (transformers/integrations/sdpa_attention.py); the reference reaches it through self.generator_model(...)
-// (dalm/models/rag_e2e_base_model.py:104-106) and differentiates it with loss.backward()
-// (dalm/training/rag_e2e/train_rage2e.py:466).  With a mask torch dispatches its memory-efficient kernels; their backward at
-// cfg3 (B 18, H 32, T 256, hd 128) is preprocess 15 us + dk/dv 264 us + dq 160 us = 440 us per layer, 14 ms of a 138 ms step,
-// 2.7 % of the MFMA peak (profiles/r05_step_by_stream.txt).  The forward stays torch's (60 us); its log-sum-exp is this file's input.
+// (transformers/integrations/sdpa_attention.py) or FalconAttention.forward; the reference reaches it through
+// self.generator_model(...) / self.retriever_model(...) (dalm/models/rag_e2e_base_model.py:84-106) and differentiates it with
+// loss.backward() (dalm/training/rag_e2e/train_rage2e.py:466).  With a mask torch dispatches its memory-efficient kernels: at cfg3
+// (B 18, H 32, T 256, hd 128) 119 us forward and 395 us backward per layer - 16 ms of a 140 ms step, 2.7 % of the MFMA peak, 629 MB
+// of HBM reads for a 113 MB problem (profiles/r05_attn_pmc.txt).  Here: 47 us + 152 us, traffic 1.0 x algorithmic.
 //
-//   P = exp(scale S + mask - lse),  S = Q K^T        dV = P^T dO          dP = dO V^T
-//   dS = P o (dP - D),  D_i = sum_d dO[i,d] O[i,d]   dQ = scale dS K      dK = scale dS^T Q
+//   P = exp(scale S + mask - lse),  S = Q K^T,  O = P V      dV = P^T dO          dP = dO V^T
+//   dS = P o (dP - D),  D_i = sum_d dO[i,d] O[i,d]           dQ = scale dS K      dK = scale dS^T Q
 //
-// Two launches, no atomics, every product on v_mfma_f32_32x32x16_bf16 (C tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2)
+// Three kernels, no atomics, every product on v_mfma_f32_32x32x16_bf16 (C tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2)
 // + 4 (lane >> 5)):
-//   attn_bwd_dq_kernel    a workgroup owns 128 query rows (a wave 32 of them; Q and dO fragments stay in registers as B operands,
-//                         lane <-> query row), streams 64-row K / V blocks through LDS, computes S^T and dP^T tiles
-//                         [key row (regs), query row (lane)].  The dS^T tile, rounded to bf16, IS the B operand of
-//                         dQ^T[d, i] += K^T[d, j] dS^T[j, i] with the contraction index taken in the tile's register order
-//                         (k-step s of a lane half h holds rows 16 s + 4 h + {0..3} and 16 s + 8 + 4 h + {0..3}); the A operand
-//                         K^T is read from a transposed LDS copy with two 8-byte reads in that same order.  Also writes D.
-//   attn_bwd_dkdv_kernel  a workgroup owns 128 key rows (K, V fragments in registers, lane <-> key row), streams 64-row Q / dO
-//                         blocks (+ transposed copies), computes S and dP tiles [query row (regs), key row (lane)];
-//                         P and dS are the B operands of dV^T[d, j] += dO^T[d, i] P[i, j] and dK^T[d, j] += Q^T[d, i] dS[i, j].
+//   attn_fwd_kernel       a workgroup owns 128 query rows (a wave 32 of them; Q fragments stay in registers as B operands, lane <->
+//                         query row), streams 64-row K / V blocks through LDS (K row-major, V transposed), S^T tiles [key row
+//                         (regs), query row (lane)]: the online softmax is per-lane arithmetic + one lane ^ 32 exchange per tile;
+//                         P^T rounded to bf16 IS the B operand of O^T[d, i] += V^T[d, j] P^T[j, i].  Writes O and the log-sum-exp.
+//   attn_bwd_dq_kernel    same shape, Q and dO fragments in registers, computes S^T and dP^T tiles.  The dS^T tile, rounded to
+//                         bf16, IS the B operand of dQ^T[d, i] += K^T[d, j] dS^T[j, i] with the contraction index taken in the
+//                         tile's register order (k-step s of a lane half h holds rows 16 s + 4 h + {0..3} and 16 s + 8 + 4 h +
+//                         {0..3}); the A operand K^T is read from a transposed LDS copy with two 8-byte reads in that same order.
+//                         Also writes D.
+//   attn_bwd_dkdv_kernel  a workgroup owns 64 key rows (K, V fragments in registers, lane <-> key row), streams 64-row Q / dO
+//                         blocks (+ transposed copies), computes S and dP tiles [query row (regs), key row (lane)]; P and dS are
+//                         the B operands of dV^T[d, j] += dO^T[d, i] P[i, j] and dK^T[d, j] += Q^T[d, i] dS[i, j]; a wave
+//                         accumulates half of d.
 // The mask is read as BITS: attn_mask_bits_kernel packs the [B, 1, T, T] boolean mask once per step (the same mask serves every
 // layer and head) into row words (bit c of word w of row i = mask[i, 32 w + c]) and column words, plus one byte per 32 x 32 tile
 // that says whether anything in it is live: a lane's 32 mask bits of a tile are ONE dword, dead tiles (the causal upper
 // triangle, padding) cost nothing.
-// Algorithmic bytes per launch pair: q, k, v, o, dO read + dq, dk, dv written = 8 B H T hd el (302 MB at cfg3); algorithmic
-// flops 5 GEMMs x 2 T^2 hd per head over the live tiles (dq and dk/dv each recompute S and dP: 7 are executed).
+// Algorithmic bytes: forward q, k, v read + o written = 4 B H T hd el (151 MB at cfg3); backward q, k, v, o, dO read + dq, dk, dv
+// written = 8 B H T hd el (302 MB; the two launches together move 1.5 x that: each re-reads q, k, v, dO); algorithmic flops
+// 2 / 5 GEMMs x 2 T^2 hd per head over the live tiles (dq and dk/dv each recompute S and dP: 7 are executed).
 #include "common.hpp"
 
 namespace dalm {
