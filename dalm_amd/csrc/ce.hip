@@ -108,7 +108,7 @@ struct RowWin {
 
 // Write `fill` over one full row (used for masked rows and the t = Tg-1 slot).
 // NTFILL: non-temporal stores (the zero rows of a padded batch are a pure write stream: 110 of the 295 MB written per
-// launch at the bench's masks); measured against cached stores in profiles/r04_ce_row_order.txt.
+// launch at the bench's masks); measured against cached stores in profiles/history/r04_ce_row_order.txt.
 template <typename T, int BS, bool NTFILL = false>
 __device__ __forceinline__ void fill_row(T* row, int V, float fill) {
   constexpr int VEC = Elt<T>::VEC;
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(256) void marginalize_rows_kernel(const float* __re
   }
 }
 
-constexpr int kDefaultRowOrder = 0;     // decided by measurement, see profiles/r04_ce_row_order.txt
+constexpr int kDefaultRowOrder = 0;     // decided by measurement, see profiles/history/r04_ce_row_order.txt
 constexpr bool kDefaultNtFill = false;
 
 template <typename T, bool GRAD, bool ALIGNED>
@@ -738,7 +738,7 @@ void launch_fwd2(const T* logits, int64_t B, int64_t Tg, int64_t V, int64_t sb, 
   const int Tgi = static_cast<int>(Tg), Vi = static_cast<int>(V);
   constexpr int S_BIG = 64 / VEC;    // 64 floats per lane: <=128 VGPRs, 4 waves/SIMD
   constexpr int S_SMALL = 16 / VEC;  // 16 floats per lane
-  // A/B knobs of the write stream (profiles/r04_ce_row_order.txt): DALM_CE_ORDER = 0 identity | i sample-interleaved |
+  // A/B knobs of the write stream (profiles/history/r04_ce_row_order.txt): DALM_CE_ORDER = 0 identity | i sample-interleaved |
   // <s> stride inside a sample (made coprime to Tg here); DALM_CE_FILL = c cached zero fill | n non-temporal
   static const char* order_env = getenv("DALM_CE_ORDER");
   static const char* fill_env = getenv("DALM_CE_FILL");

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void lm_head_lse_kernel(const LmParams p) {
 
 // ------------------------------------------------------------------------------------------------------------------
 // Round 3: the same contraction on a structure built from measurements on the MI355X (tools/lm_head_ablate.py,
-// profiles/r03_lm_head_*): 256 x 256 x 64 tiles, FOUR waves = one per SIMD with the whole 512-register file each,
+// profiles/history/r03_lm_head_*): 256 x 256 x 64 tiles, FOUR waves = one per SIMD with the whole 512-register file each,
 // operands straight from global memory into LDS (buffer_load_dwordx4 ... lds), ONE barrier per K tile, a VALU-only epilogue,
 // one workgroup per tile.  What the intermediate forms showed:
 //   * 8 waves in ping-pong with two barriers per 8 MFMAs (the published "8-phase" shape): even its MFMA-and-barriers-only

@@ -4,7 +4,7 @@
 // retrievers): dalm/models/rag_e2e_base_model.py:145-160.  peft evaluates  out = W x + s * B(A(dropout(x)))  as eager ops; in
 // the cfg3 step each wrapped projection cost 82 us forward (dropout kernel, two weight casts, two skinny GEMMs, an add) and
 // 132 us backward (a full-size scale, four skinny GEMMs, two casts, the dropout backward, a gradient add) around a 128 us
-// base GEMM - 13.7 ms of a 160 ms step (profiles/r04_step_by_stream.txt).  With r = 8 every one of those tensors is either
+// base GEMM - 13.7 ms of a 160 ms step (profiles/history/r04_step_by_stream.txt).  With r = 8 every one of those tensors is either
 // [rows, 8] or streams the [rows, K] activation once, so the branch is three HBM-bound kernels:
 //   rowdot :  z[row, j]  = scale * sum_k m x[row, k] W(j, k)            forward z = dropout(x) A^T / (1-p);  backward dz = s g B
 //   rankupd:  y[row, c] += scale * m * sum_j z[row, j] W(j, c)          forward out += s z B^T;  backward dx += m (dz A) / (1-p)

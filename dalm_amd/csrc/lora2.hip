@@ -3,7 +3,7 @@
 //
 // The reference asks peft for r = 8, alpha = 16, dropout 0.05 adapters (dalm/models/rag_e2e_base_model.py:61-80,145-160); per
 // wrapped projection peft evaluates  out = W x + s * B(A(dropout(x))).  Round 4 (lora.hip) ran that branch as three streaming
-// kernels per projection, each regenerating the dropout mask from a counter hash.  Measured there (profiles/r04_step_by_stream.txt,
+// kernels per projection, each regenerating the dropout mask from a counter hash.  Measured there (profiles/history/r04_step_by_stream.txt,
 // [4608, 4096] bf16): 0.20-0.27 of the HBM rate on the read-only kernels.  The instruction count explains it - the mask hash
 // (4 multiplies + ~20 integer ops per two elements, in three kernels x two projections) and 8 dword loads per MFMA step for a
 // [N, r] weight - plus a 288-workgroup grid on 256 CUs with one resident workgroup each (two rounds).  This file:

@@ -186,7 +186,7 @@ extern "C" int dalm_nf4_dequantize(const uint8_t* packed, const float* absmax, i
                "out must be 16-byte aligned, packed / absmax 4-byte aligned");
   const int64_t threads = (n + 7) / 8;
   static const int steps_env = [] { const char* e = getenv("DALM_NF4_STEPS"); return e ? atoi(e) : 0; }();
-  // measured (profiles/r04_nf4_steps.txt, 8 different weights in turn inside a hipGraph): bf16 out 11008x4096 28.0 / 23.0 /
+  // measured (profiles/history/r04_nf4_steps.txt, 8 different weights in turn inside a hipGraph): bf16 out 11008x4096 28.0 / 23.0 /
   // 21.3 / 21.7 us and 4096^2 9.3 / 9.2 / 8.6 / 8.6 us for 1 / 2 / 4 / 8 tiles per workgroup; f32 out is best at 1 (46.7 us
   // vs 48.9 at 4: twice the store bytes per tile already); a non-temporal load of the packed words is no gain (DALM_NF4_NT=1)
   int steps = steps_env > 0 ? steps_env : ((dtype == DALM_BF16 && threads >= 256 * 4 * 2048) ? 4 : 1);

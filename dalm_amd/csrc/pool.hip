@@ -599,7 +599,7 @@ extern "C" int dalm_pool_l2norm_bwd(const float* d_emb, const float* emb, const 
   int64_t tz = (384 + B * dc - 1) / (B * dc);
   if (B * dc < 1024 && T >= 64 && tz < 2) tz = 2;
   // (slicing large batches further does NOT help: every workgroup first rebuilds du, and at [1200,128,1024] bf16 2 / 4 / 8
-  // slices measured 91 / 123 / 192 us against 81 us for one - profiles/r04_pool_probe_bwd_tz.txt; large batches take the
+  // slices measured 91 / 123 / 192 us against 81 us for one - profiles/history/r04_pool_probe_bwd_tz.txt; large batches take the
   // row-major kernel below instead)
   static const int tz_env = [] { const char* e = getenv("DALM_POOL_BWD_TZ"); return e ? atoi(e) : 0; }();
   if (tz_env > 0) tz = tz_env;
@@ -608,7 +608,7 @@ extern "C" int dalm_pool_l2norm_bwd(const float* d_emb, const float* emb, const 
   if (tz < 1) tz = 1;
   if (tz > 64) tz = 64;
   // cached stores: the encoder's backward reads dh next.  DALM_POOL_BWD_NT=1 selects non-temporal stores (measured alone:
-  // 17.5 -> 13.8 us at [150,128,1024] bf16, 79 -> 84 us at B = 1200; profiles/r04_pool_probe.txt)
+  // 17.5 -> 13.8 us at [150,128,1024] bf16, 79 -> 84 us at B = 1200; profiles/history/r04_pool_probe.txt)
   static const int nts_env = [] { const char* e = getenv("DALM_POOL_BWD_NT"); return e ? atoi(e) : -1; }();
   const bool nts = nts_env > 0;
   static const int rows_env = [] { const char* e = getenv("DALM_POOL_BWD_ROWS"); return e ? atoi(e) : -1; }();
@@ -619,7 +619,7 @@ extern "C" int dalm_pool_l2norm_bwd(const float* d_emb, const float* emb, const 
   const bool rows_ok = vok && pl.nch <= 4;
   const bool rows = rows_ok && (rows_env >= 0 ? rows_env != 0 : true);
   if (rows) {
-    // token slices: ~768 workgroups, at most 8 slices (measured, profiles/r04_pool_probe_bwd_rows.txt: [18,128,1024] bf16
+    // token slices: ~768 workgroups, at most 8 slices (measured, profiles/history/r04_pool_probe_bwd_rows.txt: [18,128,1024] bf16
     // 16.8 / 10.9 / 7.9 / 6.5 / 7.5 us for 1 / 2 / 4 / 8 / 16 slices; [1200,128,1024] 71.7 / 78.6 / 86.4 / 112 us for 1 / 2 / 4 / 8)
     int64_t rz = tz_env > 0 ? tz_env : (768 + B - 1) / B;
     if (tz_env <= 0 && rz > 8) rz = 8;

@@ -992,7 +992,7 @@ inline StreamPlan stream_plan(int64_t m, int64_t n, int64_t D, bool always = fal
   // K slices per column tile, for the sizes whose 128-column blocks give the chip only one or two workgroups per CU
   // (grid = row blocks x column blocks; measured, whole call, us: 768^2 (144) 36.0 / 37.7 / 37.5 for 1 / 2 / 4 slices,
   // 1200^2 (380) 57.2 / 54.0 / 56.2, 1536^2 (576) 74.3 / 76.4 / 68.1, 2048^2 (1024) 90.8 / 103.6 / 108.2).  What did NOT
-  // move these sizes (profiles/r03_sim_midsize_experiments.txt): 16-byte operand loads from 4-k granule copies (slower),
+  // move these sizes (profiles/history/r03_sim_midsize_experiments.txt): 16-byte operand loads from 4-k granule copies (slower),
   // capping workgroups per CU through LDS padding (slower), XCD rectangles + an L2 warm-up pass (no change).
   if (!always && f.rt == 1) {
     const int64_t g128 = static_cast<int64_t>(f.row_blocks) * ((n + 127) / 128);
@@ -1099,7 +1099,7 @@ static bool use_bf16x3(int64_t m, int64_t n, int64_t D, const float* A, const fl
     const char* off = getenv("DALM_SIM_BF16X3");
     if (off && off[0] == '0') return -1;
     const char* e = getenv("DALM_SIM_BF16X3_MIN");
-    return e ? atoi(e) : 3072;   // measured crossover: 2048^2 64 vs 100 TF (f32 wins), 3072^2 142 vs 122 TF (profiles/r04_sim_midsize_merge_inlaunch.txt)
+    return e ? atoi(e) : 3072;   // measured crossover: 2048^2 64 vs 100 TF (f32 wins), 3072^2 142 vs 122 TF (profiles/history/r04_sim_midsize_merge_inlaunch.txt)
   }();
   if (min_rows < 0 || m < min_rows || n < min_rows) return false;
   if (A && (reinterpret_cast<uintptr_t>(A) % 16 || reinterpret_cast<uintptr_t>(Bm) % 16)) return false;

@@ -731,7 +731,7 @@ __global__ __launch_bounds__(1024) void rag_loss_finalize_kernel(const float* __
 
 inline int64_t round_up(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
 
-constexpr int kDefaultPipeDepth = 4;     // measured: profiles/r04_small_pipe.txt (512^2 -8 %, 150 x 1200 -4 %; depth 2-4 alike)
+constexpr int kDefaultPipeDepth = 4;     // measured: profiles/history/r04_small_pipe.txt (512^2 -8 %, 150 x 1200 -4 %; depth 2-4 alike)
 struct SmallPlan { int sk, k_chunk; int64_t ldn, ldm; };
 inline SmallPlan small_plan(int64_t m, int64_t n, int64_t D) {
   const int64_t tiles = ((m + 31) / 32) * ((n + 31) / 32);
@@ -838,7 +838,7 @@ extern "C" size_t dalm_sim_small_fwd1_workspace_bytes(int64_t m, int64_t n, int6
   return fused1_layout(m, n, D, want_cols).total;
 }
 
-// Whether the one-launch forward is the faster form for a shape (profiles/r04_small_one_launch.txt): a tile grid of >= 128
+// Whether the one-launch forward is the faster form for a shape (profiles/history/r04_small_one_launch.txt): a tile grid of >= 128
 // tiles with at most 2 K slices per tile - the hand-offs then replace a statistics kernel that had real work to do
 // (512^2: 19.7 -> 18.6 us, 150 x 1200: 16.4 -> 15.7 us); with few tiles and 16 slices the last slice's serial sum loses
 // (18^2: 6.3 -> 8.7 us).  Callers that follow this advice keep BOTH forms available: dalm_sim_small_fwd needs no tickets.

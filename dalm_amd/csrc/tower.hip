@@ -5,7 +5,7 @@
 // transformers/models/llama/modeling_llama.py): apply_rotary_pos_emb is  q*cos + rotate_half(q)*sin  for q and k
 // (8 eager launches forward, ~14 backward per layer) and LlamaMLP is  down(silu(gate(x)) * up(x))  (2 forward, 4 backward,
 // plus a saved [tokens, intermediate] activation).  Both are pure HBM streams; measured in the cfg3 step they were ~12 ms +
-// ~5 ms of 175 ms (profiles/r04_bench_step_kernel_stats.txt: roll / addcmul / MulFunctor / silu / silu_backward rows).
+// ~5 ms of 175 ms (profiles/history/r04_bench_step_kernel_stats.txt: roll / addcmul / MulFunctor / silu / silu_backward rows).
 //
 // Rounding contract: torch evaluates every eager elementwise op in f32 and rounds its result to the tensor dtype.  These
 // kernels round at exactly the same points (rb() below: a bf16 round trip for bf16 tensors, the identity for f32; separate
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void rope_qk_kernel(const RopeParams p) {
 
 // ---------------------------------------------------------------------------------------------------
 // SwiGLU over n contiguous elements.  A workgroup walks STEPS tiles of 256*VEC elements with every load issued before the
-// first store (single-tile workgroups are bound by workgroup dispatch at this size: profiles/r04_nf4_steps.txt).
+// first store (single-tile workgroups are bound by workgroup dispatch at this size: profiles/history/r04_nf4_steps.txt).
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + expf(-x)); }
 

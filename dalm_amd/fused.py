@@ -442,7 +442,7 @@ def _lm_head_live_rows(ops, h, w, ids, mask, stats, live_rows, chunk_rows, dw, n
 
 
 # bytes of lm_head weight the fused kernel is preferred up to: 1.1 x the 256 MiB Infinity Cache.  Measured
-# (profiles/r04_lm_head_rows_sweep.txt): Llama-2-7b's head (32000 x 4096 bf16 = 262 MB) - the kernel is faster than hipBLASLt's
+# (profiles/history/r04_lm_head_rows_sweep.txt): Llama-2-7b's head (32000 x 4096 bf16 = 262 MB) - the kernel is faster than hipBLASLt's
 # default-heuristic GEMM + the forward CE kernel at 10 of 15 row counts between 1024 and 4608 (0.84 ... 1.05, mean 0.97) and
 # allocates no logits; Falcon-7B's head (65024 x 4544 = 591 MB, re-read from HBM once per band of row tiles) - 2-14 % slower
 # at every row count.  (Both measured against hipBLASLt's DEFAULT heuristics: a data-dependent live-row count has no tuned solution.)
@@ -465,7 +465,7 @@ def _use_lm_head_kernel(ops, h, H, w=None) -> bool:
         return False
     # With the pre-tuned GEMM solution table replayed (dalm_amd.tuning - the trainers and bench.py switch it on) the library
     # path wins at the row counts the table holds (cfg3 live rows, chunks [2048, 1536]: 0.79 vs 0.84 ms,
-    # profiles/r04_lm_head_eval_paths.txt): the kernel is the default where the library runs on its default heuristics.
+    # profiles/history/r04_lm_head_eval_paths.txt): the kernel is the default where the library runs on its default heuristics.
     try:
         import torch.cuda.tunable as tunable
 

@@ -156,7 +156,7 @@ class AutoModelForRagE2E(torch.nn.Module):
             return self.retrieval_forward(input_ids, attention_mask)
         # use_cache=False: the reference leaves transformers' default (config.use_cache = True), which makes every decoder layer
         # copy its keys and values into a DynamicCache nobody reads - two 38 MB torch.cat per layer at cfg3, 3.4 ms of the
-        # step (profiles/r04_step_by_stream.txt).  The logits are the same tensor either way.
+        # step (profiles/history/r04_step_by_stream.txt).  The logits are the same tensor either way.
         return self.generator_model(input_ids=input_ids, attention_mask=attention_mask, use_cache=False).logits
 
     def mean_pooling(self, model_output: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:

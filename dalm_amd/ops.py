@@ -189,7 +189,7 @@ class HipOps:
         return bool(hip.load().dalm_sim_small_supported(int(m), int(n), int(D)))
 
     # one launch (dalm_sim_small_fwd1) or two (dalm_sim_small_fwd): by shape, as measured (dalm_sim_small_fwd1_preferred,
-    # profiles/r04_small_one_launch.txt); DALM_SMALL_FWD1 = 1 / 0 forces either
+    # profiles/history/r04_small_one_launch.txt); DALM_SMALL_FWD1 = 1 / 0 forces either
     small_one_launch = {"1": True, "0": False}.get(os.environ.get("DALM_SMALL_FWD1", ""), None)
     _tickets: dict = {}
 
@@ -241,7 +241,7 @@ class HipOps:
 
     # sliced backward (one direction of a long contraction): slices summed in the launch (dalm_sim_small_bwd1) or by a
     # second kernel (dalm_sim_small_bwd_ws); DALM_SMALL_BWD1 = 1 / 0, default decided by measurement
-    # (profiles/r04_small_one_launch.txt)
+    # (profiles/history/r04_small_one_launch.txt)
     small_bwd_one_launch = os.environ.get("DALM_SMALL_BWD1", "1") == "1"
 
     def sim_small_bwd(self, S, A, Bm, scale: float, diag_offset: int, row_coef, row_lse, col_coef, col_lse,

@@ -38,7 +38,7 @@ def init_distributed(backend: Optional[str] = None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # W > 1 on GPUs: torch.distributed(nccl) - RCCL through torch - is the default.  The library's OWN RCCL binding (dalm_comm_*
     # behind the C ABI, collectives on the caller's stream; it ties torch.distributed with one rank: 188.1 vs 188.9 ms per step,
-    # profiles/r03_comm_modes.txt) is OPT-IN until a run with two or more real ranks has been recorded (no multi-GPU box was
+    # profiles/history/r03_comm_modes.txt) is OPT-IN until a run with two or more real ranks has been recorded (no multi-GPU box was
     # available in rounds 1-5): a rank whose ncclCommInitRank stalls instead of raising would leave the others
     # blocked inside the bring-up collective, and the agreement step below only covers failures that raise.
     #   DALM_NATIVE_COMM=1     the native binding, errors propagate

@@ -8,7 +8,7 @@ Two independent checks per configuration, both on depth-1 towers built from a CP
   2. LoRA (the bench's configuration; the image has no peft, so the in-tree injector is used on both sides) vs the
      oracle's `ref_*` restatement run on this host's CPU in fp32.
 Tolerances asserted here (north_star: 1e-3 relative in fp32, stated tolerance in bf16); measured on MI355X in round 3
-(profiles/r03_realwidth_parity.json): fp32 <= 1e-6 everywhere, bf16 loss <= 4e-6 / gradient norm <= 6e-5 at real width:
+(profiles/history/r03_realwidth_parity.json): fp32 <= 1e-6 everywhere, bf16 loss <= 4e-6 / gradient norm <= 6e-5 at real width:
   fp32            loss / contrastive / generator / grad-norm  <= 1e-4
   bf16 autocast   loss / contrastive / generator              <= 1e-4   (vs the reference under CPU bf16 autocast)
                   grad-norm (global and per tower)            <= 5e-4   (bf16 has 8 mantissa bits; CPU and GPU autocast
@@ -122,7 +122,7 @@ def test_full_finetune_step_matches_the_reference_at_real_width(case, precision)
     if case.endswith("_d2") and precision == "bf16_autocast":
         # two blocks per tower: the CPU and the GPU autocast round at different operators in EVERY block, and the reference's
         # own bf16 result already sits 2.8e-3 (generator gradient norm) from its fp32 one at this depth - stated bound 2e-4 on the
-        # losses (measured 4.5e-5 ... 6.4e-5), 5e-4 on the gradient norms (measured <= 3.7e-5); profiles/r04_realwidth_parity.json
+        # losses (measured 4.5e-5 ... 6.4e-5), 5e-4 on the gradient norms (measured <= 3.7e-5); profiles/history/r04_realwidth_parity.json
         tol = {"loss": 2e-4, "grad": 5e-4}
     for k, r in rel.items():
         assert r <= (tol["grad"] if k.startswith("grad_norm") else tol["loss"]), (k, rel, got, ref)

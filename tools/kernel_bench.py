@@ -111,7 +111,7 @@ def bench_sim(m, n, D):
     med, best = time_fn(lambda: ops.sim_rowstats(A, Bm, 100.0, 0), iters=10, warmup=3)
     # the default entry point routes m, n >= 3072 to the bf16x3 form (6 x the flops on the bf16 pipe): its roofline fraction is
     # the flops ACTUALLY ISSUED over the bf16 peak - never an f32-equivalent rate over the f32 peak (that read 1.19 / 1.40 in
-    # profiles/r04_kernel_bench.txt)
+    # profiles/history/r04_kernel_bench.txt)
     on_bf16 = m >= 3072 and n >= 3072 and D % 64 == 0
     flops = (12.0 if on_bf16 else 2.0) * m * n * D
     peak = 2.5e15 if on_bf16 else MFMA_F32_PEAK
