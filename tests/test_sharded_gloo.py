@@ -436,3 +436,38 @@ def test_native_comm_rendezvous_and_all_or_none_fallback(tmp_path, fail_on):
     else:
         assert not any(r["native"] for r in res) and all(r["closed"] for r in res)
         assert all(r["fallback_sum"] == 3.0 for r in res)
+
+
+def test_bench_bring_up_path_with_two_gloo_ranks(tmp_path):
+    """The calls `bench.py --gpus N` makes around its timed region: `sharded.init_distributed()` from the
+    launcher's environment, `barrier`, `max_over_ranks` (the slowest rank's time), an all-gather of embeddings through the
+    communicator it returned, and the one JSON line from rank 0 only - with two CPU ranks (gloo), as the driver launches N GPU ranks."""
+    import json
+    import subprocess
+
+    script = tmp_path / "bring_up.py"
+    script.write_text(
+        "import json, os, torch\n"
+        "from dalm_amd.sharded import barrier, init_distributed, max_over_ranks\n"
+        "comm, dev = init_distributed()\n"
+        "rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+        "assert comm.world_size == world == 2 and comm.rank == rank and dev.type == 'cpu'\n"
+        "barrier(comm)\n"
+        "slowest = max_over_ranks(comm, 1.0 + rank)\n"
+        "rows = comm.all_gather_rows(torch.full((3, 4), float(rank)))\n"
+        "assert rows.shape == (6, 4) and float(rows[:3].sum()) == 0.0 and float(rows[3:].sum()) == 12.0\n"
+        "barrier(comm)\n"
+        "if rank == 0:\n"
+        "    print(json.dumps({'value': 1.0, 'n_gpus': world, 'slowest': slowest,\n"
+        "                      'config': {'ranks_seen_by_process_group': comm.world_size, 'collective_backend': 'gloo'}}), flush=True)\n"
+        "import torch.distributed as dist\n"
+        "dist.destroy_process_group()\n")
+    env = dict(os.environ, PYTHONPATH=str(ROOT))
+    env.pop("DALM_NATIVE_COMM", None)
+    run = subprocess.run([sys.executable, "-m", "dalm_amd.launch", "--nproc", "2", "--cpu", str(script)],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert run.returncode == 0, run.stderr
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                          # one JSON line, rank 0's
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["slowest"] == 2.0 and out["config"]["ranks_seen_by_process_group"] == 2
