@@ -15,7 +15,8 @@ Both read the mask as packed bits (packed once per mask tensor - every layer pas
 
 Attention dropout (BERT's attention_probs_dropout_prob in training mode) is applied inside the kernels, its keep mask regenerated
 from (a device seed word, a per-call salt, the element index) and never stored - this library's own generator
-(oracle/attn_dropout.py), not torch's philox stream.  DALM_ATTN_DROPOUT=0 sends dropout calls to torch.
+(oracle/attn_dropout.py), not torch's philox stream.  DALM_ATTN_DROPOUT=0 sends dropout calls to torch (needed under activation
+recompute, torch.utils.checkpoint: the salt is a host call counter, a re-run forward would draw another mask).
 Everything the kernels do not take (CPU tensors, other head widths, odd T with dropout, float masks, a KV cache, no gradient wanted) goes
 to transformers' own `sdpa_attention_forward`, unchanged.  DALM_ATTN_KERNEL=0 keeps the model on "sdpa".
 """
