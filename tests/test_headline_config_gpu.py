@@ -22,11 +22,12 @@ import torch
 pytestmark = pytest.mark.gpu
 OUT = Path(__file__).resolve().parent.parent / "gpurun_out"
 
-# measured on the MI355X (profiles/r05_headline_parity.json), worst of cfg3 / cfg5; bounds = 5 x measured:
-#   (A) vs (B)  loss 2.2e-5, contrastive 5.1e-5, generator 1.4e-5, LoRA gradient norm 1.6e-4
-#   (A) vs (C)  loss 2.1e-5, contrastive 7.2e-5, generator 9.3e-6, LoRA gradient norm 1.34e-3
+# measured on the MI355X on the final tree (profiles/r05_headline_parity.json), worst of cfg3 / cfg5; bounds = 5 x measured:
+#   (A) vs (B)  loss 1.6e-5, contrastive 2.9e-5, generator 1.5e-5, LoRA gradient norm 4.5e-4
+#               (1.6e-4 before the attention kernels: torch's attention and this library's round P and dS at different points)
+#   (A) vs (C)  loss 2.6e-5, contrastive 8.3e-5, generator 1.1e-5, LoRA gradient norm 1.04e-3
 #   (for scale: kernels OFF vs (C): loss 3.0e-5, gradient norm 1.5e-3 - the kernels are the closer of the two to float32)
-TOL_KERNELS_OFF = {"loss": 2.5e-4, "grad": 8e-4}     # (A) vs (B): both bf16 autocast; the kernels round where the eager chains round
+TOL_KERNELS_OFF = {"loss": 2.5e-4, "grad": 2.2e-3}   # (A) vs (B): both bf16 autocast; the kernels round where the eager chains round
 TOL_HOST_FP32 = {"loss": 4e-4, "grad": 7e-3}         # (A) vs (C): bf16 activations against float32 activations
 
 KERNEL_ENVS = ("DALM_FAST_ROPE", "DALM_ROPE_KERNEL", "DALM_SWIGLU_KERNEL", "DALM_NORM_KERNEL", "DALM_FALCON_KERNELS")
