@@ -100,6 +100,27 @@ def _tower_kernels(model) -> dict:
             "use_cache": False}
 
 
+def _matmul_params(module) -> int:
+    """Parameters that multiply every token (all 2-D weights except the embedding tables; the lm_head counts even when it is
+    tied to the input embedding)."""
+    skip = {id(m.weight) for m in module.modules() if isinstance(m, torch.nn.Embedding)}
+    n = sum(p.numel() for p in module.parameters() if p.dim() == 2 and id(p) not in skip)
+    head = module.get_output_embeddings() if hasattr(module, "get_output_embeddings") else None
+    if head is not None and id(head.weight) in skip:
+        n += head.weight.numel()
+    return n
+
+
+def step_model_tflops(model, gen_tokens: float, retr_tokens: float) -> float:
+    """Informational step-level model FLOPs from THIS model and the token rows that go through its GEMMs:
+    2 x matmul-parameters x tokens forward, the same again backward (frozen base + LoRA: activation gradients only; attention
+    score products not counted).  cfg3 padded: generator 6.74e9 x 4608 -> 62 + 62 TFLOP, retriever 0.30e9 x 3204 -> 1.9 + 1.9."""
+    gen = 4.0 * _matmul_params(model.generator_model) * gen_tokens if getattr(model, "generator_model", None) is not None else 0.0
+    retr_mod = getattr(model, "retriever_model", None) or getattr(model, "model", None)
+    retr = 4.0 * _matmul_params(retr_mod) * retr_tokens if retr_mod is not None else 0.0
+    return (gen + retr) / 1e12
+
+
 def _resident_weight_bytes(model):
     from dalm_amd.models import nf4
 
@@ -583,13 +604,17 @@ def main():
                     help="graph the tower fwd/bwd and keep collectives eager (the default when --gpus > 1)")
     ap.add_argument("--fuse-lm-head", action="store_true",
                     help="SURVEY 8(f) rank 1: chunked lm_head + CE, the [B,Tg,V] logits are never materialised")
-    ap.add_argument("--data-path", default="fixed", choices=["fixed", "bucketed", "loader"],
+    ap.add_argument("--data-path", default="fixed", choices=["fixed", "bucketed", "loader", "packed"],
                     help="fixed (default, the named configuration): every batch padded to Tq50/Tp128/Tg256 and resident in HBM "
                          "before the timed region; loader: the same rows fed through the trainer's host data path inside the "
                          "timed loop (ShardedBatches: int32 pinned columns, one index_select per column into pinned staging, "
                          "H2D of batch i+1 on a copy stream) - shows what the loader costs the step; bucketed: the trainer's "
                          "opt-in --length_bucketing + --trim_padding applied to a pool of synthetic rows "
-                         "(extra lines next to the headline, never the headline)")
+                         "(extra lines next to the headline, never the headline); packed: the SAME rows of the SAME named "
+                         "configuration as `fixed`, resident in HBM, with the host-side list of live tokens next to every mask "
+                         "(dalm_amd/packed.py): both towers run on the un-padded [n_live, H] rows (per-sequence attention through "
+                         "dalm_attn_*_packed, original positions kept) - padding contributes exactly zero to the reference's loss "
+                         "and gradients, so the step computes the same update; a line BESIDE the padded headline")
     ap.add_argument("--all-rows", action="store_true",
                     help="with --fuse-lm-head: run the padding rows through the lm_head GEMMs too (sample chunks)")
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg5", "cfg2", "cfg1"],
@@ -681,6 +706,12 @@ def main():
     loader = None
     if args.data_path == "fixed":
         batches = [synthetic_batch(dev, 100 + 17 * rank + i, V=V) for i in range(4)]
+    elif args.data_path == "packed":
+        from dalm_amd.packed import add_pack_plans
+
+        host = [add_pack_plans(synthetic_batch(torch.device("cpu"), 100 + 17 * rank + i, V=V)) for i in range(4)]
+        batches = [{k: v.to(dev) for k, v in b.items()} for b in host]
+        args.warmup = max(args.warmup, len(batches))   # one hipGraph per packed row count, captured before the timed region
     elif args.data_path == "loader":
         from dalm_amd.training.common import ShardedBatches
 
@@ -757,7 +788,7 @@ def main():
         # tools/pmc_bench.sh writes profiles/roofline_traffic.json; the value is per launch, FETCH doubled as the
         # gfx950 guide prescribes.  Only quoted for the workload/dtype it was collected on.
         traffic, traffic_source = None, "not collected this run"
-        if args.gpus == 1 and not args.no_pmc and not args.fuse_lm_head and args.data_path != "bucketed":
+        if args.gpus == 1 and not args.no_pmc and not args.fuse_lm_head and args.data_path in ("fixed", "loader"):
             try:
                 traffic, traffic_source = collect_ce_traffic(args.workload, args.dtype, V)
             except Exception as e:
@@ -775,6 +806,17 @@ def main():
             except Exception:
                 pass
         value = args.gpus * B * args.steps / elapsed
+        # token rows that go through the towers' GEMMs per step (mean over the staged batches): every padded position on the
+        # fixed / loader paths, the trimmed width on the bucketed path, the packed row lists on the packed path
+        def _rows(b, prefix, ids_key):
+            return float(b[f"{prefix}_pack_rows"].numel()) if f"{prefix}_pack_rows" in b else float(b[ids_key].numel())
+        gen_tokens = sum(_rows(b, "generator", "generator_input_input_ids") for b in batches) / len(batches)
+        retr_tokens = sum(_rows(b, "retriever_query", "retriever_query_input_ids")
+                          + _rows(b, "retriever_passage", "retriever_passage_input_ids") for b in batches) / len(batches)
+        live_tokens = {"generator": sum(float((b["generator_input_attention_mask"] != 0).sum()) for b in batches) / len(batches),
+                       "retriever": sum(float((b["retriever_query_attention_mask"] != 0).sum()
+                                              + (b["retriever_passage_attention_mask"] != 0).sum()) for b in batches) / len(batches)}
+        model_tf = step_model_tflops(model, gen_tokens, retr_tokens)
         out = {
             "metric": "training pairs/sec (global batch) RAG-e2e bge-large+" + ("Llama-2-7b" if gen_name == "llama-2-7b" else "Falcon-7B"),
             "value": value, "unit": "pairs/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
@@ -788,6 +830,9 @@ def main():
                                    + ("" if args.data_path == "fixed" else
                                       ("; DATA PATH: batches come through the trainer's host loader inside the timed loop (ShardedBatches: "
                                        "pinned int32 columns, staged index_select, H2D on a copy stream)" if args.data_path == "loader" else
+                                       "; DATA PATH: packed - the same rows, both towers run on the un-padded live tokens "
+                                       "(dalm_amd/packed.py; same loss and gradients as the padded step, tests/test_packed_gpu.py)"
+                                       if args.data_path == "packed" else
                                        "; DATA PATH: length-bucketed batches with all-padding columns trimmed (the trainer's opt-in "
                                        "--length_bucketing --trim_padding), fewer tokens per pair than the named configuration")),
                        "global_batch": args.gpus * B, "parallelism": f"dp{args.gpus} + sharded in-batch negatives",
@@ -799,7 +844,10 @@ def main():
                        "use_bnb": (None if not args.use_bnb else
                                    {"towers": args.use_bnb, "format": "nf4, blocks of 64, f32 absmax, bf16 compute (dalm_nf4_* kernels)",
                                     "weight_bytes_resident": _resident_weight_bytes(model)}),
-                       "lm_head": (("fused with the CE in row chunks over the rows that carry loss (no logits tensor)" if not args.all_rows
+                       "tower_rows_per_step": {"generator": gen_tokens, "retriever": retr_tokens, "live_tokens": live_tokens,
+                                               "padded": {"generator": B * Tg, "retriever": B * (CFG["Tq"] + CFG["Tp"])}},
+                       "lm_head": ("chunked over the packed rows with the CE kernel (no [B,Tg,V] logits tensor)" if args.data_path == "packed" else
+                                   ("fused with the CE in row chunks over the rows that carry loss (no logits tensor)" if not args.all_rows
                                     else "fused with the CE in sample chunks (no logits tensor)") if args.fuse_lm_head
                                    else f"logits materialised ({args.dtype})"),
                        "tower_gemms": "pre-tuned solution table (dalm_amd/tuning)" if args.tuned_gemms else "library defaults",
@@ -810,11 +858,10 @@ def main():
                                         "eager" + (f" (capture failed: {getattr(step, 'failed', None) or getattr(step, 'towers_failed', None)})"
                                                    if (getattr(step, "failed", None) or getattr(step, "towers_failed", None)) else ""))),
                        "baseline_ref": "reference README.md:34-40: 200k rows in 7 h on 1x A100-80GB = 7.94 pairs/s",
-                       # informational step-level roofline: ~124 TFLOP of tower work per 18-pair step with
-                       # LoRA (generator 2*6.74e9*4608 fwd, x2 for activation grads; retriever 2.1 TFLOP fwd x3)
+                       # informational step-level roofline, from this model's parameters and the rows its GEMMs see
                        "peak_hbm_gb": torch.cuda.max_memory_allocated() / 1e9,
-                       "step_model_tflops": 124.0 + 6.3,
-                       "step_frac_of_bf16_mfma_peak": (124.0 + 6.3) / (elapsed / args.steps) / 2500.0,
+                       "step_model_tflops": model_tf,
+                       "step_frac_of_bf16_mfma_peak": model_tf / (elapsed / args.steps) / 2500.0,
                        "final_loss": loss_val},
             "roofline": {"bound": "hbm", "kernel": f"marg_ce_row kernel (fused fwd+grad, {args.dtype} logits, V={V})",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,

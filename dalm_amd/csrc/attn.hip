@@ -71,7 +71,21 @@ struct AttnBwdParams {
   float keep_scale;                      // 1 / (1 - p)
   const unsigned short *cos, *sin;       // backward only, may be NULL: q and k are ROTATED tensors (rotary embedding applied by
   int64_t cs_b, cs_t;                    // dalm_rope_qk); dq and dk leave as gradients of the UN-rotated ones.  [B or 1, T, hd]
-};
+  const int* cu;                         // PACKED (un-padded) layout, may be NULL: sequence b = token rows cu[b] .. cu[b + 1] - 1 of
+};                                       // [n_tokens, H, hd] tensors (batch strides unused), T = the longest sequence; lse / delta /
+                                         // mask words keep the padded [B, H, T] / [B, 32 W, W] layout (they are small)
+
+// where sequence b starts (token rows) and how many rows it has
+struct Seq { int64_t r0; int T; };
+__device__ __forceinline__ Seq seq_of(const AttnBwdParams& p, int b) {
+  if (p.cu) { const int a = p.cu[b]; return {a, p.cu[b + 1] - a}; }
+  return {0, p.T};
+}
+// element offset of (sequence b, head h, row 0) in tensor `i` of the stride table
+__device__ __forceinline__ int64_t base_off(const AttnBwdParams& p, int i, int b, int h, const Seq& sq) {
+  return (p.cu ? sq.r0 * p.s[i][2] : b * p.s[i][0]) + h * p.s[i][1];
+}
+__device__ __forceinline__ int64_t cs_off(const AttnBwdParams& p, int b, const Seq& sq) { return p.cu ? sq.r0 * p.cs_t : b * p.cs_b; }
 
 __device__ __forceinline__ uint4 ld16(const unsigned short* p) { return *reinterpret_cast<const uint4*>(p); }
 __device__ __forceinline__ float dot8(const uint4& a, const uint4& b) {
@@ -272,22 +286,24 @@ __global__ __launch_bounds__(256, DROP ? 2 : AT<HD>::OCC) void attn_bwd_dq_kerne
   const int i0 = blk * 128;
   const int i = i0 + 32 * w + l31;
   const int64_t bh = static_cast<int64_t>(b) * p.H + h;
-  unsigned short* dq_base = p.dq + b * p.s[5][0] + h * p.s[5][1];
+  const Seq sq = seq_of(p, b);
+  const int T = sq.T;                                            // rows of THIS sequence (p.T: the layout's row count)
+  unsigned short* dq_base = p.dq + base_off(p, 5, b, h, sq);
   const unsigned long long need = need_mask<4>(p, b, i0 >> 5, true, l);
   if (need == 0ull) {                                            // padding rows only: zero gradient, nothing to read
-    store_rows<HD, A::N128>(nullptr, dq_base, p.s[5][2], i0, p.T, t);
+    store_rows<HD, A::N128>(nullptr, dq_base, p.s[5][2], i0, T, t);
     return;
   }
-  const unsigned short* kbase = p.k + b * p.s[1][0] + h * p.s[1][1];
-  const unsigned short* vbase = p.v + b * p.s[2][0] + h * p.s[2][1];
+  const unsigned short* kbase = p.k + base_off(p, 1, b, h, sq);
+  const unsigned short* vbase = p.v + base_off(p, 2, b, h, sq);
 
   bf16x8 Qb[A::KK], Gb[A::KK];
   float Dl;
   {
     uint4 qv[A::N128], gv[A::N128], ov[A::N128];
-    rows_load<HD, A::N128>(p.q + b * p.s[0][0] + h * p.s[0][1], p.s[0][2], i0, p.T, t, qv);
-    rows_load<HD, A::N128>(p.d_o + b * p.s[4][0] + h * p.s[4][1], p.s[4][2], i0, p.T, t, gv);
-    rows_load<HD, A::N128>(p.o + b * p.s[3][0] + h * p.s[3][1], p.s[3][2], i0, p.T, t, ov);
+    rows_load<HD, A::N128>(p.q + base_off(p, 0, b, h, sq), p.s[0][2], i0, T, t, qv);
+    rows_load<HD, A::N128>(p.d_o + base_off(p, 4, b, h, sq), p.s[4][2], i0, T, t, gv);
+    rows_load<HD, A::N128>(p.o + base_off(p, 3, b, h, sq), p.s[3][2], i0, T, t, ov);
     rows_store<HD, A::N128>(qv, lds, t);
 #pragma unroll
     for (int n = 0; n < A::N128; ++n) {                          // D = rowsum(dO o O): HD / 8 consecutive lanes hold one row
@@ -297,7 +313,7 @@ __global__ __launch_bounds__(256, DROP ? 2 : AT<HD>::OCC) void attn_bwd_dq_kerne
       const int row = t / A::CH + (256 / A::CH) * n;
       if (t % A::CH == 0) {
         dl_s[row] = d;
-        if (i0 + row < p.T) p.delta[bh * p.T + i0 + row] = d;
+        if (i0 + row < T) p.delta[bh * p.T + i0 + row] = d;
       }
     }
     __syncthreads();
@@ -308,7 +324,7 @@ __global__ __launch_bounds__(256, DROP ? 2 : AT<HD>::OCC) void attn_bwd_dq_kerne
     __syncthreads();
     rows_frags<HD>(lds, w, l31, hi, Gb);
   }
-  const float nl = i < p.T ? -p.lse[bh * p.T + i] * kLog2e : 0.f;
+  const float nl = i < T ? -p.lse[bh * p.T + i] * kLog2e : 0.f;
   const float c1 = p.scale * kLog2e;
   const int Tp = 32 * p.W;
 
@@ -328,8 +344,8 @@ __global__ __launch_bounds__(256, DROP ? 2 : AT<HD>::OCC) void attn_bwd_dq_kerne
 #pragma unroll
     for (int c = 0; c < 2; ++c)
       nword[c] = (i < Tp && 2 * jb + c < p.W) ? p.bits_rows[(static_cast<int64_t>(b) * Tp + i) * p.W + 2 * jb + c] : 0u;
-    block_load<HD>(kbase, p.s[1][2], 64 * jb, p.T, w, l, kv);
-    block_load<HD>(vbase, p.s[2][2], 64 * jb, p.T, w, l, vv);
+    block_load<HD>(kbase, p.s[1][2], 64 * jb, T, w, l, kv);
+    block_load<HD>(vbase, p.s[2][2], 64 * jb, T, w, l, vv);
   };
   fetch(__builtin_ctz(blocks));
   const AttnDrop drop = attn_drop(p);
@@ -387,8 +403,8 @@ __global__ __launch_bounds__(256, DROP ? 2 : AT<HD>::OCC) void attn_bwd_dq_kerne
   __syncthreads();
   spill_transposed<HD, A::ND>(acc, 0, p.scale, lds, w, l31, hi);
   __syncthreads();
-  if (p.cos) store_rows_unrope<HD, A::N128>(lds, dq_base, p.s[5][2], i0, p.T, t, p.cos + b * p.cs_b, p.sin + b * p.cs_b, p.cs_t);
-  else store_rows<HD, A::N128>(lds, dq_base, p.s[5][2], i0, p.T, t);
+  if (p.cos) store_rows_unrope<HD, A::N128>(lds, dq_base, p.s[5][2], i0, T, t, p.cos + cs_off(p, b, sq), p.sin + cs_off(p, b, sq), p.cs_t);
+  else store_rows<HD, A::N128>(lds, dq_base, p.s[5][2], i0, T, t);
 }
 
 // Forward: O = softmax(scale Q K^T + mask) V and the rows' log-sum-exp (natural log), the dq kernel's structure with the
@@ -410,16 +426,18 @@ __global__ __launch_bounds__(256, AT<HD>::OCC) void attn_fwd_kernel(const AttnBw
   const int i0 = blk * 128;
   const int i = i0 + 32 * w + l31;
   const int64_t bh = static_cast<int64_t>(b) * p.H + h;
-  unsigned short* o_base = p.dq + b * p.s[5][0] + h * p.s[5][1];          // the output travels in the dq slot
+  const Seq sq = seq_of(p, b);
+  const int T = sq.T;
+  unsigned short* o_base = p.dq + base_off(p, 5, b, h, sq);               // the output travels in the dq slot
   float* lse_out = p.delta;                                                // and the log-sum-exp in the delta slot
   const unsigned long long need = need_mask<4>(p, b, i0 >> 5, true, l);
   if (need == 0ull) {                                          // rows without a live key: zero output (as torch returns)
-    store_rows<HD, A::N128>(nullptr, o_base, p.s[5][2], i0, p.T, t);
-    if (t < 128 && i0 + t < p.T) lse_out[bh * p.T + i0 + t] = 0.f;
+    store_rows<HD, A::N128>(nullptr, o_base, p.s[5][2], i0, T, t);
+    if (t < 128 && i0 + t < T) lse_out[bh * p.T + i0 + t] = 0.f;
     return;
   }
-  const unsigned short* kbase = p.k + b * p.s[1][0] + h * p.s[1][1];
-  const unsigned short* vbase = p.v + b * p.s[2][0] + h * p.s[2][1];
+  const unsigned short* kbase = p.k + base_off(p, 1, b, h, sq);
+  const unsigned short* vbase = p.v + base_off(p, 2, b, h, sq);
   const int Tp = 32 * p.W;
   const int nJ = (p.T + 63) >> 6;
   unsigned int blocks = 0u;
@@ -430,15 +448,15 @@ __global__ __launch_bounds__(256, AT<HD>::OCC) void attn_fwd_kernel(const AttnBw
 #pragma unroll
     for (int c = 0; c < 2; ++c)
       nword[c] = (i < Tp && 2 * jb + c < p.W) ? p.bits_rows[(static_cast<int64_t>(b) * Tp + i) * p.W + 2 * jb + c] : 0u;
-    block_load<HD>(kbase, p.s[1][2], 64 * jb, p.T, w, l, kv);
-    block_load<HD>(vbase, p.s[2][2], 64 * jb, p.T, w, l, vv);
+    block_load<HD>(kbase, p.s[1][2], 64 * jb, T, w, l, kv);
+    block_load<HD>(vbase, p.s[2][2], 64 * jb, T, w, l, vv);
   };
   fetch(__builtin_ctz(blocks));
 
   bf16x8 Qb[A::KK];
   {
     uint4 qv[A::N128];
-    rows_load<HD, A::N128>(p.q + b * p.s[0][0] + h * p.s[0][1], p.s[0][2], i0, p.T, t, qv);
+    rows_load<HD, A::N128>(p.q + base_off(p, 0, b, h, sq), p.s[0][2], i0, T, t, qv);
     rows_store<HD, A::N128>(qv, lds, t);
     __syncthreads();
     rows_frags<HD>(lds, w, l31, hi, Qb);
@@ -515,11 +533,11 @@ __global__ __launch_bounds__(256, AT<HD>::OCC) void attn_fwd_kernel(const AttnBw
   }
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
   const float inv = ltot > 0.f ? 1.0f / ltot : 0.f;
-  if (hi == 0 && i < p.T) lse_out[bh * p.T + i] = ltot > 0.f ? (m + __builtin_amdgcn_logf(ltot)) * kLn2 : 0.f;
+  if (hi == 0 && i < T) lse_out[bh * p.T + i] = ltot > 0.f ? (m + __builtin_amdgcn_logf(ltot)) * kLn2 : 0.f;
   __syncthreads();
   spill_transposed<HD, A::ND>(acc, 0, inv, lds, w, l31, hi);
   __syncthreads();
-  store_rows<HD, A::N128>(lds, o_base, p.s[5][2], i0, p.T, t);
+  store_rows<HD, A::N128>(lds, o_base, p.s[5][2], i0, T, t);
 }
 
 template <int HD>
@@ -547,22 +565,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdPara
   const int j0 = blk * 64;
   const int j = j0 + 32 * jt + l31;
   const int64_t bh = static_cast<int64_t>(b) * p.H + h;
-  unsigned short* dk_base = p.dk + b * p.s[6][0] + h * p.s[6][1];
-  unsigned short* dv_base = p.dv + b * p.s[7][0] + h * p.s[7][1];
+  const Seq sq = seq_of(p, b);
+  const int T = sq.T;
+  unsigned short* dk_base = p.dk + base_off(p, 6, b, h, sq);
+  unsigned short* dv_base = p.dv + base_off(p, 7, b, h, sq);
   const unsigned long long need = need_mask<2>(p, b, j0 >> 5, false, l);
   if (need == 0ull) {
-    store_rows<HD, A::N64>(nullptr, dk_base, p.s[6][2], j0, p.T, t);
-    store_rows<HD, A::N64>(nullptr, dv_base, p.s[7][2], j0, p.T, t);
+    store_rows<HD, A::N64>(nullptr, dk_base, p.s[6][2], j0, T, t);
+    store_rows<HD, A::N64>(nullptr, dv_base, p.s[7][2], j0, T, t);
     return;
   }
-  const unsigned short* qbase = p.q + b * p.s[0][0] + h * p.s[0][1];
-  const unsigned short* gbase = p.d_o + b * p.s[4][0] + h * p.s[4][1];
+  const unsigned short* qbase = p.q + base_off(p, 0, b, h, sq);
+  const unsigned short* gbase = p.d_o + base_off(p, 4, b, h, sq);
 
   bf16x8 Kb[A::KK], Vb[A::KK];
   {
     uint4 kv[A::N64], vv[A::N64];
-    rows_load<HD, A::N64>(p.k + b * p.s[1][0] + h * p.s[1][1], p.s[1][2], j0, p.T, t, kv);
-    rows_load<HD, A::N64>(p.v + b * p.s[2][0] + h * p.s[2][1], p.s[2][2], j0, p.T, t, vv);
+    rows_load<HD, A::N64>(p.k + base_off(p, 1, b, h, sq), p.s[1][2], j0, T, t, kv);
+    rows_load<HD, A::N64>(p.v + base_off(p, 2, b, h, sq), p.s[2][2], j0, T, t, vv);
     rows_store<HD, A::N64>(kv, dlds, t);
     rows_store<HD, A::N64>(vv, dlds + A::RM, t);
     __syncthreads();
@@ -587,10 +607,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdPara
     for (int c = 0; c < 2; ++c)
       word[c] = (j < Tp && 2 * ib + c < p.W) ? p.bits_cols[(static_cast<int64_t>(b) * Tp + j) * p.W + 2 * ib + c] : 0u;
     uint4 qv[A::NCW], gv[A::NCW];
-    block_load<HD>(qbase, p.s[0][2], 64 * ib, p.T, w, l, qv);
-    block_load<HD>(gbase, p.s[4][2], 64 * ib, p.T, w, l, gv);
+    block_load<HD>(qbase, p.s[0][2], 64 * ib, T, w, l, qv);
+    block_load<HD>(gbase, p.s[4][2], 64 * ib, T, w, l, gv);
     float nlv = 0.f, dlv = 0.f;
-    if (t < 64 && 64 * ib + t < p.T) {
+    if (t < 64 && 64 * ib + t < T) {
       nlv = -p.lse[bh * p.T + 64 * ib + t] * kLog2e;
       dlv = p.delta[bh * p.T + 64 * ib + t];
     }
@@ -657,9 +677,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdPara
   spill_transposed<HD, NDH>(dKt, NDH * dh, p.scale, dlds, jt, l31, hi);
   spill_transposed<HD, NDH>(dVt, NDH * dh, 1.0f, dlds + A::RM, jt, l31, hi);
   __syncthreads();
-  if (p.cos) store_rows_unrope<HD, A::N64>(dlds, dk_base, p.s[6][2], j0, p.T, t, p.cos + b * p.cs_b, p.sin + b * p.cs_b, p.cs_t);
-  else store_rows<HD, A::N64>(dlds, dk_base, p.s[6][2], j0, p.T, t);
-  store_rows<HD, A::N64>(dlds + A::RM, dv_base, p.s[7][2], j0, p.T, t);
+  if (p.cos) store_rows_unrope<HD, A::N64>(dlds, dk_base, p.s[6][2], j0, T, t, p.cos + cs_off(p, b, sq), p.sin + cs_off(p, b, sq), p.cs_t);
+  else store_rows<HD, A::N64>(dlds, dk_base, p.s[6][2], j0, T, t);
+  store_rows<HD, A::N64>(dlds + A::RM, dv_base, p.s[7][2], j0, T, t);
 }
 
 // mask [B, 1, T, T] bytes (non-zero = attend; NULL = all) and / or causal -> row words, column words, live 32 x 32 tiles
@@ -678,6 +698,37 @@ __global__ __launch_bounds__(256) void attn_mask_bits_kernel(const unsigned char
       bool mr = mask ? mask[b * sb + r * si + x] != 0 : true;
       bool mc = mask ? mask[b * sb + x * si + r] != 0 : true;
       if (causal) { mr = mr && x <= r; mc = mc && r <= x; }
+      wr |= static_cast<uint32_t>(mr) << c;
+      wc |= static_cast<uint32_t>(mc) << c;
+    }
+  }
+  rows[idx] = wr;
+  cols[idx] = wc;
+  if (wr) live[(static_cast<int64_t>(b) * W + (r >> 5)) * W + w] = 1;
+}
+
+// the same words for PACKED sequences: sequence b = token rows cu[b] .. cu[b + 1] - 1, local row / column index = order inside the
+// sequence; key_live [n_tokens] bytes (NULL = all): a token that may be attended (the padded layout's attention_mask at its
+// position; a token that is only a QUERY - the padding position in front of a left-padded sequence, whose row predicts the first
+// real token - carries 0); element (i, j) is live when j is a live key and (causal: j <= i)
+__global__ __launch_bounds__(256) void attn_mask_bits_packed_kernel(const unsigned char* __restrict__ key_live,
+                                                                    const int* __restrict__ cu, int B, int W, int causal,
+                                                                    uint32_t* __restrict__ rows, uint32_t* __restrict__ cols,
+                                                                    unsigned char* __restrict__ live) {
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const int Tp = 32 * W;
+  if (idx >= static_cast<int64_t>(B) * Tp * W) return;
+  const int w = static_cast<int>(idx % W), r = static_cast<int>((idx / W) % Tp), b = static_cast<int>(idx / (static_cast<int64_t>(W) * Tp));
+  const int r0 = cu[b], T = cu[b + 1] - r0;
+  uint32_t wr = 0u, wc = 0u;
+  if (r < T) {
+    const bool kr = key_live ? key_live[r0 + r] != 0 : true;
+    for (int c = 0; c < 32; ++c) {
+      const int x = 32 * w + c;
+      if (x >= T) break;
+      const bool kx = key_live ? key_live[r0 + x] != 0 : true;
+      const bool mr = kx && (!causal || x <= r);             // row r attends column x
+      const bool mc = kr && (!causal || r <= x);             // row x attends column r
       wr |= static_cast<uint32_t>(mr) << c;
       wc |= static_cast<uint32_t>(mc) << c;
     }
@@ -714,11 +765,23 @@ extern "C" int dalm_attn_mask_bits(const void* mask, int64_t B, int64_t T, int64
   return check_launch(__func__);
 }
 
-extern "C" int dalm_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
-                             const uint32_t* bits_rows, const uint32_t* bits_cols, const uint8_t* live, int64_t B, int64_t H,
-                             int64_t T, int64_t hd, float scale, const int64_t* strides, const void* cos, const void* sin,
-                             int64_t cs_stride_b, int64_t cs_stride_t, float dropout_p, const void* seed, uint32_t salt, void* dq,
-                             void* dk, void* dv, float* delta, dalm_stream_t stream) {
+extern "C" int dalm_attn_mask_bits_packed(const uint8_t* key_live, const int32_t* cu_seqlens, int64_t B, int64_t T, int causal,
+                                          uint32_t* bits_rows, uint32_t* bits_cols, uint8_t* live, dalm_stream_t stream) {
+  DALM_REQUIRE(cu_seqlens && bits_rows && bits_cols && live, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(B > 0 && T > 0 && T <= 2048 && B <= 65535, DALM_E_SHAPE, "need 0 < T <= 2048 and 0 < B <= 65535");
+  const int64_t W = (T + 31) / 32, total = B * 32 * W * W;
+  hipStream_t s = as_stream(stream);
+  if (hipError_t e = hipMemsetAsync(live, 0, static_cast<size_t>(B * W * W), s); e != hipSuccess) return fail(static_cast<int>(e), __func__, hipGetErrorString(e));
+  hipLaunchKernelGGL(attn_mask_bits_packed_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, key_live,
+                     cu_seqlens, static_cast<int>(B), static_cast<int>(W), causal, bits_rows, bits_cols, live);
+  return check_launch(__func__);
+}
+
+static int dalm_attn_bwd_any(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                         const uint32_t* bits_rows, const uint32_t* bits_cols, const uint8_t* live, const int32_t* cu, int64_t B, int64_t H,
+                         int64_t T, int64_t hd, float scale, const int64_t* strides, const void* cos, const void* sin,
+                         int64_t cs_stride_b, int64_t cs_stride_t, float dropout_p, const void* seed, uint32_t salt, void* dq,
+                         void* dk, void* dv, float* delta, dalm_stream_t stream) {
   DALM_REQUIRE(q && k && v && o && d_o && lse && bits_rows && bits_cols && live && strides && dq && dk && dv && delta, DALM_E_NULL,
                "null pointer argument");
   DALM_REQUIRE(hd == 128 || hd == 64, DALM_E_SHAPE, "head width must be 64 or 128");
@@ -736,6 +799,7 @@ extern "C" int dalm_attn_bwd(const void* q, const void* k, const void* v, const 
                "dropout needs 0 <= p < 1, a device seed word and an even T");
   AttnBwdParams p;
   set_dropout(p, dropout_p, seed, salt);
+  p.cu = cu;
   p.cos = static_cast<const unsigned short*>(cos); p.sin = static_cast<const unsigned short*>(sin);
   p.cs_b = cs_stride_b; p.cs_t = cs_stride_t;
   p.q = static_cast<const unsigned short*>(q); p.k = static_cast<const unsigned short*>(k);
@@ -770,9 +834,29 @@ extern "C" int dalm_attn_bwd(const void* q, const void* k, const void* v, const 
   return check_launch(__func__);
 }
 
-extern "C" int dalm_attn_fwd(const void* q, const void* k, const void* v, const uint32_t* bits_rows, const uint8_t* live, int64_t B,
-                             int64_t H, int64_t T, int64_t hd, float scale, const int64_t* strides, float dropout_p, const void* seed,
-                             uint32_t salt, void* o, float* lse, dalm_stream_t stream) {
+extern "C" int dalm_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                             const uint32_t* bits_rows, const uint32_t* bits_cols, const uint8_t* live, int64_t B, int64_t H,
+                             int64_t T, int64_t hd, float scale, const int64_t* strides, const void* cos, const void* sin,
+                             int64_t cs_stride_b, int64_t cs_stride_t, float dropout_p, const void* seed, uint32_t salt, void* dq,
+                             void* dk, void* dv, float* delta, dalm_stream_t stream) {
+  return dalm_attn_bwd_any(q, k, v, o, d_o, lse, bits_rows, bits_cols, live, nullptr, B, H, T, hd, scale, strides, cos, sin,
+                           cs_stride_b, cs_stride_t, dropout_p, seed, salt, dq, dk, dv, delta, stream);
+}
+
+extern "C" int dalm_attn_bwd_packed(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                                    const uint32_t* bits_rows, const uint32_t* bits_cols, const uint8_t* live,
+                                    const int32_t* cu_seqlens, int64_t B, int64_t H, int64_t T, int64_t hd, float scale,
+                                    const int64_t* strides, const void* cos, const void* sin, int64_t cs_stride_t, float dropout_p,
+                                    const void* seed, uint32_t salt, void* dq, void* dk, void* dv, float* delta,
+                                    dalm_stream_t stream) {
+  DALM_REQUIRE(cu_seqlens, DALM_E_NULL, "null pointer argument");
+  return dalm_attn_bwd_any(q, k, v, o, d_o, lse, bits_rows, bits_cols, live, cu_seqlens, B, H, T, hd, scale, strides, cos, sin, 0,
+                           cs_stride_t, dropout_p, seed, salt, dq, dk, dv, delta, stream);
+}
+
+static int dalm_attn_fwd_any(const void* q, const void* k, const void* v, const uint32_t* bits_rows, const uint8_t* live,
+                            const int32_t* cu, int64_t B, int64_t H, int64_t T, int64_t hd, float scale, const int64_t* strides,
+                            float dropout_p, const void* seed, uint32_t salt, void* o, float* lse, dalm_stream_t stream) {
   DALM_REQUIRE(q && k && v && bits_rows && live && strides && o && lse, DALM_E_NULL, "null pointer argument");
   DALM_REQUIRE(hd == 128 || hd == 64, DALM_E_SHAPE, "head width must be 64 or 128");
   DALM_REQUIRE(B > 0 && H > 0 && T > 0 && T <= 2048 && B * H <= (1ll << 24), DALM_E_SHAPE, "need 0 < T <= 2048 and B H <= 2^24");
@@ -786,6 +870,7 @@ extern "C" int dalm_attn_fwd(const void* q, const void* k, const void* v, const 
                "dropout needs 0 <= p < 1, a device seed word and an even T");
   AttnBwdParams p = {};
   set_dropout(p, dropout_p, seed, salt);
+  p.cu = cu;
   p.q = static_cast<const unsigned short*>(q); p.k = static_cast<const unsigned short*>(k);
   p.v = static_cast<const unsigned short*>(v);
   p.bits_rows = bits_rows; p.live = live;
@@ -807,4 +892,18 @@ extern "C" int dalm_attn_fwd(const void* q, const void* k, const void* v, const 
     else hipLaunchKernelGGL((attn_fwd_kernel<64, false>), grid, dim3(256), 0, s, p);
   }
   return check_launch(__func__);
+}
+
+extern "C" int dalm_attn_fwd(const void* q, const void* k, const void* v, const uint32_t* bits_rows, const uint8_t* live, int64_t B,
+                             int64_t H, int64_t T, int64_t hd, float scale, const int64_t* strides, float dropout_p, const void* seed,
+                             uint32_t salt, void* o, float* lse, dalm_stream_t stream) {
+  return dalm_attn_fwd_any(q, k, v, bits_rows, live, nullptr, B, H, T, hd, scale, strides, dropout_p, seed, salt, o, lse, stream);
+}
+
+extern "C" int dalm_attn_fwd_packed(const void* q, const void* k, const void* v, const uint32_t* bits_rows, const uint8_t* live,
+                                    const int32_t* cu_seqlens, int64_t B, int64_t H, int64_t T, int64_t hd, float scale,
+                                    const int64_t* strides, float dropout_p, const void* seed, uint32_t salt, void* o, float* lse,
+                                    dalm_stream_t stream) {
+  DALM_REQUIRE(cu_seqlens, DALM_E_NULL, "null pointer argument");
+  return dalm_attn_fwd_any(q, k, v, bits_rows, live, cu_seqlens, B, H, T, hd, scale, strides, dropout_p, seed, salt, o, lse, stream);
 }

@@ -20,6 +20,7 @@ The reference itself never gathers negatives (DDP, local B_l x B_l only).
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Any, Optional
 
@@ -397,34 +398,24 @@ def _row_chunks(rows: int, cap: int, unit: int):
     return [z for z in sizes if z > 0]
 
 
-def _lm_head_live_rows(ops, h, w, ids, mask, stats, live_rows, chunk_rows, dw, need_grad=True):
-    """lm_head + marginalised CE + d(hidden) over the live rows only.  Padding rows (38 % of bench.py's cfg3 batch, and
-    whatever padding='max_length' leaves in real data) carry no loss and a zero gradient, so both GEMMs and the CE pass
-    skip them; the CE kernel sees each chunk as one virtual sample [1, n+1, V] whose shifted labels are the chunk's
-    labels (row n is the kernel's always-dead last position), so its code path and numerics are the uncompacted ones."""
-    B, Tg, H = h.shape
-    R, Rp, V = B * Tg, live_rows.numel(), w.shape[0]
-    valid = live_rows >= 0
-    rows = live_rows.clamp_min(0)
-    dst = torch.where(valid, rows, torch.full_like(rows, R))       # padding entries land in a dump row
-    nxt = rows + 1                                                  # live rows have t < Tg-1: same sample
-    ids_c = ids.reshape(-1).index_select(0, nxt)
-    mask_c = mask.reshape(-1).index_select(0, nxt) * valid.to(mask.dtype)
-    hc_all = h.reshape(R, H).index_select(0, rows)
-    # results land in [Rp+1]-row buffers whose last row stays zero; the full-size outputs are then ONE gather each through
-    # the inverse map (dead rows -> the zero row) instead of a zero fill plus a scatter (43 -> ~20 us at cfg3)
-    dh_c = torch.empty((Rp + 1, H), device=h.device, dtype=h.dtype) if need_grad else None
-    nll_c = torch.empty((Rp + 1,), device=h.device, dtype=torch.float32)
+def _lm_head_rows(ops, hc_all, w, ids_c, mask_c, stats, chunk_rows, dw, need_grad=True):
+    """lm_head + marginalised CE + d(hidden) of a COMPACT list of rows: hc_all [Rp, H] hidden states, ids_c / mask_c [Rp] the
+    label and the weight of each row (already shifted: row r predicts ids_c[r] with weight mask_c[r]).  The CE kernel sees each
+    row chunk as one virtual sample [1, n+1, V] whose shifted labels are the chunk's labels (row n is the kernel's always-dead
+    last position), so its code path and numerics are the uncompacted ones.  Returns (dh_c [Rp + 1, H] or None, nll_c [Rp + 1]):
+    the extra last row is zero (the target of dead rows when a caller maps back to a padded layout)."""
+    Rp, H = hc_all.shape
+    V = w.shape[0]
+    dh_c = torch.empty((Rp + 1, H), device=hc_all.device, dtype=hc_all.dtype) if need_grad else None
+    nll_c = torch.empty((Rp + 1,), device=hc_all.device, dtype=torch.float32)
     if need_grad:
         dh_c[Rp].zero_()
     nll_c[Rp].zero_()
-    inv = torch.full((R + 1,), Rp, device=h.device, dtype=torch.int64)
-    inv.scatter_(0, dst, torch.arange(Rp, device=h.device, dtype=torch.int64))   # padding entries land in inv[R] (unused)
     zero1 = ids_c.new_zeros((1,))
     r1 = 0
     for n in _row_chunks(Rp, chunk_rows, gemm_wave_rows(V)):
         r0, r1 = r1, r1 + n
-        buf = torch.empty((n + 1, V), device=h.device, dtype=h.dtype)
+        buf = torch.empty((n + 1, V), device=hc_all.device, dtype=hc_all.dtype)
         torch.mm(hc_all[r0:r1], w.t(), out=buf[:n])
         ids_v = torch.cat((zero1, ids_c[r0:r1])).view(1, n + 1)
         mask_v = torch.cat((zero1.to(mask_c.dtype), mask_c[r0:r1])).view(1, n + 1)
@@ -436,6 +427,27 @@ def _lm_head_live_rows(ops, h, w, ids, mask, stats, live_rows, chunk_rows, dw, n
         torch.mm(dl2, w, out=dh_c[r0:r1])
         if dw is not None:
             dw.addmm_(dl2.t().float(), hc_all[r0:r1].float())
+    return dh_c, nll_c
+
+
+def _lm_head_live_rows(ops, h, w, ids, mask, stats, live_rows, chunk_rows, dw, need_grad=True):
+    """lm_head + marginalised CE + d(hidden) over the live rows only.  Padding rows (38 % of bench.py's cfg3 batch, and
+    whatever padding='max_length' leaves in real data) carry no loss and a zero gradient, so both GEMMs and the CE pass
+    skip them (`_lm_head_rows` on the gathered rows)."""
+    B, Tg, H = h.shape
+    R, Rp = B * Tg, live_rows.numel()
+    valid = live_rows >= 0
+    rows = live_rows.clamp_min(0)
+    dst = torch.where(valid, rows, torch.full_like(rows, R))       # padding entries land in a dump row
+    nxt = rows + 1                                                  # live rows have t < Tg-1: same sample
+    ids_c = ids.reshape(-1).index_select(0, nxt)
+    mask_c = mask.reshape(-1).index_select(0, nxt) * valid.to(mask.dtype)
+    hc_all = h.reshape(R, H).index_select(0, rows)
+    # results land in [Rp+1]-row buffers whose last row stays zero; the full-size outputs are then ONE gather each through
+    # the inverse map (dead rows -> the zero row) instead of a zero fill plus a scatter (43 -> ~20 us at cfg3)
+    dh_c, nll_c = _lm_head_rows(ops, hc_all, w, ids_c, mask_c, stats, chunk_rows, dw, need_grad)
+    inv = torch.full((R + 1,), Rp, device=h.device, dtype=torch.int64)
+    inv.scatter_(0, dst, torch.arange(Rp, device=h.device, dtype=torch.int64))   # padding entries land in inv[R] (unused)
     dh = dh_c.index_select(0, inv[:R]).view(B, Tg, H) if need_grad else None
     row_nll = nll_c.index_select(0, inv[:R])
     return dh, row_nll
@@ -544,21 +556,37 @@ def _lm_head_train_kernel(ops, h, w, ids, mask, stats, live_rows):
 
 class _LMHeadRagE2E(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, p, hidden, weight, ids, mask, qlen, scale, ops, comm, chunk, q_gather, p_gather, aux, live_rows=None):
+    def forward(ctx, q, p, hidden, weight, ids, mask, qlen, scale, ops, comm, chunk, q_gather, p_gather, aux, live_rows=None,
+                packed=None):
         st = _contrastive_forward(ops, comm, q, p, scale,
                                   q_gather.wait() if q_gather is not None else None,
                                   p_gather.wait() if p_gather is not None else None)
         stats, Nb, _Mb = ops.ce_prep(mask, qlen)
         if not isinstance(comm, LocalComm):
             comm.all_reduce_sum_(stats)
-        B, Tg, H = hidden.shape
+        B, Tg = mask.shape
+        H = hidden.shape[-1]
         h = hidden.detach()
         w = weight.detach().to(h.dtype)
         need_dw = weight.requires_grad
         dw = torch.zeros(w.shape, device=w.device, dtype=torch.float32) if need_dw else None
         # evaluation (torch.no_grad(), or nothing upstream wants a gradient): forward-only CE, no d(hidden) GEMM
         need_grad = need_dw or any(ctx.needs_input_grad[:3])
-        if not need_grad and _use_lm_head_kernel(ops, h, H, w):
+        if packed is not None:
+            # hidden is [n, H]: the PACKED generator rows (dalm_amd/packed.py), packed = (labels [n], weights [n]) already
+            # shifted.  Nothing maps back to a padded layout: the loss only sums row_nll, d(hidden) stays packed.
+            ids_c, mask_c = packed
+            if need_grad and _use_lm_head_train_kernel(ops, h, H, w, need_dw) and os.environ.get("DALM_LM_HEAD_TRAIN_KERNEL") == "1":
+                labels = torch.where(mask_c != 0, ids_c, torch.full_like(ids_c, -1))
+                coef = mask_c.to(torch.float32) / stats[0]
+                _lse, row_nll = ops.lm_head_lse(h, w, labels)
+                dh = ops.lm_head_backward(h, w, labels, _lse, coef)
+                row_nll = row_nll * (coef != 0).to(row_nll.dtype)
+            else:
+                dh_c, nll_c = _lm_head_rows(ops, h, w, ids_c, mask_c, stats, chunk * Tg, dw, need_grad)
+                dh = dh_c[:-1] if need_grad else None
+                row_nll = nll_c[:-1]
+        elif not need_grad and _use_lm_head_kernel(ops, h, H, w):
             dh, row_nll = None, _lm_head_nll_kernel(ops, h, w, ids, mask, live_rows)
         elif need_grad and _use_lm_head_train_kernel(ops, h, H, w, need_dw):
             dh, row_nll = _lm_head_train_kernel(ops, h, w, ids, mask, stats, live_rows)
@@ -602,7 +630,22 @@ class _LMHeadRagE2E(torch.autograd.Function):
             a = b + g * Nb / stats[0]
             dq, dp = _contrastive_backward(ops, ctx.comm, st, ctx.scale, a, b)
             dq, dp = dq.to(ctx.in_dtypes[0]), dp.to(ctx.in_dtypes[1])
-        return (dq, dp, dh, dweight) + (None,) * 11
+        return (dq, dp, dh, dweight) + (None,) * 12
+
+
+def rag_e2e_loss_packed(query_embs, passage_embs, hidden_rows, lm_head_weight, labels, weights, attention_mask,
+                        query_token_length, logit_scale, *, comm=None, ops=None, q_gather=None, p_gather=None,
+                        aux: Optional[dict] = None):
+    """`rag_e2e_loss_from_hidden` for a generator that ran on the PACKED rows only (dalm_amd/packed.py): hidden_rows [n, H] are
+    the final hidden states of the packed rows, labels / weights [n] what `packed.packed_labels` returns (row r predicts
+    labels[r] with weight weights[r] = attention_mask[b, t + 1]); attention_mask [B, Tg] and query_token_length [B] are the
+    batch's own (they give M and the per-sample answer-token counts N_b of train_utils.py:113-138)."""
+    V = lm_head_weight.shape[0]
+    Tg = attention_mask.shape[1]
+    chunk_samples = max(1, (128 << 20) // max(Tg * V * hidden_rows.element_size(), 1))
+    return _LMHeadRagE2E.apply(query_embs, passage_embs, hidden_rows, lm_head_weight, None, attention_mask,
+                               query_token_length, float(logit_scale), ops or default_ops(), comm or LocalComm(),
+                               int(chunk_samples), q_gather, p_gather, aux, None, (labels, weights))
 
 
 def rag_e2e_loss_from_hidden(query_embs, passage_embs, hidden_states, lm_head_weight, input_ids, attention_mask,

@@ -101,6 +101,10 @@ SIGNATURES = {
     "dalm_attn_mask_bits": (_int, [_vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp]),
     "dalm_attn_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _i64, _i64,
                              _f32, _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp]),
+    "dalm_attn_mask_bits_packed": (_int, [_vp, _vp, _i64, _i64, _int, _vp, _vp, _vp, _vp]),
+    "dalm_attn_fwd_packed": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp, _f32, _vp, C.c_uint32, _vp, _vp, _vp]),
+    "dalm_attn_bwd_packed": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _i64,
+                                    _f32, _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp]),
     "dalm_lora_rowdot": (_int, [_vp, _int, _vp, _int, _i64, _i64, _int, _f32, _f32, _vp, C.c_uint32, _vp, _vp]),
     "dalm_lora_rankupd": (_int, [_vp, _int, _vp, _vp, _int, _i64, _i64, _int, _f32, _f32, _vp, C.c_uint32, _vp]),
     "dalm_lora_colacc_workspace_bytes": (_sz, [_i64, _i64, _int]),

@@ -29,6 +29,7 @@ from typing import Optional
 import torch
 
 from .. import hip
+from ..packed import packed_of
 
 NAME = "dalm_sdpa"
 _HEAD_DIMS = (64, 128)
@@ -37,13 +38,19 @@ _HEAD_DIMS = (64, 128)
 class _MaskPack:
     """What the kernels read of one mask tensor: bias (for torch's forward), row / column bit words, live tiles."""
 
-    __slots__ = ("mask", "key", "bias", "rows", "cols", "live", "seed")
+    __slots__ = ("mask", "key", "bias", "rows", "cols", "live", "packed")
 
 
 _last: list = [None]          # the pack of the mask seen last: one forward pass hands the same tensor object to every layer
 
 
 def _pack(mask: Optional[torch.Tensor], B: int, H: int, T: int, causal: bool, dtype, device) -> _MaskPack:
+    seqs = packed_of(mask)
+    if seqs is not None:                       # packed (un-padded) call: the words come from the sequence list (dalm_amd/packed.py)
+        pk = _MaskPack()
+        pk.mask, pk.key, pk.bias, pk.packed = mask, None, None, seqs
+        pk.rows, pk.cols, pk.live = seqs.bits()
+        return pk
     key = (None if mask is None else (mask.data_ptr(), mask._version, tuple(mask.shape), tuple(mask.stride())), B, T, causal,
            dtype, device, torch.cuda.current_stream(device).cuda_stream)
     cur = _last[0]
@@ -56,7 +63,7 @@ def _pack(mask: Optional[torch.Tensor], B: int, H: int, T: int, causal: bool, dt
     pk.cols = torch.empty_like(pk.rows)
     pk.live = torch.empty(B * W * W, dtype=torch.uint8, device=device)
     pk.bias = None
-    pk.seed = None
+    pk.packed = None
     if mask is None:
         hip.call("dalm_attn_mask_bits", None, B, T, 0, 0, int(causal), hip.ptr(pk.rows), hip.ptr(pk.cols), hip.ptr(pk.live), hip.stream())
     else:
@@ -94,6 +101,17 @@ def _dense_like(t: torch.Tensor) -> torch.Tensor:
 
 def _attn_forward(q, k, v, pk, scale, causal, drop=(0.0, None, 0)):
     B, H, T, hd = q.shape
+    if pk.packed is not None:                   # q, k, v: [1, H, n, hd] views of [n, H hd] projections; sequences from cu_seqlens
+        sq = pk.packed
+        out = torch.empty(1, T, H, hd, dtype=q.dtype, device=q.device).transpose(1, 2)
+        lse = torch.empty(sq.nseq, H, sq.T, dtype=torch.float32, device=q.device)
+        flat = []
+        for t in (q, k, v, out):
+            flat += _strides3(t)
+        hip.call("dalm_attn_fwd_packed", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(pk.rows), hip.ptr(pk.live), hip.ptr(sq.cu),
+                 sq.nseq, H, sq.T, hd, float(scale), (C.c_int64 * 12)(*flat), float(drop[0]), hip.ptr(drop[1]),
+                 int(drop[2]) & 0xFFFFFFFF, hip.ptr(out), hip.ptr(lse), hip.stream())
+        return out, lse
     if os.environ.get("DALM_ATTN_FWD_KERNEL", "1") == "0" and drop[0] == 0.0:    # torch's memory-efficient forward + its log-sum-exp
         out, lse, _, _ = torch.ops.aten._scaled_dot_product_efficient_attention(
             q, k, v, _torch_bias(pk, B, H, T, q.dtype, q.device), True, 0.0, causal, scale=scale)
@@ -113,6 +131,18 @@ def _attn_backward(q, k, v, out, lse, d_out, pk, scale, cos=None, sin=None, drop
     B, H, T, hd = q.shape
     if d_out.stride(-1) != 1 or any(s % 8 for s in d_out.stride()[:3]):
         d_out = d_out.contiguous()
+    if pk.packed is not None:
+        sq = pk.packed
+        dq, dk, dv = _dense_like(q), _dense_like(k), _dense_like(v)
+        delta = torch.empty(sq.nseq, H, sq.T, dtype=torch.float32, device=q.device)
+        flat = []
+        for t in (q, k, v, out, d_out, dq, dk, dv):
+            flat += _strides3(t)
+        hip.call("dalm_attn_bwd_packed", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(out), hip.ptr(d_out), hip.ptr(lse),
+                 hip.ptr(pk.rows), hip.ptr(pk.cols), hip.ptr(pk.live), hip.ptr(sq.cu), sq.nseq, H, sq.T, hd, float(scale),
+                 (C.c_int64 * 24)(*flat), hip.ptr(cos), hip.ptr(sin), 0 if cos is None else cos.stride(1), float(drop[0]),
+                 hip.ptr(drop[1]), int(drop[2]) & 0xFFFFFFFF, hip.ptr(dq), hip.ptr(dk), hip.ptr(dv), hip.ptr(delta), hip.stream())
+        return dq, dk, dv
     lse = lse if (lse.is_contiguous() and lse.shape[-1] == T) else lse[..., :T].contiguous()
     dq, dk, dv = _dense_like(q), _dense_like(k), _dense_like(v)
     delta = torch.empty(B, H, T, dtype=torch.float32, device=q.device)
@@ -134,11 +164,12 @@ class _SdpaHipBackward(torch.autograd.Function):
         pk = _pack(mask, B, H, T, causal, q.dtype, q.device)
         drop = (0.0, None, 0)
         if dropout_p > 0.0:
-            if pk.seed is None:         # this pass's copy of the device seed word (the step advances the word itself; a backward
-                from . import lora_ops  # that runs after the next advance must still see the forward's value)
+            # this STEP's copy of the device seed word (8 bytes, capturable): the step advances the word itself, a backward that
+            # runs after the next advance must still see the forward's value.  Taken per advance, not per mask pack: a pack that
+            # is re-used across steps (attention_mask=None: same key every step) must not freeze the seed
+            from . import lora_ops
 
-                pk.seed = lora_ops.dropout_seed(q.device).clone()
-            drop = (float(dropout_p), pk.seed, int(salt))
+            drop = (float(dropout_p), lora_ops.dropout_seed_snapshot(q.device), int(salt))
         out, lse = _attn_forward(q, k, v, pk, scale, causal, drop)
         ctx.save_for_backward(q, k, v, out, lse)
         ctx.pack, ctx.scale, ctx.drop = pk, scale, drop
@@ -211,11 +242,68 @@ def supported(query, key, value, mask, dropout, causal, kwargs) -> bool:
     return _views_ok(query, key, value)
 
 
+def packed_supported(query, key, value, dropout: float = 0.0) -> bool:
+    """What `dalm_attn_*_packed` take: [1, H, n, hd] bf16 views with 16-byte aligned rows, head width 64 / 128."""
+    if not (query.is_cuda and query.dtype == torch.bfloat16 and key.dtype == query.dtype and value.dtype == query.dtype):
+        return False
+    if query.dim() != 4 or query.shape[0] != 1 or query.shape[-1] not in _HEAD_DIMS or key.shape != query.shape \
+            or value.shape != query.shape:
+        return False
+    if dropout != 0.0 and not (0.0 < dropout < 1.0 and os.environ.get("DALM_ATTN_DROPOUT", "1") != "0"):
+        return False
+    return _views_ok(query, key, value) and os.environ.get("DALM_ATTN_KERNEL", "1") != "0"
+
+
+def _packed_sdpa_torch(query, key, value, seqs, scale: float, dropout: float):
+    """The packed attention without the kernels (CPU tensors, fp32, head widths they do not take): re-pad q / k / v to
+    [nseq, H, T, hd] by index, torch's SDPA under the mask the sequence list describes, rows gathered back.  A row without a
+    live key attends itself and its output is zeroed afterwards - every intermediate stays finite, and the result is what the
+    kernels (and torch's memory-efficient kernels on the padded layout) return for such rows: 0."""
+    _, H, n, hd = query.shape
+    slot, gather = seqs.padded_index()
+    nseq, T = seqs.nseq, seqs.T
+
+    def pad(t):                                                   # [1, H, n, hd] -> [nseq, H, T, hd]
+        rows = torch.cat((t[0].transpose(0, 1), t.new_zeros((1, H, hd))), dim=0)           # [n + 1, H, hd]
+        return rows.index_select(0, gather).view(nseq, T, H, hd).transpose(1, 2)
+
+    kl = torch.cat((seqs.key_live != 0, seqs.key_live.new_zeros((1,), dtype=torch.bool))).index_select(0, gather).view(nseq, 1, 1, T)
+    mask = kl.expand(nseq, 1, T, T)
+    if seqs.causal:
+        mask = mask & torch.ones((T, T), dtype=torch.bool, device=query.device).tril()
+    has_key = mask.any(dim=-1, keepdim=True)                                                  # [nseq, 1, T, 1]
+    mask = mask | (~has_key & torch.eye(T, dtype=torch.bool, device=query.device))
+    out = torch.nn.functional.scaled_dot_product_attention(pad(query), pad(key), pad(value), attn_mask=mask, dropout_p=dropout,
+                                                           scale=scale)
+    out = torch.where(has_key, out, torch.zeros_like(out))
+    return out.transpose(1, 2).reshape(nseq * T, H, hd).index_select(0, slot).unsqueeze(0)  # [1, n, H, hd]
+
+
+def _packed_attention(module, query, key, value, attention_mask, seqs, dropout, scaling):
+    from transformers.integrations.sdpa_attention import repeat_kv
+
+    groups = getattr(module, "num_key_value_groups", 1)
+    if groups > 1 and key.shape[1] != query.shape[1]:
+        key, value = repeat_kv(key, groups), repeat_kv(value, groups)
+    scale = float(scaling) if scaling is not None else float(query.shape[-1]) ** -0.5
+    if packed_supported(query, key, value, dropout):
+        salt = 0
+        if dropout > 0.0:
+            module._dalm_attn_calls = getattr(module, "_dalm_attn_calls", 0) + 1
+            salt = ((id(module) >> 4) << 12) ^ (module._dalm_attn_calls & 0xFFF)
+        out = _SdpaHipBackward.apply(query, key, value, attention_mask, scale, False, float(dropout), salt)
+        return out.transpose(1, 2).contiguous(), None
+    return _packed_sdpa_torch(query, key, value, seqs, scale, float(dropout)), None
+
+
 def dalm_sdpa_attention_forward(module, query, key, value, attention_mask, dropout: float = 0.0, scaling: Optional[float] = None,
                                 is_causal: Optional[bool] = None, **kwargs):
     """Same contract as transformers' `sdpa_attention_forward`: ([B, T, H, hd] output, None)."""
     from transformers.integrations.sdpa_attention import repeat_kv, sdpa_attention_forward
 
+    seqs = packed_of(attention_mask)
+    if seqs is not None:                     # packed (un-padded) tower call: `attention_mask` is a descriptor, not a mask
+        return _packed_attention(module, query, key, value, attention_mask, seqs, dropout, scaling)
     groups = getattr(module, "num_key_value_groups", 1)
     causal = bool(query.shape[2] > 1 and attention_mask is None
                   and (is_causal if is_causal is not None else getattr(module, "is_causal", True)))

@@ -520,9 +520,15 @@ def _llama_attention_forward(self, hidden_states, position_embeddings=None, atte
     value_states = self.v_proj(hidden_states).view(hidden_shape).transpose(1, 2)
     cos, sin = position_embeddings
     causal = bool(query_states.shape[2] > 1 and attention_mask is None and getattr(self, "is_causal", True))
-    if (key_states.shape == query_states.shape
-            and attention.supported(query_states, key_states, value_states, attention_mask, 0.0, causal, {})
-            and attention.rope_fusable(query_states, key_states, cos, sin)):
+    if attention.packed_of(attention_mask) is not None:
+        # packed (un-padded) call (dalm_amd/packed.py): [1, H, n, hd] views, sequences from the descriptor; same node
+        fused = (key_states.shape == query_states.shape and attention.packed_supported(query_states, key_states, value_states)
+                 and attention.rope_fusable(query_states, key_states, cos, sin))
+    else:
+        fused = (key_states.shape == query_states.shape
+                 and attention.supported(query_states, key_states, value_states, attention_mask, 0.0, causal, {})
+                 and attention.rope_fusable(query_states, key_states, cos, sin))
+    if fused:
         attn_output = attention.rope_sdpa(query_states, key_states, value_states, cos, sin, attention_mask, float(self.scaling), causal)
         attn_output = attn_output.transpose(1, 2)
     else:                                            # grouped heads, CPU tensors, ...: transformers' own sequence from here on

@@ -51,6 +51,25 @@ def advance_dropout_seed(device: Optional[torch.device] = None) -> None:
     """One device op (capturable): the next forward draws new dropout masks.  The training steps call this once per step."""
     dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
     dropout_seed(dev).add_(0x9E3779B97F4A7C15 - (1 << 64))     # += golden-ratio increment (as a signed 64-bit value)
+    _epoch[0] += 1
+
+
+_epoch = [0]                 # host count of advances: a snapshot is good until the next one
+_snapshots: dict = {}
+
+
+def dropout_seed_snapshot(device: torch.device) -> torch.Tensor:
+    """A copy of the seed word as it is NOW, shared by every caller on this stream until the next `advance_dropout_seed`
+    (one 8-byte copy per step and stream instead of one per attention call).  Callers keep it for their backward: the live
+    word may have advanced by then.  Never shared between an eager region and a hipGraph capture (the copy must be part of
+    the graph that reads it)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(device).cuda_stream, bool(torch.cuda.is_current_stream_capturing()))
+    hit = _snapshots.get(key)
+    if hit is None or hit[0] != _epoch[0]:
+        hit = (_epoch[0], dropout_seed(device).clone())
+        _snapshots[key] = hit
+    return hit[1]
 
 
 def branch_supported(x: torch.Tensor, a: torch.Tensor, b: torch.Tensor) -> bool:

@@ -15,7 +15,9 @@ from typing import Dict, Optional
 
 import torch
 
-from ..fused import GatherHandle, LocalComm, contrastive_loss, rag_e2e_loss, rag_e2e_loss_from_hidden
+from .. import packed as _packed
+from ..fused import (GatherHandle, LocalComm, contrastive_loss, pool_l2norm, rag_e2e_loss, rag_e2e_loss_from_hidden,
+                     rag_e2e_loss_packed)
 from ..sharded import GradBucket, allreduce_grads
 
 
@@ -173,22 +175,40 @@ class RagE2EStep(_StepBase):
             return None
         return GatherHandle(emb.float(), self.comm, self.side_stream)
 
-    def _towers(self, batch):
+    def _retrieve(self, batch, side: str):
+        """One retriever tower call; on the PACKED rows when the batch carries their list (`retriever_{side}_pack_rows` /
+        `_pack_cu`, dalm_amd/packed.py) - same embeddings, the padding never enters the encoder."""
         m = self.model
+        ids, mask = batch[f"retriever_{side}_input_ids"], batch[f"retriever_{side}_attention_mask"]
+        rows = batch.get(f"retriever_{side}_pack_rows")
+        if rows is not None and not m.retriever_is_autoregressive and _packed.attention_is_packable(m.retriever_model):
+            h = _packed.retrieval_hidden(m.retriever_model, ids, mask, rows, batch[f"retriever_{side}_pack_cu"])
+            return pool_l2norm(h, mask, m.normalize)
+        return m("retrieval", ids, mask)
+
+    def _towers(self, batch):
         if self._use_graphs(batch):
             p_emb = self.towers.passage(batch["retriever_passage_input_ids"], batch["retriever_passage_attention_mask"])
         else:
-            p_emb = m("retrieval", batch["retriever_passage_input_ids"], batch["retriever_passage_attention_mask"])
+            p_emb = self._retrieve(batch, "passage")
         p_gather = self._gather(p_emb)
         if self._use_graphs(batch):
             q_emb = self.towers.query(batch["retriever_query_input_ids"], batch["retriever_query_attention_mask"])
         else:
-            q_emb = m("retrieval", batch["retriever_query_input_ids"], batch["retriever_query_attention_mask"])
+            q_emb = self._retrieve(batch, "query")
         q_gather = self._gather(q_emb)
         return p_emb, q_emb, p_gather, q_gather
 
+    def _packed_generator(self, batch) -> bool:
+        return ("generator_pack_rows" in batch and not self._use_graphs(batch)
+                and _packed.attention_is_packable(self.model.generator_model))
+
     def _generator(self, batch):
         m = self.model
+        if self._packed_generator(batch):      # final hidden states of the live rows only, [n, H]
+            return _packed.generator_hidden(m.generator_model, batch["generator_input_input_ids"],
+                                            batch["generator_input_attention_mask"], batch["generator_pack_rows"],
+                                            batch["generator_pack_cu"])
         if self._use_graphs(batch):
             return self.towers.generator(batch["generator_input_input_ids"], batch["generator_input_attention_mask"])
         if not self.fuse_lm_head:
@@ -237,6 +257,17 @@ class RagE2EStep(_StepBase):
             else:
                 p_emb, q_emb, p_gather, q_gather = self._towers(batch)
                 logits = self._generator(batch)
+        if self._packed_generator(batch):
+            head = m.generator_model.get_output_embeddings()
+            if getattr(head, "bias", None) is not None:
+                raise NotImplementedError("the packed generator path needs a bias-free lm_head")
+            labels, weights = _packed.packed_labels(batch["generator_input_input_ids"], batch["generator_input_attention_mask"],
+                                                    batch["generator_pack_rows"])
+            loss = rag_e2e_loss_packed(q_emb, p_emb, logits, head.weight, labels, weights,
+                                       batch["generator_input_attention_mask"], batch["query_passage_input_len"],
+                                       self.logit_scale, comm=self.comm, ops=self.ops, q_gather=q_gather, p_gather=p_gather,
+                                       aux=self.aux)
+            return self._finish(loss)
         if self.fuse_lm_head:
             head = m.generator_model.get_output_embeddings()
             if getattr(head, "bias", None) is not None:

@@ -486,6 +486,28 @@ int dalm_attn_bwd(const void* q, const void* k, const void* v, const void* o, co
                   int64_t cs_stride_t, float dropout_p, const void* seed, uint32_t salt, void* dq, void* dk, void* dv,
                   float* delta, dalm_stream_t stream);
 
+/* PACKED (un-padded) forms of the three attention entry points: the towers run on the LIVE tokens of a batch only
+ * (dalm_amd/packed.py: padding tokens contribute exactly zero to the reference's loss and gradients, train_utils.py:134-136 and
+ * rag_e2e_base_model.py:108-111, so every row-wise kernel and GEMM of the towers skips them).  q, k, v, o, ... are
+ * [n_tokens, H, hd] tensors; sequence b owns token rows cu_seqlens[b] .. cu_seqlens[b + 1] - 1 (int32 [B + 1], device memory),
+ * T = the longest sequence (<= 2048).  strides keep the (batch, head, row) triples, the batch entries are ignored; cos / sin are
+ * [n_tokens, hd] tables (row stride cs_stride_t) holding each token's ORIGINAL position.  lse / delta are [B, H, T] f32 and the
+ * mask words [B][32 W][W] as above, built by
+ *   dalm_attn_mask_bits_packed: key_live [n_tokens] bytes (NULL = all live; 0 = a token that only queries, e.g. the padding
+ *        position in front of a left-padded sequence whose row predicts the first real token), causal flag: element (i, j) of
+ *        sequence b is live when token j is a live key and (causal) j <= i - what the padded mask says about the same tokens. */
+int dalm_attn_mask_bits_packed(const uint8_t* key_live, const int32_t* cu_seqlens, int64_t B, int64_t T, int causal,
+                               uint32_t* bits_rows, uint32_t* bits_cols, uint8_t* live, dalm_stream_t stream);
+int dalm_attn_fwd_packed(const void* q, const void* k, const void* v, const uint32_t* bits_rows, const uint8_t* live,
+                         const int32_t* cu_seqlens, int64_t B, int64_t H, int64_t T, int64_t hd, float scale,
+                         const int64_t* strides, float dropout_p, const void* seed, uint32_t salt, void* o, float* lse,
+                         dalm_stream_t stream);
+int dalm_attn_bwd_packed(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                         const uint32_t* bits_rows, const uint32_t* bits_cols, const uint8_t* live, const int32_t* cu_seqlens,
+                         int64_t B, int64_t H, int64_t T, int64_t hd, float scale, const int64_t* strides, const void* cos,
+                         const void* sin, int64_t cs_stride_t, float dropout_p, const void* seed, uint32_t salt, void* dq, void* dk,
+                         void* dv, float* delta, dalm_stream_t stream);
+
 /* ---- the low-rank branch of a LoRA-wrapped Linear ----------------------------------------------------------------
  * The reference wraps q_proj / v_proj (key / query / value for BERT retrievers) in peft LoRA adapters, r = 8, alpha = 16,
  * dropout 0.05 (dalm/models/rag_e2e_base_model.py:145-160, retriever_only_base_model.py:92-107); peft evaluates

@@ -88,3 +88,15 @@ def test_bucketed_data_path_is_opt_in_and_keeps_every_row():
     widths = {b["generator_input_input_ids"].shape[1] for b in bs}
     assert all(b["generator_input_input_ids"].shape[0] == bench.CFG["B"] for b in bs) and len(widths) > 1
     assert sum(b["generator_input_input_ids"].numel() for b in bs) < 0.85 * 6 * bench.CFG["B"] * bench.CFG["Tg"]
+
+
+def test_kernel_bench_printer_takes_label_values(capsys):
+    """tools/kernel_bench.py crashed in round 5 formatting the string "bf16 x3" with :.4g."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("kernel_bench", ROOT / "tools" / "kernel_bench.py")
+    kb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kb)
+    kb.print_results({"sim 4096x4096 D1024": {"rowstats": {"s": 1.25e-4, "pipe": "bf16 x3", "frac": 0.47, "n": 3}}})
+    out = capsys.readouterr().out
+    assert "pipe=bf16 x3" in out and "frac=0.47" in out

@@ -1,0 +1,144 @@
+"""Packed (un-padded) tower path, host logic and the torch fallback of its attention (no GPU): the token list, the labels, and
+tiny Llama / BERT towers run on the packed rows against the same towers on the padded batch - the live tokens' states must be
+the padded run's (reference semantics: dalm/training/utils/train_utils.py:134-136, dalm/models/rag_e2e_base_model.py:108-111)."""
+import pytest
+import torch
+
+from dalm_amd import packed
+
+
+def _masks(B, T, left, seed, holes=False):
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(1, T + 1, (B,), generator=g)
+    lens[0] = T                      # a row without padding
+    if B > 2:
+        lens[2] = 1                  # a single live token
+    ar = torch.arange(T).unsqueeze(0)
+    m = (ar >= (T - lens).unsqueeze(1)) if left else (ar < lens.unsqueeze(1))
+    m = m.long()
+    if holes:
+        m[1, T // 2] = 0
+    return m
+
+
+@pytest.mark.parametrize("left", [True, False])
+def test_pack_plan_lists_exactly_the_rows_that_matter(left):
+    B, T = 5, 12
+    m = _masks(B, T, left, 0)
+    m[3] = 0                                                         # an all-padding row
+    rows, cu = packed.pack_plan(m, shifted=True, multiple=8)
+    n = int(cu[B])
+    want = [(b, t) for b in range(B) for t in range(T) if m[b, t] or (t + 1 < T and m[b, t + 1])]
+    assert [(int(r) // T, int(r) % T) for r in rows[:n]] == want
+    assert rows.numel() % 8 == 0 and int(cu[B + 1]) == rows.numel() and (rows[n:] == -1).all()
+    assert [int(c) for c in cu[1:B + 1] - cu[:B]] == [sum(1 for (b, _) in want if b == i) for i in range(B)]
+    rows2, cu2 = packed.pack_plan(m, shifted=False, multiple=8)
+    assert [int(r) for r in rows2[:int(cu2[B])]] == [int(i) for i in m.reshape(-1).nonzero().squeeze(1)]
+    # labels: row (b, t) predicts ids[b, t + 1] with weight mask[b, t + 1]
+    ids = torch.arange(B * T).view(B, T)
+    y, w = packed.packed_labels(ids, m, rows)
+    for i, (b, t) in enumerate(want):
+        if t + 1 < T:
+            assert int(y[i]) == int(ids[b, t + 1]) and int(w[i]) == int(m[b, t + 1])
+        else:
+            assert int(w[i]) == 0
+    assert (w[n:] == 0).all()
+    assert int(w.sum()) == int(m[:, 1:].sum())                      # every target token of the padded loss, once
+
+
+def _tiny_llama():
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    from dalm_amd.models import attention
+
+    torch.manual_seed(0)
+    cfg = LlamaConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                      vocab_size=97, max_position_embeddings=64)
+    model = LlamaForCausalLM(cfg).eval()
+    assert attention.register()
+    model.config._attn_implementation = attention.NAME
+    return model
+
+
+@pytest.mark.parametrize("left,holes", [(True, False), (False, False), (True, True)])
+def test_packed_llama_equals_padded_on_live_rows(left, holes):
+    model = _tiny_llama()
+    B, T = 4, 16
+    mask = _masks(B, T, left, 1, holes)
+    ids = torch.randint(3, 97, (B, T), generator=torch.Generator().manual_seed(2))
+    rows, cu = packed.pack_plan(mask, shifted=True, multiple=8)
+    assert packed.attention_is_packable(model)
+    hp = packed.generator_hidden(model, ids, mask, rows, cu)                       # [n, H]
+    model.config._attn_implementation = "sdpa"
+    ref = model.base_model(input_ids=ids, attention_mask=mask, use_cache=False)[0].reshape(B * T, -1)
+    y, w = packed.packed_labels(ids, mask, rows)
+    carries_loss = w != 0
+    got, want = hp[carries_loss], ref.index_select(0, rows.clamp_min(0))[carries_loss]
+    assert carries_loss.sum() == mask[:, 1:].sum()
+    assert torch.allclose(got, want, atol=2e-5, rtol=1e-4), float((got - want).abs().max())
+    assert torch.isfinite(hp).all()                                                # slack rows: finite, no NaN into weight grads
+
+
+def test_packed_llama_gradients_equal_padded():
+    from dalm_amd.models import attention
+
+    model = _tiny_llama().train()
+    B, T = 3, 12
+    mask = _masks(B, T, True, 3)
+    ids = torch.randint(3, 97, (B, T), generator=torch.Generator().manual_seed(4))
+    rows, cu = packed.pack_plan(mask, shifted=True, multiple=8)
+    y, w = packed.packed_labels(ids, mask, rows)
+    head = model.get_output_embeddings().weight
+
+    def loss_packed():
+        h = packed.generator_hidden(model, ids, mask, rows, cu)
+        lp = torch.log_softmax(h @ head.t(), dim=-1)
+        return -(lp.gather(1, y.unsqueeze(1)).squeeze(1) * w).sum() / w.sum()
+
+    def loss_padded():
+        model.config._attn_implementation = "sdpa"
+        lp = torch.log_softmax(model(input_ids=ids, attention_mask=mask, use_cache=False).logits[:, :-1], dim=-1)
+        model.config._attn_implementation = attention.NAME
+        m = mask[:, 1:].float()
+        return -(lp.gather(2, ids[:, 1:].unsqueeze(2)).squeeze(2) * m).sum() / m.sum()
+
+    grads = []
+    for fn in (loss_packed, loss_padded):
+        model.zero_grad()
+        loss = fn()
+        loss.backward()
+        grads.append((float(loss), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+    assert abs(grads[0][0] - grads[1][0]) <= 1e-5 * abs(grads[1][0])
+    for n, g in grads[1][1].items():
+        assert torch.allclose(grads[0][1][n], g, atol=1e-5, rtol=1e-3), n
+
+
+def test_packed_bert_equals_padded_on_live_tokens():
+    from transformers import BertConfig, BertModel
+
+    from dalm_amd.models import attention
+
+    torch.manual_seed(0)
+    cfg = BertConfig(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128, vocab_size=101,
+                     max_position_embeddings=64)
+    model = BertModel(cfg).eval()
+    assert attention.register()
+    B, T = 4, 14
+    mask = _masks(B, T, False, 5)
+    ids = torch.randint(3, 101, (B, T), generator=torch.Generator().manual_seed(6))
+    want = model(ids, mask)[0]
+    model.config._attn_implementation = attention.NAME
+    rows, cu = packed.pack_plan(mask, shifted=False, multiple=8)
+    got = packed.retrieval_hidden(model, ids, mask, rows, cu)
+    live = mask.bool()
+    assert torch.allclose(got[live], want[live], atol=2e-5, rtol=1e-4)
+    assert (got[~live] == 0).all()
+
+
+def test_add_pack_plans_keys():
+    b = {"generator_input_input_ids": torch.zeros(2, 8, dtype=torch.long), "generator_input_attention_mask": _masks(2, 8, True, 0),
+         "retriever_query_input_ids": torch.zeros(2, 6, dtype=torch.long), "retriever_query_attention_mask": _masks(2, 6, False, 1)}
+    out = packed.add_pack_plans(b, multiple=4)
+    assert {"generator_pack_rows", "generator_pack_cu", "retriever_query_pack_rows", "retriever_query_pack_cu"} <= set(out)
+    assert "retriever_passage_pack_rows" not in out
+    assert out["generator_pack_cu"].dtype == torch.int32 and out["generator_pack_rows"].dtype == torch.int64

@@ -1,0 +1,375 @@
+"""The packed (un-padded) tower path on the GPU (dalm_amd/packed.py, `dalm_attn_*_packed`):
+
+* the packed attention kernels against a float64 evaluation of the same per-sequence masked attention and against the padded
+  kernels on the same tokens (forward, dq, dk, dv; causal + left / right padding incl. the key-dead leading row, bidirectional
+  encoder masks, an empty sequence, the rotary-fused node, attention dropout);
+* one RagE2EStep at REAL WIDTH (cfg3 shapes, LoRA on both towers, depth 1) run three ways - padded, packed, and the reference's op
+  sequence on the host (`oracle.ref_*`) - on loss, its parts and EVERY LoRA gradient, in fp32 (<= 1e-4) and in the headline
+  configuration (bf16-stored base, bf16 autocast, every kernel on; bounds of tests/test_headline_config_gpu.py).
+Padding rows contribute exactly zero to the reference's loss and gradients (train_utils.py:134-136), so the three must agree.
+"""
+import copy
+import json
+import os
+from pathlib import Path
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+OUT = Path(__file__).resolve().parent.parent / "gpurun_out"
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _seq_ref64(q, k, v, key_live, causal, scale, go):
+    """float64 attention of ONE sequence [H, n, hd] with key-live flags [n]; rows without a live key: 0."""
+    q, k, v = [t.detach().double().requires_grad_(True) for t in (q, k, v)]
+    s = (q @ k.transpose(-1, -2)) * scale
+    n = s.shape[-1]
+    live = key_live.bool()[None, :].expand(n, n)
+    if causal:
+        live = live & torch.ones(n, n, dtype=torch.bool, device=s.device).tril()
+    s = s.masked_fill(~live[None], float("-inf"))
+    p = torch.nan_to_num(torch.softmax(s, -1), nan=0.0)
+    o = p @ v
+    o.backward(go.double())
+    return o, q.grad, k.grad, v.grad
+
+
+def _mask_2d(B, T, lens, left):
+    ar = torch.arange(T).unsqueeze(0)
+    L = torch.tensor(lens).unsqueeze(1)
+    return ((ar >= T - L) if left else (ar < L)).long()
+
+
+ATTN_CASES = [
+    # B, H, T, lens, left padding, causal (generator) / bidirectional (encoder), head width, with rotary
+    (4, 3, 256, [256, 100, 1, 37], True, True, 128, False),
+    (4, 3, 256, [256, 100, 1, 37], True, True, 128, True),
+    (3, 2, 256, [200, 0, 129], False, True, 128, True),          # an all-padding row: an empty sequence
+    (4, 4, 128, [128, 30, 77, 5], False, False, 64, False),      # BERT passages
+    (5, 2, 50, [5, 15, 9, 50, 1], False, False, 64, False),      # BERT queries
+    (2, 2, 320, [320, 191], True, True, 64, True),               # Falcon head width
+]
+
+
+@pytest.mark.parametrize("B,H,T,lens,left,causal,hd,rope", ATTN_CASES)
+def test_packed_attention_kernels_vs_float64_and_padded(dev, B, H, T, lens, left, causal, hd, rope):
+    from dalm_amd import packed
+    from dalm_amd.models import attention
+
+    g = torch.Generator().manual_seed(B * 1000 + T + hd)
+    m2 = _mask_2d(B, T, lens, left)
+    rows, cu = packed.pack_plan(m2, shifted=causal, multiple=64)
+    rows_d, cu_d = rows.to(dev), cu.to(dev)
+    n = rows.numel()
+    ids = torch.zeros(B, T, dtype=torch.long, device=dev)
+    _ids_p, pos, desc, valid = packed.packed_inputs(ids, m2.to(dev), rows_d, cu_d, causal)
+    seqs = packed.packed_of(desc)
+    q, k, v, go = [(0.7 * torch.randn(1, n, H, hd, generator=g)).to(dev, torch.bfloat16).transpose(1, 2) for _ in range(4)]
+    scale = hd ** -0.5
+    cos = sin = None
+    if rope:
+        inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, device=dev).float() / hd))
+        ang = pos[0].float()[:, None] * inv[None, :]
+        cos = torch.cat((ang.cos(), ang.cos()), -1).to(torch.bfloat16)[None]
+        sin = torch.cat((ang.sin(), ang.sin()), -1).to(torch.bfloat16)[None]
+
+    def run(fn):
+        qq, kk, vv = [t.detach().clone().requires_grad_(True) for t in (q, k, v)]
+        o = fn(qq, kk, vv)
+        o.backward(go if o.shape == go.shape else go.transpose(1, 2))
+        return o.detach(), qq.grad, kk.grad, vv.grad
+
+    assert attention.packed_supported(q, k, v)
+    if rope:
+        assert attention.rope_fusable(q, k, cos, sin)
+        got = run(lambda a, b, c: attention.rope_sdpa(a, b, c, cos, sin, desc, scale, False))
+        from dalm_amd.models import tower_ops
+
+        def torch_path(a, b, c):
+            a2, b2 = tower_ops.rope_qk(a, b, cos, sin)
+            return attention._packed_sdpa_torch(a2, b2, c, seqs, scale, 0.0).transpose(1, 2)
+    else:
+        got = run(lambda a, b, c: attention.sdpa(a, b, c, desc, scale, False))
+
+        def torch_path(a, b, c):
+            return attention._packed_sdpa_torch(a, b, c, seqs, scale, 0.0).transpose(1, 2)
+    alt = run(torch_path)                                        # torch's own bf16 kernels on the re-padded tensors
+
+    # float64, sequence by sequence (the rotation applied in float64 from the bf16 tables)
+    def rot(x):
+        if not rope:
+            return x
+        h2 = hd // 2
+        xr = torch.cat((-x[..., h2:], x[..., :h2]), -1)
+        return x * cos.double()[:, None] + xr * sin.double()[:, None]
+
+    q64, k64 = [t.detach().double().requires_grad_(True) for t in (q, k)]
+    qr, kr = rot(q64), rot(k64)
+    # rounding of the rotated tensors to bf16 is part of both implementations: evaluate the reference on the rounded values
+    qr_b, kr_b = qr.detach().to(torch.bfloat16).double(), kr.detach().to(torch.bfloat16).double()
+    want_o = torch.zeros(1, H, n, hd, dtype=torch.float64, device=dev)
+    want = [torch.zeros_like(want_o) for _ in range(3)]
+    for b in range(B + 1):
+        a, e = int(cu[b]), int(cu[b + 1])
+        if e == a:
+            continue
+        o, dq_, dk_, dv_ = _seq_ref64(qr_b[0, :, a:e], kr_b[0, :, a:e], v[0, :, a:e], seqs.key_live[a:e], causal, scale,
+                                      go[0, :, a:e])
+        want_o[0, :, a:e] = o
+        for t, gsrc in zip(want, (dq_, dk_, dv_)):
+            t[0, :, a:e] = gsrc
+    if rope:    # chain the rotation's backward in float64
+        qr.backward(want[0])
+        kr.backward(want[1])
+        want[0], want[1] = q64.grad, k64.grad
+    names = ("out", "dq", "dk", "dv")
+    for name, gt, al, wt in zip(names, got, alt, [want_o] + want):
+        e_k, e_t = _rel(gt, wt), _rel(al, wt)
+        assert e_k <= 1.5 * e_t + 2e-3, (name, e_k, e_t)
+        assert torch.isfinite(gt).all(), name
+    # slack rows and key-dead rows: exactly zero output / gradients
+    dead_q = torch.zeros(n, dtype=torch.bool, device=dev)
+    for b in range(B + 1):
+        a, e = int(cu[b]), int(cu[b + 1])
+        kl = seqs.key_live[a:e].bool()
+        for i in range(e - a):
+            has = bool(kl[:i + 1].any()) if causal else bool(kl.any())
+            dead_q[a + i] = not has
+    assert (got[0][0, :, dead_q] == 0).all() and (got[1][0, :, dead_q] == 0).all()
+    dead_k = seqs.key_live == 0
+    assert (got[2][0, :, dead_k] == 0).all() and (got[3][0, :, dead_k] == 0).all()
+
+
+def test_packed_mask_words_match_numpy(dev):
+    import numpy as np
+
+    from dalm_amd import packed
+
+    B, T = 4, 96
+    m2 = _mask_2d(B, T, [96, 40, 1, 0], True)
+    rows, cu = packed.pack_plan(m2, shifted=True, multiple=32)
+    _i, _p, desc, _v = packed.packed_inputs(torch.zeros(B, T, dtype=torch.long, device=dev), m2.to(dev), rows.to(dev), cu.to(dev), True)
+    sq = packed.packed_of(desc)
+    rb, cb, lt = [t.cpu().numpy() for t in sq.bits()]
+    W = (T + 31) // 32
+    rb, cb = rb.view(np.uint32).reshape(B + 1, 32 * W, W), cb.view(np.uint32).reshape(B + 1, 32 * W, W)
+    kl = sq.key_live.cpu().numpy()
+    for b in range(B + 1):
+        a, e = int(cu[b]), int(cu[b + 1])
+        L = e - a
+        M = np.zeros((32 * W, 32 * W), dtype=bool)
+        for i in range(L):
+            for j in range(i + 1):
+                M[i, j] = kl[a + j] != 0
+        bitw = (1 << np.arange(32, dtype=np.uint64))
+        want_r = (M.reshape(32 * W, W, 32) * bitw).sum(-1).astype(np.uint32)
+        want_c = (M.T.reshape(32 * W, W, 32) * bitw).sum(-1).astype(np.uint32)
+        assert (rb[b] == want_r).all() and (cb[b] == want_c).all()
+        live = M.reshape(W, 32, W, 32).any(axis=(1, 3))
+        assert (lt.reshape(B + 1, W, W)[b].astype(bool) == live).all()
+
+
+def test_packed_attention_dropout_statistics_and_backward(dev):
+    """BERT's attention dropout inside the packed kernels: the dropped forward is reproduced by the backward (gradients against
+    float64 with the SAME keep pattern, recovered from a forward with V = identity-like probes is overkill; here: finite,
+    deterministic for one seed, different after an advance, and E[out] close to the no-dropout output)."""
+    from dalm_amd import packed
+    from dalm_amd.models import attention, lora_ops
+
+    B, H, T, hd, p = 6, 4, 128, 64, 0.1
+    m2 = _mask_2d(B, T, [128, 64, 100, 33, 128, 90], False)
+    rows, cu = packed.pack_plan(m2, shifted=False, multiple=64)
+    _i, _p, desc, _v = packed.packed_inputs(torch.zeros(B, T, dtype=torch.long, device=dev), m2.to(dev), rows.to(dev), cu.to(dev), False)
+    n = rows.numel()
+    g = torch.Generator().manual_seed(5)
+    q, k, v = [(0.5 * torch.randn(1, n, H, hd, generator=g)).to(dev, torch.bfloat16).transpose(1, 2).requires_grad_(True) for _ in range(3)]
+    base = attention.sdpa(q, k, v, desc, hd ** -0.5, False).float()
+    lora_ops.advance_dropout_seed(dev)
+    a = attention.sdpa(q, k, v, desc, hd ** -0.5, False, p, 7).float()
+    b = attention.sdpa(q, k, v, desc, hd ** -0.5, False, p, 7).float()
+    assert torch.equal(a, b)
+    lora_ops.advance_dropout_seed(dev)
+    c = attention.sdpa(q, k, v, desc, hd ** -0.5, False, p, 7).float()
+    assert not torch.equal(a, c)
+    acc = torch.zeros_like(base)
+    reps = 24
+    for i in range(reps):
+        lora_ops.advance_dropout_seed(dev)
+        acc += attention.sdpa(q, k, v, desc, hd ** -0.5, False, p, 7).float()
+    assert _rel(acc / reps, base) < 0.12                       # ~ sqrt(p / (1 - p) / reps / keys) scale, loose
+    out = attention.sdpa(q, k, v, desc, hd ** -0.5, False, p, 7)
+    out.float().square().sum().backward()
+    assert all(torch.isfinite(t.grad).all() for t in (q, k, v))
+
+
+# -----------------------------------------------------------------------------------------------------------------------
+# step level, real width
+# -----------------------------------------------------------------------------------------------------------------------
+class _GradSnapshot:
+    """optimizer pre-step hook: copies of every trainable gradient while they still exist."""
+
+    def __init__(self, named):
+        self.named, self.grads = named, {}
+
+    def __call__(self, *_):
+        self.grads = {n: p.grad.detach().float().cpu().clone() for n, p in self.named if p.grad is not None}
+
+
+def _record(name, payload):
+    try:
+        OUT.mkdir(exist_ok=True)
+        path = OUT / "packed_parity.json"
+        cur = json.loads(path.read_text()) if path.exists() else {}
+        cur[name] = payload
+        path.write_text(json.dumps(cur, indent=1))
+    except OSError:
+        pass
+
+
+def _step(retriever, generator, batch, mode, precision, dev):
+    from dalm_amd import packed
+    from dalm_amd.models import AutoModelForRagE2E
+    from dalm_amd.training.step import RagE2EStep
+
+    r, g = copy.deepcopy(retriever), copy.deepcopy(generator)
+    model = AutoModelForRagE2E.from_modules(r, g, None, None, normalize=True, get_peft=None).to(dev)
+    if precision == "bf16":
+        for p in model.parameters():
+            if not p.requires_grad:
+                p.data = p.data.to(torch.bfloat16)
+    model.train()
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    opt = torch.optim.SGD([p for _, p in named], lr=0.0)
+    snap = _GradSnapshot(named)
+    opt.register_step_pre_hook(snap)
+    step = RagE2EStep(model, opt, None, 100, autocast_dtype=torch.bfloat16 if precision == "bf16" else None, inplace_grad=True,
+                      overlap_towers=True, track_grad_norm=True)
+    host = dict(batch)
+    if mode == "packed":
+        host = packed.add_pack_plans(host)
+    dbatch = {k: v.to(dev) for k, v in host.items()}
+    loss = float(step(dbatch))
+    out = {"loss": loss, "contrastive": float(step.aux["contrastive"]), "generator": float(step.aux["generator"]),
+           "grad_norm": float(step.grad_norm)}
+    if mode == "packed":
+        assert step._packed_generator(dbatch), "the packed generator path did not run"
+        out["rows"] = {k: int(v.numel()) for k, v in dbatch.items() if k.endswith("_pack_rows")}
+    grads = snap.grads
+    del model, step, opt, r, g
+    torch.cuda.empty_cache()
+    return out, grads
+
+
+def _special_batch(batch):
+    """The real-width synthetic batch with the edge rows the packed path must get right: a row without padding, a row with ONE
+    live generator token, a right-padded generator row among the left-padded ones, a single-token query."""
+    b = {k: v.clone() for k, v in batch.items()}
+    Tg = b["generator_input_attention_mask"].shape[1]
+    am = b["generator_input_attention_mask"]
+    am[0] = 1
+    am[1] = 0
+    am[1, -1] = 1
+    am[2] = (torch.arange(Tg) < 77).long()
+    b["query_passage_input_len"][1] = 1
+    b["query_passage_input_len"][2] = 60
+    b["retriever_query_attention_mask"][3] = 0
+    b["retriever_query_attention_mask"][3, 0] = 1
+    return b
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_packed_step_equals_padded_step_and_oracle_at_real_width(dev, precision):
+    import dalm_oracle as O
+    import realwidth as RW
+    from test_step_realwidth_gpu import _build, _randomise_lora_b
+
+    from dalm_amd.models import lora
+
+    retriever, generator = _build("cfg3")
+    if precision == "bf16":
+        with torch.no_grad():
+            for mod in (retriever, generator):
+                for p in mod.parameters():
+                    p.copy_(p.to(torch.bfloat16).float())
+    lora.inject_lora(retriever, ["key", "query", "value"], lora_dropout=0.0)
+    _randomise_lora_b(retriever, 11)
+    lora.inject_lora(generator, ["q_proj", "v_proj"], lora_dropout=0.0)
+    _randomise_lora_b(generator, 12)
+    batch = _special_batch(RW.synthetic_batch("cfg3"))
+
+    padded, g_pad = _step(retriever, generator, batch, "padded", precision, dev)
+    packd, g_pack = _step(retriever, generator, batch, "packed", precision, dev)
+    live_gen = int((batch["generator_input_attention_mask"] != 0).sum())
+    assert packd["rows"]["generator_pack_rows"] < batch["generator_input_attention_mask"].numel()
+    assert packd["rows"]["generator_pack_rows"] >= live_gen
+
+    old_threads = torch.get_num_threads()
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    try:
+        q = O.ref_retrieval_embed(retriever(batch["retriever_query_input_ids"], batch["retriever_query_attention_mask"])[0],
+                                  batch["retriever_query_attention_mask"])
+        p = O.ref_retrieval_embed(retriever(batch["retriever_passage_input_ids"], batch["retriever_passage_attention_mask"])[0],
+                                  batch["retriever_passage_attention_mask"])
+        logits = generator(input_ids=batch["generator_input_input_ids"], attention_mask=batch["generator_input_attention_mask"]).logits
+        out = O.ref_step_loss(q, p, logits, batch["generator_input_input_ids"], batch["generator_input_attention_mask"],
+                              batch["query_passage_input_len"], 100)
+        out["loss"].backward()
+    finally:
+        torch.set_num_threads(old_threads)
+    named_cpu = {("retriever_model." + n): p for n, p in retriever.named_parameters() if p.requires_grad}
+    named_cpu.update({("generator_model." + n): p for n, p in generator.named_parameters() if p.requires_grad})
+    host = {"loss": float(out["loss"]), "contrastive": float(out["contrastive"]), "generator": float(out["generator"]),
+            "grad_norm": RW.grad_norm(list(named_cpu.values()))}
+    g_host = {n: p.grad.detach().float() for n, p in named_cpu.items()}
+    assert set(g_host) == set(g_pad) == set(g_pack)
+
+    def worst(ga, gb):
+        """largest per-parameter relative gradient deviation, against the tensor's own norm (a LoRA factor whose gradient is a
+        rounding-level residue of a much larger one is scaled by the largest norm of its kind instead)."""
+        big = {}
+        for n, t in gb.items():
+            kind = n.split(".")[-3] + "." + n.split(".")[0]
+            big[kind] = max(big.get(kind, 0.0), float(t.double().norm()))
+        w, wn = 0.0, None
+        for n, t in gb.items():
+            kind = n.split(".")[-3] + "." + n.split(".")[0]
+            d = float((ga[n].double() - t.double()).norm()) / max(float(t.double().norm()), 0.05 * big[kind], 1e-30)
+            if d > w:
+                w, wn = d, n
+        return w, wn
+
+    keys = ("loss", "contrastive", "generator", "grad_norm")
+    rel = {"packed_vs_padded": {k: abs(packd[k] - padded[k]) / max(abs(padded[k]), 1e-30) for k in keys},
+           "packed_vs_host": {k: abs(packd[k] - host[k]) / max(abs(host[k]), 1e-30) for k in keys},
+           "padded_vs_host": {k: abs(padded[k] - host[k]) / max(abs(host[k]), 1e-30) for k in keys}}
+    gw = {"packed_vs_padded": worst(g_pack, g_pad), "packed_vs_host": worst(g_pack, g_host), "padded_vs_host": worst(g_pad, g_host)}
+    _record(f"cfg3/{precision}", {"padded": padded, "packed": packd, "host_fp32_oracle": host, "rel": rel,
+                                  "worst_parameter_gradient": {k: {"rel": v[0], "name": v[1]} for k, v in gw.items()}})
+    if precision == "fp32":
+        tol_s, tol_g = 1e-4, 1e-4
+        for pair in rel:
+            for k in keys:
+                assert rel[pair][k] <= tol_s, (pair, k, rel)
+        for pair, (w, name) in gw.items():
+            assert w <= tol_g, (pair, name, w)
+    else:
+        # the headline configuration's bounds (tests/test_headline_config_gpu.py): both bf16 runs against each other at the
+        # kernels-on / kernels-off bounds, against the host's float32 at the bf16-vs-float32 bounds; per-parameter gradients
+        # are bf16 sums of ~3 k rows - bounded by what the PADDED run shows against the host (x 1.5 + 2e-3)
+        for k in keys:
+            assert rel["packed_vs_padded"][k] <= (2.2e-3 if k == "grad_norm" else 2.5e-4), (k, rel)
+            assert rel["packed_vs_host"][k] <= (7e-3 if k == "grad_norm" else 4e-4), (k, rel)
+        assert gw["packed_vs_host"][0] <= 1.5 * gw["padded_vs_host"][0] + 2e-3, gw

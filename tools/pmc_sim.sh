@@ -4,9 +4,9 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_sim
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python tools/kernel_bench.py --only sim --quick > $OUT/trace.log 2>&1 || true
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $OUT/mfma -- python tools/kernel_bench.py --only sim --quick > $OUT/mfma.log 2>&1 || true
-rocprofv3 --pmc MfmaUtil --output-format csv -d $OUT/util -- python tools/kernel_bench.py --only sim --quick > $OUT/util.log 2>&1 || true
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python tools/kernel_bench.py --only sim --sizes ${SIM_SIZES:-4096,16384} > $OUT/trace.log 2>&1 || true
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $OUT/mfma -- python tools/kernel_bench.py --only sim --sizes ${SIM_SIZES:-4096,16384} > $OUT/mfma.log 2>&1 || true
+rocprofv3 --pmc MfmaUtil --output-format csv -d $OUT/util -- python tools/kernel_bench.py --only sim --sizes ${SIM_SIZES:-4096,16384} > $OUT/util.log 2>&1 || true
 python - <<'PY'
 import csv, glob, re
 from collections import defaultdict
