@@ -968,6 +968,13 @@ def main_retriever_only(args):
             "passage_attention_mask": (torch.arange(Tp).unsqueeze(0) < pl).long()}.items()}
 
     batches = [batch(200 + 17 * comm.rank + i) for i in range(4)]
+    if args.data_path == "packed":       # the same rows, the encoder run on the live tokens only (dalm_amd/packed.py)
+        from dalm_amd.packed import RETRIEVER_GROUPS, add_pack_plans
+
+        batches = [add_pack_plans(b, RETRIEVER_GROUPS) for b in batches]
+        args.warmup = max(args.warmup, 4)
+    rows_per_step = sum(float(b["query_pack_rows"].numel() + b["passage_pack_rows"].numel()) if "query_pack_rows" in b
+                        else float(b["query_input_ids"].numel() + b["passage_input_ids"].numel()) for b in batches) / 4
     for i in range(max(args.warmup, 1)):
         step(batches[i % 4])
     torch.cuda.synchronize()
@@ -988,7 +995,12 @@ def main_retriever_only(args):
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload} retriever-only: {'bge-small-en' if small else 'bge-large-en'} architecture (random init), "
-                                   f"LoRA r=8 q/k/v, per-GPU batch {B}, Tq50/Tp128, logit_scale 100, Adam, {args.dtype}",
+                                   f"LoRA r=8 q/k/v, per-GPU batch {B}, Tq50/Tp128, logit_scale 100, Adam, {args.dtype}"
+                                   + ("; DATA PATH: packed - the same rows, the encoder runs on the un-padded live tokens "
+                                      "(dalm_amd/packed.py; same loss and gradients)" if args.data_path == "packed" else ""),
+                       "tower_rows_per_step": {"encoder": rows_per_step, "padded": B * (Tq + Tp)},
+                       "step_model_tflops": step_model_tflops(model, 0.0, rows_per_step),
+                       "step_frac_of_bf16_mfma_peak": step_model_tflops(model, 0.0, rows_per_step) / (elapsed / args.steps) / 2500.0,
                        "global_batch": args.gpus * B,
                        "parallelism": f"dp{args.gpus} + sharded in-batch negatives", "final_loss": float(loss),
                        "launch": "hipGraph replay" if (use_graph and getattr(step, "graph", None) is not None) else "eager"}}),

@@ -48,12 +48,13 @@ FLAGS = [
     ("use_peft", dict(action="store_true", help="LoRA on the retriever")),
     ("use_bnb", dict(action="store_true", help="nf4 storage of the frozen base weights (HIP kernels; needs the GPU)")),
     ("is_autoregressive", dict(action="store_true", help="Retriever is an autoregressive LM")),
-    ("mixed_precision", dict(type=_S, default="bf16", choices=["no", "bf16"], help="[ext] autocast dtype")),
+    ("mixed_precision", dict(type=_S, default=None, choices=["no", "bf16"], help="[ext] autocast dtype; default: $ACCELERATE_MIXED_PRECISION, else 'no' (the reference's Accelerator() default); 'bf16' is the fast setting")),
     ("no_hip_graph", dict(action="store_true", help="[ext] launch every step eagerly instead of replaying a hipGraph")),
     ("token_cache_dir", dict(type=_S, default=None, help="[ext] keep the tokenised dataset as int32 shards here; reused when unchanged")),
     ("length_bucketing", dict(action="store_true", help="[ext] batch rows of similar passage length together")),
     ("trim_padding", dict(action="store_true", help="[ext] drop all-padding columns per batch (loss-preserving)")),
     ("async_checkpoint", dict(action="store_true", help="[ext] write optimizer/scheduler state from a background thread")),
+    ("pack_tokens", dict(action="store_true", help="[ext] run the encoder on the live tokens only (un-padded rows, per-sequence attention, original positions): same loss and gradients")),
 ]
 
 
@@ -90,17 +91,19 @@ def train_retriever(
     use_bnb: bool = True,
     is_autoregressive: bool = False,
     *,
-    mixed_precision: str = "bf16",
+    mixed_precision: Optional[str] = None,
     no_hip_graph: bool = False,
     token_cache_dir: Optional[str] = None,
     length_bucketing: bool = False,
     trim_padding: bool = False,
     async_checkpoint: bool = False,
+    pack_tokens: bool = False,
     model: Optional[AutoModelForSentenceEmbedding] = None,
     on_step=None,
 ) -> None:
     config = {k: v for k, v in dict(locals()).items() if v is None or isinstance(v, (float, int, str))}
     comm, device = init_distributed()
+    mixed_precision = common.resolve_mixed_precision(mixed_precision)
     gradient_accumulation_steps = common.effective_grad_accum(gradient_accumulation_steps)
     if device.type != "cuda":
         raise RuntimeError("train_retriever needs an MI355X: the loss path has no CPU implementation in this package")
@@ -143,9 +146,15 @@ def train_retriever(
         model.print_trainable_parameters()
     trim = dict(groups=[("query_input_ids", "query_attention_mask"), ("passage_input_ids", "passage_attention_mask")]) \
         if trim_padding else None
+    pack = None
+    if pack_tokens and not is_autoregressive:
+        from ... import packed as packed_mod
+
+        pack = dict(groups=packed_mod.RETRIEVER_GROUPS, multiple={"query": 256, "passage": 512})
     batches = common.ShardedBatches(processed, per_device_train_batch_size, comm.rank, comm.world_size,
                                     seed if seed is not None else 0, columns,
-                                    bucket_by="passage_attention_mask" if length_bucketing else None, trim=trim)
+                                    bucket_by="passage_attention_mask" if length_bucketing else None, trim=trim,
+                                    pack=pack)
     params = [p for p in model.parameters() if p.requires_grad]
     # one GPU: the whole step is captured once and replayed as a hipGraph (capturable Adam + tensor lr);
     # W > 1 launches eagerly (RCCL collectives stay outside graphs for now)
@@ -181,7 +190,7 @@ def train_retriever(
                             autocast_dtype=torch.bfloat16 if mixed_precision == "bf16" else None,
                             grad_accum=gradient_accumulation_steps)
     if use_graph:
-        step_fn = GraphedStep(step_fn, warmup=0, eager_steps=2)
+        step_fn = GraphedStep(step_fn, warmup=0, eager_steps=2, max_graphs=32 if pack else 8)
     meter = common.Throughput()
     saver = common.AsyncSaver() if async_checkpoint else None
 

@@ -294,26 +294,35 @@ class RetrieverStep(_StepBase):
         self.tower_stream = torch.cuda.Stream() if (overlap_towers and torch.cuda.is_available()) else None
         self.autocast_cache = self.tower_stream is None   # one model on two streams: no shared cast cache
 
-    def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+    def _embed(self, batch, side: str):
+        """One encoder call; on the PACKED rows when the batch carries their list (`{side}_pack_rows` / `_pack_cu`)."""
         m = self.model
+        ids, mask = batch[f"{side}_input_ids"], batch[f"{side}_attention_mask"]
+        rows = batch.get(f"{side}_pack_rows")
+        if rows is not None and not getattr(m, "is_autoregressive", False) and _packed.attention_is_packable(m.model):
+            h = _packed.retrieval_hidden(m.model, ids, mask, rows, batch[f"{side}_pack_cu"])
+            return pool_l2norm(h, mask, m.normalize)
+        return m(ids, mask)
+
+    def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         _advance_dropout(batch)
         with self._autocast():
             if self.tower_stream is not None:
                 cur = torch.cuda.current_stream()
                 self.tower_stream.wait_stream(cur)
                 with torch.cuda.stream(self.tower_stream):
-                    q_emb = m(batch["query_input_ids"], batch["query_attention_mask"])
+                    q_emb = self._embed(batch, "query")
                     q_gather = GatherHandle(q_emb.float(), self.comm, self.side_stream)
-                p_emb = m(batch["passage_input_ids"], batch["passage_attention_mask"])
+                p_emb = self._embed(batch, "passage")
                 p_gather = GatherHandle(p_emb.float(), self.comm, self.side_stream)
                 cur.wait_stream(self.tower_stream)
                 for t in (q_emb, q_gather.result):
                     if t is not None and t.is_cuda:
                         t.record_stream(cur)
             else:
-                p_emb = m(batch["passage_input_ids"], batch["passage_attention_mask"])
+                p_emb = self._embed(batch, "passage")
                 p_gather = GatherHandle(p_emb.float(), self.comm, self.side_stream)
-                q_emb = m(batch["query_input_ids"], batch["query_attention_mask"])
+                q_emb = self._embed(batch, "query")
                 q_gather = GatherHandle(q_emb.float(), self.comm, self.side_stream)
         loss = contrastive_loss(q_emb, p_emb, self.logit_scale, comm=self.comm, ops=self.ops, q_gather=q_gather,
                                 p_gather=p_gather)

@@ -331,7 +331,7 @@ def test_packed_step_equals_padded_step_and_oracle_at_real_width(dev, precision)
         torch.set_num_threads(old_threads)
     named_cpu = {("retriever_model." + n): p for n, p in retriever.named_parameters() if p.requires_grad}
     named_cpu.update({("generator_model." + n): p for n, p in generator.named_parameters() if p.requires_grad})
-    host = {"loss": float(out["loss"]), "contrastive": float(out["contrastive"]), "generator": float(out["generator"]),
+    host = {"loss": float(out["loss"].detach()), "contrastive": float(out["contrastive"].detach()), "generator": float(out["generator"].detach()),
             "grad_norm": RW.grad_norm(list(named_cpu.values()))}
     g_host = {n: p.grad.detach().float() for n, p in named_cpu.items()}
     assert set(g_host) == set(g_pad) == set(g_pack)
