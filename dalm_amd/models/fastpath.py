@@ -231,17 +231,16 @@ def _split_heads_sliced(self, fused_qkv: torch.Tensor):
     b, t, _ = fused_qkv.shape
     x = fused_qkv.view(b, t, self.num_heads + 2, self.head_dim)
     n = self.num_heads
-    if getattr(self, "_dalm_expand_kv", False):
-        # one shared key / value head BROADCAST to the query heads (views; FalconAttention.forward's reshape materialises them):
-        # scaled_dot_product_attention then sees equal head counts and takes its fused kernel.  With [B, 1, T, hd] keys it
-        # falls back to the unfused "math" path - f32 scores, softmax, masks: ~1.5 ms per layer at cfg5, 48 ms of a 230 ms
-        # step (profiles/r05cfg5_step_by_stream_before.txt)
-        return x[..., :n, :], x[..., n:n + 1, :].expand(b, t, n, self.head_dim), x[..., n + 1:, :].expand(b, t, n, self.head_dim)
     return x[..., :n, :], x[..., n:n + 1, :], x[..., n + 1:, :]
 
 
 def use_capturable_falcon_heads(model: torch.nn.Module) -> int:
-    """Patch FalconAttention modules of the 7B flavour (multi_query, old decoder architecture); returns the count."""
+    """Patch FalconAttention modules of the 7B flavour (multi_query, old decoder architecture); returns the count.
+
+    The module's `num_kv_heads` is NOT touched (round 5 set it to `num_heads` so that SDPA saw equal head counts,
+    which also made every reader outside the training call - the KV cache of eval / generate, export, sharding - see 71 key /
+    value heads).  The broadcast of the shared key / value head happens inside the patched TRAINING call only
+    (`_falcon_attention_forward`, `layer_past is None`); `_dalm_expand_kv` merely says that call may do it."""
     n = 0
     for mod in model.modules():
         if type(mod).__name__ != "FalconAttention":
@@ -249,36 +248,13 @@ def use_capturable_falcon_heads(model: torch.nn.Module) -> int:
         if getattr(mod, "new_decoder_architecture", False) or not getattr(mod, "multi_query", False):
             continue
         mod._split_heads = types.MethodType(_split_heads_sliced, mod)
-        # multi-query + SDPA: hand the attention equal head counts (see _split_heads_sliced).  forward() reshapes the key / value
-        # to `self.num_kv_heads` heads - the attribute follows.  DALM_FALCON_EXPAND_KV=0 keeps the [B, 1, T, hd] form.
-        if (os.environ.get("DALM_FALCON_EXPAND_KV", "1") != "0" and getattr(mod, "num_kv_heads", None) == 1
-                and getattr(getattr(mod, "config", None), "_attn_implementation", None) == "sdpa"
-                and _falcon_forward_reshapes_by_num_kv_heads(type(mod))):
-            mod._dalm_expand_kv = True
-            mod.num_kv_heads = mod.num_heads
+        # multi-query + SDPA with [B, 1, T, hd] keys falls back to torch's unfused "math" path - f32 scores, softmax, masks:
+        # ~1.5 ms per layer at cfg5, 48 ms of a 230 ms step (profiles/r05cfg5_step_by_stream_before.txt).
+        # DALM_FALCON_EXPAND_KV=0 keeps the [B, 1, T, hd] form.
+        mod._dalm_expand_kv = (os.environ.get("DALM_FALCON_EXPAND_KV", "1") != "0" and getattr(mod, "num_kv_heads", None) == 1
+                               and getattr(getattr(mod, "config", None), "_attn_implementation", None) == "sdpa")
         n += 1
     return n
-
-
-def _falcon_forward_reshapes_by_num_kv_heads(cls) -> bool:
-    """Run-time guard: the expansion relies on FalconAttention.forward reshaping key / value by `self.num_kv_heads` and on nothing
-    else reading that attribute in the forward (checked on the source of the installed transformers, once per class)."""
-    key = ("falcon-kv", cls)
-    if key not in _checked:
-        try:
-            import inspect
-
-            src = inspect.getsource(cls.forward)
-            _checked[key] = (src.count("num_kv_heads") == 4 and "self._split_heads(fused_qkv)" in src
-                             and "num_kv_heads = self.num_heads if self.new_decoder_architecture else self.num_kv_heads" in src
-                             and "key_layer.transpose(1, 2).reshape(batch_size, num_kv_heads" in src
-                             and "value_layer.transpose(1, 2).reshape(batch_size, num_kv_heads" in src)
-        except Exception:
-            _checked[key] = False
-        if not _checked[key]:
-            _warn_once("falcon-kv", "FalconAttention.forward does not handle key / value heads the way this patch expects: "
-                       "the multi-query attention keeps transformers' broadcast form")
-    return _checked[key]
 
 
 # ---------------------------------------------------------------------------
@@ -424,11 +400,32 @@ def _falcon_attention_forward(self, hidden_states, alibi, attention_mask, positi
     num_kv_heads = self.num_heads if self.new_decoder_architecture else self.num_kv_heads
     query_layer, key_layer, value_layer = self._split_heads(fused_qkv)
     batch_size, query_length, _, _ = query_layer.shape
+    if getattr(self, "_dalm_expand_kv", False) and num_kv_heads == 1 and key_layer.shape[2] == 1:
+        # THIS call only (training, no KV cache): the one shared key / value head broadcast to the query heads (views; the
+        # reshape below materialises them) - equal head counts for the kernels and for torch's fused SDPA
+        key_layer = key_layer.expand(batch_size, query_length, self.num_heads, self.head_dim)
+        value_layer = value_layer.expand(batch_size, query_length, self.num_heads, self.head_dim)
+        num_kv_heads = self.num_heads
     query_layer = query_layer.transpose(1, 2).reshape(batch_size, self.num_heads, query_length, self.head_dim)
     key_layer = key_layer.transpose(1, 2).reshape(batch_size, num_kv_heads, query_length, self.head_dim)
     value_layer = value_layer.transpose(1, 2).reshape(batch_size, num_kv_heads, query_length, self.head_dim)
     cos, sin = position_embeddings
     is_causal = bool(self.is_causal and attention_mask is None and query_length > 1)
+    seqs = attention.packed_of(attention_mask)
+    if seqs is not None:
+        # packed (un-padded) call (dalm_amd/packed.py): [1, H, n, hd], sequences from the descriptor
+        if (attention.packed_supported(query_layer, key_layer, value_layer) and attention.rope_fusable(query_layer, key_layer, cos, sin)
+                and os.environ.get("DALM_ROPE_KERNEL", "1") != "0" and os.environ.get("DALM_FAST_ROPE", "1") != "0"):
+            attn_output = attention.rope_sdpa(query_layer, key_layer, value_layer, cos, sin, attention_mask,
+                                              float(self.head_dim) ** -0.5, False)
+            attn_output = attn_output.permute(0, 2, 1, 3)
+        else:
+            rope = importlib.import_module(type(self).__module__).apply_rotary_pos_emb
+            query_layer, key_layer = rope(query_layer, key_layer, cos, sin)
+            attn_output, _ = attention._packed_attention(self, query_layer, key_layer, value_layer, attention_mask, seqs, 0.0,
+                                                         float(self.head_dim) ** -0.5)            # [1, n, H, hd]
+        attn_output = attn_output.reshape(batch_size, query_length, self.num_heads * self.head_dim)
+        return self.dense(attn_output), None
     if (attention.supported(query_layer, key_layer, value_layer, attention_mask, 0.0, is_causal, {})
             and attention.rope_fusable(query_layer, key_layer, cos, sin) and os.environ.get("DALM_ROPE_KERNEL", "1") != "0"
             and os.environ.get("DALM_FAST_ROPE", "1") != "0"):

@@ -150,7 +150,14 @@ def attention_is_packable(model) -> bool:
     from .models import attention
 
     cfg = getattr(model, "config", None)
-    return cfg is not None and getattr(cfg, "_attn_implementation", None) == attention.NAME
+    if cfg is None:
+        return False
+    if getattr(cfg, "_attn_implementation", None) == attention.NAME:
+        return True
+    # Falcon (7B flavour) stays on "sdpa": its attention modules are patched one by one (fastpath.use_falcon_attention_kernels),
+    # and the patched forward is the one that reads the descriptor
+    att = [m for m in model.modules() if type(m).__name__ == "FalconAttention"]
+    return bool(att) and all(getattr(getattr(m.forward, "__func__", None), "__name__", "") == "_falcon_attention_forward" for m in att)
 
 
 def generator_hidden(generator_model, input_ids, attention_mask, rows, cu):

@@ -89,7 +89,7 @@ def test_falcon_shared_kv_head_is_broadcast_for_sdpa_and_keeps_the_values():
     from dalm_amd.models import fastpath
 
     torch.manual_seed(0)
-    cfg = FalconConfig(num_hidden_layers=2, hidden_size=128, num_attention_heads=4, vocab_size=100)
+    cfg = FalconConfig(num_hidden_layers=2, hidden_size=256, num_attention_heads=4, vocab_size=100)   # head width 64
     ref = FalconForCausalLM(cfg).train()
     new = FalconForCausalLM(cfg).train()
     new.load_state_dict(ref.state_dict())
@@ -97,11 +97,34 @@ def test_falcon_shared_kv_head_is_broadcast_for_sdpa_and_keeps_the_values():
     am = torch.ones(2, 9, dtype=torch.long)
     am[0, :3] = 0                                                   # left padding
     assert fastpath.use_capturable_falcon_heads(new) == 2
+    assert fastpath.use_falcon_attention_kernels(new) == 2          # the patched training call is where the broadcast happens
     att = new.transformer.h[0].self_attention
-    assert att._dalm_expand_kv and att.num_kv_heads == att.num_heads == 4
+    # the module's own head count is untouched - readers outside the training call (KV cache, export) see 1
+    assert att._dalm_expand_kv and att.num_kv_heads == 1 and att.num_heads == 4
+    seen = []
+    orig_sdpa = torch.nn.functional.scaled_dot_product_attention
+
+    def spy(q, k, v, *a, **kw):
+        seen.append((tuple(q.shape), tuple(k.shape)))
+        return orig_sdpa(q, k, v, *a, **kw)
+
+    torch.nn.functional.scaled_dot_product_attention = spy
+    try:
+        new(input_ids=x, attention_mask=am, use_cache=False)         # the trainers' call (models/rag_e2e_base_model.py forward)
+    finally:
+        torch.nn.functional.scaled_dot_product_attention = orig_sdpa
+    assert seen and all(qs[1] == ks[1] == 4 for qs, ks in seen)      # equal head counts in the training call
+    new.eval()
+    with torch.no_grad():
+        cache = new(input_ids=x, attention_mask=am, use_cache=True).past_key_values
+        want_cache = ref.eval()(input_ids=x, attention_mask=am, use_cache=True).past_key_values
+    k_new, k_ref = cache.layers[0].keys, want_cache.layers[0].keys
+    assert k_new.shape == k_ref.shape and k_new.shape[1] == 1        # the KV cache holds ONE head, as transformers' own
+    torch.testing.assert_close(k_new, k_ref, rtol=1e-5, atol=1e-5)
+    ref.train(); new.train()
     outs = []
     for m in (ref, new):
-        logits = m(input_ids=x, attention_mask=am).logits
+        logits = m(input_ids=x, attention_mask=am, use_cache=False).logits
         logits.square().sum().backward()
         outs.append((logits.detach(), m.transformer.h[0].self_attention.query_key_value.weight.grad.clone()))
     torch.testing.assert_close(outs[1][0], outs[0][0], rtol=1e-5, atol=1e-5)

@@ -181,3 +181,30 @@ def test_mixed_precision_default_follows_accelerate(monkeypatch):
     assert inspect.signature(train_retriever).parameters["mixed_precision"].default is None
     a = parse_args(["--dataset_path", "x.csv", "--retriever_name_or_path", "r", "--generator_name_or_path", "g"])
     assert a.mixed_precision is None and a.pack_tokens is False
+
+
+def test_packed_falcon_equals_padded_on_live_rows():
+    """Falcon-7B flavour (multi-query, parallel attention, rotary): stays on "sdpa", its patched attention forward reads the
+    descriptor (fastpath._falcon_attention_forward)."""
+    from transformers import FalconConfig, FalconForCausalLM
+
+    from dalm_amd.models import fastpath
+
+    torch.manual_seed(0)
+    cfg = FalconConfig(num_hidden_layers=2, hidden_size=256, num_attention_heads=4, vocab_size=100)
+    ref = FalconForCausalLM(cfg).eval()
+    new = FalconForCausalLM(cfg).eval()
+    new.load_state_dict(ref.state_dict())
+    assert not packed.attention_is_packable(new)
+    fastpath.use_capturable_falcon_heads(new)
+    assert fastpath.use_falcon_attention_kernels(new) == 2 and packed.attention_is_packable(new)
+    B, T = 4, 16
+    mask = _masks(B, T, True, 9)
+    ids = torch.randint(3, 100, (B, T), generator=torch.Generator().manual_seed(10))
+    rows, cu = packed.pack_plan(mask, shifted=True, multiple=8)
+    hp = packed.generator_hidden(new, ids, mask, rows, cu)
+    want = ref.base_model(input_ids=ids, attention_mask=mask, use_cache=False)[0].reshape(B * T, -1)
+    _y, w = packed.packed_labels(ids, mask, rows)
+    sel = w != 0
+    assert torch.allclose(hp[sel], want.index_select(0, rows.clamp_min(0))[sel], atol=2e-5, rtol=1e-4)
+    assert torch.isfinite(hp).all()

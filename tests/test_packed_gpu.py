@@ -290,15 +290,15 @@ def _special_batch(batch):
     return b
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_packed_step_equals_padded_step_and_oracle_at_real_width(dev, precision):
+@pytest.mark.parametrize("case,precision", [("cfg3", "fp32"), ("cfg3", "bf16"), ("cfg5", "bf16")])
+def test_packed_step_equals_padded_step_and_oracle_at_real_width(dev, case, precision):
     import dalm_oracle as O
     import realwidth as RW
     from test_step_realwidth_gpu import _build, _randomise_lora_b
 
     from dalm_amd.models import lora
 
-    retriever, generator = _build("cfg3")
+    retriever, generator = _build(case)
     if precision == "bf16":
         with torch.no_grad():
             for mod in (retriever, generator):
@@ -308,7 +308,7 @@ def test_packed_step_equals_padded_step_and_oracle_at_real_width(dev, precision)
     _randomise_lora_b(retriever, 11)
     lora.inject_lora(generator, ["q_proj", "v_proj"], lora_dropout=0.0)
     _randomise_lora_b(generator, 12)
-    batch = _special_batch(RW.synthetic_batch("cfg3"))
+    batch = _special_batch(RW.synthetic_batch(case))
 
     padded, g_pad = _step(retriever, generator, batch, "padded", precision, dev)
     packd, g_pack = _step(retriever, generator, batch, "packed", precision, dev)
@@ -356,7 +356,7 @@ def test_packed_step_equals_padded_step_and_oracle_at_real_width(dev, precision)
            "packed_vs_host": {k: abs(packd[k] - host[k]) / max(abs(host[k]), 1e-30) for k in keys},
            "padded_vs_host": {k: abs(padded[k] - host[k]) / max(abs(host[k]), 1e-30) for k in keys}}
     gw = {"packed_vs_padded": worst(g_pack, g_pad), "packed_vs_host": worst(g_pack, g_host), "padded_vs_host": worst(g_pad, g_host)}
-    _record(f"cfg3/{precision}", {"padded": padded, "packed": packd, "host_fp32_oracle": host, "rel": rel,
+    _record(f"{case}/{precision}", {"padded": padded, "packed": packd, "host_fp32_oracle": host, "rel": rel,
                                   "worst_parameter_gradient": {k: {"rel": v[0], "name": v[1]} for k, v in gw.items()}})
     if precision == "fp32":
         tol_s, tol_g = 1e-4, 1e-4
