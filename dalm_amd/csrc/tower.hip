@@ -131,6 +131,68 @@ __global__ __launch_bounds__(256) void rope_qk_kernel(const RopeParams p) {
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + expf(-x)); }
 
+// [R, C] views with a row stride (gate and up as the two halves of ONE [R, 2C] GEMM output, models/frozen_linear.py): element
+// e of the logical [R, C] matrix lives at (e / C) * ld + e % C; C is a multiple of VEC, so a vector never crosses a row
+struct SwigluLd { int64_t C, g, u, a, dg, du; };
+__device__ __forceinline__ int64_t ld_off(int64_t e, int64_t C, int64_t ld) { return (e / C) * ld + e % C; }
+
+template <typename T, int STEPS>
+__global__ __launch_bounds__(256) void swiglu_fwd_2d_kernel(const T* __restrict__ g, const T* __restrict__ u, T* __restrict__ a,
+                                                            int64_t n, SwigluLd ld) {
+  constexpr int VEC = EV<T>::VEC;
+  const int64_t base = (static_cast<int64_t>(blockIdx.x) * STEPS * 256 + threadIdx.x) * VEC;
+  float gv[STEPS][VEC], uv[STEPS][VEC];
+#pragma unroll
+  for (int k = 0; k < STEPS; ++k) {
+    const int64_t e0 = base + static_cast<int64_t>(k) * 256 * VEC;
+    if (e0 < n) { EV<T>::load(g + ld_off(e0, ld.C, ld.g), gv[k]); EV<T>::load(u + ld_off(e0, ld.C, ld.u), uv[k]); }
+  }
+#pragma unroll
+  for (int k = 0; k < STEPS; ++k) {
+    const int64_t e0 = base + static_cast<int64_t>(k) * 256 * VEC;
+    if (e0 >= n) continue;
+    float o[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o[e] = EV<T>::rb(__fmul_rn(EV<T>::rb(silu_f32(gv[k][e])), uv[k][e]));
+    EV<T>::store(a + ld_off(e0, ld.C, ld.a), o);
+  }
+}
+
+template <typename T, int STEPS>
+__global__ __launch_bounds__(256) void swiglu_bwd_2d_kernel(const T* __restrict__ da, const T* __restrict__ g,
+                                                            const T* __restrict__ u, T* __restrict__ dg, T* __restrict__ du,
+                                                            int64_t n, SwigluLd ld) {
+  constexpr int VEC = EV<T>::VEC;
+  const int64_t base = (static_cast<int64_t>(blockIdx.x) * STEPS * 256 + threadIdx.x) * VEC;
+  float av[STEPS][VEC], gv[STEPS][VEC], uv[STEPS][VEC];
+#pragma unroll
+  for (int k = 0; k < STEPS; ++k) {
+    const int64_t e0 = base + static_cast<int64_t>(k) * 256 * VEC;
+    if (e0 < n) {
+      EV<T>::load(da + ld_off(e0, ld.C, ld.a), av[k]);
+      EV<T>::load(g + ld_off(e0, ld.C, ld.g), gv[k]);
+      EV<T>::load(u + ld_off(e0, ld.C, ld.u), uv[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < STEPS; ++k) {
+    const int64_t e0 = base + static_cast<int64_t>(k) * 256 * VEC;
+    if (e0 >= n) continue;
+    float og[VEC], ou[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {                                  // the contiguous kernel's arithmetic, statement for statement
+      const float x = gv[k][e];
+      const float s = EV<T>::rb(silu_f32(x));
+      const float ds = EV<T>::rb(__fmul_rn(av[k][e], uv[k][e]));
+      ou[e] = EV<T>::rb(__fmul_rn(av[k][e], s));
+      const float sig = 1.0f / (1.0f + expf(-x));
+      og[e] = EV<T>::rb(ds * sig * (1.0f + x * (1.0f - sig)));
+    }
+    EV<T>::store(dg + ld_off(e0, ld.C, ld.dg), og);
+    EV<T>::store(du + ld_off(e0, ld.C, ld.du), ou);
+  }
+}
+
 template <typename T, int STEPS>
 __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const T* __restrict__ g, const T* __restrict__ u, T* __restrict__ a,
                                                          int64_t n) {
@@ -454,6 +516,55 @@ extern "C" int dalm_swiglu_bwd(const void* d_act, const void* gate, const void* 
     hipLaunchKernelGGL((swiglu_bwd_kernel<bf16_t, kSwigluSteps>), grid, dim3(256), 0, as_stream(stream),
                        static_cast<const bf16_t*>(d_act), static_cast<const bf16_t*>(gate), static_cast<const bf16_t*>(up),
                        static_cast<bf16_t*>(d_gate), static_cast<bf16_t*>(d_up), n);
+  return check_launch(__func__);
+}
+
+extern "C" int dalm_swiglu_fwd_2d(const void* gate, const void* up, void* act, int dtype, int64_t R, int64_t C, int64_t ld_gate,
+                                  int64_t ld_up, int64_t ld_act, dalm_stream_t stream) {
+  DALM_REQUIRE(R >= 0 && C >= 0, DALM_E_SHAPE, "R, C must be >= 0");
+  if (R == 0 || C == 0) return 0;
+  DALM_REQUIRE(gate && up && act, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(dtype == DALM_F32 || dtype == DALM_BF16, DALM_E_DTYPE, "dtype must be DALM_F32 or DALM_BF16");
+  const int vec = dtype == DALM_F32 ? 4 : 8;
+  DALM_REQUIRE(al16(gate) && al16(up) && al16(act) && C % vec == 0 && ld_gate % vec == 0 && ld_up % vec == 0 && ld_act % vec == 0
+                   && ld_gate >= C && ld_up >= C && ld_act >= C,
+               DALM_E_ALIGN, "16-byte aligned pointers, C and the row strides multiples of 16 bytes, strides >= C");
+  const int64_t n = R * C, blocks = swiglu_blocks(n, vec);
+  DALM_REQUIRE(blocks <= 0x7fffffffLL, DALM_E_SHAPE, "tensor too large for one launch");
+  const dim3 grid(static_cast<unsigned>(blocks));
+  const SwigluLd ld = {C, ld_gate, ld_up, ld_act, 0, 0};
+  if (dtype == DALM_F32)
+    hipLaunchKernelGGL((swiglu_fwd_2d_kernel<float, kSwigluSteps>), grid, dim3(256), 0, as_stream(stream),
+                       static_cast<const float*>(gate), static_cast<const float*>(up), static_cast<float*>(act), n, ld);
+  else
+    hipLaunchKernelGGL((swiglu_fwd_2d_kernel<bf16_t, kSwigluSteps>), grid, dim3(256), 0, as_stream(stream),
+                       static_cast<const bf16_t*>(gate), static_cast<const bf16_t*>(up), static_cast<bf16_t*>(act), n, ld);
+  return check_launch(__func__);
+}
+
+extern "C" int dalm_swiglu_bwd_2d(const void* d_act, const void* gate, const void* up, void* d_gate, void* d_up, int dtype, int64_t R,
+                                  int64_t C, int64_t ld_dact, int64_t ld_gate, int64_t ld_up, int64_t ld_dgate, int64_t ld_dup,
+                                  dalm_stream_t stream) {
+  DALM_REQUIRE(R >= 0 && C >= 0, DALM_E_SHAPE, "R, C must be >= 0");
+  if (R == 0 || C == 0) return 0;
+  DALM_REQUIRE(d_act && gate && up && d_gate && d_up, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(dtype == DALM_F32 || dtype == DALM_BF16, DALM_E_DTYPE, "dtype must be DALM_F32 or DALM_BF16");
+  const int vec = dtype == DALM_F32 ? 4 : 8;
+  bool ok = al16(d_act) && al16(gate) && al16(up) && al16(d_gate) && al16(d_up) && C % vec == 0;
+  for (int64_t l : {ld_dact, ld_gate, ld_up, ld_dgate, ld_dup}) ok = ok && l % vec == 0 && l >= C;
+  DALM_REQUIRE(ok, DALM_E_ALIGN, "16-byte aligned pointers, C and the row strides multiples of 16 bytes, strides >= C");
+  const int64_t n = R * C, blocks = swiglu_blocks(n, vec);
+  DALM_REQUIRE(blocks <= 0x7fffffffLL, DALM_E_SHAPE, "tensor too large for one launch");
+  const dim3 grid(static_cast<unsigned>(blocks));
+  const SwigluLd ld = {C, ld_gate, ld_up, ld_dact, ld_dgate, ld_dup};
+  if (dtype == DALM_F32)
+    hipLaunchKernelGGL((swiglu_bwd_2d_kernel<float, kSwigluSteps>), grid, dim3(256), 0, as_stream(stream),
+                       static_cast<const float*>(d_act), static_cast<const float*>(gate), static_cast<const float*>(up),
+                       static_cast<float*>(d_gate), static_cast<float*>(d_up), n, ld);
+  else
+    hipLaunchKernelGGL((swiglu_bwd_2d_kernel<bf16_t, kSwigluSteps>), grid, dim3(256), 0, as_stream(stream),
+                       static_cast<const bf16_t*>(d_act), static_cast<const bf16_t*>(gate), static_cast<const bf16_t*>(up),
+                       static_cast<bf16_t*>(d_gate), static_cast<bf16_t*>(d_up), n, ld);
   return check_launch(__func__);
 }
 

@@ -90,6 +90,8 @@ SIGNATURES = {
     "dalm_rope_qk": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _int, _vp]),
     "dalm_swiglu_fwd": (_int, [_vp, _vp, _vp, _int, _i64, _vp]),
     "dalm_swiglu_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]),
+    "dalm_swiglu_fwd_2d": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _vp]),
+    "dalm_swiglu_bwd_2d": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
     "dalm_rms_norm_fwd": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _f32, _vp, _vp, _vp, _vp]),
     "dalm_rms_norm_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _i64, _i64, _vp, _vp]),
     "dalm_layer_norm_fwd": (_int, [_vp, _vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp, _vp]),

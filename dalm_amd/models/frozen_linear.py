@@ -93,7 +93,7 @@ class _FrozenPairFn(torch.autograd.Function):
         for g, w in zip((g0, g1), ctx.w):
             if g is None:
                 continue
-            g2 = g.reshape(-1, w.shape[0])
+            g2 = g.reshape(-1, w.shape[0])              # a view for the column halves of one [rows, 2 N] buffer (row stride 2 N)
             if g2.dtype != ctx.cdt:
                 g2 = g2.to(ctx.cdt)
             wt = dgrad_weight(w, ctx.cdt)
@@ -107,6 +107,69 @@ class _FrozenPairFn(torch.autograd.Function):
             return None, None, None
         dx = dx.view(ctx.xshape)
         return (dx if dx.dtype == ctx.xdtype else dx.to(ctx.xdtype)), None, None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# two frozen projections of one input as ONE forward GEMM: x [W0 | W1]^T
+# ---------------------------------------------------------------------------------------------------------------------
+_CAT = os.environ.get("DALM_CAT_GEMM", "1") != "0"
+
+
+def _cat_weights(m0: torch.nn.Linear, m1: torch.nn.Linear) -> Optional[torch.Tensor]:
+    """[W0; W1] as ONE contiguous [N0 + N1, K] tensor that the two modules' weights are VIEWS of (no second copy of the weights:
+    the parameters are re-pointed at the halves, state_dict keys and values unchanged).  Made on first use; re-made when a
+    parameter was replaced or moved (its storage is then no longer the cat's).  None when the pair cannot share (devices,
+    dtypes, trainable, not on a GPU) or DALM_CAT_GEMM=0.
+
+    Why: hipBLASLt runs the [rows, K] x [K, N] projections on 256 x 256 tiles; one GEMM over 2 N columns fills the last wave of
+    tiles better than two over N (measured, tools/gemm_concat_probe.py: gate | up forward 672 -> 621 us at 4608 rows,
+    493 -> 425 us at 2944 packed rows; q | k | v 408 -> 355 us at 4608 rows)."""
+    w0, w1 = m0.weight, m1.weight
+    if not _CAT or w0.requires_grad or w1.requires_grad or not w0.is_cuda or w0.device != w1.device or w0.dtype != w1.dtype \
+            or w0.dim() != 2 or w1.dim() != 2 or w0.shape[1] != w1.shape[1]:
+        return None
+    cat = getattr(m0, "_dalm_cat", None)
+    n0, el = w0.shape[0], w0.element_size()
+    if cat is not None and cat.dtype == w0.dtype and cat.shape[0] == n0 + w1.shape[0] and w0.data_ptr() == cat.data_ptr() \
+            and w1.data_ptr() == cat.data_ptr() + n0 * w0.shape[1] * el and w0.is_contiguous() and w1.is_contiguous():
+        return cat
+    if torch.cuda.is_current_stream_capturing():
+        return None                            # never re-point parameters inside a hipGraph capture
+    with torch.no_grad():
+        cat = torch.cat((w0.detach(), w1.detach()), dim=0)
+        w0.data = cat[:n0]
+        w1.data = cat[n0:]
+    for w in (w0, w1):                         # transposed dgrad copies made from the old storage are still VALUES-correct, but
+        if hasattr(w, "_dalm_wt"):             # keyed by pointer: drop them, they are rebuilt on the next backward
+            try:
+                del w._dalm_wt
+            except Exception:
+                pass
+    try:
+        m0._dalm_cat = cat
+    except Exception:
+        return None
+    return cat
+
+
+class _FrozenCatPairFn(torch.autograd.Function):
+    """(x W0^T, x W1^T) as the two column halves of ONE GEMM output x [W0; W1]^T; backward: the two accumulating dgrad GEMMs of
+    `_FrozenPairFn` (one GEMM over the 2 N-deep contraction measured slower at 4608 rows, tools/gemm_concat_probe.py), reading the
+    gradient halves in place when they arrive as the halves of one buffer (tower_ops._SwiGLU does that)."""
+
+    @staticmethod
+    def forward(ctx, x, cat, w0, w1):
+        y = F.linear(x, cat)
+        n0 = w0.shape[0]
+        ctx.w = (w0, w1)
+        ctx.cdt = y.dtype
+        ctx.xshape, ctx.xdtype = x.shape, x.dtype
+        ctx.set_materialize_grads(False)
+        return y[..., :n0], y[..., n0:]
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        return _FrozenPairFn.backward(ctx, g0, g1) + (None,)
 
 
 def _eligible(x: torch.Tensor, *mods) -> bool:
@@ -134,6 +197,9 @@ def pair_forward(x: torch.Tensor, m0: torch.nn.Linear, m1: torch.nn.Linear):
     """(m0(x), m1(x)); one autograd node with an accumulating backward when both are frozen and bias-free."""
     plain = (torch.nn.Linear, FrozenLinearT)
     if m0.bias is None and m1.bias is None and type(m0) in plain and type(m1) in plain and _eligible(x, m0, m1):
+        cat = _cat_weights(m0, m1)
+        if cat is not None:
+            return _FrozenCatPairFn.apply(x, cat, m0.weight, m1.weight)
         return _FrozenPairFn.apply(x, m0.weight, m1.weight)
     return m0(x), m1(x)
 

@@ -68,10 +68,34 @@ def rope_qk(q, k, cos, sin):
     return _RopeQK.apply(q, k, cos, sin)
 
 
+def _halves_of_one(gate: torch.Tensor, up: torch.Tensor) -> bool:
+    """gate and up are the two column halves of ONE contiguous [R, 2 C] buffer (the output of the concatenated gate | up GEMM,
+    frozen_linear.pair_forward)."""
+    if gate.dim() < 2 or gate.shape != up.shape or gate.stride() != up.stride() or gate.stride(-1) != 1:
+        return False
+    C = gate.shape[-1]
+    el = gate.element_size()
+    lead = 1
+    for d in range(gate.dim() - 2, -1, -1):            # rows must be laid out as one [R, 2 C] matrix
+        if gate.shape[d] != 1 and gate.stride(d) != 2 * C * lead:
+            return False
+        lead *= gate.shape[d]
+    return up.data_ptr() == gate.data_ptr() + C * el and C % (16 // el) == 0 and gate.data_ptr() % 16 == 0
+
+
 class _SwiGLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gate, up):
         hip.require_gpu(gate, up)
+        ctx.halves = _halves_of_one(gate, up)
+        if ctx.halves:                     # strided views of one [R, 2 C] GEMM output: read in place, no .contiguous() copies
+            C = gate.shape[-1]
+            R = gate.numel() // C
+            act = torch.empty(gate.shape, dtype=gate.dtype, device=gate.device)
+            hip.call("dalm_swiglu_fwd_2d", hip.ptr(gate), hip.ptr(up), hip.ptr(act), hip.dtype_code(gate), R, C, 2 * C, 2 * C, C,
+                     hip.stream())
+            ctx.save_for_backward(gate, up)
+            return act
         gate, up = gate.contiguous(), up.contiguous()
         act = torch.empty_like(gate)
         hip.call("dalm_swiglu_fwd", hip.ptr(gate), hip.ptr(up), hip.ptr(act), hip.dtype_code(gate), gate.numel(), hip.stream())
@@ -82,6 +106,14 @@ class _SwiGLU(torch.autograd.Function):
     def backward(ctx, d_act):
         gate, up = ctx.saved_tensors
         d_act = d_act.contiguous()
+        if ctx.halves:                     # d_gate | d_up as the halves of one [R, 2 C] buffer: the dgrad GEMMs read it in place
+            C = gate.shape[-1]
+            R = gate.numel() // C
+            both = torch.empty((*gate.shape[:-1], 2 * C), dtype=gate.dtype, device=gate.device)
+            dg, du = both[..., :C], both[..., C:]
+            hip.call("dalm_swiglu_bwd_2d", hip.ptr(d_act), hip.ptr(gate), hip.ptr(up), hip.ptr(dg), hip.ptr(du),
+                     hip.dtype_code(gate), R, C, C, 2 * C, 2 * C, 2 * C, 2 * C, hip.stream())
+            return dg, du
         dg, du = torch.empty_like(gate), torch.empty_like(up)
         hip.call("dalm_swiglu_bwd", hip.ptr(d_act), hip.ptr(gate), hip.ptr(up), hip.ptr(dg), hip.ptr(du),
                  hip.dtype_code(gate), gate.numel(), hip.stream())

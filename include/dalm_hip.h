@@ -427,6 +427,15 @@ int dalm_rope_qk(const void* q, const void* k, void* q_out, void* k_out, const v
 int dalm_swiglu_fwd(const void* gate, const void* up, void* act, int dtype, int64_t n, dalm_stream_t stream);
 int dalm_swiglu_bwd(const void* d_act, const void* gate, const void* up, void* d_gate, void* d_up, int dtype, int64_t n,
                     dalm_stream_t stream);
+/* The same two functions on [R, C] VIEWS with row strides (in elements; C and the strides multiples of 16 bytes): gate and up
+ * as the two halves of the ONE [R, 2 C] output of x [W_gate | W_up]^T (frozen projections that share their input run as one
+ * GEMM, dalm_amd/models/frozen_linear.py), d_gate / d_up written into the halves of one [R, 2 C] buffer.  Same arithmetic and
+ * rounding points as the contiguous forms. */
+int dalm_swiglu_fwd_2d(const void* gate, const void* up, void* act, int dtype, int64_t R, int64_t C, int64_t ld_gate,
+                       int64_t ld_up, int64_t ld_act, dalm_stream_t stream);
+int dalm_swiglu_bwd_2d(const void* d_act, const void* gate, const void* up, void* d_gate, void* d_up, int dtype, int64_t R,
+                       int64_t C, int64_t ld_dact, int64_t ld_gate, int64_t ld_up, int64_t ld_dgate, int64_t ld_dup,
+                       dalm_stream_t stream);
 /* RMSNorm of a decoder layer (modeling_llama.py LlamaRMSNorm: w * (x * rsqrt(mean(x^2) + eps)).to(dtype)), optionally with the
  * residual add in front of it, one wave per row, [R, D] row-major, D a multiple of 16 bytes, at most 8192 (bf16) / 4096 (f32):
  *   fwd: delta != NULL: h_out = x + delta (rounded to dtype) and the norm is taken of h_out; delta == NULL (then h_out == NULL

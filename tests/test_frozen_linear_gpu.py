@@ -79,3 +79,63 @@ def test_pair_node_accumulates_one_dx_and_trainable_layers_keep_autograd(dev):
     assert y0.grad_fn is not y1.grad_fn
     (y0.float().sum() + y1.float().sum()).backward()
     assert m1.weight.grad is not None
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f32-autocast"])
+def test_gate_up_as_one_gemm_equals_the_two_gemms(dev, mode):
+    """`pair_forward` on frozen projections: ONE forward GEMM over [W0; W1] (the weights become views of one tensor, values and
+    state_dict unchanged), SwiGLU reading / writing the halves in place (`dalm_swiglu_*_2d`): same values as the separate path."""
+    from dalm_amd.models import frozen_linear as FL
+    from dalm_amd.models import tower_ops
+
+    torch.manual_seed(2)
+    wdt = torch.bfloat16 if mode == "bf16" else torch.float32
+    K, N, R = 512, 1408, 300
+    m0 = torch.nn.Linear(K, N, bias=False).to(dev, wdt).requires_grad_(False)
+    m1 = torch.nn.Linear(K, N, bias=False).to(dev, wdt).requires_grad_(False)
+    sd0, sd1 = m0.weight.detach().clone(), m1.weight.detach().clone()
+    x = torch.randn(2, R // 2, K, device=dev, dtype=torch.bfloat16 if mode == "bf16" else torch.float32)
+    up = torch.randn(2, R // 2, N, device=dev)
+
+    def run(cat: bool):
+        old = FL._CAT
+        FL._CAT = cat
+        try:
+            xi = x.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode == "f32-autocast"):
+                g, u = FL.pair_forward(xi, m0, m1)
+                name = type(g.grad_fn).__name__
+                act = tower_ops.swiglu(g, u)
+            (act.float() * up).sum().backward()
+            return name, g.detach().clone(), u.detach().clone(), act.detach(), xi.grad
+        finally:
+            FL._CAT = old
+
+    sep = run(False)
+    cat = run(True)
+    assert "FrozenPairFn" in sep[0] and "FrozenCatPairFn" in cat[0]
+    # the weights are now the halves of one tensor - same values, same keys
+    assert torch.equal(m0.weight, sd0) and torch.equal(m1.weight, sd1)
+    assert m1.weight.data_ptr() == m0.weight.data_ptr() + N * K * m0.weight.element_size()
+    assert not m0.weight.requires_grad and m0.weight.is_contiguous() and m1.weight.is_contiguous()
+    assert _rel(cat[1], sep[1]) < 2e-3 and _rel(cat[2], sep[2]) < 2e-3          # another GEMM solution: summation order only
+    assert _rel(cat[3], sep[3]) < 4e-3 and _rel(cat[4], sep[4]) < 6e-3
+    # SwiGLU on the halves EQUALS SwiGLU on contiguous copies of the same values (same arithmetic, strided addressing)
+    g, u = cat[1], cat[2]
+    both = torch.cat((g, u), dim=-1)
+    gh, uh = both[..., :N].requires_grad_(True), both[..., N:].requires_grad_(True)
+    assert tower_ops._halves_of_one(gh, uh)
+    gc, uc = g.clone().requires_grad_(True), u.clone().requires_grad_(True)
+    d = torch.randn_like(g)
+    a_h = tower_ops.swiglu(gh, uh)
+    a_c = tower_ops.swiglu(gc, uc)
+    dg_h, du_h = torch.autograd.grad(a_h, (gh, uh), d)
+    dg_c, du_c = torch.autograd.grad(a_c, (gc, uc), d)
+    assert torch.equal(a_h, a_c) and torch.equal(dg_h, dg_c) and torch.equal(du_h, du_c)
+    assert du_h.data_ptr() == dg_h.data_ptr() + N * dg_h.element_size()          # one [R, 2N] gradient buffer
+    # a moved module: the cat is rebuilt, not used stale
+    m0.to(torch.device("cpu")); m0.to(dev)
+    xi = x.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode == "f32-autocast"):
+        g2, _ = FL.pair_forward(xi, m0, m1)
+    assert _rel(g2, sep[1]) < 2e-3 and m1.weight.data_ptr() == m0.weight.data_ptr() + N * K * m0.weight.element_size()
