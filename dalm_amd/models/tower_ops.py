@@ -106,13 +106,16 @@ class _SwiGLU(torch.autograd.Function):
     def backward(ctx, d_act):
         gate, up = ctx.saved_tensors
         d_act = d_act.contiguous()
-        if ctx.halves:                     # d_gate | d_up as the halves of one [R, 2 C] buffer: the dgrad GEMMs read it in place
+        if ctx.halves:
+            # gate / up read in place; d_gate and d_up leave as two CONTIGUOUS tensors: the two dgrad GEMMs then are the shapes
+            # (and leading dimensions) the tuned solution table holds - gradient halves of one [R, 2 C] buffer (lda = 2 C) cost
+            # the padded cfg3 step 20 ms (148 vs 128 ms/step, library-default solutions for the strided operand)
             C = gate.shape[-1]
             R = gate.numel() // C
-            both = torch.empty((*gate.shape[:-1], 2 * C), dtype=gate.dtype, device=gate.device)
-            dg, du = both[..., :C], both[..., C:]
+            dg = torch.empty(gate.shape, dtype=gate.dtype, device=gate.device)
+            du = torch.empty(gate.shape, dtype=gate.dtype, device=gate.device)
             hip.call("dalm_swiglu_bwd_2d", hip.ptr(d_act), hip.ptr(gate), hip.ptr(up), hip.ptr(dg), hip.ptr(du),
-                     hip.dtype_code(gate), R, C, C, 2 * C, 2 * C, 2 * C, 2 * C, hip.stream())
+                     hip.dtype_code(gate), R, C, C, 2 * C, 2 * C, C, C, hip.stream())
             return dg, du
         dg, du = torch.empty_like(gate), torch.empty_like(up)
         hip.call("dalm_swiglu_bwd", hip.ptr(d_act), hip.ptr(gate), hip.ptr(up), hip.ptr(dg), hip.ptr(du),

@@ -34,6 +34,10 @@ from typing import Optional, Tuple
 import torch
 
 PACK_MULTIPLE = 128
+# row multiples of the trainers' loaders and of bench.py --data-path packed: coarse on purpose - the packed row counts are part of
+# a hipGraph's shape (one graph per combination seen) and of a GEMM's M (dalm_amd/tuning holds a tuned solution for every value
+# these multiples can produce at the BASELINE lengths, tools/tune_packed.py)
+ROW_MULTIPLES = {"generator": 256, "retriever_query": 256, "retriever_passage": 512, "query": 256, "passage": 512}
 
 
 def pack_plan(attention_mask: torch.Tensor, shifted: bool, multiple: int = PACK_MULTIPLE) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -185,15 +189,17 @@ RETRIEVER_GROUPS = (("query", "query_input_ids", "query_attention_mask", False),
                     ("passage", "passage_input_ids", "passage_attention_mask", False))
 
 
-def add_pack_plans(batch: dict, groups=RAG_GROUPS, multiple: int = PACK_MULTIPLE, device=None) -> dict:
+def add_pack_plans(batch: dict, groups=RAG_GROUPS, multiple=None, device=None) -> dict:
     """HOST side (data loader / batch staging): add `<prefix>_pack_rows` / `<prefix>_pack_cu` for every tower input of a batch
     whose masks are host memory (a device mask is copied back: one sync - do this where batches are staged, not per step).
     The training steps take the packed path for every tower that finds its keys."""
     out = dict(batch)
+    if multiple is None:
+        multiple = ROW_MULTIPLES
     for prefix, _ids, mask_key, shifted in groups:
         if mask_key not in batch:
             continue
-        rows, cu = pack_plan(batch[mask_key], shifted, multiple)
+        rows, cu = pack_plan(batch[mask_key], shifted, multiple.get(prefix, PACK_MULTIPLE) if isinstance(multiple, dict) else int(multiple))
         dev = device if device is not None else batch[mask_key].device
         out[f"{prefix}_pack_rows"] = rows.to(dev)
         out[f"{prefix}_pack_cu"] = cu.to(dev)

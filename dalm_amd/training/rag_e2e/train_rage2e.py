@@ -194,7 +194,7 @@ def train_e2e(
         # coarse row multiples: the packed row counts are part of a hipGraph's shape (one graph per combination seen)
         from ... import packed as packed_mod
 
-        pack = dict(groups=packed_mod.RAG_GROUPS, multiple={"generator": 256, "retriever_query": 256, "retriever_passage": 512})
+        pack = dict(groups=packed_mod.RAG_GROUPS, multiple=packed_mod.ROW_MULTIPLES)
         live_rows = None          # the packed generator path lists its own rows
     batches = common.ShardedBatches(processed, per_device_train_batch_size, comm.rank, comm.world_size,
                                     seed if seed is not None else 0, columns,

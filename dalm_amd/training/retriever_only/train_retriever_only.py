@@ -150,7 +150,7 @@ def train_retriever(
     if pack_tokens and not is_autoregressive:
         from ... import packed as packed_mod
 
-        pack = dict(groups=packed_mod.RETRIEVER_GROUPS, multiple={"query": 256, "passage": 512})
+        pack = dict(groups=packed_mod.RETRIEVER_GROUPS, multiple=packed_mod.ROW_MULTIPLES)
     batches = common.ShardedBatches(processed, per_device_train_batch_size, comm.rank, comm.world_size,
                                     seed if seed is not None else 0, columns,
                                     bucket_by="passage_attention_mask" if length_bucketing else None, trim=trim,

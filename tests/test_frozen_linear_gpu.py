@@ -62,7 +62,7 @@ def test_pair_node_accumulates_one_dx_and_trainable_layers_keep_autograd(dev):
     ((m0(xa).float() * u0).sum() + (m1(xa).float() * u1).sum()).backward()
     xb = x.clone().requires_grad_(True)
     y0, y1 = FL.pair_forward(xb, m0, m1)
-    assert y0.grad_fn is y1.grad_fn and "FrozenPair" in type(y0.grad_fn).__name__
+    assert y0.grad_fn is y1.grad_fn and "Pair" in type(y0.grad_fn).__name__       # _FrozenPairFn, or _FrozenCatPairFn (one forward GEMM)
     ((y0.float() * u0).sum() + (y1.float() * u1).sum()).backward()
     assert _rel(xb.grad, xa.grad) < 4e-3
     # only one of the two outputs used: the other arrives as None
@@ -132,7 +132,7 @@ def test_gate_up_as_one_gemm_equals_the_two_gemms(dev, mode):
     dg_h, du_h = torch.autograd.grad(a_h, (gh, uh), d)
     dg_c, du_c = torch.autograd.grad(a_c, (gc, uc), d)
     assert torch.equal(a_h, a_c) and torch.equal(dg_h, dg_c) and torch.equal(du_h, du_c)
-    assert du_h.data_ptr() == dg_h.data_ptr() + N * dg_h.element_size()          # one [R, 2N] gradient buffer
+    assert dg_h.is_contiguous() and du_h.is_contiguous()                          # the dgrad GEMMs keep their tuned shapes
     # a moved module: the cat is rebuilt, not used stale
     m0.to(torch.device("cpu")); m0.to(dev)
     xi = x.clone().requires_grad_(True)
