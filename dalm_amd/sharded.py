@@ -85,8 +85,8 @@ def native_comm_or_none(rank: int, world: int, insist: bool = False, make=None):
     rdv, comm, err = None, None, None
     try:
         rdv = Rendezvous(rank, world)
-        comm = (make or (lambda r: NativeRcclComm(rendezvous=r)))(rdv)
-        comm.self_test()
+        comm = _bring_up_with_deadline(make or (lambda r: NativeRcclComm(rendezvous=r)), rdv,
+                                       float(os.environ.get("DALM_COMM_BRINGUP_TIMEOUT_S", "90")))
     except Exception as e:
         err = e
         if rdv is not None:
@@ -113,6 +113,46 @@ def native_comm_or_none(rank: int, world: int, insist: bool = False, make=None):
     warnings.warn("dalm_amd: native RCCL communicator unavailable on at least one rank"
                   + (f" (here: {err!r})" if err is not None else "") + "; all ranks use torch.distributed(nccl)")
     return None
+
+
+def _bring_up_with_deadline(make, rdv, deadline_s: float):
+    """WATCHDOG around the bring-up of the native communicator (ncclCommInitRank + the self-test's two collectives): the work
+    runs in a helper thread and this thread waits for it at most `deadline_s`.  RCCL's bring-up is a collective - a rank that
+    STALLS in it (instead of raising) used to leave every other rank blocked inside the same call with no way out (ADVICE r4,
+    VERDICT r5 item 3a).  With the deadline, every rank that is stuck - the stalled one and the ones waiting for it - gives up
+    with a TimeoutError, reports "failed" through the rendezvous store (`agree`), and ALL ranks fall back to
+    torch.distributed(nccl) together (or raise together under DALM_NATIVE_COMM=1).  The helper thread of a stalled rank is a
+    daemon and is left behind; it holds no lock the fallback needs."""
+    import threading
+
+    box = {}
+    device = torch.cuda.current_device() if torch.cuda.is_available() else None
+
+    def work():
+        try:
+            if device is not None:
+                torch.cuda.set_device(device)          # the current HIP device is per thread
+            c = make(rdv)
+            box["made"] = c
+            c.self_test()
+            box["comm"] = c
+        except BaseException as e:                     # noqa: BLE001 - handed to the waiting thread
+            box["err"] = e
+
+    t = threading.Thread(target=work, name="dalm-comm-bringup", daemon=True)
+    t.start()
+    t.join(deadline_s)
+    if t.is_alive():
+        raise TimeoutError(f"native RCCL communicator: bring-up / self-test did not finish within {deadline_s:.0f} s "
+                           "(DALM_COMM_BRINGUP_TIMEOUT_S); a rank is stalled inside ncclCommInitRank or its first collective")
+    if "err" in box:
+        if box.get("made") is not None:                # constructed, failed its self-test: release it before falling back
+            try:
+                box["made"].close()
+            except Exception:
+                pass
+        raise box["err"]
+    return box["comm"]
 
 
 def allreduce_grads(params: Iterable[torch.nn.Parameter], comm) -> None:

@@ -385,6 +385,12 @@ class _FakeComm:
     def self_test(self):
         if self.fail_on == self.rank:
             raise RuntimeError("self-test failed on this rank")
+        if self.fail_on == "stall-1":
+            # rank 1 stalls inside its first collective (it never returns, it does not raise); rank 0's collective waits for it
+            # - what a hung ncclCommInitRank / all-reduce looks like from both sides
+            import time
+
+            time.sleep(3600)
 
     def close(self):
         self.closed = True
@@ -395,6 +401,8 @@ def _rdv_worker(rank, world, port, out_dir, fail_on):
                       LOCAL_RANK=str(rank))
     os.environ.pop("DALM_COMM_ID_FILE", None)
     os.environ.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+    if fail_on == "stall-1":
+        os.environ["DALM_COMM_BRINGUP_TIMEOUT_S"] = "3"
     import warnings
 
     import torch.distributed as dist
@@ -421,12 +429,17 @@ def _rdv_worker(rank, world, port, out_dir, fail_on):
     torch.save(res, os.path.join(out_dir, f"r{rank}.pt"))
 
 
-@pytest.mark.parametrize("fail_on", [None, 1, 0, "rank0-early"])
+@pytest.mark.parametrize("fail_on", [None, 1, 0, "rank0-early", "stall-1"])
 def test_native_comm_rendezvous_and_all_or_none_fallback(tmp_path, fail_on):
     """Both ranks get rank 0's unique id through the store; when ONE rank's communicator fails its self-test, BOTH ranks
-    drop the native communicator (the healthy one is closed) and meet again in torch.distributed on the same port."""
+    drop the native communicator (the healthy one is closed) and meet again in torch.distributed on the same port.
+    "stall-1": the bring-up does not fail, it HANGS (both ranks sit in the first collective) - the watchdog
+    (sharded._bring_up_with_deadline) times both out and both fall back together."""
     _spawn(_rdv_worker, 2, str(tmp_path), fail_on)
     res = [torch.load(tmp_path / f"r{r}.pt") for r in range(2)]
+    if fail_on == "stall-1":
+        assert not any(r["native"] for r in res) and all(r["fallback_sum"] == 3.0 for r in res)
+        return
     if fail_on == "rank0-early":       # rank 1 is told at once that no id will come (no 120 s timeout), both fall back
         assert not any(r["native"] for r in res) and all(r["fallback_sum"] == 3.0 for r in res)
         return
