@@ -22,7 +22,7 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = CSRC / "libdalm_hip.so"
-SOURCES = ["lib.hip", "ce.hip", "sim.hip", "sim_small.hip", "pool.hip", "comm.hip", "lmhead.hip", "nf4.hip", "tower.hip", "falcon.hip", "attn.hip", "lora.hip", "lora2.hip"]
+SOURCES = ["lib.hip", "ce.hip", "sim.hip", "sim_small.hip", "pool.hip", "comm.hip", "lmhead.hip", "nf4.hip", "tower.hip", "falcon.hip", "attn.hip", "lora.hip", "lora2.hip", "bert.hip"]
 HEADERS = [CSRC / "common.hpp", CSRC / "lora_common.hpp", CSRC.parent.parent / "include" / "dalm_hip.h"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC"]

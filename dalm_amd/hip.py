@@ -99,6 +99,8 @@ SIGNATURES = {
     "dalm_gelu_fwd": (_int, [_vp, _vp, _i64, _vp]),
     "dalm_gelu_bwd": (_int, [_vp, _vp, _vp, _i64, _vp]),
     "dalm_add3": (_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "dalm_bert_add_norm_fwd": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _i64, _f32, _f32, _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dalm_bert_add_norm_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp]),
     "dalm_attn_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp, _f32, _vp, C.c_uint32, _vp, _vp, _vp]),
     "dalm_attn_mask_bits": (_int, [_vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp]),
     "dalm_attn_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _i64, _i64,

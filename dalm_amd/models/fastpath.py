@@ -376,6 +376,66 @@ def _falcon_mlp_matches(cls) -> bool:
 
 
 # ---------------------------------------------------------------------------
+# BERT encoder layer: dropout + residual add + LayerNorm of BertSelfOutput / BertOutput in one launch each way
+# ---------------------------------------------------------------------------
+def _bert_output_forward(self, hidden_states: torch.Tensor, input_tensor: torch.Tensor) -> torch.Tensor:
+    """transformers' BertSelfOutput.forward / BertOutput.forward (the same three statements):
+        hidden_states = self.dense(hidden_states); hidden_states = self.dropout(hidden_states)
+        hidden_states = self.LayerNorm(hidden_states + input_tensor)
+    with the last two on `dalm_bert_add_norm_{fwd,bwd}` where the tensors are what bf16 autocast over a frozen base produces
+    (bf16 dense output, f32 residual); everything else runs the statements as they are."""
+    from . import bert_ops
+
+    hidden_states = self.dense(hidden_states)
+    if bert_ops.supported(hidden_states, input_tensor, self.LayerNorm):
+        p = float(self.dropout.p) if self.training else 0.0
+        self._dalm_calls = getattr(self, "_dalm_calls", 0) + 1
+        salt = ((id(self) >> 4) << 12) ^ (self._dalm_calls & 0xFFF)     # module id above a host call counter (graph replays: the
+        return bert_ops.add_norm(hidden_states, input_tensor, self.LayerNorm, p, salt)   # device seed word changes the masks)
+    hidden_states = self.dropout(hidden_states)
+    return self.LayerNorm(hidden_states + input_tensor)
+
+
+def use_bert_layer_kernels(model: torch.nn.Module) -> int:
+    """Patch BertSelfOutput / BertOutput modules whose forward is the three statements above (source checked once per class) and
+    whose LayerNorm is frozen.  DALM_BERT_KERNELS=0 disables.  Returns how many modules were patched."""
+    if os.environ.get("DALM_BERT_KERNELS", "1") == "0":
+        return 0
+    n = 0
+    for mod in model.modules():
+        if type(mod).__name__ not in ("BertSelfOutput", "BertOutput"):
+            continue
+        ln, drop = getattr(mod, "LayerNorm", None), getattr(mod, "dropout", None)
+        if not isinstance(ln, torch.nn.LayerNorm) or not isinstance(drop, torch.nn.Dropout) or not hasattr(mod, "dense"):
+            continue
+        if not _bert_output_matches(type(mod)):
+            continue
+        mod.forward = types.MethodType(_bert_output_forward, mod)
+        n += 1
+    return n
+
+
+def _bert_output_matches(cls) -> bool:
+    key = ("bert-output", cls)
+    if key not in _checked:
+        try:
+            import inspect
+
+            params = list(inspect.signature(cls.forward).parameters)
+            src = inspect.getsource(cls.forward)
+            body = [ln.strip() for ln in src.splitlines()[1:] if ln.strip() and not ln.strip().startswith("#")]
+            _checked[key] = (params == ["self", "hidden_states", "input_tensor"]
+                             and body == ["hidden_states = self.dense(hidden_states)", "hidden_states = self.dropout(hidden_states)",
+                                          "hidden_states = self.LayerNorm(hidden_states + input_tensor)", "return hidden_states"])
+        except Exception:
+            _checked[key] = False
+        if not _checked[key]:
+            _warn_once("bert-output:" + cls.__name__, f"{cls.__name__}.forward is not dense -> dropout -> LayerNorm(h + input) here: "
+                       "transformers' own code stays in place")
+    return _checked[key]
+
+
+# ---------------------------------------------------------------------------
 # Falcon attention (7B flavour, rotary, sdpa): the attention itself on dalm_attn_fwd / dalm_attn_bwd
 # ---------------------------------------------------------------------------
 _FALCON_ATTN_PARAMS = ["self", "hidden_states", "alibi", "attention_mask", "position_ids", "layer_past", "use_cache",

@@ -189,7 +189,9 @@ class FrozenLinearT(torch.nn.Linear):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if _eligible(x, self):
-            return _FrozenLinearFn.apply(x, self.weight, self.bias)
+            from .bert_ops import twin
+
+            return _FrozenLinearFn.apply(twin(x), self.weight, self.bias)       # an f32 LayerNorm output carrying its bf16 copy
         return super().forward(x)
 
 

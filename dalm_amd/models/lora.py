@@ -162,10 +162,19 @@ class LoRAGroup:
             if not self._outs:
                 self._x = None
             return out
-        if self._outs:                       # an earlier stash was never claimed: this model does not share inputs here
-            self.enabled = False
+        if self._outs:
+            # an earlier stash was never claimed (an exception / OOM retry in the middle of a forward, or a model that does not
+            # feed these projections the same tensor): drop it and try again; three in a row -> this model does not share
+            # inputs here, the group switches itself off WITH a warning (it used to go silent on the first one)
             self._x, self._outs = None, {}
-            return None
+            self._misses = getattr(self, "_misses", 0) + 1
+            if self._misses >= 3:
+                self.enabled = False
+                import warnings
+
+                warnings.warn("dalm_amd.lora: a q / k / v projection group saw three unclaimed outputs in a row - its members do "
+                              "not read one shared input in this model; the group node is off (per-projection kernels stay on)")
+                return None
         from . import lora_ops
 
         if any(isinstance(m, LoRALinear) and m.merged for m in self.members):
@@ -178,6 +187,7 @@ class LoRAGroup:
         if not lora_ops.group_supported(x, args):
             return None
         outs = lora_ops.lora_group_forward(x, args)
+        self._misses = 0
         self._x = x
         self._outs = {id(m): o for m, o in zip(self.members, outs)}
         out = self._outs.pop(id(module))

@@ -458,6 +458,9 @@ class _LoRAGroupFn(torch.autograd.Function):
 
 def lora_group_forward(x, members):
     """members: list of (weight, bias, lora_A or None, lora_B or None, scaling, p, salt).  Returns the tuple of outputs."""
+    from .bert_ops import twin
+
+    x = twin(x)               # an f32 LayerNorm output carrying its bf16 copy (bert_ops): no second cast, same autograd node
     meta, flat = [], []
     for (w, bias, a, b, scaling, p, salt) in members:
         if a is None:

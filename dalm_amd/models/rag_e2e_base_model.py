@@ -15,7 +15,7 @@ from ..fused import pool_l2norm
 from ..utils import eos_mask
 from . import lora
 from .attention import use_hip_attention_backward
-from .fastpath import (use_capturable_falcon_heads, use_falcon_attention_kernels, use_falcon_layer_kernels,
+from .fastpath import (use_bert_layer_kernels, use_capturable_falcon_heads, use_falcon_attention_kernels, use_falcon_layer_kernels,
                        use_fused_residual_norm, use_llama_attention_node, use_native_rms_norm, use_roll_rope, use_swiglu_kernel)
 
 
@@ -137,6 +137,7 @@ class AutoModelForRagE2E(torch.nn.Module):
 
         use_transposed_dgrad(self.generator_model)
         use_transposed_dgrad(self.retriever_model)
+        use_bert_layer_kernels(self.retriever_model)              # dropout + add + LayerNorm of a BERT layer: one launch each way
 
     # ---- retrieval tower ---------------------------------------------------------------
     def retrieval_hidden(self, input_ids: torch.Tensor, attention_mask: torch.Tensor):

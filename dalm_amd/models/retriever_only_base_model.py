@@ -50,6 +50,13 @@ class AutoModelForSentenceEmbedding(torch.nn.Module):
         use_hip_attention_backward(self.model)        # BERT / Llama-family: dalm_attn_* (attention dropout inside the kernels)
         if get_peft:
             lora.inject_lora(self.model, ["key", "query", "value"] if not is_autoregressive else ["q_proj", "v_proj"])
+        # frozen projections: backward GEMM through a transposed weight copy; BERT layers: dropout + add + LayerNorm in one launch
+        # each way (both no-ops for a model that is fine-tuned in full: they look at requires_grad)
+        from .fastpath import use_bert_layer_kernels
+        from .frozen_linear import use_transposed_dgrad
+
+        use_transposed_dgrad(self.model)
+        use_bert_layer_kernels(self.model)
         self.normalize = normalize
         self.is_autoregressive = is_autoregressive
         self.tokenizer = tokenizer

@@ -465,6 +465,23 @@ int dalm_gelu_fwd(const void* x, void* y, int64_t n, dalm_stream_t stream);
 int dalm_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, dalm_stream_t stream);
 int dalm_add3(const void* a, const void* b, const void* c, void* out, int64_t n, dalm_stream_t stream);
 
+/* BERT encoder layer: dropout + residual add + LayerNorm of BertSelfOutput / BertOutput (transformers modeling_bert.py; the
+ * reference reaches them through self.retriever_model(...), dalm/models/rag_e2e_base_model.py:84-93) as one launch per direction,
+ * rounding where the eager chain rounds under bf16 autocast (dalm_amd/csrc/bert.hip):
+ *   fwd: d = bf16(a keep / (1 - p)); s = f32(d) + res; y32 = (s - mean) rstd w + b; y16 = bf16(y32).  a [R, D] bf16 (the dense
+ *        output), res [R, D] f32, w / b [D] f32 (w_bf16 == 0) or bf16; D a multiple of 8, at most 2048.  mean / rstd [R] f32 and
+ *        keep_bits [R][D / 8] (bit e of byte c = element 8 c + e survives; NULL when dropout_p == 0) are kept for the backward.
+ *        The keep mask is regenerated from (the 64-bit word at `seed` in DEVICE memory, salt, flat element index):
+ *        oracle/lora_mask.py::keep_mask_v2 restates it.
+ *   bwd: dy = g32 + f32(g16) (either may be NULL); ds = LayerNorm backward (f32); d_res = ds; d_a = bf16(bf16(ds) keep / (1 - p)).
+ *        The weight / bias gradients are not produced (frozen under LoRA; trainable LayerNorms keep transformers' code). */
+int dalm_bert_add_norm_fwd(const void* a, const float* res, const void* w, const void* b, int w_bf16, int64_t R, int64_t D,
+                           float eps, float dropout_p, const void* seed, uint32_t salt, float* y32, void* y16, uint8_t* keep_bits,
+                           float* mean, float* rstd, dalm_stream_t stream);
+int dalm_bert_add_norm_bwd(const float* g32, const void* g16, const void* a, const float* res, const void* w, int w_bf16,
+                           const uint8_t* keep_bits, const float* mean, const float* rstd, int64_t R, int64_t D, float dropout_p,
+                           float* d_res, void* d_a, dalm_stream_t stream);
+
 /* Backward of scaled-dot-product attention, bf16, head width 128, boolean mask (dalm_amd/csrc/attn.hip).  Stands in for the
  * backward of torch.nn.functional.scaled_dot_product_attention as transformers' sdpa_attention_forward calls it inside
  * self.generator_model(...) (dalm/models/rag_e2e_base_model.py:104-106; loss.backward(), train_rage2e.py:466).
