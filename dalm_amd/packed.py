@@ -41,15 +41,18 @@ ROW_MULTIPLES = {"generator": 256, "retriever_query": 256, "retriever_passage": 
 
 
 def pack_plan(attention_mask: torch.Tensor, shifted: bool, multiple: int = PACK_MULTIPLE) -> Tuple[torch.Tensor, torch.Tensor]:
-    """HOST side.  attention_mask [B, T] (any integer / bool dtype) -> (rows int64 [n_pad], cu int32 [B + 2]).
-    shifted=True (generator): a token also stays when the NEXT column is live (its row carries a label)."""
+    """HOST side.  attention_mask [B, T] (any integer / bool dtype) -> (rows int64 [n_pad], cu int32 [B + 1 + n_slack]).
+    shifted=True (generator): a token also stays when the NEXT column is live (its row carries a label).
+    The slack rows (n_pad - n < multiple) form n_slack = ceil(multiple / T) extra sequences of at most T rows each (one when
+    multiple <= T): a sequence must fit the T rows of the attention layout, and the number of cu entries must not depend on the
+    batch (it is a tensor shape)."""
     m = attention_mask.detach()
     if m.is_cuda:
         m = m.cpu()
     live = m != 0
     B, T = live.shape
-    if multiple > T:
-        multiple = max(1, T)                 # the slack sequence must fit the layout's T rows
+    multiple = max(1, int(multiple))
+    n_slack = max(1, -(-multiple // max(T, 1)))
     keep = live.clone()
     if shifted:
         keep[:, :-1] |= live[:, 1:]
@@ -58,9 +61,11 @@ def pack_plan(attention_mask: torch.Tensor, shifted: bool, multiple: int = PACK_
     n_pad = max(multiple, -(-n // multiple) * multiple)
     rows = torch.full((n_pad,), -1, dtype=torch.int64)
     rows[:n] = idx
-    cu = torch.zeros(B + 2, dtype=torch.int32)
+    cu = torch.zeros(B + 1 + n_slack, dtype=torch.int32)
     cu[1:B + 1] = keep.sum(dim=1).cumsum(0).to(torch.int32)
-    cu[B + 1] = n_pad
+    for j in range(n_slack):                 # slack sequences: T rows each until the slack is used up, the rest empty
+        cu[B + 1 + j] = min(n_pad, n + (j + 1) * T)
+    cu[B + n_slack] = n_pad
     return rows, cu
 
 
@@ -69,7 +74,7 @@ class PackedSeqs:
     """What the attention of one packed tower call reads (device side, built once per call, shared by every layer)."""
 
     cu: torch.Tensor                       # int32 [nseq + 1]
-    nseq: int                              # B + 1 (the slack sequence last)
+    nseq: int                              # B + the slack sequences (last)
     T: int                                 # rows of the mask-word / lse layout: the padded layout's T
     n: int                                 # packed rows
     key_live: torch.Tensor                 # uint8 [n]

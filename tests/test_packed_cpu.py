@@ -44,6 +44,13 @@ def test_pack_plan_lists_exactly_the_rows_that_matter(left):
             assert int(w[i]) == 0
     assert (w[n:] == 0).all()
     assert int(w.sum()) == int(m[:, 1:].sum())                      # every target token of the padded loss, once
+    # a row multiple above the sequence length (query tower: T 50, multiple 256): the slack is cut into sequences of <= T rows
+    mq = _masks(6, 10, False, 3)
+    rq, cq = packed.pack_plan(mq, shifted=False, multiple=32)
+    assert rq.numel() % 32 == 0 and cq.numel() == 6 + 1 + 4 and int(cq[-1]) == rq.numel()
+    assert all(0 <= int(b - a) <= 10 for a, b in zip(cq[:-1], cq[1:]))
+    r0, c0 = packed.pack_plan(torch.zeros(2, 10, dtype=torch.long), shifted=False, multiple=32)          # nothing live at all
+    assert r0.numel() == 32 and (r0 == -1).all() and all(0 <= int(b - a) <= 10 for a, b in zip(c0[:-1], c0[1:]))
 
 
 def _tiny_llama():

@@ -122,7 +122,7 @@ def test_packed_attention_kernels_vs_float64_and_padded(dev, B, H, T, lens, left
     qr_b, kr_b = qr.detach().to(torch.bfloat16).double(), kr.detach().to(torch.bfloat16).double()
     want_o = torch.zeros(1, H, n, hd, dtype=torch.float64, device=dev)
     want = [torch.zeros_like(want_o) for _ in range(3)]
-    for b in range(B + 1):
+    for b in range(cu.numel() - 1):
         a, e = int(cu[b]), int(cu[b + 1])
         if e == a:
             continue
@@ -142,7 +142,7 @@ def test_packed_attention_kernels_vs_float64_and_padded(dev, B, H, T, lens, left
         assert torch.isfinite(gt).all(), name
     # slack rows and key-dead rows: exactly zero output / gradients
     dead_q = torch.zeros(n, dtype=torch.bool, device=dev)
-    for b in range(B + 1):
+    for b in range(cu.numel() - 1):
         a, e = int(cu[b]), int(cu[b + 1])
         kl = seqs.key_live[a:e].bool()
         for i in range(e - a):
@@ -165,9 +165,10 @@ def test_packed_mask_words_match_numpy(dev):
     sq = packed.packed_of(desc)
     rb, cb, lt = [t.cpu().numpy() for t in sq.bits()]
     W = (T + 31) // 32
-    rb, cb = rb.view(np.uint32).reshape(B + 1, 32 * W, W), cb.view(np.uint32).reshape(B + 1, 32 * W, W)
+    S = cu.numel() - 1
+    rb, cb = rb.view(np.uint32).reshape(S, 32 * W, W), cb.view(np.uint32).reshape(S, 32 * W, W)
     kl = sq.key_live.cpu().numpy()
-    for b in range(B + 1):
+    for b in range(S):
         a, e = int(cu[b]), int(cu[b + 1])
         L = e - a
         M = np.zeros((32 * W, 32 * W), dtype=bool)
@@ -179,7 +180,7 @@ def test_packed_mask_words_match_numpy(dev):
         want_c = (M.T.reshape(32 * W, W, 32) * bitw).sum(-1).astype(np.uint32)
         assert (rb[b] == want_r).all() and (cb[b] == want_c).all()
         live = M.reshape(W, 32, W, 32).any(axis=(1, 3))
-        assert (lt.reshape(B + 1, W, W)[b].astype(bool) == live).all()
+        assert (lt.reshape(S, W, W)[b].astype(bool) == live).all()
 
 
 def test_packed_attention_dropout_statistics_and_backward(dev):
