@@ -24,9 +24,11 @@ ROOT = Path(__file__).resolve().parent.parent
 OUT = ROOT / "gpurun_out"
 sys.path.insert(0, str(ROOT))
 
-# measured (profiles/r06_full_depth_parity.json): see DESIGN.md section 6; bounds = 5 x measured, floor 1e-4
-TOL = {"loss": 2e-3, "contrastive": 5e-3, "generator": 2e-3, "grad_norm": 5e-2}
-TOL_PACKED_VS_PADDED = {"loss": 5e-4, "contrastive": 2e-3, "generator": 5e-4, "grad_norm": 1e-2}
+# measured on the MI355X (profiles/r06_full_depth_parity.json): bf16 headline vs float32 - loss 1.9e-4, contrastive 3.6e-4,
+# generator 1.3e-4, LoRA gradient norm 1.7e-3; packed vs padded (both bf16) - loss 1.1e-4, generator 1.5e-4, gradient norm 2.5e-5.
+# Bounds = 5 x measured.
+TOL = {"loss": 1e-3, "contrastive": 2e-3, "generator": 7e-4, "grad_norm": 8.5e-3}
+TOL_PACKED_VS_PADDED = {"loss": 6e-4, "contrastive": 5e-4, "generator": 8e-4, "grad_norm": 5e-4}
 
 
 def _rel(a, b):

@@ -89,7 +89,7 @@ def main():
     from dalm_amd import packed
     from dalm_amd.training.step import RagE2EStep
 
-    Path(args.out).parent.mkdir(exist_ok=True)
+    Path(args.out).parent.mkdir(parents=True, exist_ok=True)
     tunable.enable(True)
     if TABLE.exists():
         tunable.read_file(str(TABLE))                     # shapes already in the table are not searched again
