@@ -648,7 +648,8 @@ def main():
         import trainer_bench
 
         argv = ["--workload", args.workload, "--rows", str(args.trainer_rows), "--retriever-layers", str(args.retriever_layers),
-                "--generator-layers", str(args.generator_layers)] + (["--bench-line", args.bench_line] if args.bench_line else [])
+                "--generator-layers", str(args.generator_layers)] + (["--bench-line", args.bench_line] if args.bench_line else []) \
+            + (["--pack-tokens"] if args.data_path == "packed" else [])
         return trainer_bench.main(argv)
     if args.gpus > 1 and not in_distributed_env():
         # `python bench.py --gpus N`: no torchrun needed - spawn one rank per GPU ourselves (RANK / LOCAL_RANK /

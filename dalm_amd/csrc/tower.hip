@@ -134,7 +134,14 @@ __device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + expf(-x)
 // [R, C] views with a row stride (gate and up as the two halves of ONE [R, 2C] GEMM output, models/frozen_linear.py): element
 // e of the logical [R, C] matrix lives at (e / C) * ld + e % C; C is a multiple of VEC, so a vector never crosses a row
 struct SwigluLd { int64_t C, g, u, a, dg, du; };
-__device__ __forceinline__ int64_t ld_off(int64_t e, int64_t C, int64_t ld) { return (e / C) * ld + e % C; }
+// element index -> (row, column): 32-bit arithmetic (the entry points require R C < 2^32; a 64-bit division per vector made the
+// first form of these kernels run at 0.47 of HBM where the contiguous ones reach 0.66)
+struct RowCol { unsigned int row, col; };
+__device__ __forceinline__ RowCol row_col(int64_t e, int64_t C) {
+  const unsigned int ee = static_cast<unsigned int>(e), cc = static_cast<unsigned int>(C), r = ee / cc;
+  return {r, ee - r * cc};
+}
+__device__ __forceinline__ int64_t ld_at(const RowCol& rc, int64_t ld) { return static_cast<int64_t>(rc.row) * ld + rc.col; }
 
 template <typename T, int STEPS>
 __global__ __launch_bounds__(256) void swiglu_fwd_2d_kernel(const T* __restrict__ g, const T* __restrict__ u, T* __restrict__ a,
@@ -145,7 +152,11 @@ __global__ __launch_bounds__(256) void swiglu_fwd_2d_kernel(const T* __restrict_
 #pragma unroll
   for (int k = 0; k < STEPS; ++k) {
     const int64_t e0 = base + static_cast<int64_t>(k) * 256 * VEC;
-    if (e0 < n) { EV<T>::load(g + ld_off(e0, ld.C, ld.g), gv[k]); EV<T>::load(u + ld_off(e0, ld.C, ld.u), uv[k]); }
+    if (e0 < n) {
+      const RowCol rc = row_col(e0, ld.C);
+      EV<T>::load(g + ld_at(rc, ld.g), gv[k]);
+      EV<T>::load(u + ld_at(rc, ld.u), uv[k]);
+    }
   }
 #pragma unroll
   for (int k = 0; k < STEPS; ++k) {
@@ -154,7 +165,7 @@ __global__ __launch_bounds__(256) void swiglu_fwd_2d_kernel(const T* __restrict_
     float o[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) o[e] = EV<T>::rb(__fmul_rn(EV<T>::rb(silu_f32(gv[k][e])), uv[k][e]));
-    EV<T>::store(a + ld_off(e0, ld.C, ld.a), o);
+    EV<T>::store(a + ld_at(row_col(e0, ld.C), ld.a), o);
   }
 }
 
@@ -169,9 +180,10 @@ __global__ __launch_bounds__(256) void swiglu_bwd_2d_kernel(const T* __restrict_
   for (int k = 0; k < STEPS; ++k) {
     const int64_t e0 = base + static_cast<int64_t>(k) * 256 * VEC;
     if (e0 < n) {
-      EV<T>::load(da + ld_off(e0, ld.C, ld.a), av[k]);
-      EV<T>::load(g + ld_off(e0, ld.C, ld.g), gv[k]);
-      EV<T>::load(u + ld_off(e0, ld.C, ld.u), uv[k]);
+      const RowCol rc = row_col(e0, ld.C);
+      EV<T>::load(da + ld_at(rc, ld.a), av[k]);
+      EV<T>::load(g + ld_at(rc, ld.g), gv[k]);
+      EV<T>::load(u + ld_at(rc, ld.u), uv[k]);
     }
   }
 #pragma unroll
@@ -188,8 +200,9 @@ __global__ __launch_bounds__(256) void swiglu_bwd_2d_kernel(const T* __restrict_
       const float sig = 1.0f / (1.0f + expf(-x));
       og[e] = EV<T>::rb(ds * sig * (1.0f + x * (1.0f - sig)));
     }
-    EV<T>::store(dg + ld_off(e0, ld.C, ld.dg), og);
-    EV<T>::store(du + ld_off(e0, ld.C, ld.du), ou);
+    const RowCol rc = row_col(e0, ld.C);
+    EV<T>::store(dg + ld_at(rc, ld.dg), og);
+    EV<T>::store(du + ld_at(rc, ld.du), ou);
   }
 }
 
@@ -530,7 +543,7 @@ extern "C" int dalm_swiglu_fwd_2d(const void* gate, const void* up, void* act, i
                    && ld_gate >= C && ld_up >= C && ld_act >= C,
                DALM_E_ALIGN, "16-byte aligned pointers, C and the row strides multiples of 16 bytes, strides >= C");
   const int64_t n = R * C, blocks = swiglu_blocks(n, vec);
-  DALM_REQUIRE(blocks <= 0x7fffffffLL, DALM_E_SHAPE, "tensor too large for one launch");
+  DALM_REQUIRE(n < (1ll << 32) && blocks <= 0x7fffffffLL, DALM_E_SHAPE, "tensor too large for one launch (R C must stay below 2^32)");
   const dim3 grid(static_cast<unsigned>(blocks));
   const SwigluLd ld = {C, ld_gate, ld_up, ld_act, 0, 0};
   if (dtype == DALM_F32)
@@ -554,7 +567,7 @@ extern "C" int dalm_swiglu_bwd_2d(const void* d_act, const void* gate, const voi
   for (int64_t l : {ld_dact, ld_gate, ld_up, ld_dgate, ld_dup}) ok = ok && l % vec == 0 && l >= C;
   DALM_REQUIRE(ok, DALM_E_ALIGN, "16-byte aligned pointers, C and the row strides multiples of 16 bytes, strides >= C");
   const int64_t n = R * C, blocks = swiglu_blocks(n, vec);
-  DALM_REQUIRE(blocks <= 0x7fffffffLL, DALM_E_SHAPE, "tensor too large for one launch");
+  DALM_REQUIRE(n < (1ll << 32) && blocks <= 0x7fffffffLL, DALM_E_SHAPE, "tensor too large for one launch (R C must stay below 2^32)");
   const dim3 grid(static_cast<unsigned>(blocks));
   const SwigluLd ld = {C, ld_gate, ld_up, ld_dact, ld_dgate, ld_dup};
   if (dtype == DALM_F32)

@@ -55,6 +55,8 @@ if has trainer; then
   for w in cfg3 cfg2 cfg5; do
     run $P/r06_trainer_$w.json python bench.py --workload $w --through-trainer --bench-line $P/r06_bench_$( [ $w = cfg3 ] && echo default || echo $w ).json
     tail -1 $P/r06_trainer_$w.json | cut -c1-400
+    run $P/r06_trainer_${w}_packed.json python bench.py --workload $w --through-trainer --data-path packed --bench-line $P/r06_bench_${w}_packed.json
+    tail -1 $P/r06_trainer_${w}_packed.json | cut -c1-400
   done
 fi
 if has prof; then

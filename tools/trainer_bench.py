@@ -190,7 +190,7 @@ def run(args) -> dict:
     def train(model, phase, resume=None):
         kw = dict(per_device_train_batch_size=B, query_max_len=50, passage_max_len=128, learning_rate=1e-4, logit_scale=100,
                   num_train_epochs=1, output_dir=out_dir, seed=42, checkpointing_steps=ckpt, resume_from_checkpoint=resume,
-                  with_tracking=True, mixed_precision="bf16", token_cache_dir=cache,
+                  with_tracking=True, mixed_precision="bf16", token_cache_dir=cache, pack_tokens=bool(args.pack_tokens),
                   on_step=on_step_factory(phase, ckpt if resume else 0))
         t0 = time.perf_counter()
         try:
@@ -237,7 +237,7 @@ def run(args) -> dict:
     res = {
         "metric": "training pairs/sec through the trainer entry point (" + ("train_retriever" if retriever_only else "train_e2e") + ")",
         "value": rate_a, "unit": "pairs/s", "n_gpus": 1, "dtype": "bf16", "data": "synthetic csv",
-        "config": {"workload": args.workload, "rows": args.rows, "per_device_train_batch_size": B, "batches_per_epoch": nb,
+        "config": {"workload": args.workload, "rows": args.rows, "pack_tokens": bool(args.pack_tokens), "per_device_train_batch_size": B, "batches_per_epoch": nb,
                    "partial_last_batch_rows": args.rows - (nb - 1) * B, "retriever_layers": args.retriever_layers,
                    "generator_layers": None if retriever_only else args.generator_layers,
                    "generator": None if retriever_only else gen_name,
@@ -279,6 +279,7 @@ def main(argv=None):
     ap.add_argument("--workdir", default="/tmp")
     ap.add_argument("--bench-line", default=None, help="file holding bench.py's JSON line of the same workload (ratio)")
     ap.add_argument("--tokenise-only", action="store_true")
+    ap.add_argument("--pack-tokens", action="store_true", help="the trainers' --pack_tokens: towers on the live tokens only")
     a = ap.parse_args(argv)
     if a.tokenise_only:
         d = tempfile.mkdtemp(prefix="dalm_tok_", dir=a.workdir)
