@@ -489,7 +489,8 @@ inline PoolPlan pool_plan(int64_t B, int64_t T, int64_t D, int vec) {
   const int64_t groups = 1024 / tpr;
   int64_t tz = 1;
   // one CU streams ~50-80 GB/s on its own: slice when a sample is more than a few microseconds of that
-  if (B < 64 && T * D * (16 / vec) >= (1 << 20)) {
+  static const int64_t slice_bytes = [] { const char* e = getenv("DALM_POOL_SLICE_BYTES"); return e ? atoll(e) : (1ll << 20); }();
+  if (B < 64 && T * D * (16 / vec) >= slice_bytes) {
     tz = (192 + B - 1) / B;
     const int64_t tz_max = (T + 4 * groups - 1) / (4 * groups);
     if (tz > tz_max) tz = tz_max;

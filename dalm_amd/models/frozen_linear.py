@@ -27,24 +27,51 @@ def enabled() -> bool:
     return _ENABLED
 
 
+import weakref
+
+# the copies live in a side table keyed (weakly) by the parameter OBJECT, not on it: `torch.save(model)` / pickling a module does
+# not serialise them, and a parameter that goes away takes its copy with it
+_WT_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
 def dgrad_weight(w: torch.Tensor, dtype: Optional[torch.dtype] = None) -> Optional[torch.Tensor]:
-    """W^T [K, N], contiguous, in `dtype` (default: w's own) - cached on the parameter object; None when disabled, when w is
-    trainable or not on a GPU.  The cache is keyed by the weight's storage, version, device and dtype: a reloaded or moved weight
-    gets a fresh copy."""
+    """W^T [K, N], contiguous, in `dtype` (default: w's own); None when disabled, when w is trainable or not on a GPU, when the
+    copy would not fit comfortably (free HBM < 4 x its size: the backward then runs on W as stored), or when the first request
+    for it comes from inside a hipGraph capture (an allocation that must outlive the graph's pool).  The cache is keyed by the
+    weight's storage, version, device and dtype: a reloaded or moved weight gets a fresh copy."""
     if not _ENABLED or w.requires_grad or not w.is_cuda or w.dim() != 2:
         return None
     dtype = dtype or w.dtype
     key = (w.data_ptr(), w._version, w.device, dtype, tuple(w.shape))
-    cached = getattr(w, "_dalm_wt", None)
+    try:
+        cached = _WT_CACHE.get(w)
+    except TypeError:
+        cached = None
     if cached is not None and cached[0] == key:
         return cached[1]
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    need = w.numel() * torch.empty((), dtype=dtype).element_size()
+    try:
+        free, _total = torch.cuda.mem_get_info(w.device)
+        if free < 4 * need:
+            return None
+    except Exception:
+        pass
     with torch.no_grad():
         wt = w.detach().to(dtype).t().contiguous()
     try:
-        w._dalm_wt = (key, wt)
-    except Exception:       # an object that takes no attributes: recompute next time
+        _WT_CACHE[w] = (key, wt)
+    except TypeError:       # an object that cannot be weakly referenced: recompute next time
         pass
     return wt
+
+
+def drop_dgrad_copy(w: torch.Tensor) -> None:
+    try:
+        _WT_CACHE.pop(w, None)
+    except TypeError:
+        pass
 
 
 def _compute_dtype(x: torch.Tensor) -> torch.dtype:
@@ -140,11 +167,7 @@ def _cat_weights(m0: torch.nn.Linear, m1: torch.nn.Linear) -> Optional[torch.Ten
         w0.data = cat[:n0]
         w1.data = cat[n0:]
     for w in (w0, w1):                         # transposed dgrad copies made from the old storage are still VALUES-correct, but
-        if hasattr(w, "_dalm_wt"):             # keyed by pointer: drop them, they are rebuilt on the next backward
-            try:
-                del w._dalm_wt
-            except Exception:
-                pass
+        drop_dgrad_copy(w)                     # keyed by pointer: drop them, they are rebuilt on the next backward
     try:
         m0._dalm_cat = cat
     except Exception:

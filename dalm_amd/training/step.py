@@ -218,15 +218,23 @@ class RagE2EStep(_StepBase):
                              attention_mask=batch["generator_input_attention_mask"], use_cache=False)[0]
 
     def _resolve_fuse(self, batch) -> None:
-        if self.fuse_lm_head != "auto":
+        """fuse_lm_head="auto": decided PER BATCH SHAPE (cached) - a later, longer batch that exceeds DALM_LOGITS_BUDGET_MB takes
+        the logits-free path even when the first batch was small, and a large first batch does not lock the slower path in
+        (ADVICE r5).  Inside a hipGraph the decision is part of the captured shape."""
+        if getattr(self, "_fuse_auto", None) is None:
+            self._fuse_auto = {} if self.fuse_lm_head == "auto" else False
+        if self._fuse_auto is False:
             return
         import os
 
         head = self.model.generator_model.get_output_embeddings()
         ids = batch["generator_input_input_ids"]
-        el = 2 if self.autocast_dtype in (torch.bfloat16, torch.float16) or head.weight.dtype != torch.float32 else 4
-        mb = ids.shape[0] * ids.shape[1] * head.weight.shape[0] * el / 2 ** 20
-        self.fuse_lm_head = bool(mb > float(os.environ.get("DALM_LOGITS_BUDGET_MB", "1024")) and getattr(head, "bias", None) is None)
+        key = tuple(ids.shape)
+        if key not in self._fuse_auto:
+            el = 2 if self.autocast_dtype in (torch.bfloat16, torch.float16) or head.weight.dtype != torch.float32 else 4
+            mb = ids.shape[0] * ids.shape[1] * head.weight.shape[0] * el / 2 ** 20
+            self._fuse_auto[key] = bool(mb > float(os.environ.get("DALM_LOGITS_BUDGET_MB", "1024")) and getattr(head, "bias", None) is None)
+        self.fuse_lm_head = self._fuse_auto[key]
 
     def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         m = self.model

@@ -54,6 +54,7 @@ def test_full_depth_cfg3_bf16_headline_vs_fp32():
     import bench
 
     from dalm_amd import packed
+    from dalm_amd.models import frozen_linear
     from dalm_amd.models.lora import LoRALinear
 
     if not torch.cuda.is_available():
@@ -79,8 +80,7 @@ def test_full_depth_cfg3_bf16_headline_vs_fp32():
         for p in model.parameters():
             if not p.requires_grad:
                 p.data = p.data.to(torch.bfloat16)          # exact: the values are bf16-representable
-            if hasattr(p, "_dalm_wt"):
-                del p._dalm_wt
+            frozen_linear.drop_dgrad_copy(p)
     torch.cuda.empty_cache()
     bf16 = _run(model, batch, torch.bfloat16, dev)
     bf16_packed = _run(model, packed.add_pack_plans(batch), torch.bfloat16, dev)
