@@ -584,6 +584,17 @@ def cpu_reference_baseline(max_seconds=90.0, parity_dev=None):
     return {"value": CFG["B"] / full, "unit": "training pairs/s", "cores": threads, "kind": kind, "sample": note}, parity
 
 
+def _flush_c_stdio() -> None:
+    """RCCL prints its version banner through C stdio; on a pipe that buffer is flushed at process exit - AFTER Python's own
+    output, i.e. after the JSON line.  Flush it now so that the JSON line stays the LAST line on stdout."""
+    try:
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -921,10 +932,24 @@ def main():
                                     "what": "pool + normalise x2, similarity / contrastive, marginalised CE, forward + backward at "
                                             f"[B=18, Tg=256, V={V}]: HIP kernels (hipGraph replay) vs the reference's op sequence "
                                             "on the host cores; a baseline, not a target - kernel quality is roofline.frac"}
+        _flush_c_stdio()
         print(json.dumps(out), flush=True)
     barrier(comm)
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+    _quiet_exit()
+
+
+def _quiet_exit() -> None:
+    """Anything a library still holds in C stdio buffers (RCCL's banner) goes to stderr's side of the world: point fd 1 at
+    /dev/null for what is flushed during interpreter shutdown, after our own output has been written."""
+    try:
+        sys.stdout.flush()
+        _flush_c_stdio()
+        devnull = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(devnull, 1)
+    except Exception:
+        pass
 
 
 def main_retriever_only(args):
@@ -1001,6 +1026,7 @@ def main_retriever_only(args):
     elapsed = max_over_ranks(comm, elapsed)
     if comm.rank == 0:
         value = args.gpus * B * args.steps / elapsed
+        _flush_c_stdio()
         print(json.dumps({
             "metric": "training pairs/sec (global batch) retriever-only " + ("bge-small" if small else "bge-large"), "value": value, "unit": "pairs/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -1019,6 +1045,7 @@ def main_retriever_only(args):
     barrier(comm)
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+    _quiet_exit()
 
 
 if __name__ == "__main__":

@@ -91,6 +91,12 @@ class Rendezvous:
             except Exception:
                 all_ok = False
         self.store.add(self.prefix + "/read", 1)
+        if self.rank == 0 and not self.agent:
+            # this rank HOSTS the store: do not walk away (a short-lived process would take the server with it) before every
+            # rank has read the verdict - a rank that found the store gone used to count that as "failed" and fall back alone
+            t0 = time.time()
+            while self.store.add(self.prefix + "/read", 0) < self.world_size and time.time() - t0 < 30.0:
+                time.sleep(0.005)
         return all_ok
 
     def release(self) -> None:

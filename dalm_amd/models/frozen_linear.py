@@ -29,9 +29,10 @@ def enabled() -> bool:
 
 import weakref
 
-# the copies live in a side table keyed (weakly) by the parameter OBJECT, not on it: `torch.save(model)` / pickling a module does
-# not serialise them, and a parameter that goes away takes its copy with it
-_WT_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+# the copies live in a side table keyed by the parameter OBJECT's id, not on the parameter: `torch.save(model)` / pickling a
+# module does not serialise them, and a parameter that goes away takes its copy with it (a finalizer removes the entry; a
+# WeakKeyDictionary cannot hold tensors - its key comparison calls Tensor.__eq__)
+_WT_CACHE: dict = {}
 
 
 def dgrad_weight(w: torch.Tensor, dtype: Optional[torch.dtype] = None) -> Optional[torch.Tensor]:
@@ -43,11 +44,8 @@ def dgrad_weight(w: torch.Tensor, dtype: Optional[torch.dtype] = None) -> Option
         return None
     dtype = dtype or w.dtype
     key = (w.data_ptr(), w._version, w.device, dtype, tuple(w.shape))
-    try:
-        cached = _WT_CACHE.get(w)
-    except TypeError:
-        cached = None
-    if cached is not None and cached[0] == key:
+    cached = _WT_CACHE.get(id(w))
+    if cached is not None and cached[0] == key and cached[2]() is w:
         return cached[1]
     if torch.cuda.is_current_stream_capturing():
         return None
@@ -61,17 +59,17 @@ def dgrad_weight(w: torch.Tensor, dtype: Optional[torch.dtype] = None) -> Option
     with torch.no_grad():
         wt = w.detach().to(dtype).t().contiguous()
     try:
-        _WT_CACHE[w] = (key, wt)
+        fresh = id(w) not in _WT_CACHE
+        _WT_CACHE[id(w)] = (key, wt, weakref.ref(w))
+        if fresh:
+            weakref.finalize(w, _WT_CACHE.pop, id(w), None)
     except TypeError:       # an object that cannot be weakly referenced: recompute next time
-        pass
+        _WT_CACHE.pop(id(w), None)
     return wt
 
 
 def drop_dgrad_copy(w: torch.Tensor) -> None:
-    try:
-        _WT_CACHE.pop(w, None)
-    except TypeError:
-        pass
+    _WT_CACHE.pop(id(w), None)
 
 
 def _compute_dtype(x: torch.Tensor) -> torch.dtype:

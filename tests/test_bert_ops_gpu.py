@@ -72,9 +72,11 @@ def test_add_norm_without_dropout_vs_eager_chain(dev, R, D, wdt):
     torch.autograd.backward([y0, y0.to(torch.bfloat16)], [up32, up16])     # the consumers' cast: its backward up-casts the bf16 gradient
     torch.testing.assert_close(y32.detach(), y0.detach(), rtol=3e-6, atol=3e-6)
     torch.testing.assert_close(r1.grad, r0.grad, rtol=2e-5, atol=2e-6)
-    # d_a = bf16(d_res): equal up to a bf16 rounding flip where d_res differs in its last f32 bits
+    # d_a = bf16(d_res): equal up to a bf16 rounding flip where d_res differs in its last f32 bits (one bf16 ulp of the value; an
+    # element that is the small difference of large terms carries the f32 summation-order error of those terms instead)
     diff = (a1.grad.float() - a0.grad.float()).abs()
-    assert bool((diff <= a0.grad.float().abs() * 2.0 ** -7 + 1e-30).all())
+    ref = a0.grad.float().abs()
+    assert bool((diff <= ref * 2.0 ** -7 + 1e-5 * float(ref.max())).all())
     assert float((diff > 0).float().mean()) < 2e-3
     # only one of the two outputs used downstream
     a2, r2 = a.clone().requires_grad_(True), res.clone().requires_grad_(True)
