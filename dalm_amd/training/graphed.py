@@ -119,7 +119,9 @@ class GraphedStep:
 
     def _capture(self, batch) -> None:
         static = {k: v.clone() for k, v in batch.items()}
-        s = torch.cuda.Stream()
+        if getattr(self, "_warm_stream", None) is None:
+            self._warm_stream = torch.cuda.Stream()
+        s = self._warm_stream
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):  # warm-up off the default stream, as the capture API asks
             for _ in range(self.warmup):
@@ -136,7 +138,13 @@ class GraphedStep:
         # every later eager step then runs on a stream stuck in an invalidated capture (seen with HF Falcon's
         # list-indexed head split: the fall-back step died in dropout's RNG-state lookup)
         g = torch.cuda.CUDAGraph()
-        cs = torch.cuda.Stream()
+        # ONE capture stream for every graph of this step: the caching allocator hands a freed block only to requests on the
+        # stream it was allocated on, so a fresh stream per capture meant that no graph could reuse the pool memory of the graphs
+        # before it (reserved memory grew by a full set of activations per batch shape: 12 trimmed shapes at cfg3 ran out of
+        # 288 GB; tools/graph_pool_probe.py)
+        if getattr(self, "_capture_stream", None) is None:
+            self._capture_stream = torch.cuda.Stream()
+        cs = self._capture_stream
         cs.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(cs):
             g.capture_begin(pool=self.pool)
