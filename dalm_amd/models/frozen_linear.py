@@ -58,6 +58,10 @@ def dgrad_weight(w: torch.Tensor, dtype: Optional[torch.dtype] = None) -> Option
         pass
     with torch.no_grad():
         wt = w.detach().to(dtype).t().contiguous()
+    # the copy is made by kernels on THIS stream and then shared through the cache: a backward of the same module running on
+    # another stream (the retriever-only step runs its two towers on two streams) would pick it up before it is written - one
+    # host sync per weight, once (seen as a wrong first-step gradient at cfg2: 0.62 instead of 0.34)
+    torch.cuda.current_stream(w.device).synchronize()
     try:
         fresh = id(w) not in _WT_CACHE
         _WT_CACHE[id(w)] = (key, wt, weakref.ref(w))
@@ -162,6 +166,7 @@ def _cat_weights(m0: torch.nn.Linear, m1: torch.nn.Linear) -> Optional[torch.Ten
         return None                            # never re-point parameters inside a hipGraph capture
     with torch.no_grad():
         cat = torch.cat((w0.detach(), w1.detach()), dim=0)
+        torch.cuda.current_stream(w0.device).synchronize()      # other streams may run these modules next (see dgrad_weight)
         w0.data = cat[:n0]
         w1.data = cat[n0:]
     for w in (w0, w1):                         # transposed dgrad copies made from the old storage are still VALUES-correct, but

@@ -161,6 +161,7 @@ class LoRAGroup:
             out = self._outs.pop(id(module), None)
             if not self._outs:
                 self._x = None
+                self._misses = 0             # a stash claimed in full: the members do share their input
             return out
         if self._outs:
             # an earlier stash was never claimed (an exception / OOM retry in the middle of a forward, or a model that does not
@@ -187,7 +188,6 @@ class LoRAGroup:
         if not lora_ops.group_supported(x, args):
             return None
         outs = lora_ops.lora_group_forward(x, args)
-        self._misses = 0
         self._x = x
         self._outs = {id(m): o for m, o in zip(self.members, outs)}
         out = self._outs.pop(id(module))

@@ -144,6 +144,7 @@ def test_patched_bert_layers_match_transformers(dev):
     mask = torch.ones(3, 40, dtype=torch.long, device=dev)
     mask[1, 25:] = 0
     outs = []
+    up = torch.randn(3, 40, 256, device=dev)        # (sum h^2 of a LayerNorm output is a constant: a random upstream gradient)
     for m in (ref, new):
         emb = m.embeddings.word_embeddings.weight
         emb.requires_grad_(True)
@@ -151,12 +152,12 @@ def test_patched_bert_layers_match_transformers(dev):
         with torch.autocast("cuda", dtype=torch.bfloat16):
             h = m(ids, mask)[0]
         assert h.dtype == torch.float32
-        (h.float() * mask.unsqueeze(-1)).square().sum().backward()
+        (h.float() * mask.unsqueeze(-1) * up).sum().backward()
         outs.append((h.detach(), emb.grad.clone()))
         emb.requires_grad_(False)
     live = mask.bool()
     assert _rel(outs[1][0][live], outs[0][0][live]) < 2e-3                # bf16 GEMM inputs on both sides; same rounding points
-    assert _rel(outs[1][1], outs[0][1]) < 1e-2
+    assert _rel(outs[1][1], outs[0][1]) < 2e-2
     # the twin is what the next GEMM reads
     lin = new.encoder.layer[0].intermediate.dense
     x = outs[1][0].clone()

@@ -291,13 +291,24 @@ def test_group_protocol(dev):
     finally:
         lora_mod._GROUPS = True
     assert torch.equal(k, k1) and _rel(q, q1) < 1e-4 and _rel(v, v1) < 1e-4   # one member per launch: the same values
-    # a sibling called with ANOTHER tensor while outputs wait in the stash: this model does not share inputs - the group
-    # switches itself off and every member computes on its own from then on
+    # a sibling called with ANOTHER tensor while outputs wait in the stash (an exception / OOM retry mid-forward looks like
+    # this too): the stale stash is dropped and the group serves the new input; THREE such misses in a row - this model does
+    # not share inputs - and the group switches itself off with a warning, every member computes on its own from then on
+    import warnings
+
     q = m.q_proj(x)
     k2 = m.k_proj(x.clone())
     assert torch.equal(k2, k1)
+    assert grp.enabled and grp._misses == 1 and len(grp._outs) == 2        # q / v of the NEW input wait now
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        for _ in range(3):
+            m.k_proj(x.clone())
+            if not grp.enabled:
+                break
     assert not grp.enabled and grp._x is None and not grp._outs
-    assert torch.equal(m.q_proj(x), q1) and torch.equal(m.v_proj(x), v1)
+    assert any("projection group" in str(i.message) for i in w)
+    assert _rel(m.q_proj(x), q1) < 1e-4 and _rel(m.v_proj(x), v1) < 1e-4 and torch.equal(m.k_proj(x), k1)
     assert type(m.k_proj) is lora_mod.GroupedLinear and sorted(m.state_dict()) == sorted(
         ["q_proj.base_layer.weight", "q_proj.lora_A.default.weight", "q_proj.lora_B.default.weight", "k_proj.weight",
          "v_proj.base_layer.weight", "v_proj.lora_A.default.weight", "v_proj.lora_B.default.weight"])
