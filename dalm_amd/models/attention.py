@@ -193,7 +193,12 @@ class _RopeSdpaHip(torch.autograd.Function):
         B, H, T, hd = q.shape
         q2, k2 = tower_ops._rope_launch(q, k, cos, sin, False)
         pk = _pack(mask, B, H, T, causal, q.dtype, q.device)
-        out, lse = _attn_forward(q2, k2, v, pk, scale, causal)
+        # multi-query (ONE key / value head, Falcon-7B): the kernels read it through stride-0 head views - nothing is broadcast
+        # in memory; the backward kernels write per-head dk / dv, summed over the heads below
+        ctx.mqa = k.shape[1] == 1 and H > 1
+        kx = k2.expand(B, H, T, hd) if ctx.mqa else k2
+        vx = v.expand(B, H, T, hd) if ctx.mqa else v
+        out, lse = _attn_forward(q2, kx, vx, pk, scale, causal)
         ctx.save_for_backward(q2, k2, v, out, lse, cos, sin)
         ctx.pack, ctx.scale = pk, scale
         return out
@@ -201,6 +206,10 @@ class _RopeSdpaHip(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_out):
         q2, k2, v, out, lse, cos, sin = ctx.saved_tensors
+        if ctx.mqa:
+            B, H, T, hd = q2.shape
+            dq, dk, dv = _attn_backward(q2, k2.expand(B, H, T, hd), v.expand(B, H, T, hd), out, lse, d_out, ctx.pack, ctx.scale, cos, sin)
+            return dq, dk.sum(dim=1, keepdim=True), dv.sum(dim=1, keepdim=True), None, None, None, None, None
         dq, dk, dv = _attn_backward(q2, k2, v, out, lse, d_out, ctx.pack, ctx.scale, cos, sin)
         return dq, dk, dv, None, None, None, None, None
 
@@ -211,7 +220,8 @@ def rope_fusable(q, k, cos, sin) -> bool:
 
     return (tower_ops.rope_supported(q, k, cos, sin) and cos.dtype == torch.bfloat16 and cos.shape[-1] == q.shape[-1]
             and cos.stride(1) % 8 == 0 and (cos.shape[0] == 1 or cos.stride(0) % 8 == 0)
-            and cos.data_ptr() % 16 == 0 and sin.data_ptr() % 16 == 0 and k.shape == q.shape)
+            and cos.data_ptr() % 16 == 0 and sin.data_ptr() % 16 == 0
+            and (k.shape == q.shape or (k.shape[1] == 1 and k.shape[0] == q.shape[0] and k.shape[2:] == q.shape[2:])))
 
 
 def rope_sdpa(query, key, value, cos, sin, mask, scale: float, causal: bool):

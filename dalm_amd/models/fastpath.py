@@ -460,22 +460,42 @@ def _falcon_attention_forward(self, hidden_states, alibi, attention_mask, positi
     num_kv_heads = self.num_heads if self.new_decoder_architecture else self.num_kv_heads
     query_layer, key_layer, value_layer = self._split_heads(fused_qkv)
     batch_size, query_length, _, _ = query_layer.shape
-    if getattr(self, "_dalm_expand_kv", False) and num_kv_heads == 1 and key_layer.shape[2] == 1:
-        # THIS call only (training, no KV cache): the one shared key / value head broadcast to the query heads (views; the
-        # reshape below materialises them) - equal head counts for the kernels and for torch's fused SDPA
+    cos, sin = position_embeddings
+    is_causal = bool(self.is_causal and attention_mask is None and query_length > 1)
+    rope_on = os.environ.get("DALM_ROPE_KERNEL", "1") != "0" and os.environ.get("DALM_FAST_ROPE", "1") != "0"
+    mqa = bool(getattr(self, "_dalm_expand_kv", False) and num_kv_heads == 1 and key_layer.shape[2] == 1)
+    if mqa and rope_on and os.environ.get("DALM_FALCON_MQA_VIEWS", "1") != "0":
+        # multi-query, THIS call only (training, no KV cache): the ONE shared key / value head stays one head in memory.  The
+        # rotation runs on the single key head, the attention kernels read key / value through stride-0 head views (every head
+        # the same rows, served by the caches) - the 71 copies of K and V that the broadcast-then-reshape form materialises per
+        # layer (2 x 93 us at cfg5, profiles/r06cfg5packed_step_by_stream.txt) never exist; dk / dv are summed over the heads
+        # after the backward kernels, as autograd's expand backward would
+        H, hd = self.num_heads, self.head_dim
+        q4 = query_layer.transpose(1, 2).reshape(batch_size, H, query_length, hd)
+        k1, v1 = key_layer.transpose(1, 2), value_layer.transpose(1, 2)                      # [b, 1, t, hd] views of fused_qkv
+        kx, vx = k1.expand(batch_size, H, query_length, hd), v1.expand(batch_size, H, query_length, hd)
+        seqs = attention.packed_of(attention_mask)
+        ok = (attention.packed_supported(q4, kx, vx) if seqs is not None
+              else attention.supported(q4, kx, vx, attention_mask, 0.0, is_causal, {}))
+        if ok and attention.rope_fusable(q4, k1, cos, sin):
+            attn_output = attention.rope_sdpa(q4, k1, v1, cos, sin, attention_mask, float(hd) ** -0.5,
+                                              False if seqs is not None else is_causal)
+            attn_output = attn_output.permute(0, 2, 1, 3).reshape(batch_size, query_length, H * hd)
+            return self.dense(attn_output), None
+    if mqa:
+        # the one shared key / value head broadcast to the query heads (views; the reshape below materialises them) - equal head
+        # counts for the kernels and for torch's fused SDPA
         key_layer = key_layer.expand(batch_size, query_length, self.num_heads, self.head_dim)
         value_layer = value_layer.expand(batch_size, query_length, self.num_heads, self.head_dim)
         num_kv_heads = self.num_heads
     query_layer = query_layer.transpose(1, 2).reshape(batch_size, self.num_heads, query_length, self.head_dim)
     key_layer = key_layer.transpose(1, 2).reshape(batch_size, num_kv_heads, query_length, self.head_dim)
     value_layer = value_layer.transpose(1, 2).reshape(batch_size, num_kv_heads, query_length, self.head_dim)
-    cos, sin = position_embeddings
-    is_causal = bool(self.is_causal and attention_mask is None and query_length > 1)
     seqs = attention.packed_of(attention_mask)
     if seqs is not None:
         # packed (un-padded) call (dalm_amd/packed.py): [1, H, n, hd], sequences from the descriptor
-        if (attention.packed_supported(query_layer, key_layer, value_layer) and attention.rope_fusable(query_layer, key_layer, cos, sin)
-                and os.environ.get("DALM_ROPE_KERNEL", "1") != "0" and os.environ.get("DALM_FAST_ROPE", "1") != "0"):
+        if attention.packed_supported(query_layer, key_layer, value_layer) and attention.rope_fusable(query_layer, key_layer, cos, sin) \
+                and rope_on:
             attn_output = attention.rope_sdpa(query_layer, key_layer, value_layer, cos, sin, attention_mask,
                                               float(self.head_dim) ** -0.5, False)
             attn_output = attn_output.permute(0, 2, 1, 3)
@@ -487,8 +507,7 @@ def _falcon_attention_forward(self, hidden_states, alibi, attention_mask, positi
         attn_output = attn_output.reshape(batch_size, query_length, self.num_heads * self.head_dim)
         return self.dense(attn_output), None
     if (attention.supported(query_layer, key_layer, value_layer, attention_mask, 0.0, is_causal, {})
-            and attention.rope_fusable(query_layer, key_layer, cos, sin) and os.environ.get("DALM_ROPE_KERNEL", "1") != "0"
-            and os.environ.get("DALM_FAST_ROPE", "1") != "0"):
+            and attention.rope_fusable(query_layer, key_layer, cos, sin) and rope_on):
         attn_output = attention.rope_sdpa(query_layer, key_layer, value_layer, cos, sin, attention_mask,
                                           float(self.head_dim) ** -0.5, is_causal)     # the rotation's backward: in dalm_attn_bwd
         attn_output = attn_output.view(batch_size, self.num_heads, query_length, self.head_dim)

@@ -265,6 +265,12 @@ class RagE2EStep(_StepBase):
             else:
                 p_emb, q_emb, p_gather, q_gather = self._towers(batch)
                 logits = self._generator(batch)
+        if (self._packed_generator(batch) or self.fuse_lm_head) and self.autocast_dtype is not None \
+                and logits.dtype != self.autocast_dtype:
+            # the reference's lm_head runs INSIDE the autocast'ed model forward: nn.Linear casts its input to the autocast dtype.
+            # A decoder whose final norm is an nn.LayerNorm (Falcon: autocast runs layer_norm in f32) hands back f32 hidden
+            # states - without this cast the head GEMMs of the from-hidden paths ran in f32 (2.2 ms each at cfg5)
+            logits = logits.to(self.autocast_dtype)
         if self._packed_generator(batch):
             head = m.generator_model.get_output_embeddings()
             if getattr(head, "bias", None) is not None:

@@ -404,3 +404,55 @@ def test_bert_layer_on_dalm_sdpa_trains_with_dropout(dev):
         h2 = new(input_ids=ids, attention_mask=am)[0]
     assert torch.isfinite(h1).all() and torch.equal(h1, h2) and not torch.equal(h1[live], outs[1][0][live])
     h1.float().sum().backward()
+
+
+@pytest.mark.parametrize("packed_mode", [False, True])
+def test_multi_query_shared_head_through_stride0_views(dev, packed_mode):
+    """Falcon-7B's multi-query attention: ONE key / value head.  `rope_sdpa` with a [B, 1, T, hd] key / value reads them through
+    stride-0 head views (nothing broadcast in memory) and sums dk / dv over the heads - against the same call on keys / values
+    broadcast and materialised first (what transformers' FalconAttention.forward builds), padded and packed layouts."""
+    from dalm_amd import packed
+    from dalm_amd.models import attention
+
+    B, H, T, hd = 3, 7, 128, 64
+    g = torch.Generator().manual_seed(17)
+    lens = [128, 50, 90]
+    m2 = (torch.arange(T).unsqueeze(0) >= (T - torch.tensor(lens)).unsqueeze(1)).long()
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, device=dev).float() / hd))
+    if packed_mode:
+        rows, cu = packed.pack_plan(m2, shifted=True, multiple=64)
+        _i, pos, mask, _v = packed.packed_inputs(torch.zeros(B, T, dtype=torch.long, device=dev), m2.to(dev), rows.to(dev), cu.to(dev), True)
+        n, Bq = rows.numel(), 1
+        ang = pos[0].float()[:, None] * inv[None, :]
+        causal = False
+    else:
+        n, Bq = T, B
+        mask = _hf_mask(B, T, [T - l for l in lens], dev)
+        ang = torch.arange(T, device=dev).float()[:, None] * inv[None, :]
+        causal = False
+    cos = torch.cat((ang.cos(), ang.cos()), -1).to(torch.bfloat16)[None]
+    sin = torch.cat((ang.sin(), ang.sin()), -1).to(torch.bfloat16)[None]
+    fused = (0.7 * torch.randn(Bq, n, H + 2, hd, generator=g)).to(dev, torch.bfloat16)
+    go = torch.randn(Bq, H, n, hd, generator=g).to(dev, torch.bfloat16)
+    scale = hd ** -0.5
+
+    def run(materialise):
+        f = fused.clone().requires_grad_(True)
+        q = f[..., :H, :].transpose(1, 2).reshape(Bq, H, n, hd)
+        k1, v1 = f[..., H:H + 1, :].transpose(1, 2), f[..., H + 1:, :].transpose(1, 2)
+        if materialise:
+            k = k1.expand(Bq, H, n, hd).reshape(Bq, H, n, hd).contiguous()
+            v = v1.expand(Bq, H, n, hd).reshape(Bq, H, n, hd).contiguous()
+            assert attention.rope_fusable(q, k, cos, sin)
+            out = attention.rope_sdpa(q, k, v, cos, sin, mask, scale, causal)
+        else:
+            assert attention.rope_fusable(q, k1, cos, sin) and k1.shape[1] == 1
+            out = attention.rope_sdpa(q, k1, v1, cos, sin, mask, scale, causal)
+        out.backward(go)
+        return out.detach(), f.grad
+
+    o_ref, g_ref = run(True)
+    o_mqa, g_mqa = run(False)
+    assert torch.equal(o_mqa, o_ref)                                   # the same kernel on the same values
+    assert _rel(g_mqa[..., :H, :], g_ref[..., :H, :]) < 1e-6           # dq: identical launches
+    assert _rel(g_mqa[..., H:, :], g_ref[..., H:, :]) < 4e-3           # dk, dv: per-head bf16 gradients summed over the heads
