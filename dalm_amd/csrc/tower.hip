@@ -142,6 +142,13 @@ __device__ __forceinline__ RowCol row_col(int64_t e, int64_t C) {
   return {r, ee - r * cc};
 }
 __device__ __forceinline__ int64_t ld_at(const RowCol& rc, int64_t ld) { return static_cast<int64_t>(rc.row) * ld + rc.col; }
+// the tile `step` elements further on: no division (ONE per thread for its first tile; the silu itself is a dozen f32 operations
+// per element, eight divisions per thread cost the first form a third of its rate)
+__device__ __forceinline__ RowCol advance(RowCol rc, unsigned int step, unsigned int C) {
+  rc.col += step;
+  while (rc.col >= C) { rc.col -= C; ++rc.row; }
+  return rc;
+}
 
 template <typename T, int STEPS>
 __global__ __launch_bounds__(256) void swiglu_fwd_2d_kernel(const T* __restrict__ g, const T* __restrict__ u, T* __restrict__ a,
@@ -149,13 +156,16 @@ __global__ __launch_bounds__(256) void swiglu_fwd_2d_kernel(const T* __restrict_
   constexpr int VEC = EV<T>::VEC;
   const int64_t base = (static_cast<int64_t>(blockIdx.x) * STEPS * 256 + threadIdx.x) * VEC;
   float gv[STEPS][VEC], uv[STEPS][VEC];
+  RowCol rc[STEPS];
+  rc[0] = row_col(base < n ? base : 0, ld.C);
+#pragma unroll
+  for (int k = 1; k < STEPS; ++k) rc[k] = advance(rc[k - 1], 256 * VEC, static_cast<unsigned int>(ld.C));
 #pragma unroll
   for (int k = 0; k < STEPS; ++k) {
     const int64_t e0 = base + static_cast<int64_t>(k) * 256 * VEC;
     if (e0 < n) {
-      const RowCol rc = row_col(e0, ld.C);
-      EV<T>::load(g + ld_at(rc, ld.g), gv[k]);
-      EV<T>::load(u + ld_at(rc, ld.u), uv[k]);
+      EV<T>::load(g + ld_at(rc[k], ld.g), gv[k]);
+      EV<T>::load(u + ld_at(rc[k], ld.u), uv[k]);
     }
   }
 #pragma unroll
@@ -165,7 +175,7 @@ __global__ __launch_bounds__(256) void swiglu_fwd_2d_kernel(const T* __restrict_
     float o[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) o[e] = EV<T>::rb(__fmul_rn(EV<T>::rb(silu_f32(gv[k][e])), uv[k][e]));
-    EV<T>::store(a + ld_at(row_col(e0, ld.C), ld.a), o);
+    EV<T>::store(a + ld_at(rc[k], ld.a), o);
   }
 }
 
@@ -176,14 +186,17 @@ __global__ __launch_bounds__(256) void swiglu_bwd_2d_kernel(const T* __restrict_
   constexpr int VEC = EV<T>::VEC;
   const int64_t base = (static_cast<int64_t>(blockIdx.x) * STEPS * 256 + threadIdx.x) * VEC;
   float av[STEPS][VEC], gv[STEPS][VEC], uv[STEPS][VEC];
+  RowCol rc[STEPS];
+  rc[0] = row_col(base < n ? base : 0, ld.C);
+#pragma unroll
+  for (int k = 1; k < STEPS; ++k) rc[k] = advance(rc[k - 1], 256 * VEC, static_cast<unsigned int>(ld.C));
 #pragma unroll
   for (int k = 0; k < STEPS; ++k) {
     const int64_t e0 = base + static_cast<int64_t>(k) * 256 * VEC;
     if (e0 < n) {
-      const RowCol rc = row_col(e0, ld.C);
-      EV<T>::load(da + ld_at(rc, ld.a), av[k]);
-      EV<T>::load(g + ld_at(rc, ld.g), gv[k]);
-      EV<T>::load(u + ld_at(rc, ld.u), uv[k]);
+      EV<T>::load(da + ld_at(rc[k], ld.a), av[k]);
+      EV<T>::load(g + ld_at(rc[k], ld.g), gv[k]);
+      EV<T>::load(u + ld_at(rc[k], ld.u), uv[k]);
     }
   }
 #pragma unroll
@@ -200,9 +213,8 @@ __global__ __launch_bounds__(256) void swiglu_bwd_2d_kernel(const T* __restrict_
       const float sig = 1.0f / (1.0f + expf(-x));
       og[e] = EV<T>::rb(ds * sig * (1.0f + x * (1.0f - sig)));
     }
-    const RowCol rc = row_col(e0, ld.C);
-    EV<T>::store(dg + ld_at(rc, ld.dg), og);
-    EV<T>::store(du + ld_at(rc, ld.du), ou);
+    EV<T>::store(dg + ld_at(rc[k], ld.dg), og);
+    EV<T>::store(du + ld_at(rc[k], ld.du), ou);
   }
 }
 

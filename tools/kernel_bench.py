@@ -125,8 +125,10 @@ def bench_sim(m, n, D):
         # f32-EQUIVALENT rate 2 m n D / t (the kernel executes 6 x that on the bf16 pipe); sim_rowstats itself routes
         # m, n >= 4096 there, so the exact-f32 kernel is timed through its pinned entry point
         med, _ = time_fn(lambda: ops.sim_rowstats_bf16x3(A, Bm, 100.0, 0), iters=10, warmup=3)
-        out["rowstats_bf16x3"] = {"s": med, "TFLOPs": 2.0 * m * n * D / med / 1e12, "frac_of_f32_peak": 2.0 * m * n * D / med / MFMA_F32_PEAK,
-                                  "bf16_TFLOPs": 12.0 * m * n * D / med / 1e12, "frac_of_bf16_peak": 12.0 * m * n * D / med / 2.5e15}
+        # priced on the flops ISSUED against the bf16 peak only: an f32-equivalent rate over the f32 peak reads above 1 here
+        # (1.21 / 1.43 in earlier files) and says nothing about the kernel
+        out["rowstats_bf16x3"] = {"s": med, "TFLOPs_f32_equivalent": 2.0 * m * n * D / med / 1e12, "pipe": "bf16 x3",
+                                  "TFLOPs_issued": 12.0 * m * n * D / med / 1e12, "frac": 12.0 * m * n * D / med / 2.5e15}
         med, _ = time_fn(lambda: ops.sim_rowstats_f32(A, Bm, 100.0, 0), iters=10, warmup=3)
         out["rowstats_f32"] = {"s": med, "TFLOPs": 2.0 * m * n * D / med / 1e12, "frac": 2.0 * m * n * D / med / MFMA_F32_PEAK}
     if m * n <= 20000 * 20000:
@@ -253,6 +255,16 @@ def bench_tower(B, T, H, hd, inter, dtype):
     out["swiglu bwd (1 launch)"] = {"s": med, "GBps": 5 * n * el / med / 1e9, "frac": 5 * n * el / med / HBM_PEAK}
     med, _ = time_graph(lambda: torch.nn.functional.silu(gate) * up)
     out["swiglu fwd eager (2 launches)"] = {"s": med, "GBps": 3 * n * el / med / 1e9, "frac": 3 * n * el / med / HBM_PEAK}
+    # the same on the two halves of ONE [rows, 2 C] GEMM output (gate | up as one forward GEMM, models/frozen_linear.py)
+    R, Cc = B * T, inter
+    both = torch.randn(R, 2 * Cc, device=dev, dtype=dtype)
+    g2, u2 = both[:, :Cc], both[:, Cc:]
+    med, _ = time_graph(lambda: hip.call("dalm_swiglu_fwd_2d", hip.ptr(g2), hip.ptr(u2), hip.ptr(act), code, R, Cc, 2 * Cc, 2 * Cc, Cc,
+                                         hip.stream()))
+    out["swiglu fwd, halves of one buffer"] = {"s": med, "GBps": 3 * n * el / med / 1e9, "frac": 3 * n * el / med / HBM_PEAK}
+    med, _ = time_graph(lambda: hip.call("dalm_swiglu_bwd_2d", hip.ptr(da), hip.ptr(g2), hip.ptr(u2), hip.ptr(dg), hip.ptr(du), code,
+                                         R, Cc, Cc, 2 * Cc, 2 * Cc, Cc, Cc, hip.stream()))
+    out["swiglu bwd, halves of one buffer"] = {"s": med, "GBps": 5 * n * el / med / 1e9, "frac": 5 * n * el / med / HBM_PEAK}
     return out
 
 
