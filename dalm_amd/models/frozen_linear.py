@@ -178,6 +178,29 @@ def _cat_weights(m0: torch.nn.Linear, m1: torch.nn.Linear) -> Optional[torch.Ten
     return cat
 
 
+def uncat_weights(model: torch.nn.Module) -> int:
+    """Give every projection pair that shares ONE concatenated weight tensor (`_cat_weights`) its own storage again - for callers
+    that serialise whole modules tensor by tensor (`save_pretrained` of a frozen full model: safetensors refuses tensors that share
+    memory).  The next eligible forward concatenates again.  Returns how many pairs were separated."""
+    n = 0
+    for m in model.modules():
+        if getattr(m, "_dalm_cat", None) is None:
+            continue
+        cat = m._dalm_cat
+        for other in model.modules():
+            w = getattr(other, "weight", None)
+            if isinstance(w, torch.Tensor) and w.dim() == 2 and w.untyped_storage().data_ptr() == cat.untyped_storage().data_ptr():
+                with torch.no_grad():
+                    w.data = w.detach().clone()
+                drop_dgrad_copy(w)
+        try:
+            del m._dalm_cat
+        except Exception:
+            m._dalm_cat = None
+        n += 1
+    return n
+
+
 class _FrozenCatPairFn(torch.autograd.Function):
     """(x W0^T, x W1^T) as the two column halves of ONE GEMM output x [W0; W1]^T; backward: the two accumulating dgrad GEMMs of
     `_FrozenPairFn` (one GEMM over the 2 N-deep contraction measured slower at 4608 rows, tools/gemm_concat_probe.py), reading the

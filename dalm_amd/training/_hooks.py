@@ -18,6 +18,9 @@ def save_submodel(model: torch.nn.Module, path: str) -> None:
     if lora.has_lora(model):
         lora.save_adapter(model, path)
     else:
+        from ..models.frozen_linear import uncat_weights
+
+        uncat_weights(model)          # projection pairs that run as one GEMM share one weight tensor: separate them for the writer
         model.save_pretrained(path)
 
 

@@ -139,3 +139,22 @@ def test_gate_up_as_one_gemm_equals_the_two_gemms(dev, mode):
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode == "f32-autocast"):
         g2, _ = FL.pair_forward(xi, m0, m1)
     assert _rel(g2, sep[1]) < 2e-3 and m1.weight.data_ptr() == m0.weight.data_ptr() + N * K * m0.weight.element_size()
+
+
+def test_uncat_weights_restores_separate_storages(dev):
+    from dalm_amd.models import frozen_linear as FL
+
+    torch.manual_seed(3)
+    mlp = torch.nn.ModuleDict({"gate_proj": torch.nn.Linear(128, 256, bias=False), "up_proj": torch.nn.Linear(128, 256, bias=False)})
+    mlp = mlp.to(dev, torch.bfloat16).requires_grad_(False)
+    want = {k: v.detach().clone() for k, v in mlp.state_dict().items()}
+    x = torch.randn(8, 128, device=dev, dtype=torch.bfloat16, requires_grad=True)
+    FL.pair_forward(x, mlp["gate_proj"], mlp["up_proj"])
+    g, u = mlp["gate_proj"].weight, mlp["up_proj"].weight
+    assert g.untyped_storage().data_ptr() == u.untyped_storage().data_ptr()
+    assert FL.uncat_weights(mlp) == 1
+    g, u = mlp["gate_proj"].weight, mlp["up_proj"].weight
+    assert g.untyped_storage().data_ptr() != u.untyped_storage().data_ptr()
+    assert all(torch.equal(v, want[k]) for k, v in mlp.state_dict().items())
+    y0, y1 = FL.pair_forward(x, mlp["gate_proj"], mlp["up_proj"])                  # concatenates again
+    assert mlp["gate_proj"].weight.untyped_storage().data_ptr() == mlp["up_proj"].weight.untyped_storage().data_ptr()
