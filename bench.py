@@ -335,7 +335,7 @@ def f1_head_paths(dev, batch, model, iters=6):
     res = {}
     saved = os.environ.get("DALM_LM_HEAD_TRAIN_KERNEL")
     try:
-        for name, env in (("kernels", "1"), ("library", "0")):
+        for name, env in (("kernels", "1"), ("kernels2", "2"), ("library", "0")):
             os.environ["DALM_LM_HEAD_TRAIN_KERNEL"] = env
 
             def call():
@@ -359,14 +359,18 @@ def f1_head_paths(dev, batch, model, iters=6):
             os.environ.pop("DALM_LM_HEAD_TRAIN_KERNEL", None)
         else:
             os.environ["DALM_LM_HEAD_TRAIN_KERNEL"] = saved
-    k, l = res["kernels"], res["library"]
+    k, l, k2 = res["kernels"], res["library"], res["kernels2"]
     return {"rows": int(live.numel()) if live is not None else B * Tg, "V": V, "H": H,
             "kernels_ms": k[0], "library_ms": l[0], "kernels_over_library": k[0] / l[0],
+            "kernels_two_contractions_ms": k2[0], "kernels_two_contractions_over_library": k2[0] / l[0],
+            "kernels_two_contractions_dhidden_rel_diff": float((k2[2] - l[2]).norm() / l[2].norm()),
             "loss_rel_diff": abs(k[1] - l[1]) / max(abs(l[1]), 1e-30),
             "dhidden_rel_diff": float((k[2] - l[2]).norm() / l[2].norm()),
             "note": "lm_head + marginalised CE + d(hidden) over the live rows, eager launches (HIP events over "
                     f"{iters} calls): `kernels` = dalm_lm_head_lse_fwd + dalm_lm_head_dlogits / dalm_transpose_bf16 / "
-                    "dalm_lm_head_dhidden (three contractions, the logits recomputed; workspace <= 160 MB), `library` = torch.mm "
+                    "dalm_lm_head_dhidden (three contractions, the logits recomputed; workspace <= 160 MB), `kernels_two_contractions` "
+                    "= dalm_lm_head_logits + the fused CE kernel in place + dalm_lm_head_dhidden per row chunk (hand-written, no "
+                    "recomputation: the chunk's logits stay in the Infinity Cache; DALM_LM_HEAD_TRAIN_KERNEL=2), `library` = torch.mm "
                     "x2 + the fused CE kernel in row chunks.  RagE2EStep(fuse_lm_head='auto') takes the fused path when a batch's "
                     "logits would exceed DALM_LOGITS_BUDGET_MB (1024)"}
 

@@ -236,7 +236,7 @@ struct Lm8Params {
 };
 
 constexpr int L8_BUF = 65536;
-constexpr int EPI_LSE = 0, EPI_DLOGITS = 2, EPI_CSTORE = 3, EPI_DS3 = 4;
+constexpr int EPI_LSE = 0, EPI_DLOGITS = 2, EPI_CSTORE = 3, EPI_DS3 = 4, EPI_LOGITS = 5;
 
 // Tile order.  The ordered tile list walks the output in bands of gh row tiles - within a band vocabulary tile by vocabulary
 // tile, the band's row tiles innermost - and every XCD (workgroup L runs on XCD L % 8, own 4 MB L2) works through ONE
@@ -425,13 +425,16 @@ __device__ __forceinline__ void lm_tile_epilogue_gmax(const Lm8Params& p, f32x16
 // operand of the d(hidden) contraction).  Reference math: dalm/training/utils/train_utils.py:113-138 differentiated (SURVEY 8a:
 // dL/dlogits[b,t,:] = (m_bt / M) (softmax - onehot)); coef carries m_bt / M.  Lanes l and l ^ 1 hold adjacent columns: one DPP
 // exchange per pair of accumulator registers lets every lane store one dword (2 bf16) instead of two shorts.
+// RAW (EPI_LOGITS): the tile leaves as it is, rounded to bf16 - the logits chunk of the two-contraction training path (round 6:
+// logits chunk kept in the Infinity Cache, the fused CE kernel turns it into d(logits) in place, dalm_lm_head_dhidden contracts it).
+template <bool RAW>
 __device__ __forceinline__ void lm_tile_epilogue_dlogits(const Lm8Params& p, f32x16 (&acc)[4][4], unsigned char* lds, int r0, int c0,
                                                          int wr, int wc, int tid) {
   const int lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
   float* lse_s = reinterpret_cast<float*>(lds);              // [256] -lse * log2(e)
   float* cf_s = lse_s + 256;                                  // [256] coef
   int* lab_s = reinterpret_cast<int*>(lse_s + 512);           // [256] label - c0 (or -1)
-  {
+  if constexpr (!RAW) {
     const int r = r0 + tid;
     float l = 0.f, c = 0.f;
     int y = -1;
@@ -452,11 +455,16 @@ __device__ __forceinline__ void lm_tile_epilogue_dlogits(const Lm8Params& p, f32
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int rl4 = wr * 128 + i * 32 + 8 * g + 4 * lhi;     // rows rl4 .. rl4 + 3 = accumulator registers 4 g .. 4 g + 3
-      const float4 l4 = *reinterpret_cast<const float4*>(lse_s + rl4);
-      const float4 c4 = *reinterpret_cast<const float4*>(cf_s + rl4);
-      const int4 y4 = *reinterpret_cast<const int4*>(lab_s + rl4);
-      const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, cs[4] = {c4.x, c4.y, c4.z, c4.w};
-      const int ys[4] = {y4.x, y4.y, y4.z, y4.w};
+      float ls[4] = {0.f, 0.f, 0.f, 0.f}, cs[4] = {0.f, 0.f, 0.f, 0.f};
+      int ys[4] = {-1, -1, -1, -1};
+      if constexpr (!RAW) {
+        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + rl4);
+        const float4 c4 = *reinterpret_cast<const float4*>(cf_s + rl4);
+        const int4 y4 = *reinterpret_cast<const int4*>(lab_s + rl4);
+        ls[0] = l4.x; ls[1] = l4.y; ls[2] = l4.z; ls[3] = l4.w;
+        cs[0] = c4.x; cs[1] = c4.y; cs[2] = c4.z; cs[3] = c4.w;
+        ys[0] = y4.x; ys[1] = y4.y; ys[2] = y4.z; ys[3] = y4.w;
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int col = colw + 32 * j;
@@ -464,8 +472,12 @@ __device__ __forceinline__ void lm_tile_epilogue_dlogits(const Lm8Params& p, f32
         float v[4];
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-          const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[i][j][4 * g + rr], kLog2e, ls[rr]));
-          v[rr] = live ? cs[rr] * (pr - (ys[rr] == col ? 1.f : 0.f)) : 0.f;
+          if constexpr (RAW) {
+            v[rr] = live ? acc[i][j][4 * g + rr] : 0.f;
+          } else {
+            const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[i][j][4 * g + rr], kLog2e, ls[rr]));
+            v[rr] = live ? cs[rr] * (pr - (ys[rr] == col ? 1.f : 0.f)) : 0.f;
+          }
         }
         // register pairs (0, 1) and (2, 3): the even lane stores row a (its column and the odd neighbour's), the odd lane row b
 #pragma unroll
@@ -719,7 +731,8 @@ __global__ __launch_bounds__(256, 1) void lm_head_lse4w_kernel(const Lm8Params p
   __builtin_amdgcn_s_barrier();
 
   if constexpr (EPI == EPI_DS3) lm_tile_epilogue_ds3(p, acc, lds, r0, c0, wr, wc, tid);
-  else if constexpr (EPI == EPI_DLOGITS) lm_tile_epilogue_dlogits(p, acc, lds, r0, c0, wr, wc, tid);
+  else if constexpr (EPI == EPI_DLOGITS) lm_tile_epilogue_dlogits<false>(p, acc, lds, r0, c0, wr, wc, tid);
+  else if constexpr (EPI == EPI_LOGITS) lm_tile_epilogue_dlogits<true>(p, acc, lds, r0, c0, wr, wc, tid);
   else if constexpr (EPI == EPI_CSTORE) lm_tile_epilogue_cstore(p, acc, r0, c0, wr, wc, tid);
   else if constexpr (GMAX) lm_tile_epilogue_gmax(p, acc, r0, c0, wr, wc, tid);
   else lm_tile_epilogue<ABL>(p, acc, lds, r0, c0, nt, wr, wc, tid);
@@ -1119,6 +1132,30 @@ extern "C" int dalm_lm_head_dlogits(const void* hidden, const void* weight_chunk
   q.out = dl; q.out_pitch = pitch; q.out_cols = static_cast<int>(pitch); q.accumulate = 0;
   DALM_REQUIRE(static_cast<int64_t>(q.MT) * q.NT <= 0x7fffffffll, DALM_E_SHAPE, "too many tiles for one launch");
   hipLaunchKernelGGL((lm_head_lse4w_kernel<8, 8, 0, 0, 0, false, false, EPI_DLOGITS>), dim3(static_cast<unsigned>(q.MT) * q.NT),
+                     dim3(256), 0, as_stream(stream), q);
+  return check_launch(__func__);
+}
+
+extern "C" int dalm_lm_head_logits(const void* hidden, const void* weight, int64_t R, int64_t V, int64_t K, void* logits, int64_t pitch,
+                                   dalm_stream_t stream) {
+  DALM_REQUIRE(hidden && weight && logits, DALM_E_NULL, "null pointer argument");
+  DALM_REQUIRE(R > 0 && V > 0 && K > 0 && K % 64 == 0, DALM_E_SHAPE, "need R, V > 0 and K a positive multiple of 64");
+  DALM_REQUIRE(pitch >= V && pitch % 2 == 0, DALM_E_SHAPE, "pitch must be even and at least V");
+  DALM_REQUIRE(reinterpret_cast<uintptr_t>(hidden) % 16 == 0 && reinterpret_cast<uintptr_t>(weight) % 16 == 0 &&
+               reinterpret_cast<uintptr_t>(logits) % 4 == 0, DALM_E_ALIGN, "hidden / weight must be 16-byte aligned");
+  const uint64_t bytesH = static_cast<uint64_t>(R + 256) * K * 2, bytesW = static_cast<uint64_t>(V + 256) * K * 2;
+  DALM_REQUIRE(bytesH < 0xffffff00ull && bytesW < 0xffffff00ull, DALM_E_SHAPE, "operands above 4 GB: use smaller chunks");
+  Lm8Params q;
+  q.H = hidden; q.W = weight; q.labels = nullptr; q.K = static_cast<int>(K);
+  lm8_geometry(q, R, V);
+  q.bytesH = static_cast<unsigned>(static_cast<uint64_t>(R) * K * 2);
+  q.bytesW = static_cast<unsigned>(static_cast<uint64_t>(V) * K * 2);
+  q.pitchH = q.pitchW = static_cast<unsigned>(K * 2);
+  q.row_lse = nullptr; q.coef = nullptr; q.col_base = 0;
+  q.out = logits; q.out_pitch = pitch; q.out_cols = static_cast<int>(V % 2 ? V + 1 : V) <= pitch ? static_cast<int>(V % 2 ? V + 1 : V) : static_cast<int>(pitch);
+  q.accumulate = 0;
+  DALM_REQUIRE(static_cast<int64_t>(q.MT) * q.NT <= 0x7fffffffll, DALM_E_SHAPE, "too many tiles for one launch");
+  hipLaunchKernelGGL((lm_head_lse4w_kernel<8, 8, 0, 0, 0, false, false, EPI_LOGITS>), dim3(static_cast<unsigned>(q.MT) * q.NT),
                      dim3(256), 0, as_stream(stream), q);
   return check_launch(__func__);
 }

@@ -398,6 +398,15 @@ def _row_chunks(rows: int, cap: int, unit: int):
     return [z for z in sizes if z > 0]
 
 
+def _use_two_contraction_kernels(ops, hc_all, w, dw, need_grad) -> bool:
+    """DALM_LM_HEAD_TRAIN_KERNEL=2: the row-chunk path below with BOTH contractions on the library's own bf16 MFMA kernels
+    (`dalm_lm_head_logits`, `dalm_lm_head_dhidden`) instead of hipBLASLt - the hand-written form of f1 WITHOUT the third
+    contraction (round 5 recomputed the logits for the backward): frozen bf16 head, V a multiple of 64, hidden width a multiple of 64."""
+    return (os.environ.get("DALM_LM_HEAD_TRAIN_KERNEL") == "2" and need_grad and dw is None and hc_all.is_cuda
+            and hc_all.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0
+            and hasattr(ops, "lm_head_logits"))
+
+
 def _lm_head_rows(ops, hc_all, w, ids_c, mask_c, stats, chunk_rows, dw, need_grad=True):
     """lm_head + marginalised CE + d(hidden) of a COMPACT list of rows: hc_all [Rp, H] hidden states, ids_c / mask_c [Rp] the
     label and the weight of each row (already shifted: row r predicts ids_c[r] with weight mask_c[r]).  The CE kernel sees each
@@ -413,10 +422,21 @@ def _lm_head_rows(ops, hc_all, w, ids_c, mask_c, stats, chunk_rows, dw, need_gra
     nll_c[Rp].zero_()
     zero1 = ids_c.new_zeros((1,))
     r1 = 0
+    kernels2 = _use_two_contraction_kernels(ops, hc_all, w, dw, need_grad)
+    wt = None
+    if kernels2:
+        from .models.frozen_linear import dgrad_weight
+
+        wt = dgrad_weight(w, torch.bfloat16)                     # the head's transposed copy [K, V] (frozen: made once)
+        if wt is None:
+            wt = w.t().contiguous()
     for n in _row_chunks(Rp, chunk_rows, gemm_wave_rows(V)):
         r0, r1 = r1, r1 + n
         buf = torch.empty((n + 1, V), device=hc_all.device, dtype=hc_all.dtype)
-        torch.mm(hc_all[r0:r1], w.t(), out=buf[:n])
+        if kernels2:
+            ops.lm_head_logits(hc_all[r0:r1], w, buf)
+        else:
+            torch.mm(hc_all[r0:r1], w.t(), out=buf[:n])
         ids_v = torch.cat((zero1, ids_c[r0:r1])).view(1, n + 1)
         mask_v = torch.cat((zero1.to(mask_c.dtype), mask_c[r0:r1])).view(1, n + 1)
         _lse, nll_v, dl_v = ops.ce_fwd(buf.view(1, n + 1, V), ids_v, mask_v, stats, need_grad, need_grad)
@@ -424,6 +444,9 @@ def _lm_head_rows(ops, hc_all, w, ids_c, mask_c, stats, chunk_rows, dw, need_gra
         if not need_grad:
             continue
         dl2 = dl_v.view(n + 1, V)[:n]
+        if kernels2:
+            dh_c[r0:r1] = ops.lm_head_dhidden(dl2, wt)
+            continue
         torch.mm(dl2, w, out=dh_c[r0:r1])
         if dw is not None:
             dw.addmm_(dl2.t().float(), hc_all[r0:r1].float())
@@ -521,7 +544,7 @@ def _use_lm_head_train_kernel(ops, h, H, w, need_dw: bool) -> bool:
     if env == "1" and not ok:
         raise RuntimeError("DALM_LM_HEAD_TRAIN_KERNEL=1 needs bf16 hidden states, a frozen bf16 head and a hidden width that is a "
                            "multiple of 64")
-    return ok and env != "0"
+    return ok and env not in ("0", "2")        # "2": the two-contraction form inside _lm_head_rows
 
 
 def _lm_head_train_kernel(ops, h, w, ids, mask, stats, live_rows):

@@ -122,6 +122,7 @@ SIGNATURES = {
     "dalm_sim_grad_bf16x3_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "dalm_sim_grad_bf16x3": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dalm_lm_head_dlogits": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp]),
+    "dalm_lm_head_logits": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     "dalm_lm_head_dhidden": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _int, _vp]),
     "dalm_transpose_bf16": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     "dalm_f32_to_bf16": (_int, [_vp, _vp, _i64, _vp]),

@@ -359,6 +359,35 @@ class HipOps:
         hip.call("dalm_f32_to_bf16", hip.ptr(dh32), hip.ptr(dh), R * K, st)
         return dh
 
+    def lm_head_logits(self, hidden: torch.Tensor, weight: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        """out[:R, :V] = hidden [R, K] . weight [V, K]^T in bf16 through the library's own MFMA main loop (`dalm_lm_head_logits`);
+        `out` is a caller-provided [>= R, V] bf16 buffer with a contiguous last dimension (row pitch = its stride)."""
+        hip.require_gpu(hidden, weight, out)
+        if hidden.dtype != torch.bfloat16 or weight.dtype != torch.bfloat16 or out.dtype != torch.bfloat16:
+            raise TypeError("lm_head_logits needs bf16 tensors")
+        hidden, weight = hidden.contiguous(), weight.contiguous()
+        R, K = hidden.shape
+        V = weight.shape[0]
+        if out.stride(-1) != 1 or out.shape[0] < R or out.shape[1] < V:
+            raise ValueError("lm_head_logits: out must be [>= R, >= V] with a contiguous last dimension")
+        hip.call("dalm_lm_head_logits", hip.ptr(hidden), hip.ptr(weight), R, V, K, hip.ptr(out), out.stride(0), hip.stream())
+        return out
+
+    def lm_head_dhidden(self, dlogits: torch.Tensor, weight_t: torch.Tensor) -> torch.Tensor:
+        """d(hidden) [R, K] bf16 = dlogits [R, V] . weight_t [K, V]^T (weight_t: the head's transposed copy), f32 accumulation,
+        one rounding (`dalm_lm_head_dhidden` + `dalm_f32_to_bf16`).  dlogits rows must be contiguous with pitch V, V % 64 == 0."""
+        dev = hip.require_gpu(dlogits, weight_t)
+        R, V = dlogits.shape
+        K = weight_t.shape[0]
+        if dlogits.stride(0) != V or dlogits.stride(1) != 1 or not weight_t.is_contiguous() or weight_t.shape[1] != V or V % 64:
+            raise ValueError("lm_head_dhidden: contiguous [R, V] d(logits), [K, V] transposed weight, V a multiple of 64")
+        dh32 = torch.empty((R, K), device=dev, dtype=torch.float32)
+        st = hip.stream()
+        hip.call("dalm_lm_head_dhidden", hip.ptr(dlogits), hip.ptr(weight_t), R, V, K, hip.ptr(dh32), 0, st)
+        dh = torch.empty((R, K), device=dev, dtype=torch.bfloat16)
+        hip.call("dalm_f32_to_bf16", hip.ptr(dh32), hip.ptr(dh), R * K, st)
+        return dh
+
     def contrastive_finalize(self, row_lse, col_lse, diag, n_global: int):
         dev = hip.require_gpu(row_lse, col_lse, diag)
         n_local = row_lse.shape[0]

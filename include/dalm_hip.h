@@ -605,6 +605,12 @@ int dalm_lora2_colacc(const void* x0, const void* x1, const float* z0, const flo
 int dalm_lm_head_dlogits(const void* hidden, const void* weight_chunk, const int64_t* labels, const float* row_lse,
                          const float* coef, int64_t R, int64_t Vc, int64_t K, int64_t col_base, void* dl, int64_t pitch,
                          dalm_stream_t stream);
+/* round 6, the two-contraction form of the training step (no recomputation): logits [R, pitch] bf16 = hidden [R, K] . weight [V, K]^T
+ * through the same bf16 MFMA main loop (columns V .. pitch - 1 are not written).  A row chunk of logits (<= ~128 MB) stays in the
+ * Infinity Cache while dalm_marg_ce_fwd turns it into d(logits) in place and dalm_lm_head_dhidden (Vp = pitch = V, wt = the
+ * head's transposed copy [K, V]) contracts it. */
+int dalm_lm_head_logits(const void* hidden, const void* weight, int64_t R, int64_t V, int64_t K, void* logits, int64_t pitch,
+                        dalm_stream_t stream);
 int dalm_lm_head_dhidden(const void* dl, const void* wt, int64_t R, int64_t Vp, int64_t K, float* dh, int accumulate,
                          dalm_stream_t stream);
 int dalm_transpose_bf16(const void* src, int64_t rows, int64_t cols, int64_t ld_src, void* dst, int64_t ld_dst,

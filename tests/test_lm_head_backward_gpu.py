@@ -96,7 +96,7 @@ def _batch(B, Tg, H, V, D, seed, dev, pad_left=True):
 def _run(q, p, h, W, ids, mask, qlen, live, kernel: bool):
     from dalm_amd.fused import rag_e2e_loss_from_hidden
 
-    os.environ["DALM_LM_HEAD_TRAIN_KERNEL"] = "1" if kernel else "0"
+    os.environ["DALM_LM_HEAD_TRAIN_KERNEL"] = kernel if isinstance(kernel, str) else ("1" if kernel else "0")
     try:
         qq, pp, hh = [t.clone().requires_grad_(True) for t in (q, p, h)]
         aux = {}
@@ -149,5 +149,25 @@ def test_full_size_heads_match_the_chunked_library_path(dev, cfg, V, H):
     # the two paths round different things to bf16 (the library: logits and their gradient; the kernels: the gradient only)
     assert _rel(dh_k, dh_l) < 8e-3
     assert float((dh_k.float() - dh_l.float()).abs().max()) <= 0.05 * float(dh_l.float().abs().max())
+    dead = (torch.cat((mask[:, 1:], torch.zeros_like(mask[:, :1])), 1) == 0)
+    assert float(dh_k[dead].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("cfg,V,H", [("cfg3", 32000, 4096), ("cfg5", 65024, 4544), ("small", 3008, 128)])
+def test_two_contraction_kernels_match_the_library_path(dev, cfg, V, H):
+    """Round 6: the hand-written head WITHOUT the third contraction (DALM_LM_HEAD_TRAIN_KERNEL=2: `dalm_lm_head_logits` stores the
+    bf16 logits of a row chunk, the fused CE kernel turns them into d(logits) in place, `dalm_lm_head_dhidden` contracts them) -
+    the same algorithm as the library path (torch.mm x 2 around the same CE kernel), so the two agree to the summation order of
+    the two GEMMs: loss and every element of d(hidden)."""
+    from dalm_amd.fused import gemm_wave_rows, live_row_index
+
+    B, Tg, D = (18, 256, 1024) if cfg != "small" else (6, 64, 64)
+    q, p, h, W, ids, mask, qlen = _batch(B, Tg, H, V, D, 7, dev)
+    live = live_row_index(mask, multiple=gemm_wave_rows(V) if cfg != "small" else 64).to(dev)
+    loss_k, dq_k, dp_k, dh_k, _ = _run(q, p, h, W, ids, mask, qlen, live, "2")
+    loss_l, dq_l, dp_l, dh_l, _ = _run(q, p, h, W, ids, mask, qlen, live, "0")
+    assert abs(float(loss_k) - float(loss_l)) <= 2e-5 * abs(float(loss_l))
+    assert _rel(dh_k, dh_l) < 4e-3                     # bf16 logits rounded from differently ordered f32 sums; dh rounded once
+    assert _rel(dq_k, dq_l) < 1e-4 and _rel(dp_k, dp_l) < 1e-4
     dead = (torch.cat((mask[:, 1:], torch.zeros_like(mask[:, :1])), 1) == 0)
     assert float(dh_k[dead].abs().max()) == 0.0
