@@ -430,6 +430,25 @@ def _lm_head_rows(ops, hc_all, w, ids_c, mask_c, stats, chunk_rows, dw, need_gra
         wt = dgrad_weight(w, torch.bfloat16)                     # the head's transposed copy [K, V] (frozen: made once)
         if wt is None:
             wt = w.t().contiguous()
+    if kernels2:
+        # both contractions on the library's own kernels.  The logits GEMM and the CE run per row chunk (the chunk is still in the
+        # Infinity Cache when the CE reads it); d(logits) of ALL chunks stays in one [Rp + 1, V] buffer and is contracted by
+        # ONE dalm_lm_head_dhidden launch: its 256 x 256 output tiles number (Rp / 256) x (K / 256) - a 2048-row chunk alone gives
+        # 128 tiles on a 256-CU part (measured 2.4 x the library path that way)
+        sizes = _row_chunks(Rp, chunk_rows, gemm_wave_rows(V))
+        big = torch.empty((Rp + 1, V), device=hc_all.device, dtype=hc_all.dtype)
+        for n in sizes:
+            # GEMM of chunk i, then its CE in place.  The CE kernel's virtual sample [1, n + 1, V] has ONE always-dead last row whose
+            # gradient it zeroes: that is the first row of chunk i + 1 (not computed yet - its own GEMM writes it next) or, for the
+            # last chunk, the extra row Rp
+            r0, r1 = r1, r1 + n
+            ops.lm_head_logits(hc_all[r0:r1], w, big[r0:r1])
+            ids_v = torch.cat((zero1, ids_c[r0:r1])).view(1, n + 1)
+            mask_v = torch.cat((zero1.to(mask_c.dtype), mask_c[r0:r1])).view(1, n + 1)
+            _lse, nll_v, _dl = ops.ce_fwd(big[r0:r1 + 1].view(1, n + 1, V), ids_v, mask_v, stats, True, True)
+            nll_c[r0:r1] = nll_v.reshape(-1)[:n]
+        dh_c[:Rp] = ops.lm_head_dhidden(big[:Rp], wt)
+        return dh_c, nll_c
     for n in _row_chunks(Rp, chunk_rows, gemm_wave_rows(V)):
         r0, r1 = r1, r1 + n
         buf = torch.empty((n + 1, V), device=hc_all.device, dtype=hc_all.dtype)
