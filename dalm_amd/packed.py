@@ -187,6 +187,35 @@ def retrieval_hidden(retriever_model, input_ids, attention_mask, rows, cu):
     return full[:B * T].view(B, T, -1)
 
 
+def retrieval_hidden_pair(retriever_model, first, second):
+    """BOTH retriever inputs of a step (queries and passages) through the encoder in ONE packed call: `first` / `second` are
+    (input_ids, attention_mask, rows, cu).  The reference runs the encoder twice (rag_e2e_base_model.py:84-93 per call,
+    train_rage2e.py:431-438); every op of an encoder layer is row-wise except attention, which runs per sequence here, so one
+    call over the concatenated rows computes the same token states with half the kernel launches and larger GEMMs.
+    Returns the two padded [B, T, D] tensors (zeros at the padding)."""
+    parts = []
+    off = 0
+    for ids, mask, rows, cu in (first, second):
+        ids_p, pos, desc, valid = packed_inputs(ids, mask, rows, cu, causal=False)
+        sq = packed_of(desc)
+        parts.append((ids_p, pos, sq, valid, rows, ids.shape, off))
+        off += int(rows.numel())
+    T = max(p[2].T for p in parts)
+    cu_all = torch.cat([parts[0][2].cu] + [(p[2].cu[1:] + p[6]) for p in parts[1:]])
+    seqs = PackedSeqs(cu=cu_all.to(torch.int32), nseq=int(cu_all.numel()) - 1, T=int(T), n=off,
+                      key_live=torch.cat([p[2].key_live for p in parts]), causal=False)
+    desc = attach(torch.ones((1, 1, 1, 1), dtype=torch.bool, device=cu_all.device), seqs)
+    h = retriever_model(input_ids=torch.cat([p[0] for p in parts], dim=1), attention_mask=desc,
+                        position_ids=torch.cat([p[1] for p in parts], dim=1))[0][0]                  # [n_first + n_second, D]
+    outs = []
+    for _ids_p, _pos, _sq, valid, rows, (B, Tn), o in parts:
+        hp = h[o:o + rows.numel()]
+        dst = torch.where(valid, rows, torch.full_like(rows, B * Tn))
+        full = hp.new_zeros((B * Tn + 1, hp.shape[-1])).index_copy(0, dst, hp)
+        outs.append(full[:B * Tn].view(B, Tn, -1))
+    return outs[0], outs[1]
+
+
 RAG_GROUPS = (("generator", "generator_input_input_ids", "generator_input_attention_mask", True),
               ("retriever_query", "retriever_query_input_ids", "retriever_query_attention_mask", False),
               ("retriever_passage", "retriever_passage_input_ids", "retriever_passage_attention_mask", False))

@@ -78,6 +78,23 @@ class _StepBase:
             return contextlib.nullcontext()
         return torch.autocast("cuda", dtype=self.autocast_dtype, cache_enabled=self.autocast_cache)
 
+    def _retrieve_pair(self, batch, q_prefix: str, p_prefix: str):
+        """Queries AND passages through the encoder in one packed call (one rank: there is no passage all-gather to overlap with
+        the query tower) - or None when the batch / model does not allow it."""
+        import os as _os
+
+        m = self.model
+        enc = getattr(m, "retriever_model", None) or getattr(m, "model", None)
+        if (_os.environ.get("DALM_PACK_PAIR", "1") == "0" or not isinstance(self.comm, LocalComm)
+                or f"{q_prefix}_pack_rows" not in batch or f"{p_prefix}_pack_rows" not in batch
+                or getattr(m, "retriever_is_autoregressive", getattr(m, "is_autoregressive", False))
+                or not _packed.attention_is_packable(enc)):
+            return None
+        q = (batch[f"{q_prefix}_input_ids"], batch[f"{q_prefix}_attention_mask"], batch[f"{q_prefix}_pack_rows"], batch[f"{q_prefix}_pack_cu"])
+        p = (batch[f"{p_prefix}_input_ids"], batch[f"{p_prefix}_attention_mask"], batch[f"{p_prefix}_pack_rows"], batch[f"{p_prefix}_pack_cu"])
+        hp, hq = _packed.retrieval_hidden_pair(enc, p, q)
+        return pool_l2norm(hp, p[1], m.normalize), pool_l2norm(hq, q[1], m.normalize)
+
     def _finish(self, loss: torch.Tensor) -> torch.Tensor:
         if self.grad_accum > 1:
             (loss / self.grad_accum).backward()
@@ -187,6 +204,11 @@ class RagE2EStep(_StepBase):
         return m("retrieval", ids, mask)
 
     def _towers(self, batch):
+        if not self._use_graphs(batch):
+            pair = self._retrieve_pair(batch, "retriever_query", "retriever_passage")
+            if pair is not None:
+                p_emb, q_emb = pair
+                return p_emb, q_emb, self._gather(p_emb), self._gather(q_emb)
         if self._use_graphs(batch):
             p_emb = self.towers.passage(batch["retriever_passage_input_ids"], batch["retriever_passage_attention_mask"])
         else:
@@ -320,6 +342,14 @@ class RetrieverStep(_StepBase):
 
     def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         _advance_dropout(batch)
+        with self._autocast():
+            pair = self._retrieve_pair(batch, "query", "passage")
+        if pair is not None:             # packed, one rank: both inputs through the encoder in ONE call, one stream
+            p_emb, q_emb = pair
+            loss = contrastive_loss(q_emb, p_emb, self.logit_scale, comm=self.comm, ops=self.ops,
+                                    q_gather=GatherHandle(q_emb.float(), self.comm, self.side_stream),
+                                    p_gather=GatherHandle(p_emb.float(), self.comm, self.side_stream))
+            return self._finish(loss)
         with self._autocast():
             if self.tower_stream is not None:
                 cur = torch.cuda.current_stream()

@@ -215,3 +215,27 @@ def test_packed_falcon_equals_padded_on_live_rows():
     sel = w != 0
     assert torch.allclose(hp[sel], want.index_select(0, rows.clamp_min(0))[sel], atol=2e-5, rtol=1e-4)
     assert torch.isfinite(hp).all()
+
+
+def test_query_and_passage_in_one_encoder_call_equal_two_calls():
+    from transformers import BertConfig, BertModel
+
+    from dalm_amd.models import attention
+
+    torch.manual_seed(0)
+    cfg = BertConfig(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128, vocab_size=101,
+                     max_position_embeddings=64)
+    model = BertModel(cfg).eval()
+    assert attention.register()
+    model.config._attn_implementation = attention.NAME
+    B = 5
+    mq, mp = _masks(B, 10, False, 11), _masks(B, 24, False, 12)
+    iq = torch.randint(3, 101, (B, 10), generator=torch.Generator().manual_seed(13))
+    ip = torch.randint(3, 101, (B, 24), generator=torch.Generator().manual_seed(14))
+    rq, cq = packed.pack_plan(mq, False, 16)           # a multiple above the query length: several slack sequences
+    rp, cp = packed.pack_plan(mp, False, 16)
+    hq1 = packed.retrieval_hidden(model, iq, mq, rq, cq)
+    hp1 = packed.retrieval_hidden(model, ip, mp, rp, cp)
+    hp2, hq2 = packed.retrieval_hidden_pair(model, (ip, mp, rp, cp), (iq, mq, rq, cq))
+    assert hq2.shape == hq1.shape and hp2.shape == hp1.shape
+    assert torch.allclose(hq2, hq1, atol=2e-5, rtol=1e-4) and torch.allclose(hp2, hp1, atol=2e-5, rtol=1e-4)

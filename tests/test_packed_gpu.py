@@ -383,3 +383,69 @@ def test_packed_step_equals_padded_step_and_oracle_at_real_width(dev, case, prec
         d_pack, d_pad = per_param(g_pack, g_host), per_param(g_pad, g_host)
         for n in d_pack:
             assert d_pack[n] <= 2.0 * d_pad[n] + 5e-3 and d_pack[n] <= 4e-2, (n, d_pack[n], d_pad[n])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_packed_retriever_only_step_equals_padded_and_oracle_at_real_width(dev, precision):
+    """BASELINE configs[1] (retriever-only, bge-large width, batch 150, LoRA): padded step vs packed step (queries and passages
+    through the encoder in ONE packed call) vs the reference's op sequence on the host."""
+    import dalm_oracle as O
+    import realwidth as RW
+    from test_step_realwidth_gpu import _build, _randomise_lora_b
+
+    from dalm_amd import packed
+    from dalm_amd.models import AutoModelForSentenceEmbedding, lora
+    from dalm_amd.training.step import RetrieverStep
+
+    bert, _ = _build("cfg2")
+    if precision == "bf16":
+        with torch.no_grad():
+            for p in bert.parameters():
+                p.copy_(p.to(torch.bfloat16).float())
+    lora.inject_lora(bert, ["key", "query", "value"], lora_dropout=0.0)
+    _randomise_lora_b(bert, 11)
+    batch = RW.synthetic_batch("cfg2")
+    batch["query_attention_mask"][3] = 0
+    batch["query_attention_mask"][3, 0] = 1                         # a single-token query
+    res = {}
+    for mode in ("padded", "packed"):
+        model = AutoModelForSentenceEmbedding.from_modules(copy.deepcopy(bert), None, normalize=True, get_peft=False).to(dev)
+        if precision == "bf16":
+            for p in model.parameters():
+                if not p.requires_grad:
+                    p.data = p.data.to(torch.bfloat16)
+        model.train()
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        opt = torch.optim.SGD([p for _, p in named], lr=0.0)
+        snap = _GradSnapshot(named)
+        opt.register_step_pre_hook(snap)
+        step = RetrieverStep(model, opt, None, 100, autocast_dtype=torch.bfloat16 if precision == "bf16" else None,
+                             overlap_towers=True, track_grad_norm=True)
+        host = packed.add_pack_plans(batch, packed.RETRIEVER_GROUPS) if mode == "packed" else batch
+        loss = float(step({k: v.to(dev) for k, v in host.items()}))
+        res[mode] = ({"loss": loss, "grad_norm": float(step.grad_norm)}, snap.grads)
+        del model, step, opt
+        torch.cuda.empty_cache()
+    old = torch.get_num_threads()
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    try:
+        q = O.ref_retrieval_embed(bert(batch["query_input_ids"], batch["query_attention_mask"])[0], batch["query_attention_mask"])
+        p = O.ref_retrieval_embed(bert(batch["passage_input_ids"], batch["passage_attention_mask"])[0], batch["passage_attention_mask"])
+        out = O.ref_step_loss(q, p, None, None, None, None, 100)
+        out["loss"].backward()
+    finally:
+        torch.set_num_threads(old)
+    host_s = {"loss": float(out["loss"].detach()), "grad_norm": RW.grad_norm([p for p in bert.parameters() if p.requires_grad])}
+    rel = {f"{a}_vs_{b}": {k: abs(x[k] - y[k]) / max(abs(y[k]), 1e-30) for k in ("loss", "grad_norm")}
+           for a, x, b, y in (("packed", res["packed"][0], "padded", res["padded"][0]), ("packed", res["packed"][0], "host", host_s),
+                              ("padded", res["padded"][0], "host", host_s))}
+    _record(f"cfg2/{precision}", {"padded": res["padded"][0], "packed": res["packed"][0], "host_fp32_oracle": host_s, "rel": rel})
+    tol = {"loss": 1e-4, "grad_norm": 1e-4} if precision == "fp32" else {"loss": 2.5e-4, "grad_norm": 7e-3}
+    for pair, d in rel.items():
+        for k, v in d.items():
+            assert v <= tol[k], (pair, k, rel)
+    if precision == "fp32":
+        gp, gq = res["packed"][1], res["padded"][1]
+        for n in gq:
+            den = max(float(gq[n].double().norm()), 1e-30)
+            assert float((gp[n].double() - gq[n].double()).norm()) / den <= 1e-4 or float(gq[n].double().norm()) < 1e-7, n
