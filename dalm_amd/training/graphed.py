@@ -239,6 +239,46 @@ class _GeneratorCall(torch.nn.Module):
             return self._run(input_ids, attention_mask)
 
 
+class _PackedRetrievalCall(torch.nn.Module):
+    """`_RetrievalCall` on the packed rows of a batch (dalm_amd/packed.py): ids, mask, rows, cu -> embeddings."""
+
+    def __init__(self, rag_model, autocast_dtype):
+        super().__init__()
+        self.retriever = rag_model.retriever_model
+        self.normalize = rag_model.normalize
+        self.autocast_dtype = autocast_dtype
+
+    def forward(self, input_ids, attention_mask, rows, cu):
+        from .. import packed
+        from ..fused import pool_l2norm
+
+        if self.autocast_dtype is None:
+            h = packed.retrieval_hidden(self.retriever, input_ids, attention_mask, rows, cu)
+        else:
+            with torch.autocast("cuda", dtype=self.autocast_dtype, cache_enabled=False):
+                h = packed.retrieval_hidden(self.retriever, input_ids, attention_mask, rows, cu)
+        return pool_l2norm(h, attention_mask, self.normalize)
+
+
+class _PackedGeneratorCall(torch.nn.Module):
+    """The decoder on the packed rows: ids, mask, rows, cu -> final hidden states [n, H] (in the autocast dtype: what the
+    reference's lm_head, an nn.Linear inside the autocast'ed forward, would read)."""
+
+    def __init__(self, rag_model, autocast_dtype):
+        super().__init__()
+        self.generator = rag_model.generator_model
+        self.autocast_dtype = autocast_dtype
+
+    def forward(self, input_ids, attention_mask, rows, cu):
+        from .. import packed
+
+        if self.autocast_dtype is None:
+            return packed.generator_hidden(self.generator, input_ids, attention_mask, rows, cu)
+        with torch.autocast("cuda", dtype=self.autocast_dtype, cache_enabled=False):
+            h = packed.generator_hidden(self.generator, input_ids, attention_mask, rows, cu)
+        return h if h.dtype == self.autocast_dtype else h.to(self.autocast_dtype)
+
+
 class GraphedTowers:
     """Forward AND backward of the three tower calls (passage, query, generator) as hipGraphs
     (torch.cuda.make_graphed_callables), everything that talks to other GPUs - the embedding all-gathers, the
@@ -249,14 +289,26 @@ class GraphedTowers:
         if getattr(rag_model, "retriever_is_autoregressive", False):
             raise NotImplementedError("graphed towers: autoregressive retrievers run eagerly")
         b = sample_batch
-        self.key = tuple(tuple(b[k].shape) for k in self.KEYS)
-        calls = (_RetrievalCall(rag_model, autocast_dtype), _RetrievalCall(rag_model, autocast_dtype),
-                 _GeneratorCall(rag_model, autocast_dtype, hidden_only))
+        self.key = self.key_of(b)
+        # a batch that carries the packed row lists of all three tower inputs gets PACKED graphs (round 6): the same captures
+        # around dalm_amd/packed.py's calls; the row counts are part of the key (one set of graphs per combination)
+        self.packed = self.is_packed(b)
+        if self.packed:
+            calls = (_PackedRetrievalCall(rag_model, autocast_dtype), _PackedRetrievalCall(rag_model, autocast_dtype),
+                     _PackedGeneratorCall(rag_model, autocast_dtype))
+        else:
+            calls = (_RetrievalCall(rag_model, autocast_dtype), _RetrievalCall(rag_model, autocast_dtype),
+                     _GeneratorCall(rag_model, autocast_dtype, hidden_only))
         for c in calls:
             c.train(rag_model.training)
-        args = ((b["retriever_passage_input_ids"].clone(), b["retriever_passage_attention_mask"].clone()),
-                (b["retriever_query_input_ids"].clone(), b["retriever_query_attention_mask"].clone()),
-                (b["generator_input_input_ids"].clone(), b["generator_input_attention_mask"].clone()))
+
+        def arg(prefix, ids, mask):
+            a = (b[ids].clone(), b[mask].clone())
+            return a + (b[f"{prefix}_pack_rows"].clone(), b[f"{prefix}_pack_cu"].clone()) if self.packed else a
+
+        args = (arg("retriever_passage", "retriever_passage_input_ids", "retriever_passage_attention_mask"),
+                arg("retriever_query", "retriever_query_input_ids", "retriever_query_attention_mask"),
+                arg("generator", "generator_input_input_ids", "generator_input_attention_mask"))
         # Callables captured in ONE make_graphed_callables call share a memory pool and must replay in capture
         # order on one stream.  The retrieval pair runs on the tower stream concurrently with the generator on
         # the main stream, so the generator gets its own capture (own pool); within the pair the order is
@@ -267,6 +319,21 @@ class GraphedTowers:
             calls[2], args[2], num_warmup_iters=3, allow_unused_input=True)
 
     KEYS = ("retriever_passage_input_ids", "retriever_query_input_ids", "generator_input_input_ids")
+    PACK_KEYS = ("retriever_passage_pack_rows", "retriever_query_pack_rows", "generator_pack_rows",
+                 "retriever_passage_pack_cu", "retriever_query_pack_cu", "generator_pack_cu")
+
+    @classmethod
+    def is_packed(cls, batch) -> bool:
+        return all(k in batch for k in cls.PACK_KEYS)
+
+    @classmethod
+    def key_of(cls, batch):
+        keys = cls.KEYS + (cls.PACK_KEYS if cls.is_packed(batch) else ())
+        return tuple(tuple(batch[k].shape) for k in keys)
 
     def matches(self, batch) -> bool:
-        return tuple(tuple(batch[k].shape) for k in self.KEYS) == self.key
+        return self.key_of(batch) == self.key
+
+    def call_args(self, batch, prefix: str, ids: str, mask: str):
+        a = (batch[ids], batch[mask])
+        return a + (batch[f"{prefix}_pack_rows"], batch[f"{prefix}_pack_cu"]) if self.packed else a

@@ -168,15 +168,32 @@ class RagE2EStep(_StepBase):
         self.tower_stream = torch.cuda.Stream() if (overlap_towers and torch.cuda.is_available()) else None
 
     def _maybe_build_towers(self, batch) -> None:
-        if not self.graph_towers or self.towers is not None or self.towers_failed is not None:
+        """One set of tower graphs per batch shape (packed batches: per row-count combination), at most DALM_TOWER_SETS (4) alive:
+        every set keeps its own activations between its forward and backward graphs.  Other shapes launch eagerly."""
+        if not self.graph_towers or self.towers_failed is not None:
             return
         if self.calls <= self.graph_after:  # first real steps run eagerly (library warm-up, as GraphedStep)
             return
-        try:
-            from .graphed import GraphedTowers
+        from .graphed import GraphedTowers
 
+        key = GraphedTowers.key_of(batch)
+        sets = self.__dict__.setdefault("_tower_sets", {})
+        if key in sets:
+            self.towers = sets[key]
+            return
+        import os as _os3
+
+        if len(sets) >= int(_os3.environ.get("DALM_TOWER_SETS", "4")):
+            self.towers = None
+            return
+        if any(k in batch for k in GraphedTowers.PACK_KEYS) and not (
+                GraphedTowers.is_packed(batch) and _packed.attention_is_packable(self.model.generator_model)
+                and _packed.attention_is_packable(self.model.retriever_model)):
+            self.towers = None              # row lists for some towers only, or a model the packed call cannot serve: eager
+            return
+        try:
             torch.cuda.synchronize()
-            self.towers = GraphedTowers(self.model, self.autocast_dtype, batch, hidden_only=self.fuse_lm_head)
+            sets[key] = self.towers = GraphedTowers(self.model, self.autocast_dtype, batch, hidden_only=self.fuse_lm_head)
         except Exception as e:  # same kernels, eager launches
             self.towers_failed = repr(e)
             self.towers = None
@@ -210,29 +227,33 @@ class RagE2EStep(_StepBase):
                 p_emb, q_emb = pair
                 return p_emb, q_emb, self._gather(p_emb), self._gather(q_emb)
         if self._use_graphs(batch):
-            p_emb = self.towers.passage(batch["retriever_passage_input_ids"], batch["retriever_passage_attention_mask"])
+            p_emb = self.towers.passage(*self.towers.call_args(batch, "retriever_passage", "retriever_passage_input_ids",
+                                                               "retriever_passage_attention_mask"))
         else:
             p_emb = self._retrieve(batch, "passage")
         p_gather = self._gather(p_emb)
         if self._use_graphs(batch):
-            q_emb = self.towers.query(batch["retriever_query_input_ids"], batch["retriever_query_attention_mask"])
+            q_emb = self.towers.query(*self.towers.call_args(batch, "retriever_query", "retriever_query_input_ids",
+                                                             "retriever_query_attention_mask"))
         else:
             q_emb = self._retrieve(batch, "query")
         q_gather = self._gather(q_emb)
         return p_emb, q_emb, p_gather, q_gather
 
     def _packed_generator(self, batch) -> bool:
-        return ("generator_pack_rows" in batch and not self._use_graphs(batch)
-                and _packed.attention_is_packable(self.model.generator_model))
+        if self._use_graphs(batch):
+            return self.towers.packed
+        return "generator_pack_rows" in batch and _packed.attention_is_packable(self.model.generator_model)
 
     def _generator(self, batch):
         m = self.model
+        if self._use_graphs(batch):            # padded graphs: logits / hidden states; packed graphs: hidden rows [n, H]
+            return self.towers.generator(*self.towers.call_args(batch, "generator", "generator_input_input_ids",
+                                                                "generator_input_attention_mask"))
         if self._packed_generator(batch):      # final hidden states of the live rows only, [n, H]
             return _packed.generator_hidden(m.generator_model, batch["generator_input_input_ids"],
                                             batch["generator_input_attention_mask"], batch["generator_pack_rows"],
                                             batch["generator_pack_cu"])
-        if self._use_graphs(batch):
-            return self.towers.generator(batch["generator_input_input_ids"], batch["generator_input_attention_mask"])
         if not self.fuse_lm_head:
             return m("generation", batch["generator_input_input_ids"], batch["generator_input_attention_mask"])
         gm = m.generator_model

@@ -449,3 +449,61 @@ def test_packed_retriever_only_step_equals_padded_and_oracle_at_real_width(dev, 
         for n in gq:
             den = max(float(gq[n].double().norm()), 1e-30)
             assert float((gp[n].double() - gq[n].double()).norm()) / den <= 1e-4 or float(gq[n].double().norm()) < 1e-7, n
+
+
+def test_packed_graphed_towers_in_the_multi_gpu_launch_mode_on_one_rank(dev, monkeypatch):
+    """The W > 1 launch mode (tower forward / backward as hipGraphs, eager collectives + loss + optimizer) on PACKED batches, through
+    a live one-rank RCCL process group: one set of packed tower graphs per row-count combination, same loss and gradient norm as
+    the single-process packed step (dropout off)."""
+    import torch.distributed as dist
+    import realwidth as RW
+    from test_step_realwidth_gpu import _build, _randomise_lora_b
+
+    from dalm_amd import packed
+    from dalm_amd.fused import TorchDistComm
+    from dalm_amd.models import AutoModelForRagE2E, lora
+    from dalm_amd.sharded import init_distributed
+    from dalm_amd.training.step import RagE2EStep
+
+    retriever, generator = _build("cfg3")
+    lora.inject_lora(retriever, ["key", "query", "value"], lora_dropout=0.0)
+    _randomise_lora_b(retriever, 11)
+    lora.inject_lora(generator, ["q_proj", "v_proj"], lora_dropout=0.0)
+    _randomise_lora_b(generator, 12)
+    batches = [packed.add_pack_plans(RW.synthetic_batch("cfg3", seed=s)) for s in (0, 1)]
+    model = AutoModelForRagE2E.from_modules(retriever, generator, None, None, normalize=True, get_peft=None).to(dev)
+    for p in model.parameters():
+        if not p.requires_grad:
+            p.data = p.data.to(torch.bfloat16)
+    model.eval()
+    trainable = [p for p in model.parameters() if p.requires_grad]
+
+    def run(comm, graph_towers):
+        opt = torch.optim.SGD(trainable, lr=0.0)
+        step = RagE2EStep(model, opt, None, 100, comm=comm, autocast_dtype=torch.bfloat16, inplace_grad=True, overlap_towers=True,
+                          track_grad_norm=True, graph_towers=graph_towers, graph_after=0)
+        out = []
+        for b in batches + batches:                       # every shape twice: the second call replays the graphs
+            loss = float(step({k: v.to(dev) for k, v in b.items()}))
+            out.append((loss, float(step.grad_norm)))
+        return out, step
+
+    want, _ = run(None, False)
+    monkeypatch.setenv("DALM_FORCE_DIST", "1")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29647")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.delenv("DALM_NATIVE_COMM", raising=False)
+    comm, _dev = init_distributed()
+    try:
+        assert isinstance(comm, TorchDistComm)
+        got, step = run(comm, True)
+        assert step.towers_failed is None and step.towers is not None and step.towers.packed
+        assert 1 <= len(step._tower_sets) <= 2
+        for (l0, g0), (l1, g1) in zip(want, got):
+            assert abs(l1 - l0) <= 2.5e-4 * abs(l0) and abs(g1 - g0) <= 2.2e-3 * abs(g0), (want, got)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
