@@ -1054,3 +1054,8 @@ def main_retriever_only(args):
 
 if __name__ == "__main__":
     main()
+    # the line is out; what is left is interpreter + HIP teardown (a dozen hipGraphs, their pools, RCCL): its exit status is not the
+    # bench's (seen: status 1 after a complete bucketed run, nothing on stderr)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0)

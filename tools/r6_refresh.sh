@@ -86,6 +86,7 @@ if has dist; then
   # the W > 1 launch mode with ONE rank (DALM_FORCE_DIST=1): torch.distributed communicator, then the library's own
   DALM_FORCE_DIST=1 run $P/r06_bench_one_rank_dist_torch.json python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-pmc
   DALM_FORCE_DIST=1 DALM_NATIVE_COMM=1 run $P/r06_bench_one_rank_dist_native.json python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-pmc
+  DALM_FORCE_DIST=1 run $P/r06_bench_one_rank_dist_torch_packed.json python bench.py --data-path packed --steps 20 --warmup 6 --no-cpu-baseline --no-pmc
   lines $P/r06_bench_one_rank_dist_*.json | tee $P/r06_bench_one_rank_dist_lines.txt
 fi
 find gpurun_out -name "*kernel_trace.csv" -size +4M -delete
