@@ -70,6 +70,20 @@ def _worker(rank, world, port, mode, out_dir):
         lg = hidden_all[sl].clone().requires_grad_(True)
         loss = rag_e2e_loss_from_hidden(ql, pl, lg, head, ids[sl], mask[sl], qlen[sl], 100, comm=comm, ops=ops,
                                         chunk_samples=2, live_rows=live_row_index(mask[sl], 4))
+    elif mode == "e2e_packed":
+        # round 6: every rank runs its generator on its own PACKED rows (dalm_amd/packed.py); the loss gets the hidden states of
+        # those rows + their shifted labels, the token count M and the softmax statistics still span the global batch
+        from dalm_amd import packed
+        from dalm_amd.fused import rag_e2e_loss_packed
+
+        g = torch.Generator().manual_seed(7)
+        hidden_all = torch.randn(world * B_l, Tg, 12, generator=g)
+        head = 0.5 * torch.randn(V, 12, generator=g)
+        rows, _cu = packed.pack_plan(mask[sl], shifted=True, multiple=4)
+        lg = hidden_all[sl].clone().requires_grad_(True)
+        hp = lg.reshape(-1, 12).index_select(0, rows.clamp_min(0))      # what the packed generator would hand over
+        y, wts = packed.packed_labels(ids[sl], mask[sl], rows)
+        loss = rag_e2e_loss_packed(ql, pl, hp, head, y, wts, mask[sl], qlen[sl], 100, comm=comm, ops=ops)
     elif mode == "e2e":
         ph = GatherHandle(pl, comm)             # the early all-gather the trainer starts after the passage tower
         loss = rag_e2e_loss(ql, pl, lg, ids[sl], mask[sl], qlen[sl], 100, comm=comm, ops=ops, p_gather=ph)
@@ -88,7 +102,7 @@ def _worker(rank, world, port, mode, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,world", [("e2e", 2), ("contrastive", 2), ("e2e", 3), ("e2e", 8), ("e2e_hidden", 2)])
+@pytest.mark.parametrize("mode,world", [("e2e", 2), ("contrastive", 2), ("e2e", 3), ("e2e", 8), ("e2e_hidden", 2), ("e2e_packed", 2)])
 def test_ranks_equal_one_process_at_global_batch(tmp_path, mode, world):
     import dalm_oracle as O
     from helpers import synth_batch
@@ -102,7 +116,7 @@ def test_ranks_equal_one_process_at_global_batch(tmp_path, mode, world):
     w = (torch.eye(D) + 0.01 * torch.arange(D * D, dtype=torch.float32).reshape(D, D) / (D * D)).double().requires_grad_(True)
     lg = logits.double().requires_grad_(True)
     full = lg
-    if mode == "e2e_hidden":
+    if mode in ("e2e_hidden", "e2e_packed"):
         g = torch.Generator().manual_seed(7)
         lg = torch.randn(world * B_l, Tg, 12, generator=g).double().requires_grad_(True)   # the hidden states
         full = lg @ (0.5 * torch.randn(V, 12, generator=g)).double().t()
