@@ -27,8 +27,8 @@ def twin(x: torch.Tensor) -> torch.Tensor:
     """The bf16 copy a `_BertAddNorm` output carries, when the caller is about to cast x to bf16 anyway (bf16 autocast)."""
     t = getattr(x, "_dalm_bf16", None)
     if t is not None and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == t.dtype \
-            and t.shape == x.shape:
-        return t
+            and t.shape == x.shape and x._version == getattr(x, "_dalm_bf16_version", -1) and t._version == getattr(x, "_dalm_bf16_tversion", -1):
+        return t                  # (an in-place write to either tensor since they were made: the twin is stale, cast instead)
     return x
 
 
@@ -99,4 +99,5 @@ def add_norm(a, res, ln: torch.nn.LayerNorm, p: float, salt: int) -> torch.Tenso
     """LayerNorm(dropout_p(a) + res) -> the f32 result carrying its bf16 twin."""
     y32, y16 = _BertAddNorm.apply(a, res, ln.weight, ln.bias, float(ln.eps), float(p), int(salt))
     y32._dalm_bf16 = y16
+    y32._dalm_bf16_version, y32._dalm_bf16_tversion = y32._version, y16._version
     return y32

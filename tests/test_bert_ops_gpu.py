@@ -160,12 +160,15 @@ def test_patched_bert_layers_match_transformers(dev):
     assert _rel(outs[1][1], outs[0][1]) < 2e-2
     # the twin is what the next GEMM reads
     lin = new.encoder.layer[0].intermediate.dense
-    x = outs[1][0].clone()
-    x._dalm_bf16 = (x * 0).to(torch.bfloat16)                              # a twin that differs from x: the GEMM must follow it
+    x = outs[1][0].clone().requires_grad_(True)
+    x._dalm_bf16 = (x.detach() * 0).to(torch.bfloat16).requires_grad_(True)   # a twin that differs from x: the GEMM must follow it
+    x._dalm_bf16_version, x._dalm_bf16_tversion = x._version, x._dalm_bf16._version
     with torch.autocast("cuda", dtype=torch.bfloat16):
         assert bert_ops.twin(x) is x._dalm_bf16
-        xg = x.requires_grad_(True)
-        xg._dalm_bf16 = x._dalm_bf16.requires_grad_(True)
-        y = lin(xg)
+        y = lin(x)
     assert float((y.float() - lin.bias.float()).abs().max()) < 1e-2       # W . 0 + b
     assert bert_ops.twin(x) is x                                           # outside autocast: no swap
+    with torch.no_grad():
+        x._dalm_bf16.add_(1.0)                                             # an in-place write: the twin is stale now
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert bert_ops.twin(x) is x
