@@ -239,3 +239,23 @@ def test_query_and_passage_in_one_encoder_call_equal_two_calls():
     hp2, hq2 = packed.retrieval_hidden_pair(model, (ip, mp, rp, cp), (iq, mq, rq, cq))
     assert hq2.shape == hq1.shape and hp2.shape == hp1.shape
     assert torch.allclose(hq2, hq1, atol=2e-5, rtol=1e-4) and torch.allclose(hp2, hp1, atol=2e-5, rtol=1e-4)
+
+
+def test_graphed_towers_key_distinguishes_packed_row_counts():
+    from dalm_amd.training.graphed import GraphedTowers
+
+    def batch(n_gen, with_pack=True):
+        b = {"retriever_passage_input_ids": torch.zeros(2, 8), "retriever_query_input_ids": torch.zeros(2, 4),
+             "generator_input_input_ids": torch.zeros(2, 16)}
+        if with_pack:
+            for k, n in (("retriever_passage", 8), ("retriever_query", 4), ("generator", n_gen)):
+                b[f"{k}_pack_rows"] = torch.zeros(n, dtype=torch.long)
+                b[f"{k}_pack_cu"] = torch.zeros(4, dtype=torch.int32)
+        return b
+
+    assert GraphedTowers.is_packed(batch(16)) and not GraphedTowers.is_packed(batch(16, False))
+    assert GraphedTowers.key_of(batch(16)) != GraphedTowers.key_of(batch(24))          # another row count: another set of graphs
+    assert GraphedTowers.key_of(batch(16)) != GraphedTowers.key_of(batch(16, False))   # padded graphs are their own set
+    half = batch(16)
+    del half["retriever_query_pack_rows"]
+    assert not GraphedTowers.is_packed(half)
