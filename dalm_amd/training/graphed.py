@@ -173,6 +173,9 @@ class GraphedStep:
                 # the capture itself does not execute the step; fall through to the replay below
             except Exception as e:  # keep training: same kernels, eager launches
                 self.failed = repr(e)
+                import warnings
+
+                warnings.warn(f"dalm_amd: hipGraph capture of the step failed ({self.failed[:500]}); the steps launch eagerly from here on")
                 torch.cuda.synchronize()
         hit = self.graphs.get(key)
         if hit is not None:
