@@ -81,6 +81,33 @@ class TensorLRScheduler:
         self._push()
 
 
+class _WarmBlas(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        torch.cuda.current_blas_handle()          # runs on autograd's device thread: that thread's handle
+        return g
+
+
+def warm_blas_handles(device=None) -> None:
+    """Create the hipBLAS / rocBLAS handles of THIS thread and of autograd's device thread now.  They are made lazily on first
+    use; the tuned-solution table (dalm_amd/tuning) maps some GEMM shapes to rocBLAS solutions, and a shape that meets its first
+    rocBLAS solution INSIDE a hipGraph capture made the capture fail in `hipblasCreate` (seen in the retriever-only trainer on a
+    new packed row count) - after which the eager fall-back died in torch's dropout (its generator was left in capture mode)."""
+    if not torch.cuda.is_available():
+        return
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    torch.cuda.current_blas_handle()
+    x = torch.zeros(1, device=dev, requires_grad=True)
+    _WarmBlas.apply(x).sum().backward()
+    a = torch.zeros(8, 8, device=dev)
+    torch.mm(a, a)
+    torch.cuda.synchronize()
+
+
 class GraphedStep:
     def __init__(self, step, warmup: int = 3, eager_steps: int = 0, max_graphs: int = 8):
         """warmup: hidden extra steps run on a side stream right before the capture (benchmarks);
@@ -130,6 +157,9 @@ class GraphedStep:
                     self.scheduler.step()
         torch.cuda.current_stream().wait_stream(s)
         init_adam_state(self.step.optimizer)  # no-op after a warm-up step; essential with warmup == 0
+        if not getattr(self, "_blas_warm", False):
+            warm_blas_handles()
+            self._blas_warm = True
         torch.cuda.synchronize()
         if self.pool is None:
             self.pool = torch.cuda.graph_pool_handle()
@@ -292,6 +322,7 @@ class GraphedTowers:
         if getattr(rag_model, "retriever_is_autoregressive", False):
             raise NotImplementedError("graphed towers: autoregressive retrievers run eagerly")
         b = sample_batch
+        warm_blas_handles()
         self.key = self.key_of(b)
         # a batch that carries the packed row lists of all three tower inputs gets PACKED graphs (round 6): the same captures
         # around dalm_amd/packed.py's calls; the row counts are part of the key (one set of graphs per combination)
