@@ -70,6 +70,7 @@ if has prof; then
   run $P/step_streams_packed.log bash tools/step_streams.sh r06packed "--data-path packed"; cp gpurun_out/r06packed_step_by_stream.txt $P/r06packed_step_by_stream.txt
   run $P/step_streams_cfg2.log bash tools/step_streams.sh r06cfg2 "--workload cfg2" "small_grad_kernel|sim_small|small_"; cp gpurun_out/r06cfg2_step_by_stream.txt $P/
   run $P/step_streams_cfg5.log bash tools/step_streams.sh r06cfg5 "--workload cfg5"; cp gpurun_out/r06cfg5_step_by_stream.txt $P/
+  run $P/step_streams_cfg5packed.log bash tools/step_streams.sh r06cfg5packed "--workload cfg5 --data-path packed"; cp gpurun_out/r06cfg5packed_step_by_stream.txt $P/
 fi
 if has kernels; then
   run $P/r06_kernel_bench.txt python tools/kernel_bench.py --quick
