@@ -245,12 +245,15 @@ __device__ __forceinline__ AttnDrop attn_drop(const AttnBwdParams& p) {
 // both fields of the pair that holds element index c (c even): low half = element c, high half = element c + 1
 __device__ __forceinline__ unsigned int drop_pair(const AttnDrop& d, unsigned int c) { return mix32(((c >> 1) ^ d.a) + d.b); }
 
-// launch index -> (row block, head, batch): the row blocks of one (batch, head) - which re-read the same K / V (or Q / dO) - go to
-// the same XCD (launch index mod 8) and sit 8 apart in launch order, so the second one finds the first one's lines in that L2
-__device__ __forceinline__ bool block_coords(const AttnBwdParams& p, int nblk, int& blk, int& h, int& b) {
-  const int n = blockIdx.x, x = n & 7, a = n / (8 * nblk);
-  blk = (n >> 3) % nblk;
-  const int pair = 8 * a + x;
+// launch index -> (row block, head, batch).  Workgroups are dispatched in launch order and a row block's work grows with its index
+// (causal mask: query block i multiplies i + 1 key blocks) or falls with it (key block j meets nblk - j query blocks): the HEAVY
+// blocks of every (batch, head) are launched first, the light ones fill the tail (interleaved, the last workgroups to start were
+// heavy ones and ran alone for a third of the kernel's time).  Both row blocks of one (batch, head) keep the same launch index
+// mod 8 = the same XCD: the later one finds K / V (or Q / dO) in that L2 or in the Infinity Cache.
+__device__ __forceinline__ bool block_coords(const AttnBwdParams& p, int nblk, bool last_block_first, int& blk, int& h, int& b) {
+  const int pairs8 = (p.B * p.H + 7) & ~7;
+  const int n = blockIdx.x, a = n / pairs8, pair = n - a * pairs8;
+  blk = last_block_first ? nblk - 1 - a : a;
   if (pair >= p.B * p.H) return false;
   h = pair % p.H;
   b = pair / p.H;
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(256, DROP ? 2 : AT<HD>::OCC) void attn_bwd_dq_kerne
   float* dl_s = reinterpret_cast<float*>(lds + 128 * A::LROW);          // prologue only: [128] D of the workgroup's rows
   const int t = threadIdx.x, w = t >> 6, l = t & 63, l31 = l & 31, hi = l >> 5;
   int blk, h, b;
-  if (!block_coords(p, (p.T + 127) >> 7, blk, h, b)) return;
+  if (!block_coords(p, (p.T + 127) >> 7, true, blk, h, b)) return;
   const int i0 = blk * 128;
   const int i = i0 + 32 * w + l31;
   const int64_t bh = static_cast<int64_t>(b) * p.H + h;
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(256, AT<HD>::OCC) void attn_fwd_kernel(const AttnBw
   unsigned char* VT = lds + A::RM;                             // [HD][kTRow]: V transposed
   const int t = threadIdx.x, w = t >> 6, l = t & 63, l31 = l & 31, hi = l >> 5;
   int blk, h, b;
-  if (!block_coords(p, (p.T + 127) >> 7, blk, h, b)) return;
+  if (!block_coords(p, (p.T + 127) >> 7, true, blk, h, b)) return;
   const int i0 = blk * 128;
   const int i = i0 + 32 * w + l31;
   const int64_t bh = static_cast<int64_t>(b) * p.H + h;
@@ -561,7 +564,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdPara
   float* dl_s = nl_s + 64;
   const int t = threadIdx.x, w = t >> 6, l = t & 63, l31 = l & 31, hi = l >> 5, jt = w >> 1, dh = w & 1;
   int blk, h, b;
-  if (!block_coords(p, (p.T + 63) >> 6, blk, h, b)) return;
+  if (!block_coords(p, (p.T + 63) >> 6, false, blk, h, b)) return;
   const int j0 = blk * 64;
   const int j = j0 + 32 * jt + l31;
   const int64_t bh = static_cast<int64_t>(b) * p.H + h;
