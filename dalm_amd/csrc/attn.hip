@@ -685,6 +685,235 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdPara
   store_rows<HD, A::N64>(dlds + A::RM, dv_base, p.s[7][2], j0, T, t);
 }
 
+// ---- LDS images filled by LDS-DMA (global_load_lds_dwordx4: the destination is a wave-uniform base + 16 bytes x lane, so an
+// image cannot be padded) and read by ds_read_b128 (A operands, lane <-> row) AND ds_read_b64_tr_b16 (operands whose contraction
+// index runs over the image's ROWS - what the transposed LDS copies above exist for).  A [64 rows][HD] block: row r at byte
+// 2 HD r, its 16-byte chunk x at position x ^ swz(r).  swz is chosen so that both read patterns touch every bank once
+// (MI355X_MICROARCH.md LDS table: b128 is served in 16-lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...; the transpose
+// read in 32-lane halves, each a 4-row x 64-byte patch): HD 128 (16 chunks, a row = all 64 banks): 4 (r & 3) + ((r >> 2) & 3);
+// HD 64 (8 chunks, a row = half the banks, odd rows the other half): 4 ((r >> 1) & 1) + ((r >> 2) & 3).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+#define DALM_LDS3(p) (reinterpret_cast<__attribute__((address_space(3))) void*>(reinterpret_cast<uintptr_t>(p)))
+template <int HD>
+__device__ __forceinline__ int swz(int r) {
+  return HD == 128 ? 4 * (r & 3) + ((r >> 2) & 3) : 4 * ((r >> 1) & 1) + ((r >> 2) & 3);
+}
+// One LDS-DMA piece: 16 (or 4) bytes per lane from `sbase` (wave-uniform) + voff bytes (per lane) to LDS byte address lds_dst
+// (wave-uniform) + 16 (4) lane.  Inline assembly on purpose: hipcc treats the builtin form as an LDS store it cannot tell apart
+// from the images' reads and drains vmcnt in front of every ds_read that follows - the overlap this kernel exists for.  The
+// kernel counts these loads itself (s_waitcnt vmcnt(0) + s_barrier before a stage is read).
+__device__ __forceinline__ void glds16(const void* sbase, unsigned int voff, unsigned int lds_dst) {
+  unsigned int keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds4(const void* sbase, unsigned int voff, unsigned int lds_dst) {
+  unsigned int keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+// rows row0 .. row0 + 63 of a [rows][HD] tensor -> image at LDS byte address `img` (rows past the sequence's end repeat its
+// last row: finite values that only ever meet zero probabilities); every wave issues its quarter of the 1-KiB pieces, nothing
+// passes through registers.  T row_stride < 2^31 elements (checked by the host).
+template <int HD>
+__device__ __forceinline__ void dma_block(const unsigned short* base, unsigned int row_stride, int row0, int T, unsigned int img, int w, int l) {
+  constexpr int CH = HD / 8, RPI = 64 / CH, NI = 64 / RPI / 4;   // lanes per row, rows per piece, pieces per wave
+#pragma unroll
+  for (int n = 0; n < NI; ++n) {
+    const int piece = NI * w + n, r = RPI * piece + l / CH, x = (l % CH) ^ swz<HD>(r);
+    const unsigned int row = static_cast<unsigned int>(min(row0 + r, T - 1));
+    glds16(base, 2u * (row * row_stride + 8u * x), img + 1024u * piece);
+  }
+}
+// A operand, lane <-> row (32 tile + l31), k-step kk: the 16 bytes at d = 16 kk + 8 hi
+template <int HD>
+__device__ __forceinline__ bf16x8 img_frag(const unsigned char* img, int tile, int l31, int hi, int kk) {
+  const int r = 32 * tile + l31;
+  return *reinterpret_cast<const bf16x8*>(img + r * (2 * HD) + 16 * ((2 * kk + hi) ^ swz<HD>(r)));
+}
+// A operand [d (lane & 31)][k = image rows r0 + 16 s + 4 hi + {0..3}, then + 8] of d block `dblk`: what ld_tr_frag reads from a
+// transposed copy, here two transpose reads of the row-major image (a 16-lane group reads a [4 rows][16 columns] patch, 4
+// contiguous elements per lane; lane t of the group receives column t of the four rows)
+template <int HD>
+__device__ __forceinline__ bf16x8 img_tr_frag(const unsigned char* img, int dblk, int r0, int s, int l) {
+  const int t = l & 15, g = l >> 4, hi = l >> 5;
+  const int x = 4 * dblk + 2 * (g & 1) + ((t & 3) >> 1);
+  s16x4 v[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int r = r0 + 16 * s + 8 * u + 4 * hi + (t >> 2);
+    const unsigned char* a = img + r * (2 * HD) + 16 * (x ^ swz<HD>(r)) + 8 * (t & 1);
+    v[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<__attribute__((address_space(3))) s16x4*>(reinterpret_cast<uintptr_t>(a)));
+  }
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 both = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w};
+  return __builtin_bit_cast(bf16x8, both);
+}
+
+template <int HD>
+constexpr int dkdv2_lds() { return 4 * 64 * 2 * HD + 1024; }
+
+// dk / dv, second form: the arithmetic of attn_bwd_dkdv_kernel, instruction for instruction - same tiles, same
+// operands, same order, bit-identical results - with another data path.  Q / dO blocks go HBM -> LDS by LDS-DMA into the
+// un-padded swizzled images above, TWO stages: block n + 1 is in flight while block n is multiplied (the first form held a block in
+// 32 registers per lane on its way to LDS and could not afford to keep them live across the products: every block's load latency
+// was exposed), one barrier per block instead of two.  The transposed copies (64 two-byte LDS stores per lane and block, half of
+// this kernel's LDS time) are gone: dO^T / Q^T operands are transpose reads of the row-major images.  The log-sum-exp and D of the
+// block's rows travel the same way (4-byte pieces).  K / V fragments of the workgroup's own rows come straight from HBM in
+// fragment shape (once per workgroup).
+template <int HD, bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv2_kernel(const AttnBwdParams p) {
+  using A = AT<HD>;
+  constexpr int NDH = A::ND / 2;
+  constexpr int IMG = 64 * 2 * HD;                             // one block image
+  extern __shared__ __attribute__((aligned(16))) unsigned char dlds[];
+  // stage s: Q image at s 2 IMG, dO image at s 2 IMG + IMG; lse / D of the block's rows at 4 IMG + 512 s (+ 256)
+  const int t = threadIdx.x, w = t >> 6, l = t & 63, l31 = l & 31, hi = l >> 5, jt = w >> 1, dh = w & 1;
+  int blk, h, b;
+  if (!block_coords(p, (p.T + 63) >> 6, false, blk, h, b)) return;
+  const int j0 = blk * 64;
+  const int j = j0 + 32 * jt + l31;
+  const int64_t bh = static_cast<int64_t>(b) * p.H + h;
+  const Seq sq = seq_of(p, b);
+  const int T = sq.T;
+  unsigned short* dk_base = p.dk + base_off(p, 6, b, h, sq);
+  unsigned short* dv_base = p.dv + base_off(p, 7, b, h, sq);
+  const unsigned long long need = need_mask<2>(p, b, j0 >> 5, false, l);
+  if (need == 0ull) {
+    store_rows<HD, A::N64>(nullptr, dk_base, p.s[6][2], j0, T, t);
+    store_rows<HD, A::N64>(nullptr, dv_base, p.s[7][2], j0, T, t);
+    return;
+  }
+  const unsigned short* qbase = p.q + base_off(p, 0, b, h, sq);
+  const unsigned short* gbase = p.d_o + base_off(p, 4, b, h, sq);
+  const int Tp = 32 * p.W;
+  const int nI = (p.T + 63) >> 6;
+  unsigned int blocks = 0u;                                    // bit ib: query block ib has a live tile (T <= 2048: 32 blocks)
+  for (int ib = 0; ib < nI; ++ib) blocks |= (((need >> (2 * ib)) & 3ull) != 0ull ? 1u : 0u) << ib;
+
+  uint32_t nword[2];
+  const unsigned int lds0 = static_cast<unsigned int>(reinterpret_cast<uintptr_t>(dlds));   // LDS byte address of the carve-out
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  const unsigned int sq_row = static_cast<unsigned int>(p.s[0][2]), sg_row = static_cast<unsigned int>(p.s[4][2]);
+  const float* lse_row = p.lse + bh * p.T;
+  const float* delta_row = p.delta + bh * p.T;
+  auto issue = [&](int ib, int stage) {
+    const unsigned int qi = lds0 + stage * (2 * IMG);
+    dma_block<HD>(qbase, sq_row, 64 * ib, T, qi, wu, l);
+    dma_block<HD>(gbase, sg_row, 64 * ib, T, qi + IMG, wu, l);
+    if (wu == 0) {
+      const unsigned int row = static_cast<unsigned int>(min(64 * ib + l, T - 1));
+      glds4(lse_row, 4u * row, lds0 + 4 * IMG + 512 * stage);
+      glds4(delta_row, 4u * row, lds0 + 4 * IMG + 512 * stage + 256);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      nword[c] = (j < Tp && 2 * ib + c < p.W) ? p.bits_cols[(static_cast<int64_t>(b) * Tp + j) * p.W + 2 * ib + c] : 0u;
+  };
+  int cur = __builtin_ctz(blocks);
+  blocks &= blocks - 1u;
+  issue(cur, 0);
+
+  bf16x8 Kb[A::KK], Vb[A::KK];
+  {
+    const bool ok = j < T;
+    const unsigned short* kr = p.k + base_off(p, 1, b, h, sq) + static_cast<int64_t>(j) * p.s[1][2] + 8 * hi;
+    const unsigned short* vr = p.v + base_off(p, 2, b, h, sq) + static_cast<int64_t>(j) * p.s[2][2] + 8 * hi;
+#pragma unroll
+    for (int kk = 0; kk < A::KK; ++kk) {
+      Kb[kk] = __builtin_bit_cast(bf16x8, ok ? ld16(kr + 16 * kk) : make_uint4(0u, 0u, 0u, 0u));
+      Vb[kk] = __builtin_bit_cast(bf16x8, ok ? ld16(vr + 16 * kk) : make_uint4(0u, 0u, 0u, 0u));
+    }
+  }
+  const float c1 = p.scale * kLog2e;
+  f32x16 dVt[NDH], dKt[NDH];
+#pragma unroll
+  for (int d = 0; d < NDH; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dVt[d][r] = 0.f; dKt[d][r] = 0.f; }
+
+  const AttnDrop drop = attn_drop(p);
+  (void)drop;
+  int stage = 0;
+  while (true) {
+    // this wave's pieces of block `cur` have landed; after the barrier everybody's have, and everybody is done with the block before
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    const uint32_t word[2] = {nword[0], nword[1]};
+    const int ib = cur;
+    (void)ib;
+    int nxt = -1;
+    if (blocks) {
+      nxt = __builtin_ctz(blocks);
+      blocks &= blocks - 1u;
+      issue(nxt, stage ^ 1);
+    }
+    const unsigned char* Qi = dlds + stage * (2 * IMG);
+    const unsigned char* Gi = Qi + IMG;
+    const float* nl_s = reinterpret_cast<const float*>(dlds + 4 * IMG + 512 * stage);
+    const float* dl_s = nl_s + 64;
+#pragma unroll
+    for (int is = 0; is < 2; ++is) {
+      if (__builtin_amdgcn_ballot_w64(word[is] != 0u) == 0ull) continue;
+      f32x16 S, dP;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
+#pragma unroll
+      for (int kk = 0; kk < A::KK; ++kk) {
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag<HD>(Qi, is, l31, hi, kk), Kb[kk], S, 0, 0, 0);
+        dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag<HD>(Gi, is, l31, hi, kk), Vb[kk], dP, 0, 0, 0);
+      }
+      unsigned int ppk[8], dpk[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 ls4 = *reinterpret_cast<const float4*>(nl_s + 32 * is + 8 * q + 4 * hi);
+        const float4 dl4 = *reinterpret_cast<const float4*>(dl_s + 32 * is + 8 * q + 4 * hi);
+        const float nl[4] = {-ls4.x * kLog2e, -ls4.y * kLog2e, -ls4.z * kLog2e, -ls4.w * kLog2e}, dl[4] = {dl4.x, dl4.y, dl4.z, dl4.w};
+        float pv[4], ds[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int il = 8 * q + 4 * hi + u;
+          pv[u] = ((word[is] >> il) & 1u) ? __builtin_amdgcn_exp2f(fmaf(S[4 * q + u], c1, nl[u])) : 0.f;
+          float dpe = dP[4 * q + u];
+          if constexpr (DROP) {
+            const unsigned int c = (static_cast<unsigned int>(bh) * p.T + 64 * ib + 32 * is + il) * p.T + j;
+            const unsigned int hw = drop_pair(drop, c & ~1u);
+            const bool keep = ((c & 1u) ? hw >> 16 : hw & 0xffffu) >= drop.thresh;
+            dpe = keep ? dpe * drop.ks : 0.f;
+            ds[u] = pv[u] * (dpe - dl[u]);
+            pv[u] = keep ? pv[u] * drop.ks : 0.f;                // what multiplies dO in dV = (P o M / (1 - p))^T dO
+          } else {
+            ds[u] = pv[u] * (dpe - dl[u]);
+          }
+        }
+        ppk[2 * q] = pack_bf16x2(pv[0], pv[1]);
+        ppk[2 * q + 1] = pack_bf16x2(pv[2], pv[3]);
+        dpk[2 * q] = pack_bf16x2(ds[0], ds[1]);
+        dpk[2 * q + 1] = pack_bf16x2(ds[2], ds[3]);
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 pb = __builtin_bit_cast(bf16x8, make_uint4(ppk[4 * s], ppk[4 * s + 1], ppk[4 * s + 2], ppk[4 * s + 3]));
+        const bf16x8 db = __builtin_bit_cast(bf16x8, make_uint4(dpk[4 * s], dpk[4 * s + 1], dpk[4 * s + 2], dpk[4 * s + 3]));
+#pragma unroll
+        for (int d = 0; d < NDH; ++d) {
+          dVt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_tr_frag<HD>(Gi, NDH * dh + d, 32 * is, s, l), pb, dVt[d], 0, 0, 0);
+          dKt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_tr_frag<HD>(Qi, NDH * dh + d, 32 * is, s, l), db, dKt[d], 0, 0, 0);
+        }
+      }
+    }
+    if (nxt < 0) break;
+    cur = nxt;
+    stage ^= 1;
+  }
+  __syncthreads();
+  spill_transposed<HD, NDH>(dKt, NDH * dh, p.scale, dlds, jt, l31, hi);
+  spill_transposed<HD, NDH>(dVt, NDH * dh, 1.0f, dlds + A::RM, jt, l31, hi);
+  __syncthreads();
+  if (p.cos) store_rows_unrope<HD, A::N64>(dlds, dk_base, p.s[6][2], j0, T, t, p.cos + cs_off(p, b, sq), p.sin + cs_off(p, b, sq), p.cs_t);
+  else store_rows<HD, A::N64>(dlds, dk_base, p.s[6][2], j0, T, t);
+  store_rows<HD, A::N64>(dlds + A::RM, dv_base, p.s[7][2], j0, T, t);
+}
+
 // mask [B, 1, T, T] bytes (non-zero = attend; NULL = all) and / or causal -> row words, column words, live 32 x 32 tiles
 __global__ __launch_bounds__(256) void attn_mask_bits_kernel(const unsigned char* __restrict__ mask, int B, int T, int W, int64_t sb,
                                                              int64_t si, int causal, uint32_t* __restrict__ rows,
@@ -816,11 +1045,18 @@ static int dalm_attn_bwd_any(const void* q, const void* k, const void* v, const 
   for (int i = 0; i < 8; ++i)
     for (int a = 0; a < 3; ++a) p.s[i][a] = strides[3 * i + a];
   static bool lds_set = false;
+  static bool first_form = false;                              // DALM_ATTN_DKDV=1: the register-staged dk / dv kernel (A/B runs)
   if (!lds_set) {
     for (const void* fn : {reinterpret_cast<const void*>(attn_bwd_dkdv_kernel<128, false>),
                            reinterpret_cast<const void*>(attn_bwd_dkdv_kernel<128, true>)})
       if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, dkdv_lds<128>()); e != hipSuccess)
         return fail(static_cast<int>(e), __func__, "could not raise the dynamic LDS limit of the dk / dv kernel");
+    for (const void* fn : {reinterpret_cast<const void*>(attn_bwd_dkdv2_kernel<128, false>),
+                           reinterpret_cast<const void*>(attn_bwd_dkdv2_kernel<128, true>)})
+      if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, dkdv2_lds<128>()); e != hipSuccess)
+        return fail(static_cast<int>(e), __func__, "could not raise the dynamic LDS limit of the dk / dv kernel");
+    const char* env = getenv("DALM_ATTN_DKDV");
+    first_form = env && env[0] == '1';
     lds_set = true;
   }
   const int64_t pairs8 = (B * H + 7) / 8 * 8;
@@ -829,7 +1065,8 @@ static int dalm_attn_bwd_any(const void* q, const void* k, const void* v, const 
 #define DALM_ATTN_BWD(HD, DROP)                                                                         \
   do {                                                                                                 \
     hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, DROP>), grid_dq, dim3(256), 0, s, p);                   \
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD, DROP>), grid_dkdv, dim3(256), dkdv_lds<HD>(), s, p);  \
+    if (first_form || (HD == 128 && DROP)) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD, DROP>), grid_dkdv, dim3(256), dkdv_lds<HD>(), s, p);  \
+    else hipLaunchKernelGGL((attn_bwd_dkdv2_kernel<HD, DROP>), grid_dkdv, dim3(256), dkdv2_lds<HD>(), s, p);  \
   } while (0)
   if (hd == 128) { if (p.seed) DALM_ATTN_BWD(128, true); else DALM_ATTN_BWD(128, false); }
   else { if (p.seed) DALM_ATTN_BWD(64, true); else DALM_ATTN_BWD(64, false); }
