@@ -750,6 +750,17 @@ __device__ __forceinline__ bf16x8 img_tr_frag(const unsigned char* img, int dblk
   return __builtin_bit_cast(bf16x8, both);
 }
 
+// Top of a streamed block: this wave's LDS-DMA pieces of the block have landed (vmcnt(0): the BUILTIN wait, which hipcc's own
+// counter bookkeeping sees - after an inline-assembly wait it still believed the mask words of the block, loaded one iteration
+// earlier, to be in flight and put its own vmcnt(0) in front of their first use, i.e. AFTER the next block's pieces had been
+// issued: no overlap); after the barrier everybody's have, and everybody is done reading the stage the next pieces go to.  The
+// empty statement pins the mask words' wait to this point as well.
+__device__ __forceinline__ void stage_ready(const uint32_t (&nword)[2]) {
+  __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0), expcnt / lgkmcnt untouched
+  asm volatile("s_barrier" ::: "memory");
+  asm volatile("" :: "v"(nword[0]), "v"(nword[1]) : "memory");
+}
+
 template <int HD>
 constexpr int dkdv2_lds() { return 4 * 64 * 2 * HD + 1024; }
 
@@ -836,8 +847,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv2_kernel(const AttnBwdPar
   (void)drop;
   int stage = 0;
   while (true) {
-    // this wave's pieces of block `cur` have landed; after the barrier everybody's have, and everybody is done with the block before
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    stage_ready(nword);
     const uint32_t word[2] = {nword[0], nword[1]};
     const int ib = cur;
     (void)ib;
@@ -912,6 +922,295 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv2_kernel(const AttnBwdPar
   if (p.cos) store_rows_unrope<HD, A::N64>(dlds, dk_base, p.s[6][2], j0, T, t, p.cos + cs_off(p, b, sq), p.sin + cs_off(p, b, sq), p.cs_t);
   else store_rows<HD, A::N64>(dlds, dk_base, p.s[6][2], j0, T, t);
   store_rows<HD, A::N64>(dlds + A::RM, dv_base, p.s[7][2], j0, T, t);
+}
+
+// the wave's 32 rows (lane <-> row) as B operands straight from HBM in fragment shape: k-step kk = the 16 bytes at d = 16 kk + 8 hi
+template <int HD>
+__device__ __forceinline__ void rows_frags_global(const unsigned short* base, int64_t row_stride, int row, int T, int hi, uint4 (&f)[AT<HD>::KK]) {
+  const bool ok = row < T;
+  const unsigned short* src = base + static_cast<int64_t>(row) * row_stride + 8 * hi;
+#pragma unroll
+  for (int kk = 0; kk < AT<HD>::KK; ++kk) f[kk] = ok ? ld16(src + 16 * kk) : make_uint4(0u, 0u, 0u, 0u);
+}
+
+template <int HD>
+constexpr int stream2_lds() { return 4 * 64 * 2 * HD; }      // two stages of (K image, V image)
+
+// dq, second form: the arithmetic of attn_bwd_dq_kernel with the data path of attn_bwd_dkdv2_kernel (K / V blocks by LDS-DMA into
+// two stages of swizzled images, K^T operands by transpose reads of the K image, one barrier per block).  Q / dO fragments and
+// D = rowsum(dO o O) come from fragment-shaped loads (a lane pair l, l ^ 32 holds one row: even / odd 16-byte chunks); D is summed
+// in the first form's order (chunk dot products, then the butterfly over chunk pairs) so that both forms write the same bits.
+template <int HD, bool DROP>
+__global__ __launch_bounds__(256, DROP ? 2 : AT<HD>::OCC) void attn_bwd_dq2_kernel(const AttnBwdParams p) {
+  using A = AT<HD>;
+  constexpr int IMG = 64 * 2 * HD;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dlds[];
+  const int t = threadIdx.x, w = t >> 6, l = t & 63, l31 = l & 31, hi = l >> 5;
+  int blk, h, b;
+  if (!block_coords(p, (p.T + 127) >> 7, true, blk, h, b)) return;
+  const int i0 = blk * 128;
+  const int i = i0 + 32 * w + l31;
+  const int64_t bh = static_cast<int64_t>(b) * p.H + h;
+  const Seq sq = seq_of(p, b);
+  const int T = sq.T;
+  unsigned short* dq_base = p.dq + base_off(p, 5, b, h, sq);
+  const unsigned long long need = need_mask<4>(p, b, i0 >> 5, true, l);
+  if (need == 0ull) {
+    store_rows<HD, A::N128>(nullptr, dq_base, p.s[5][2], i0, T, t);
+    return;
+  }
+  const unsigned short* kbase = p.k + base_off(p, 1, b, h, sq);
+  const unsigned short* vbase = p.v + base_off(p, 2, b, h, sq);
+  const int Tp = 32 * p.W;
+  const int nJ = (p.T + 63) >> 6;
+  unsigned int blocks = 0u;
+  for (int jb = 0; jb < nJ; ++jb) blocks |= (((need >> (2 * jb)) & 3ull) != 0ull ? 1u : 0u) << jb;
+
+  uint32_t nword[2];
+  const unsigned int lds0 = static_cast<unsigned int>(reinterpret_cast<uintptr_t>(dlds));
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  const unsigned int sk_row = static_cast<unsigned int>(p.s[1][2]), sv_row = static_cast<unsigned int>(p.s[2][2]);
+  auto issue = [&](int jb, int stage) {
+    const unsigned int ki = lds0 + stage * (2 * IMG);
+    dma_block<HD>(kbase, sk_row, 64 * jb, T, ki, wu, l);
+    dma_block<HD>(vbase, sv_row, 64 * jb, T, ki + IMG, wu, l);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      nword[c] = (i < Tp && 2 * jb + c < p.W) ? p.bits_rows[(static_cast<int64_t>(b) * Tp + i) * p.W + 2 * jb + c] : 0u;
+  };
+  int cur = __builtin_ctz(blocks);
+  blocks &= blocks - 1u;
+  issue(cur, 0);
+
+  bf16x8 Qb[A::KK], Gb[A::KK];
+  float Dl;
+  {
+    uint4 qv[A::KK], gv[A::KK], ov[A::KK];
+    rows_frags_global<HD>(p.q + base_off(p, 0, b, h, sq), p.s[0][2], i, T, hi, qv);
+    rows_frags_global<HD>(p.d_o + base_off(p, 4, b, h, sq), p.s[4][2], i, T, hi, gv);
+    rows_frags_global<HD>(p.o + base_off(p, 3, b, h, sq), p.s[3][2], i, T, hi, ov);
+    float pr[A::KK];
+#pragma unroll
+    for (int kk = 0; kk < A::KK; ++kk) {                         // chunk 2 kk + hi here, chunk 2 kk + (1 - hi) in lane l ^ 32
+      const float d = dot8(gv[kk], ov[kk]);
+      pr[kk] = d + __shfl_xor(d, 32, 64);
+      Qb[kk] = __builtin_bit_cast(bf16x8, qv[kk]);
+      Gb[kk] = __builtin_bit_cast(bf16x8, gv[kk]);
+    }
+#pragma unroll
+    for (int off = 1; off < A::KK; off <<= 1)
+#pragma unroll
+      for (int kk = 0; kk < A::KK; kk += 2 * off) pr[kk] += pr[kk + off];
+    Dl = pr[0];
+    if (hi == 0 && i < T) p.delta[bh * p.T + i] = Dl;
+  }
+  const float nl = i < T ? -p.lse[bh * p.T + i] * kLog2e : 0.f;
+  const float c1 = p.scale * kLog2e;
+
+  f32x16 acc[A::ND];
+#pragma unroll
+  for (int d = 0; d < A::ND; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+  const AttnDrop drop = attn_drop(p);
+  const unsigned int cbase = (static_cast<unsigned int>(bh) * p.T + i) * p.T;      // element index of (row i, column 0)
+  (void)drop; (void)cbase;
+  int stage = 0;
+  while (true) {
+    stage_ready(nword);
+    const uint32_t word[2] = {nword[0], nword[1]};
+    const int jb = cur;
+    (void)jb;
+    int nxt = -1;
+    if (blocks) {
+      nxt = __builtin_ctz(blocks);
+      blocks &= blocks - 1u;
+      issue(nxt, stage ^ 1);
+    }
+    const unsigned char* Ki = dlds + stage * (2 * IMG);
+    const unsigned char* Vi = Ki + IMG;
+#pragma unroll 1
+    for (int js = 0; js < 2; ++js) {
+      if (__builtin_amdgcn_ballot_w64(word[js] != 0u) == 0ull) continue;
+      f32x16 St, Pt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { St[r] = 0.f; Pt[r] = 0.f; }
+#pragma unroll
+      for (int kk = 0; kk < A::KK; ++kk) {
+        St = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag<HD>(Ki, js, l31, hi, kk), Qb[kk], St, 0, 0, 0);
+        Pt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag<HD>(Vi, js, l31, hi, kk), Gb[kk], Pt, 0, 0, 0);
+      }
+      unsigned int pk[8];
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        float ds[2];
+        const int jl0 = (r & 3) + 8 * (r >> 2) + 4 * hi;       // even: (jl0, jl0 + 1) share a hash
+        unsigned int hw = 0xffffffffu;
+        if constexpr (DROP) hw = drop_pair(drop, cbase + 64 * jb + 32 * js + jl0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int jl = jl0 + u;
+          const float pv = ((word[js] >> jl) & 1u) ? __builtin_amdgcn_exp2f(fmaf(St[r + u], c1, nl)) : 0.f;
+          float dpe = Pt[r + u];
+          if constexpr (DROP) dpe = ((u ? hw >> 16 : hw & 0xffffu) >= drop.thresh) ? dpe * drop.ks : 0.f;
+          ds[u] = pv * (dpe - Dl);
+        }
+        pk[r >> 1] = pack_bf16x2(ds[0], ds[1]);
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 dsb = __builtin_bit_cast(bf16x8, make_uint4(pk[4 * s], pk[4 * s + 1], pk[4 * s + 2], pk[4 * s + 3]));
+#pragma unroll
+        for (int d = 0; d < A::ND; ++d)
+          acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_tr_frag<HD>(Ki, d, 32 * js, s, l), dsb, acc[d], 0, 0, 0);
+      }
+    }
+    if (nxt < 0) break;
+    cur = nxt;
+    stage ^= 1;
+  }
+  __syncthreads();
+  spill_transposed<HD, A::ND>(acc, 0, p.scale, dlds, w, l31, hi);
+  __syncthreads();
+  if (p.cos) store_rows_unrope<HD, A::N128>(dlds, dq_base, p.s[5][2], i0, T, t, p.cos + cs_off(p, b, sq), p.sin + cs_off(p, b, sq), p.cs_t);
+  else store_rows<HD, A::N128>(dlds, dq_base, p.s[5][2], i0, T, t);
+}
+
+// Forward, second form: attn_fwd_kernel's arithmetic on the same data path (K image read row-wise, V image by transpose reads).
+template <int HD, bool DROP>
+__global__ __launch_bounds__(256, (DROP && HD == 64) ? 2 : AT<HD>::OCC) void attn_fwd2_kernel(const AttnBwdParams p) {
+  using A = AT<HD>;
+  constexpr int IMG = 64 * 2 * HD;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dlds[];
+  const int t = threadIdx.x, w = t >> 6, l = t & 63, l31 = l & 31, hi = l >> 5;
+  int blk, h, b;
+  if (!block_coords(p, (p.T + 127) >> 7, true, blk, h, b)) return;
+  const int i0 = blk * 128;
+  const int i = i0 + 32 * w + l31;
+  const int64_t bh = static_cast<int64_t>(b) * p.H + h;
+  const Seq sq = seq_of(p, b);
+  const int T = sq.T;
+  unsigned short* o_base = p.dq + base_off(p, 5, b, h, sq);               // the output travels in the dq slot
+  float* lse_out = p.delta;                                                // and the log-sum-exp in the delta slot
+  const unsigned long long need = need_mask<4>(p, b, i0 >> 5, true, l);
+  if (need == 0ull) {                                          // rows without a live key: zero output (as torch returns)
+    store_rows<HD, A::N128>(nullptr, o_base, p.s[5][2], i0, T, t);
+    if (t < 128 && i0 + t < T) lse_out[bh * p.T + i0 + t] = 0.f;
+    return;
+  }
+  const unsigned short* kbase = p.k + base_off(p, 1, b, h, sq);
+  const unsigned short* vbase = p.v + base_off(p, 2, b, h, sq);
+  const int Tp = 32 * p.W;
+  const int nJ = (p.T + 63) >> 6;
+  unsigned int blocks = 0u;
+  for (int jb = 0; jb < nJ; ++jb) blocks |= (((need >> (2 * jb)) & 3ull) != 0ull ? 1u : 0u) << jb;
+
+  uint32_t nword[2];
+  const unsigned int lds0 = static_cast<unsigned int>(reinterpret_cast<uintptr_t>(dlds));
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  const unsigned int sk_row = static_cast<unsigned int>(p.s[1][2]), sv_row = static_cast<unsigned int>(p.s[2][2]);
+  auto issue = [&](int jb, int stage) {
+    const unsigned int ki = lds0 + stage * (2 * IMG);
+    dma_block<HD>(kbase, sk_row, 64 * jb, T, ki, wu, l);
+    dma_block<HD>(vbase, sv_row, 64 * jb, T, ki + IMG, wu, l);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      nword[c] = (i < Tp && 2 * jb + c < p.W) ? p.bits_rows[(static_cast<int64_t>(b) * Tp + i) * p.W + 2 * jb + c] : 0u;
+  };
+  int cur = __builtin_ctz(blocks);
+  blocks &= blocks - 1u;
+  issue(cur, 0);
+
+  bf16x8 Qb[A::KK];
+  {
+    uint4 qv[A::KK];
+    rows_frags_global<HD>(p.q + base_off(p, 0, b, h, sq), p.s[0][2], i, T, hi, qv);
+#pragma unroll
+    for (int kk = 0; kk < A::KK; ++kk) Qb[kk] = __builtin_bit_cast(bf16x8, qv[kk]);
+  }
+  const float c1 = p.scale * kLog2e;
+  f32x16 acc[A::ND];
+#pragma unroll
+  for (int d = 0; d < A::ND; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+  float m = -INFINITY, lsum = 0.f;                              // running maximum (log2 domain) of the row; this lane's share of the sum
+
+  const AttnDrop drop = attn_drop(p);
+  const unsigned int cbase = (static_cast<unsigned int>(bh) * p.T + i) * p.T;
+  (void)drop; (void)cbase;
+  int stage = 0;
+  while (true) {
+    stage_ready(nword);
+    const uint32_t word[2] = {nword[0], nword[1]};
+    const int jb = cur;
+    (void)jb;
+    int nxt = -1;
+    if (blocks) {
+      nxt = __builtin_ctz(blocks);
+      blocks &= blocks - 1u;
+      issue(nxt, stage ^ 1);
+    }
+    const unsigned char* Ki = dlds + stage * (2 * IMG);
+    const unsigned char* Vi = Ki + IMG;
+#pragma unroll
+    for (int js = 0; js < 2; ++js) {
+      if (__builtin_amdgcn_ballot_w64(word[js] != 0u) == 0ull) continue;
+      f32x16 St;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) St[r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < A::KK; ++kk)
+        St = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_frag<HD>(Ki, js, l31, hi, kk), Qb[kk], St, 0, 0, 0);
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int jl = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        St[r] = ((word[js] >> jl) & 1u) ? St[r] * c1 : -INFINITY;
+        mx = fmaxf(mx, St[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m, mx);
+      const float base = mn == -INFINITY ? 0.f : mn;             // a row with nothing live so far: every p below is exp2(-inf) = 0
+      const float alpha = __builtin_amdgcn_exp2f(m - base);      // m = -inf: 0
+      m = mn;
+      float ps = 0.f;
+      unsigned int pk[8];
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(St[r] - base), p1 = __builtin_amdgcn_exp2f(St[r + 1] - base);
+        ps += p0 + p1;                                           // the softmax denominator counts dropped elements too
+        if constexpr (DROP) {
+          const unsigned int hw = drop_pair(drop, cbase + 64 * jb + 32 * js + (r & 3) + 8 * (r >> 2) + 4 * hi);
+          pk[r >> 1] = pack_bf16x2((hw & 0xffffu) >= drop.thresh ? p0 * drop.ks : 0.f, (hw >> 16) >= drop.thresh ? p1 * drop.ks : 0.f);
+        } else {
+          pk[r >> 1] = pack_bf16x2(p0, p1);
+        }
+      }
+      lsum = fmaf(lsum, alpha, ps);
+#pragma unroll
+      for (int d = 0; d < A::ND; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[d][r] *= alpha;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 pb = __builtin_bit_cast(bf16x8, make_uint4(pk[4 * s], pk[4 * s + 1], pk[4 * s + 2], pk[4 * s + 3]));
+#pragma unroll
+        for (int d = 0; d < A::ND; ++d)
+          acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_tr_frag<HD>(Vi, d, 32 * js, s, l), pb, acc[d], 0, 0, 0);
+      }
+    }
+    if (nxt < 0) break;
+    cur = nxt;
+    stage ^= 1;
+  }
+  const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+  const float inv = ltot > 0.f ? 1.0f / ltot : 0.f;
+  if (hi == 0 && i < T) lse_out[bh * p.T + i] = ltot > 0.f ? (m + __builtin_amdgcn_logf(ltot)) * kLn2 : 0.f;
+  __syncthreads();
+  spill_transposed<HD, A::ND>(acc, 0, inv, dlds, w, l31, hi);
+  __syncthreads();
+  store_rows<HD, A::N128>(dlds, o_base, p.s[5][2], i0, T, t);
 }
 
 // mask [B, 1, T, T] bytes (non-zero = attend; NULL = all) and / or causal -> row words, column words, live 32 x 32 tiles
@@ -1064,7 +1363,8 @@ static int dalm_attn_bwd_any(const void* q, const void* k, const void* v, const 
   hipStream_t s = as_stream(stream);
 #define DALM_ATTN_BWD(HD, DROP)                                                                         \
   do {                                                                                                 \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, DROP>), grid_dq, dim3(256), 0, s, p);                   \
+    if (first_form || (HD == 128 && DROP)) hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, DROP>), grid_dq, dim3(256), 0, s, p);  \
+    else hipLaunchKernelGGL((attn_bwd_dq2_kernel<HD, DROP>), grid_dq, dim3(256), stream2_lds<HD>(), s, p);  \
     if (first_form || (HD == 128 && DROP)) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD, DROP>), grid_dkdv, dim3(256), dkdv_lds<HD>(), s, p);  \
     else hipLaunchKernelGGL((attn_bwd_dkdv2_kernel<HD, DROP>), grid_dkdv, dim3(256), dkdv2_lds<HD>(), s, p);  \
   } while (0)
@@ -1124,12 +1424,21 @@ static int dalm_attn_fwd_any(const void* q, const void* k, const void* v, const 
   const int64_t pairs8 = (B * H + 7) / 8 * 8;
   const dim3 grid(static_cast<unsigned>(pairs8 * ((T + 127) / 128)));
   hipStream_t s = as_stream(stream);
-  if (hd == 128) {
-    if (p.seed) hipLaunchKernelGGL((attn_fwd_kernel<128, true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((attn_fwd_kernel<128, false>), grid, dim3(256), 0, s, p);
+  static const bool first_form = [] { const char* e = getenv("DALM_ATTN_FWD"); return e && e[0] == '1'; }();   // A/B runs
+  if (first_form) {
+    if (hd == 128) {
+      if (p.seed) hipLaunchKernelGGL((attn_fwd_kernel<128, true>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((attn_fwd_kernel<128, false>), grid, dim3(256), 0, s, p);
+    } else {
+      if (p.seed) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((attn_fwd_kernel<64, false>), grid, dim3(256), 0, s, p);
+    }
+  } else if (hd == 128) {
+    if (p.seed) hipLaunchKernelGGL((attn_fwd2_kernel<128, true>), grid, dim3(256), stream2_lds<128>(), s, p);
+    else hipLaunchKernelGGL((attn_fwd2_kernel<128, false>), grid, dim3(256), stream2_lds<128>(), s, p);
   } else {
-    if (p.seed) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((attn_fwd_kernel<64, false>), grid, dim3(256), 0, s, p);
+    if (p.seed) hipLaunchKernelGGL((attn_fwd2_kernel<64, true>), grid, dim3(256), stream2_lds<64>(), s, p);
+    else hipLaunchKernelGGL((attn_fwd2_kernel<64, false>), grid, dim3(256), stream2_lds<64>(), s, p);
   }
   return check_launch(__func__);
 }
