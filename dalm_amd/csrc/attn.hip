@@ -30,6 +30,13 @@
 // layer and head) into row words (bit c of word w of row i = mask[i, 32 w + c]) and column words, plus one byte per 32 x 32 tile
 // that says whether anything in it is live: a lane's 32 mask bits of a tile are ONE dword, dead tiles (the causal upper
 // triangle, padding) cost nothing.
+// Round 6: each kernel exists in TWO forms with the same arithmetic (bit-identical outputs, tools/attn_ab.py).
+// The first forms (attn_fwd / attn_bwd_dq / attn_bwd_dkdv) stage a block through registers into padded LDS tiles plus transposed
+// copies, two barriers per block.  The second forms (attn_fwd2 / attn_bwd_dq2 / attn_bwd_dkdv2, the default; DALM_ATTN_FWD=1 /
+// DALM_ATTN_DKDV=1 select the first) move a block HBM -> LDS by LDS-DMA into un-padded swizzled images, two stages (block n + 1
+// in flight while block n is multiplied), read the "transposed" operands with ds_read_b64_tr_b16 and take the workgroup's own rows
+// straight from HBM in fragment shape: one barrier per block, half the LDS time.  Row blocks are launched heavy-first.
+// cfg3 layer (B 18, H 32, T 256, hd 128, causal + left padding): forward 46.8 -> 35.0 us, backward 153.8 -> 113.4 us.
 // Algorithmic bytes: forward q, k, v read + o written = 4 B H T hd el (151 MB at cfg3); backward q, k, v, o, dO read + dq, dk, dv
 // written = 8 B H T hd el (302 MB; the two launches together move 1.5 x that: each re-reads q, k, v, dO); algorithmic flops
 // 2 / 5 GEMMs x 2 T^2 hd per head over the live tiles (dq and dk/dv each recompute S and dP: 7 are executed).
@@ -1323,6 +1330,8 @@ static int dalm_attn_bwd_any(const void* q, const void* k, const void* v, const 
     for (int a = 0; a < 3; ++a)
       DALM_REQUIRE(strides[3 * i + a] >= 0 && strides[3 * i + a] % 8 == 0, DALM_E_ALIGN, "strides must be non-negative multiples of 8 elements");
   }
+  for (int i : {0, 1, 2, 4})      // the streamed tensors' rows are addressed with 32-bit byte offsets from the sequence's first row
+    DALM_REQUIRE(T * strides[3 * i + 2] < (1ll << 30), DALM_E_SHAPE, "T x row stride must stay below 2^30 elements");
   DALM_REQUIRE((cos == nullptr) == (sin == nullptr), DALM_E_NULL, "cos and sin come together");
   DALM_REQUIRE(!cos || (al16(cos) && al16(sin) && cs_stride_b >= 0 && cs_stride_b % 8 == 0 && cs_stride_t >= hd && cs_stride_t % 8 == 0),
                DALM_E_ALIGN, "cos / sin: 16-byte aligned rows of hd elements");
@@ -1363,7 +1372,7 @@ static int dalm_attn_bwd_any(const void* q, const void* k, const void* v, const 
   hipStream_t s = as_stream(stream);
 #define DALM_ATTN_BWD(HD, DROP)                                                                         \
   do {                                                                                                 \
-    if (first_form || (HD == 128 && DROP)) hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, DROP>), grid_dq, dim3(256), 0, s, p);  \
+    if (first_form) hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, DROP>), grid_dq, dim3(256), 0, s, p);  \
     else hipLaunchKernelGGL((attn_bwd_dq2_kernel<HD, DROP>), grid_dq, dim3(256), stream2_lds<HD>(), s, p);  \
     if (first_form || (HD == 128 && DROP)) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD, DROP>), grid_dkdv, dim3(256), dkdv_lds<HD>(), s, p);  \
     else hipLaunchKernelGGL((attn_bwd_dkdv2_kernel<HD, DROP>), grid_dkdv, dim3(256), dkdv2_lds<HD>(), s, p);  \
@@ -1408,6 +1417,8 @@ static int dalm_attn_fwd_any(const void* q, const void* k, const void* v, const 
   }
   DALM_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f && (dropout_p == 0.f || (seed && T % 2 == 0)), DALM_E_SHAPE,
                "dropout needs 0 <= p < 1, a device seed word and an even T");
+  for (int i : {1, 2})
+    DALM_REQUIRE(T * strides[3 * i + 2] < (1ll << 30), DALM_E_SHAPE, "T x row stride must stay below 2^30 elements");
   AttnBwdParams p = {};
   set_dropout(p, dropout_p, seed, salt);
   p.cu = cu;

@@ -14,7 +14,7 @@ for f in glob.glob("gpurun_out/atp/*/**/*counter_collection.csv", recursive=True
         k = r["Kernel_Name"]
         if "attn_" not in k and "bwd_kernel" not in k:
             continue
-        name = next((n for n in ("attn_bwd_dq", "attn_bwd_dkdv", "attn_fwd_kernel", "attn_mask_bits") if n in k), k.split("(")[0][-40:])
+        name = next((n for n in ("attn_bwd_dq", "attn_bwd_dkdv", "attn_fwd_kernel", "attn_fwd2_kernel", "attn_mask_bits") if n in k), k.split("(")[0][-40:])
         agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in agg.items():
     print(k)
