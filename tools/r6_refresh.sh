@@ -77,6 +77,12 @@ if has kernels; then
   cp gpurun_out/kernel_bench.json $P/r06_kernel_bench.json
   run $P/r06_lora_bench_4608x4096.txt python tools/lora_bench.py --json $P/r06_lora_bench_4608x4096.json
   run $P/r06_attn_bench.txt python tools/attn_bench.py
+  DALM_ATTN_FWD=1 DALM_ATTN_DKDV=1 run $P/r06_attn_bench_first_forms.txt python tools/attn_bench.py
+  DALM_ATTN_FWD=1 DALM_ATTN_DKDV=1 run $P/attn_ab_first.log python tools/attn_ab.py --out /tmp/attn_first.pt
+  run $P/attn_ab_second.log python tools/attn_ab.py --out /tmp/attn_second.pt
+  run $P/r06_attn_forms_ab.txt python tools/attn_ab.py --compare /tmp/attn_first.pt /tmp/attn_second.pt
+  run $P/attn_prof.log bash tools/attn_prof.sh; cp gpurun_out/attn_kernels.txt $P/r06_attn_kernels.txt
+  run $P/attn_pmc.log bash tools/attn_pmc.sh; cp gpurun_out/attn_pmc.txt $P/r06_attn_pmc.txt
   run $P/r06_sim_grad_x3.txt python tools/sim_grad_x3_bench.py
 fi
 if has simpmc; then
