@@ -797,7 +797,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv2_kernel(const AttnBwdPar
   unsigned short* dk_base = p.dk + base_off(p, 6, b, h, sq);
   unsigned short* dv_base = p.dv + base_off(p, 7, b, h, sq);
   const unsigned long long need = need_mask<2>(p, b, j0 >> 5, false, l);
-  if (need == 0ull) {
+  if (need == 0ull || T <= 0) {
     store_rows<HD, A::N64>(nullptr, dk_base, p.s[6][2], j0, T, t);
     store_rows<HD, A::N64>(nullptr, dv_base, p.s[7][2], j0, T, t);
     return;
@@ -962,7 +962,7 @@ __global__ __launch_bounds__(256, DROP ? 2 : AT<HD>::OCC) void attn_bwd_dq2_kern
   const int T = sq.T;
   unsigned short* dq_base = p.dq + base_off(p, 5, b, h, sq);
   const unsigned long long need = need_mask<4>(p, b, i0 >> 5, true, l);
-  if (need == 0ull) {
+  if (need == 0ull || T <= 0) {
     store_rows<HD, A::N128>(nullptr, dq_base, p.s[5][2], i0, T, t);
     return;
   }
@@ -1100,7 +1100,7 @@ __global__ __launch_bounds__(256, (DROP && HD == 64) ? 2 : AT<HD>::OCC) void att
   unsigned short* o_base = p.dq + base_off(p, 5, b, h, sq);               // the output travels in the dq slot
   float* lse_out = p.delta;                                                // and the log-sum-exp in the delta slot
   const unsigned long long need = need_mask<4>(p, b, i0 >> 5, true, l);
-  if (need == 0ull) {                                          // rows without a live key: zero output (as torch returns)
+  if (need == 0ull || T <= 0) {                                          // rows without a live key: zero output (as torch returns)
     store_rows<HD, A::N128>(nullptr, o_base, p.s[5][2], i0, T, t);
     if (t < 128 && i0 + t < T) lse_out[bh * p.T + i0 + t] = 0.f;
     return;
