@@ -1220,6 +1220,15 @@ __global__ __launch_bounds__(256, (DROP && HD == 64) ? 2 : AT<HD>::OCC) void att
   store_rows<HD, A::N128>(dlds, o_base, p.s[5][2], i0, T, t);
 }
 
+// The live-tile bytes are cleared by a KERNEL in front of the mask kernels, not by hipMemsetAsync: captured into a hipGraph, the
+// memset node of this small odd-sized array did not clear it on replay (tools/live_tiles_graph_check.py: bytes of the previous
+// batch stayed set) - harmless for the first forms of the kernels above beyond the work spent on dead tiles (their mask words are
+// zero), a fault for the second forms once a stale byte belonged to a sequence that is empty in the current batch.
+__global__ __launch_bounds__(256) void attn_clear_bytes_kernel(unsigned char* __restrict__ p, int64_t n) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
+
 // mask [B, 1, T, T] bytes (non-zero = attend; NULL = all) and / or causal -> row words, column words, live 32 x 32 tiles
 __global__ __launch_bounds__(256) void attn_mask_bits_kernel(const unsigned char* __restrict__ mask, int B, int T, int W, int64_t sb,
                                                              int64_t si, int causal, uint32_t* __restrict__ rows,
@@ -1296,7 +1305,7 @@ extern "C" int dalm_attn_mask_bits(const void* mask, int64_t B, int64_t T, int64
   DALM_REQUIRE(B > 0 && T > 0 && T <= 32768 && B <= 65535, DALM_E_SHAPE, "need 0 < T <= 32768 and 0 < B <= 65535");
   const int64_t W = (T + 31) / 32, total = B * 32 * W * W;
   hipStream_t s = as_stream(stream);
-  if (hipError_t e = hipMemsetAsync(live, 0, static_cast<size_t>(B * W * W), s); e != hipSuccess) return fail(static_cast<int>(e), __func__, hipGetErrorString(e));
+  hipLaunchKernelGGL(attn_clear_bytes_kernel, dim3(static_cast<unsigned>((B * W * W + 255) / 256)), dim3(256), 0, s, live, B * W * W);
   hipLaunchKernelGGL(attn_mask_bits_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s,
                      static_cast<const unsigned char*>(mask), static_cast<int>(B), static_cast<int>(T), static_cast<int>(W),
                      mask_stride_b, mask_stride_row, causal, bits_rows, bits_cols, live);
@@ -1309,7 +1318,7 @@ extern "C" int dalm_attn_mask_bits_packed(const uint8_t* key_live, const int32_t
   DALM_REQUIRE(B > 0 && T > 0 && T <= 2048 && B <= 65535, DALM_E_SHAPE, "need 0 < T <= 2048 and 0 < B <= 65535");
   const int64_t W = (T + 31) / 32, total = B * 32 * W * W;
   hipStream_t s = as_stream(stream);
-  if (hipError_t e = hipMemsetAsync(live, 0, static_cast<size_t>(B * W * W), s); e != hipSuccess) return fail(static_cast<int>(e), __func__, hipGetErrorString(e));
+  hipLaunchKernelGGL(attn_clear_bytes_kernel, dim3(static_cast<unsigned>((B * W * W + 255) / 256)), dim3(256), 0, s, live, B * W * W);
   hipLaunchKernelGGL(attn_mask_bits_packed_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, key_live,
                      cu_seqlens, static_cast<int>(B), static_cast<int>(W), causal, bits_rows, bits_cols, live);
   return check_launch(__func__);
