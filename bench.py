@@ -12,6 +12,10 @@ A "step" = passage tower + query tower + generator forward, the fused HIP loss p
 in the same pass), backward, gradient all-reduce (N>1), Adam, scheduler, zero_grad - nothing skipped.
 With N>1 every rank keeps batch 18 (weak scaling) and the in-batch negatives span the global batch
 (RCCL all-gather of the embeddings over xGMI, overlapped with the query tower on a side stream).
+Launch structure (`config.launch`): one single-stream hipGraph per tower and direction (generator on the main stream, the retriever
+pair on a side stream), loss / optimizer / collectives launched eagerly between them - at every N.  (`--whole-step-graph`: the
+whole step as ONE hipGraph, the default of rounds 2-5; a graph captured across two streams replays with a dependency bubble per
+node and measures 5-6 ms per step slower on the same box, tools/queue_ab.sh.)
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant hand-written kernel
 (marg_ce_row_kernel: 2*R*V*el algorithmic bytes per launch, R = B*(Tg-1) dense rows), timed live with
@@ -616,7 +620,14 @@ def main():
                          "around torch.distributed's nccl ops aborts).  Measured with one rank: 192.7 ms/step against 188.1 ms "
                          "for graphed towers + eager collectives, so the latter stays the default")
     ap.add_argument("--graph-towers", action="store_true",
-                    help="graph the tower fwd/bwd and keep collectives eager (the default when --gpus > 1)")
+                    help="graph the tower fwd/bwd (one single-stream hipGraph per tower and direction) and launch loss / optimizer / "
+                         "collectives eagerly between them: the default at every rank count since round 6 (bucketed data path "
+                         "excepted: more batch shapes than tower-graph sets)")
+    ap.add_argument("--whole-step-graph", action="store_true",
+                    help="one rank: capture the WHOLE step (both streams, loss, optimizer) as ONE hipGraph - the default of rounds "
+                         "2-5.  A graph captured across two streams replays with a dependency bubble at every node (1400 idle gaps "
+                         "per step in the kernel trace against 180): measured 5-6 ms per step slower than the tower graphs on the "
+                         "same box (tools/queue_ab.sh)")
     ap.add_argument("--fuse-lm-head", action="store_true",
                     help="SURVEY 8(f) rank 1: chunked lm_head + CE, the [B,Tg,V] logits are never materialised")
     ap.add_argument("--data-path", default="fixed", choices=["fixed", "bucketed", "loader", "packed"],
@@ -703,6 +714,9 @@ def main():
     from dalm_amd.fused import LocalComm
     from dalm_amd.training.graphed import GraphedStep, TensorLRScheduler, make_capturable_adam
 
+    towers_default = (isinstance(comm, LocalComm) and not args.whole_step_graph and not args.graph_collectives
+                      and args.data_path != "bucketed")
+    args.graph_towers = args.graph_towers or towers_default
     use_graph = (isinstance(comm, LocalComm) or args.graph_collectives) and not args.no_graph and not args.graph_towers
     opt = make_capturable_adam(params, 1e-4, dev) if use_graph else torch.optim.Adam(params, lr=1e-4, fused=True)
 

@@ -208,7 +208,12 @@ def train_e2e(
     from ...fused import LocalComm
     from ..graphed import GraphedStep, TensorLRScheduler, make_capturable_adam
 
-    use_graph = isinstance(comm, LocalComm) and not no_hip_graph and gradient_accumulation_steps == 1
+    # DALM_STEP_GRAPHS=towers: one rank, but the W > 1 launch structure (single-stream tower graphs, eager loss / optimizer): a
+    # graph captured across two streams replays with a dependency bubble per node, 5-6 ms per cfg3 step (bench.py's default since
+    # round 6); the trainers keep the whole-step graph by default: its graphs share one memory pool across any number of batch
+    # shapes (packed rows), tower-graph sets do not (DALM_TOWER_SETS)
+    towers_mode = os.environ.get("DALM_STEP_GRAPHS", "whole") == "towers"
+    use_graph = isinstance(comm, LocalComm) and not no_hip_graph and gradient_accumulation_steps == 1 and not towers_mode
     optimizer = (make_capturable_adam(params, learning_rate, device) if use_graph
                  else torch.optim.Adam(params, lr=learning_rate, fused=True))
     per_epoch, max_train_steps, num_train_epochs = common.steps_and_epochs(
