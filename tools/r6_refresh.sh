@@ -38,6 +38,8 @@ PY
 }
 if has bench; then
   run $P/r06_bench_default.json python bench.py
+  run $P/r06_bench_cfg3_whole_step_graph.json python bench.py --whole-step-graph --steps 20 --warmup 5 --no-cpu-baseline --no-pmc
+  run $P/r06_bench_cfg3_packed_whole_step_graph.json python bench.py --data-path packed --whole-step-graph --steps 20 --warmup 5 --no-cpu-baseline --no-pmc
   run $P/r06_bench_cfg5.json python bench.py --workload cfg5 --no-cpu-baseline
   run $P/r06_bench_cfg2.json python bench.py --workload cfg2 --no-cpu-baseline
   run $P/r06_bench_cfg1.json python bench.py --workload cfg1 --no-cpu-baseline
