@@ -1000,14 +1000,20 @@ def main_retriever_only(args):
     model = AutoModelForSentenceEmbedding.from_modules(bert, None, normalize=True, get_peft=True)
     model.train()
     params = [p for p in model.parameters() if p.requires_grad]
-    use_graph = isinstance(comm, LocalComm) and not args.no_graph
+    # --graph-towers: the two encoder calls as single-stream graphs, loss / optimizer eager (the RAG-e2e step's default structure).
+    # NOT the default here: measured slower than the whole-step graph on this short step (cfg2 2723 against 2857 pairs/s, cfg1
+    # 3479 against 4584, same box, tools/cfg2_overlap_ab.sh) - the eager loss sits on the critical path between the forward and
+    # backward graphs and there is no long generator graph to hide it behind.  Packed batches go through the encoder in ONE call.
+    towers = (isinstance(comm, LocalComm) and not args.no_graph and args.graph_towers and args.data_path != "packed"
+              and not args.no_overlap)
+    use_graph = isinstance(comm, LocalComm) and not args.no_graph and not towers
     opt = make_capturable_adam(params, 1e-4, dev) if use_graph else torch.optim.Adam(params, lr=1e-4, fused=True)
     def mk_sched(o):
         return get_scheduler("linear", optimizer=o, num_warmup_steps=0, num_training_steps=100000)
 
     sched = TensorLRScheduler(opt, 1e-4, mk_sched) if use_graph else mk_sched(opt)
     step = RetrieverStep(model, opt, sched, CFG["logit_scale"], comm=comm, autocast_dtype=autocast,
-                         overlap_towers=not args.no_overlap)
+                         overlap_towers=not args.no_overlap, graph_towers=towers, graph_after=0)
     if use_graph:
         step = GraphedStep(step)
 
@@ -1058,7 +1064,11 @@ def main_retriever_only(args):
                        "step_frac_of_bf16_mfma_peak": step_model_tflops(model, 0.0, rows_per_step) / (elapsed / args.steps) / 2500.0,
                        "global_batch": args.gpus * B,
                        "parallelism": f"dp{args.gpus} + sharded in-batch negatives", "final_loss": float(loss),
-                       "launch": "hipGraph replay" if (use_graph and getattr(step, "graph", None) is not None) else "eager"}}),
+                       "launch": ("hipGraph replay of the whole step" if (use_graph and getattr(step, "graph", None) is not None)
+                                  else ("hipGraph replay of the encoder calls fwd/bwd, eager loss+optimizer"
+                                        if getattr(step, "towers", None) is not None else
+                                        "eager" + (f" (capture failed: {getattr(step, 'towers_failed', None)})"
+                                                   if getattr(step, "towers_failed", None) else "")))}}),
               flush=True)
     barrier(comm)
     if torch.distributed.is_available() and torch.distributed.is_initialized():

@@ -251,6 +251,51 @@ class _RetrievalCall(torch.nn.Module):
         return pool_l2norm(h, attention_mask, self.normalize)
 
 
+class _EncoderCall(torch.nn.Module):
+    """AutoModelForSentenceEmbedding.forward (encoder + pooling + normalisation) as one graph-capturable callable."""
+
+    def __init__(self, model, autocast_dtype):
+        super().__init__()
+        self.model = model
+        self.autocast_dtype = autocast_dtype
+
+    def forward(self, input_ids, attention_mask):
+        if self.autocast_dtype is None:
+            return self.model(input_ids, attention_mask)
+        with torch.autocast("cuda", dtype=self.autocast_dtype, cache_enabled=False):
+            return self.model(input_ids, attention_mask)
+
+
+class GraphedEncoders:
+    """The retriever-only step's two encoder calls (query, passage), forward AND backward, as single-stream hipGraphs
+    (torch.cuda.make_graphed_callables, one call each: separate pools, so the query graphs replay on the tower stream while the
+    passage graphs run on the main stream); loss, optimizer and collectives stay eager.  Same reason as GraphedTowers at one rank:
+    a whole-step graph captured across the two streams replays with a dependency bubble per node."""
+
+    def __init__(self, model, autocast_dtype, sample_batch: Dict[str, torch.Tensor]):
+        if getattr(model, "is_autoregressive", False):
+            raise NotImplementedError("graphed encoders: autoregressive retrievers run eagerly")
+        warm_blas_handles()
+        self.key = self.key_of(sample_batch)
+        calls = [_EncoderCall(model, autocast_dtype) for _ in range(2)]
+        for c in calls:
+            c.train(model.training)
+        b = sample_batch
+        self.query = torch.cuda.make_graphed_callables(
+            calls[0], (b["query_input_ids"].clone(), b["query_attention_mask"].clone()), num_warmup_iters=3, allow_unused_input=True)
+        self.passage = torch.cuda.make_graphed_callables(
+            calls[1], (b["passage_input_ids"].clone(), b["passage_attention_mask"].clone()), num_warmup_iters=3, allow_unused_input=True)
+
+    KEYS = ("query_input_ids", "passage_input_ids")
+
+    @classmethod
+    def key_of(cls, batch):
+        return tuple(tuple(batch[k].shape) for k in cls.KEYS)
+
+    def matches(self, batch) -> bool:
+        return self.key_of(batch) == self.key
+
+
 class _GeneratorCall(torch.nn.Module):
     """hidden_only: stop at the decoder's final (normed) hidden states - the fused lm_head path consumes those."""
 

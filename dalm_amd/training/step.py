@@ -345,11 +345,41 @@ class RagE2EStep(_StepBase):
 class RetrieverStep(_StepBase):
     """batch keys as produced by retriever_only_dataloader_utils.preprocess_dataset."""
 
-    def __init__(self, *a, overlap_towers: bool = True, **kw):
+    def __init__(self, *a, overlap_towers: bool = True, graph_towers: bool = False, graph_after: int = 2, **kw):
         super().__init__(*a, **kw)
         # the query pass (Tq = 50) is small next to the passage pass (Tp = 128): run it on its own stream
         self.tower_stream = torch.cuda.Stream() if (overlap_towers and torch.cuda.is_available()) else None
         self.autocast_cache = self.tower_stream is None   # one model on two streams: no shared cast cache
+        # the two encoder calls as single-stream hipGraphs (GraphedEncoders), loss / optimizer / collectives eager: padded batches
+        # only (the packed batch goes through the encoder in ONE call - a whole-step graph of that is a single stream already)
+        self.graph_towers = graph_towers and torch.cuda.is_available() and self.tower_stream is not None
+        self.graph_after = graph_after
+        self.calls = 0
+        self.towers = None
+        self.towers_failed: Optional[str] = None
+        self._encoder_sets: Dict[tuple, object] = {}
+
+    def _maybe_build_encoders(self, batch) -> None:
+        self.towers = None
+        if not self.graph_towers or self.towers_failed is not None or "query_pack_rows" in batch or self.calls <= self.graph_after:
+            return
+        from .graphed import GraphedEncoders
+
+        key = GraphedEncoders.key_of(batch)
+        if key in self._encoder_sets:
+            self.towers = self._encoder_sets[key]
+            return
+        import os as _os4
+
+        if len(self._encoder_sets) >= int(_os4.environ.get("DALM_TOWER_SETS", "4")):
+            return
+        try:
+            torch.cuda.synchronize()
+            self._encoder_sets[key] = self.towers = GraphedEncoders(self.model, self.autocast_dtype, batch)
+        except Exception as e:  # same kernels, eager launches
+            self.towers_failed = repr(e)
+            self.towers = None
+            torch.cuda.synchronize()
 
     def _embed(self, batch, side: str):
         """One encoder call; on the PACKED rows when the batch carries their list (`{side}_pack_rows` / `_pack_cu`)."""
@@ -362,7 +392,24 @@ class RetrieverStep(_StepBase):
         return m(ids, mask)
 
     def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        self.calls += 1
+        self._maybe_build_encoders(batch)
         _advance_dropout(batch)
+        if self.towers is not None:       # graphed encoder calls: the structure of the two-stream branch below
+            cur = torch.cuda.current_stream()
+            self.tower_stream.wait_stream(cur)
+            with torch.cuda.stream(self.tower_stream):
+                q_emb = self.towers.query(batch["query_input_ids"], batch["query_attention_mask"])
+                q_gather = GatherHandle(q_emb.float(), self.comm, self.side_stream)
+            p_emb = self.towers.passage(batch["passage_input_ids"], batch["passage_attention_mask"])
+            p_gather = GatherHandle(p_emb.float(), self.comm, self.side_stream)
+            cur.wait_stream(self.tower_stream)
+            for t in (q_emb, q_gather.result):
+                if t is not None and t.is_cuda:
+                    t.record_stream(cur)
+            loss = contrastive_loss(q_emb, p_emb, self.logit_scale, comm=self.comm, ops=self.ops, q_gather=q_gather,
+                                    p_gather=p_gather)
+            return self._finish(loss)
         with self._autocast():
             pair = self._retrieve_pair(batch, "query", "passage")
         if pair is not None:             # packed, one rank: both inputs through the encoder in ONE call, one stream

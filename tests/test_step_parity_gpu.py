@@ -218,7 +218,7 @@ def _tiny_bge_small(vocab, seed):
                                 attention_probs_dropout_prob=0.0))
 
 
-@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("graph", [False, True, "towers"])
 def test_retriever_only_step_trajectory_matches_reference(graph):
     """5-step loss trajectory + final parameters vs the reference's train_retriever step body
     (train_retriever_only.py:365-379) run on CPU with the reference's AutoModelForSentenceEmbedding -
@@ -243,16 +243,20 @@ def test_retriever_only_step_trajectory_matches_reference(graph):
     for k, v in gold["pre_ret"].items():     # host preprocessing == the reference's, token for token
         assert [list(x) for x in enc[k]] == v, k
     full = {k: torch.tensor(v, device=dev) for k, v in enc.items()}
+    towers = graph == "towers"     # the two encoder calls fwd/bwd as single-stream graphs (GraphedEncoders), loss / optimizer eager
+    graph = bool(graph) and not towers
     opt = make_capturable_adam(model.parameters(), gold["lr"], dev) if graph else torch.optim.Adam(model.parameters(), lr=gold["lr"])
 
     def mk(o):
         return get_scheduler("linear", optimizer=o, num_warmup_steps=gold["warmup"], num_training_steps=gold["total_steps"])
 
     sched = TensorLRScheduler(opt, gold["lr"], mk) if graph else mk(opt)
-    step = RetrieverStep(model, opt, sched, 100, autocast_dtype=None, overlap_towers=graph)
+    step = RetrieverStep(model, opt, sched, 100, autocast_dtype=None, overlap_towers=graph or towers, graph_towers=towers, graph_after=0)
     if graph:
         step = GraphedStep(step, warmup=0)
     losses = [float(step({k: v[a:b] for k, v in full.items()})) for a, b in gold["batch_rows"]]
+    if towers:
+        assert step.towers_failed is None and len(step._encoder_sets) == 3, (step.towers_failed, len(step._encoder_sets))
     for got, ref in zip(losses, gold["losses"]):
         assert abs(got - ref) <= 1e-3 * abs(ref), (losses, gold["losses"])
     final = float(sum(p.detach().double().abs().sum() for p in model.model.parameters()))
