@@ -59,7 +59,8 @@ def run(tag, fn, q, k, v, go):
 CASES = [(4, 8, 256, [256, 130, 77, 200], True, True, 128, 0.0), (3, 4, 200, [200, 64, 1], True, True, 128, 0.0),
          (2, 2, 448, [448, 300], True, True, 128, 0.0), (6, 16, 128, [128, 30, 77, 5, 100, 128], False, False, 64, 0.1),
          (5, 16, 50, [5, 15, 9, 50, 1], False, False, 64, 0.1), (2, 4, 320, [320, 191], True, True, 64, 0.0),
-         (3, 4, 256, [256, 100, 31], True, True, 128, 0.1)]
+         (3, 4, 256, [256, 100, 31], True, True, 128, 0.1), (1, 4, 2048, [2048], True, True, 128, 0.0),
+         (2, 2, 1000, [1000, 517], True, True, 64, 0.1), (1, 2, 1536, [1300], False, False, 128, 0.0), (2, 3, 96, [96, 33], False, True, 64, 0.0)]
 for ci, (B, H, T, lens, left, causal, hd, p) in enumerate(CASES):
     g = torch.Generator().manual_seed(100 + ci)
     q, k, v, go = [(0.7 * torch.randn(B, T, H, hd, generator=g)).to(dev, torch.bfloat16).transpose(1, 2) for _ in range(4)]
@@ -73,7 +74,8 @@ for ci, (B, H, T, lens, left, causal, hd, p) in enumerate(CASES):
 
 # packed layout
 PACKED = [(4, 8, 256, [256, 130, 77, 200], True, True, 128), (3, 2, 256, [200, 0, 129], False, True, 128),
-          (4, 4, 128, [128, 30, 77, 5], False, False, 64), (5, 2, 50, [5, 15, 9, 50, 1], False, False, 64)]
+          (4, 4, 128, [128, 30, 77, 5], False, False, 64), (5, 2, 50, [5, 15, 9, 50, 1], False, False, 64),
+          (3, 2, 1024, [1024, 0, 700], True, True, 128), (40, 16, 50, [((7 * i) % 50) + (i % 3 == 0) for i in range(40)], False, False, 64)]
 for ci, (B, H, T, lens, left, causal, hd) in enumerate(PACKED):
     g = torch.Generator().manual_seed(200 + ci)
     m2 = mask2d(B, T, lens, left)
