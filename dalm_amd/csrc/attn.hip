@@ -700,7 +700,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdPara
 // read in 32-lane halves, each a 4-row x 64-byte patch): HD 128 (16 chunks, a row = all 64 banks): 4 (r & 3) + ((r >> 2) & 3);
 // HD 64 (8 chunks, a row = half the banks, odd rows the other half): 4 ((r >> 1) & 1) + ((r >> 2) & 3).
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-#define DALM_LDS3(p) (reinterpret_cast<__attribute__((address_space(3))) void*>(reinterpret_cast<uintptr_t>(p)))
 template <int HD>
 __device__ __forceinline__ int swz(int r) {
   return HD == 128 ? 4 * (r & 3) + ((r >> 2) & 3) : 4 * ((r >> 1) & 1) + ((r >> 2) & 3);
