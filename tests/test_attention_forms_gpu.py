@@ -28,7 +28,7 @@ def test_second_forms_write_the_first_forms_bits(tmp_path):
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         outs.append(torch.load(out))
     a, b = outs
-    assert a.keys() == b.keys() and len(a) >= 60
+    assert a.keys() == b.keys() and len(a) >= 68
     for k in a:
         assert torch.isfinite(a[k]).all(), k
         assert float(a[k].abs().max()) > 0, k

@@ -72,6 +72,20 @@ for ci, (B, H, T, lens, left, causal, hd, p) in enumerate(CASES):
     mask = mask.contiguous()
     run(f"padded{ci}", lambda x, y, z: attention.sdpa(x, y, z, mask, hd ** -0.5, False, p, 11 + ci), q, k, v, go)
 
+# rotary embedding fused into the attention node (Llama path: dq / dk leave the backward kernels as gradients of the UN-rotated tensors)
+for ci, (B, H, T, lens, hd) in enumerate([(3, 4, 256, [256, 140, 61], 128), (2, 2, 320, [320, 191], 64)]):
+    g = torch.Generator().manual_seed(300 + ci)
+    q, k, v, go = [(0.7 * torch.randn(B, T, H, hd, generator=g)).to(dev, torch.bfloat16).transpose(1, 2) for _ in range(4)]
+    m2 = mask2d(B, T, lens, True).to(dev).bool()
+    col = torch.arange(T, device=dev)
+    mask = (m2[:, None, None, :].expand(B, 1, T, T) & (col[None, None, None, :] <= col[None, None, :, None])).contiguous()
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, device=dev).float() / hd))
+    ang = col.float()[:, None] * inv[None, :]
+    cos = torch.cat((ang.cos(), ang.cos()), -1).to(torch.bfloat16)[None]
+    sin = torch.cat((ang.sin(), ang.sin()), -1).to(torch.bfloat16)[None]
+    assert attention.rope_fusable(q, k, cos, sin)
+    run(f"rope{ci}", lambda x, y, z: attention.rope_sdpa(x, y, z, cos, sin, mask, hd ** -0.5, False), q, k, v, go)
+
 # packed layout
 PACKED = [(4, 8, 256, [256, 130, 77, 200], True, True, 128), (3, 2, 256, [200, 0, 129], False, True, 128),
           (4, 4, 128, [128, 30, 77, 5], False, False, 64), (5, 2, 50, [5, 15, 9, 50, 1], False, False, 64),
