@@ -492,7 +492,10 @@ int dalm_bert_add_norm_bwd(const float* g32, const void* g16, const void* a, con
  *   dalm_attn_bwd: q, k, v, o (the forward's output), d_o, and lse [B, H, T] f32 (natural log of the row sums, what torch's
  *        memory-efficient forward returns) -> dq, dk, dv.  strides: 8 x (batch, head, row) ELEMENT strides of
  *        q, k, v, o, d_o, dq, dk, dv (last dimension contiguous, multiples of 8); delta: [B, H, T] f32 scratch
- *        (D = rowsum(dO o O)).  P and dS are rounded to bf16 for their products, sums in f32.
+ *        (D = rowsum(dO o O)).  P and dS are rounded to bf16 for their products, sums in f32.  T x (row stride) of q, k, v, d_o
+ *        must stay below 2^30 elements (the streamed blocks are addressed with 32-bit offsets from the sequence's first row).
+ *        Two forms with the same arithmetic and bit-identical outputs (register-staged tiles / LDS-DMA stages + transpose reads,
+ *        the default); DALM_ATTN_FWD=1 / DALM_ATTN_DKDV=1 select the first, read once per process (tools/attn_ab.py).
  *        cos / sin (NULL, or [B or 1, T, hd] bf16 with element strides cs_stride_b (0 for one table) / cs_stride_t): q and k
  *        are the outputs of dalm_rope_qk and dq / dk leave as the gradients of its INPUTS - that kernel's backward applied
  *        in the epilogue, same rounding points.
