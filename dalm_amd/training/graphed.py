@@ -10,6 +10,8 @@ later round).
 """
 from __future__ import annotations
 
+import contextlib
+
 from typing import Callable, Dict, Optional, Tuple
 
 import torch
@@ -177,7 +179,7 @@ class GraphedStep:
         cs = self._capture_stream
         cs.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(cs):
-            g.capture_begin(pool=self.pool)
+            g.capture_begin(pool=self.pool, capture_error_mode="thread_local")   # other threads (a process group's watchdog) may query events
             try:
                 static_loss = self.step(static)
             except BaseException:
@@ -251,6 +253,25 @@ class _RetrievalCall(torch.nn.Module):
         return pool_l2norm(h, attention_mask, self.normalize)
 
 
+@contextlib.contextmanager
+def thread_local_capture():
+    """torch.cuda.make_graphed_callables captures in hipStreamCaptureModeGlobal: while the capture is open ANY thread's event
+    query is an error - and torch.distributed's ProcessGroupNCCL watchdog thread polls the events of outstanding collectives.
+    With a live process group the tower captures aborted the process in 5 of 8 runs of the one-rank tests ("operation not permitted
+    when stream is capturing", raised in the watchdog thread, which terminates the process).  Thread-local mode keeps the check for the
+    capturing thread and lets other threads be."""
+    orig = torch.cuda.graph.__init__
+
+    def init(self, cuda_graph, pool=None, stream=None, capture_error_mode="thread_local"):
+        orig(self, cuda_graph, pool=pool, stream=stream, capture_error_mode="thread_local")
+
+    torch.cuda.graph.__init__ = init
+    try:
+        yield
+    finally:
+        torch.cuda.graph.__init__ = orig
+
+
 class _EncoderCall(torch.nn.Module):
     """AutoModelForSentenceEmbedding.forward (encoder + pooling + normalisation) as one graph-capturable callable."""
 
@@ -281,10 +302,11 @@ class GraphedEncoders:
         for c in calls:
             c.train(model.training)
         b = sample_batch
-        self.query = torch.cuda.make_graphed_callables(
-            calls[0], (b["query_input_ids"].clone(), b["query_attention_mask"].clone()), num_warmup_iters=3, allow_unused_input=True)
-        self.passage = torch.cuda.make_graphed_callables(
-            calls[1], (b["passage_input_ids"].clone(), b["passage_attention_mask"].clone()), num_warmup_iters=3, allow_unused_input=True)
+        with thread_local_capture():
+            self.query = torch.cuda.make_graphed_callables(
+                calls[0], (b["query_input_ids"].clone(), b["query_attention_mask"].clone()), num_warmup_iters=3, allow_unused_input=True)
+            self.passage = torch.cuda.make_graphed_callables(
+                calls[1], (b["passage_input_ids"].clone(), b["passage_attention_mask"].clone()), num_warmup_iters=3, allow_unused_input=True)
 
     KEYS = ("query_input_ids", "passage_input_ids")
 
@@ -392,10 +414,11 @@ class GraphedTowers:
         # order on one stream.  The retrieval pair runs on the tower stream concurrently with the generator on
         # the main stream, so the generator gets its own capture (own pool); within the pair the order is
         # passage -> query forward and (autograd: later nodes first) query -> passage backward, as required.
-        self.passage, self.query = torch.cuda.make_graphed_callables(
-            calls[:2], args[:2], num_warmup_iters=3, allow_unused_input=True)
-        self.generator = torch.cuda.make_graphed_callables(
-            calls[2], args[2], num_warmup_iters=3, allow_unused_input=True)
+        with thread_local_capture():
+            self.passage, self.query = torch.cuda.make_graphed_callables(
+                calls[:2], args[:2], num_warmup_iters=3, allow_unused_input=True)
+            self.generator = torch.cuda.make_graphed_callables(
+                calls[2], args[2], num_warmup_iters=3, allow_unused_input=True)
 
     KEYS = ("retriever_passage_input_ids", "retriever_query_input_ids", "generator_input_input_ids")
     PACK_KEYS = ("retriever_passage_pack_rows", "retriever_query_pack_rows", "generator_pack_rows",
