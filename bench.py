@@ -1004,6 +1004,8 @@ def main_retriever_only(args):
     # NOT the default here: measured slower than the whole-step graph on this short step (cfg2 2723 against 2857 pairs/s, cfg1
     # 3479 against 4584, same box, tools/cfg2_overlap_ab.sh) - the eager loss sits on the critical path between the forward and
     # backward graphs and there is no long generator graph to hide it behind.  Packed batches go through the encoder in ONE call.
+    # One rank only: with the W > 1 gradient bucket (parameter gradients as views of one flat buffer) the second replay of a set of
+    # encoder graphs produced an infinite gradient norm (one-rank RCCL run, end of round 6, not understood) - W > 1 launches eagerly.
     towers = (isinstance(comm, LocalComm) and not args.no_graph and args.graph_towers and args.data_path != "packed"
               and not args.no_overlap)
     use_graph = isinstance(comm, LocalComm) and not args.no_graph and not towers

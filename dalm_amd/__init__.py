@@ -18,7 +18,12 @@ def configure_hw_queues(world_size=None) -> str:
     world_size > 1 the runtime default stays (round 3 applied 3 at every rank count - a guess that changes the
     process-wide queue mapping).  An explicit GPU_MAX_HW_QUEUES always wins, DALM_HW_QUEUES=<n> forces a value at
     any rank count (0 = leave the runtime default).  Entry points (bench.py, the trainers) call this before the HIP
-    runtime starts; whatever is applied is logged and returned."""
+    runtime starts; whatever is applied is logged and returned.
+
+    Round 6: the cause is handled instead - `sharded.init_distributed` lets the two compute streams submit their first work (and
+    so acquire their hardware queues) BEFORE a communicator exists (dalm_amd/streams.py).  With that claim the runtime's 4 queues
+    are right at one rank for both communicators, and nothing is set at ANY rank count; the paragraph above applies only with
+    DALM_CLAIM_QUEUES=0."""
     log = logging.getLogger(__name__)
     if "GPU_MAX_HW_QUEUES" in os.environ:
         return "user:" + os.environ["GPU_MAX_HW_QUEUES"]
@@ -31,6 +36,12 @@ def configure_hw_queues(world_size=None) -> str:
         return "runtime-default"
     if world_size is None:
         world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("DALM_CLAIM_QUEUES", "1") != "0":
+        # round 6: the two compute streams submit their first work BEFORE any communicator exists (dalm_amd/streams.py,
+        # sharded.init_distributed), which fixes their queues whatever RCCL creates afterwards: with the runtime's 4 queues and one
+        # rank 151.2 pairs/s (torch.distributed) / 151.6 (native) against 127.8 without the claim; the 3-queue setting below is for
+        # the un-claimed mapping and collides WITH the claim (130.7) - tools/queue_ab.sh
+        return "runtime-default (compute streams claim their queues before the communicator exists)"
     if world_size == 1 and os.environ.get("DALM_FORCE_DIST", "0") == "1":
         os.environ["GPU_MAX_HW_QUEUES"] = "3"
         log.info("GPU_MAX_HW_QUEUES=3: one rank with a live RCCL communicator (the configuration this was measured in)")

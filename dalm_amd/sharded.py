@@ -45,6 +45,11 @@ def init_distributed(backend: Optional[str] = None):
     #   DALM_NATIVE_COMM=auto  the native binding, self-tested; every rank falls back to torch.distributed if any rank raised
     #   unset / 0              torch.distributed(nccl)
     native = os.environ.get("DALM_NATIVE_COMM", "0")
+    if torch.cuda.is_available() and os.environ.get("DALM_CLAIM_QUEUES", "1") != "0":
+        from .streams import claim_compute_queues
+
+        torch.cuda.set_device(local_rank)
+        claim_compute_queues(local_rank)      # the two compute streams get their hardware queues before RCCL's streams exist
     if torch.cuda.is_available() and backend in (None, "nccl") and native in ("1", "auto"):
         dev = torch.device("cuda", local_rank)
         torch.cuda.set_device(dev)

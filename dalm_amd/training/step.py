@@ -15,6 +15,8 @@ from typing import Dict, Optional
 
 import torch
 
+from .. import streams as _streams
+
 from .. import packed as _packed
 from ..fused import (GatherHandle, LocalComm, contrastive_loss, pool_l2norm, rag_e2e_loss, rag_e2e_loss_from_hidden,
                      rag_e2e_loss_packed)
@@ -165,7 +167,7 @@ class RagE2EStep(_StepBase):
         # the generator until the loss: run them on their own HIP stream so they fill the gaps between the
         # generator's large GEMMs; autograd replays each backward on its forward stream, so the backward
         # overlaps the same way
-        self.tower_stream = torch.cuda.Stream() if (overlap_towers and torch.cuda.is_available()) else None
+        self.tower_stream = _streams.tower_stream() if (overlap_towers and torch.cuda.is_available()) else None
 
     def _maybe_build_towers(self, batch) -> None:
         """One set of tower graphs per batch shape (packed batches: per row-count combination), at most DALM_TOWER_SETS (4) alive:
@@ -348,11 +350,13 @@ class RetrieverStep(_StepBase):
     def __init__(self, *a, overlap_towers: bool = True, graph_towers: bool = False, graph_after: int = 2, **kw):
         super().__init__(*a, **kw)
         # the query pass (Tq = 50) is small next to the passage pass (Tp = 128): run it on its own stream
-        self.tower_stream = torch.cuda.Stream() if (overlap_towers and torch.cuda.is_available()) else None
+        self.tower_stream = _streams.tower_stream() if (overlap_towers and torch.cuda.is_available()) else None
         self.autocast_cache = self.tower_stream is None   # one model on two streams: no shared cast cache
         # the two encoder calls as single-stream hipGraphs (GraphedEncoders), loss / optimizer / collectives eager: padded batches
         # only (the packed batch goes through the encoder in ONE call - a whole-step graph of that is a single stream already)
-        self.graph_towers = graph_towers and torch.cuda.is_available() and self.tower_stream is not None
+        # ONE RANK ONLY (LocalComm): next to the W > 1 gradient bucket the second replay of a set gave an infinite gradient norm
+        self.graph_towers = (graph_towers and torch.cuda.is_available() and self.tower_stream is not None
+                             and isinstance(self.comm, LocalComm))
         self.graph_after = graph_after
         self.calls = 0
         self.towers = None

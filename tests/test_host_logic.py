@@ -514,15 +514,21 @@ def test_hw_queue_setting_is_opt_in(monkeypatch):
 
     import dalm_amd
 
-    for k in ("GPU_MAX_HW_QUEUES", "DALM_HW_QUEUES", "DALM_FORCE_DIST", "WORLD_SIZE"):
+    for k in ("GPU_MAX_HW_QUEUES", "DALM_HW_QUEUES", "DALM_FORCE_DIST", "WORLD_SIZE", "DALM_CLAIM_QUEUES"):
         monkeypatch.delenv(k, raising=False)
     importlib.reload(dalm_amd)
     assert "GPU_MAX_HW_QUEUES" not in os.environ
-    assert dalm_amd.configure_hw_queues(1) == "runtime-default" and "GPU_MAX_HW_QUEUES" not in os.environ
-    assert dalm_amd.configure_hw_queues(8).startswith("runtime-default") and "GPU_MAX_HW_QUEUES" not in os.environ
+    # round 6: the compute streams claim their queues before a communicator exists (dalm_amd/streams.py): nothing is set at any
+    # rank count, the 3-queue setting only comes back with the claim switched off
+    for w in (1, 8):
+        assert dalm_amd.configure_hw_queues(w).startswith("runtime-default") and "GPU_MAX_HW_QUEUES" not in os.environ
     monkeypatch.setenv("DALM_FORCE_DIST", "1")
+    assert dalm_amd.configure_hw_queues(1).startswith("runtime-default") and "GPU_MAX_HW_QUEUES" not in os.environ
+    monkeypatch.setenv("DALM_CLAIM_QUEUES", "0")
+    assert dalm_amd.configure_hw_queues(8).startswith("runtime-default") and "GPU_MAX_HW_QUEUES" not in os.environ
     assert dalm_amd.configure_hw_queues(1) == "rccl-alive-one-rank:3" and os.environ["GPU_MAX_HW_QUEUES"] == "3"
     monkeypatch.delenv("DALM_FORCE_DIST")
+    monkeypatch.delenv("DALM_CLAIM_QUEUES")
     monkeypatch.setenv("GPU_MAX_HW_QUEUES", "4")
     assert dalm_amd.configure_hw_queues(8) == "user:4" and os.environ["GPU_MAX_HW_QUEUES"] == "4"
     monkeypatch.delenv("GPU_MAX_HW_QUEUES")

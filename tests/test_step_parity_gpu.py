@@ -170,6 +170,48 @@ def test_multi_gpu_code_path_on_one_rank_matches_reference(monkeypatch, which):
             comm.close()
 
 
+def test_retriever_only_multi_gpu_code_path_on_one_rank_matches_reference(monkeypatch):
+    """The W > 1 form of the retriever-only step - embedding all-gathers, stats exchange and the bucketed gradient all-reduce through
+    a live one-rank RCCL process group: the reference's 5-step trajectory (train_retriever_only.py:365-379).  The encoder-call graphs
+    (GraphedEncoders) are a one-rank feature: asked for next to a communicator, the step must ignore the request and launch eagerly
+    (with the gradient bucket their second replay produced an infinite gradient norm)."""
+    import torch.distributed as dist
+    from transformers import PreTrainedTokenizerFast, get_scheduler
+
+    from dalm_amd.fused import TorchDistComm
+    from dalm_amd.models import AutoModelForSentenceEmbedding
+    from dalm_amd.sharded import init_distributed
+    from dalm_amd.training.step import RetrieverStep
+    from dalm_amd.training.utils.retriever_only_dataloader_utils import preprocess_dataset
+
+    for k, v in (("DALM_FORCE_DIST", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29647"), ("RANK", "0"), ("WORLD_SIZE", "1"),
+                 ("LOCAL_RANK", "0")):
+        monkeypatch.setenv(k, v)
+    monkeypatch.delenv("DALM_NATIVE_COMM", raising=False)
+    comm, dev = init_distributed()
+    try:
+        assert isinstance(comm, TorchDistComm) and dist.get_backend() == "nccl"
+        gold = json.loads((G / "retriever_step_golden.json").read_text())
+        tok = PreTrainedTokenizerFast.from_pretrained(str(G / "wordlevel_tokenizer"))
+        model = AutoModelForSentenceEmbedding.from_modules(_tiny_bge_small(len(tok), gold["seed"]), tok, normalize=True, get_peft=False).to(dev)
+        model.train()
+        enc = preprocess_dataset(gold["rows"], tok, query_column_name="Question", passage_column_name="Abstract",
+                                 query_max_len=gold["query_max_len"], passage_max_len=gold["passage_max_len"])
+        full = {k: torch.tensor(v, device=dev) for k, v in enc.items()}
+        opt = torch.optim.Adam(model.parameters(), lr=gold["lr"])
+        sched = get_scheduler("linear", optimizer=opt, num_warmup_steps=gold["warmup"], num_training_steps=gold["total_steps"])
+        step = RetrieverStep(model, opt, sched, 100, comm=comm, autocast_dtype=None, overlap_towers=True, graph_towers=True, graph_after=0)
+        losses = [float(step({k: v[a:b] for k, v in full.items()})) for a, b in gold["batch_rows"]]
+        assert step.graph_towers is False and len(step._encoder_sets) == 0
+        for got, ref in zip(losses, gold["losses"]):
+            assert abs(got - ref) <= 1e-3 * abs(ref), (losses, gold["losses"])
+        final = float(sum(p.detach().double().abs().sum() for p in model.model.parameters()))
+        assert abs(final - gold["final_param_abs_sum"]) <= 1e-4 * gold["final_param_abs_sum"]
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
 def test_falcon_architecture_generator_runs_through_the_step():
     """cfg5 uses a Falcon generator (vocab 65024, bf16): a tiny random-init Falcon goes through the same step
     (1024-thread packed bf16 CE rows) and learns."""
